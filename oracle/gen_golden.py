@@ -1,0 +1,248 @@
+"""Generate tests/golden/*.npz by running the REFERENCE Python (see ref_loader.py) in this container.
+
+Usage (build container only):  python oracle/gen_golden.py
+
+Fixtures are data only: inputs are re-derivable from seeds (bc_workloads.seeded), outputs are what the
+reference's own TensorWrapper / BlockCopyModel / SwiftNet code produced on CPU with the oracle standing in
+for the four CUDA kernels.  The script also checks the reference-independent properties P1/P2 (SURVEY.md
+section 4) that pin the oracle's kernel restatements, and records them in properties.json.
+"""
+from __future__ import annotations
+
+import contextlib
+import io
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(ROOT, "blockcopy-video-processing-pytorch_amd"))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+import ref_loader  # noqa: E402
+from bc_workloads import seeded  # noqa: E402  (pure helpers; does not import our `blockcopy`)
+
+torch.manual_seed(0)
+torch.set_num_threads(8)
+torch.backends.mkldnn.deterministic = True if hasattr(torch.backends.mkldnn, "deterministic") else None
+
+SETTINGS = dict(block_policy="all", block_num_classes=19, block_optim_lr=1e-4, block_optim_wd=1e-3,
+                block_optim_momentum=0, block_target=0.5, block_complexity_weight=5, block_size=128,
+                block_train_interval=4, block_cost_momentum=0.9, block_policy_verbose=False)
+
+
+def quiet():
+    return contextlib.redirect_stdout(io.StringIO())
+
+
+# ----------------------------------------------------------------------------- A. index tables
+def gen_index_tables(ref):
+    rng = np.random.default_rng(1234)
+    out = {}
+    cases = [(1, 2, 4), (2, 3, 3), (1, 8, 16), (1, 1, 1), (2, 1, 5), (1, 32, 64)]
+    meta = []
+    for ci, (N, GH, GW) in enumerate(cases):
+        total = N * GH * GW
+        fracs = [1.0, 0.5, 0.25, "one", 0.5, "allbutone", 0.5]
+        prev = None
+        for fi, fr in enumerate(fracs):
+            if fr == "one":
+                g = np.zeros(total, bool); g[rng.integers(total)] = True
+            elif fr == "allbutone":
+                g = np.ones(total, bool); g[rng.integers(total)] = False
+            elif fr == 1.0:
+                g = np.ones(total, bool)
+            else:
+                g = rng.random(total) < fr
+                if not g.any():
+                    g[0] = True
+            grid = torch.from_numpy(g.reshape(N, 1, GH, GW))
+            bf = ref.tw.BlockFeatures(device="cpu")
+            bf._process_grid(grid, prev)
+            k = f"c{ci}_f{fi}"
+            out[k + "_grid"] = g.reshape(N, 1, GH, GW)
+            out[k + "_grid_idx"] = bf._grid_idx.numpy()
+            out[k + "_mapping_exec"] = bf._mapping_exec.numpy()
+            out[k + "_transfer_idx"] = (bf._transfer_idx.numpy() if bf._transfer_idx is not None else np.zeros(0, np.int32))
+            prev = bf
+        meta.append(dict(case=ci, N=N, GH=GH, GW=GW, frames=len(fracs)))
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(GOLD, "index_tables.npz"), **out)
+    print("index_tables.npz", len(out), "arrays")
+
+
+# ----------------------------------------------------------------------------- B. op-level call log
+class TinyNet(torch.nn.Module):
+    """conv k3p1 -> relu -> maxpool k3s2p1 -> conv k5p2 -> relu -> conv k3 s2 p1 ; exercises p in {1,2} and tile 8->4->2."""
+
+    def __init__(self):
+        super().__init__()
+        self.c1 = torch.nn.Conv2d(3, 4, 3, padding=1)
+        self.c2 = torch.nn.Conv2d(4, 5, 5, padding=2)
+        self.c3 = torch.nn.Conv2d(5, 6, 3, stride=2, padding=1)
+
+    def forward(self, x):
+        x = torch.relu(self.c1(x))
+        x = torch.nn.functional.max_pool2d(x, 3, 2, 1)
+        x = torch.relu(self.c2(x))
+        return self.c3(x)
+
+
+def tiny_net_weights(net):
+    net.load_state_dict(seeded.name_seeded_state_dict(net.state_dict()))
+    return net
+
+
+def tiny_grids():
+    N, GH, GW = 2, 2, 3
+    gs = [torch.ones(N, 1, GH, GW, dtype=torch.bool)]
+    for s, n in ((11, 6), (12, 3), (13, 1), (14, 11)):
+        gs.append(seeded.fixed_fraction_grid(s, N, GH, GW, n))
+    return gs
+
+
+def gen_ops(ref):
+    net = tiny_net_weights(TinyNet()).eval()
+    st = dict(SETTINGS, block_size=8)
+    model = ref.bc.BlockCopyModel(net, st)
+    grids = tiny_grids()
+    model.policy = ref_loader.make_forced_policy(ref, 8, grids)
+    model.reset_temporal()
+    ref_loader.CALL_LOG = []
+    outs = []
+    with torch.no_grad():
+        for t in range(len(grids)):
+            x = seeded.synthetic_frame(100 + t, (2, 3, 16, 24))
+            outs.append(model(x).clone())
+    log, ref_loader.CALL_LOG = ref_loader.CALL_LOG, None
+    out = {}
+    names = []
+    for i, (name, kw) in enumerate(log):
+        names.append(name)
+        for k, v in kw.items():
+            out[f"k{i}_{k}"] = v.numpy() if torch.is_tensor(v) else np.asarray(v)
+    out["names"] = np.frombuffer(json.dumps(names).encode(), dtype=np.uint8)
+    for t, o in enumerate(outs):
+        out[f"net_out{t}"] = o.numpy()
+    np.savez_compressed(os.path.join(GOLD, "ops_tinynet.npz"), **out)
+    print("ops_tinynet.npz", len(log), "kernel calls:", {n: names.count(n) for n in set(names)})
+
+
+# ----------------------------------------------------------------------------- C. SwiftNet end to end
+def build_ref_swiftnet(ref, backbone, block_size, grids):
+    with quiet():
+        bb = getattr(ref.resnet, backbone)(pretrained=False)
+        model = ref.swiftnet.SwiftNet(backbone=bb, num_classes=19, num_features=128, use_spp=True)
+        model.load_state_dict(seeded.name_seeded_state_dict(model.state_dict()), strict=True)
+        model.eval()
+        dense_model = None
+        wrapped = ref.bc.BlockCopyModel(model, dict(SETTINGS, block_size=block_size))
+        wrapped.policy = ref_loader.make_forced_policy(ref, block_size, grids)
+        wrapped = ref.bn_fusion.fuse_bn_recursively(wrapped)
+    return wrapped, dense_model
+
+
+def scenario_grids(N, GH, GW, seed):
+    total = N * GH * GW
+    gs = [torch.ones(N, 1, GH, GW, dtype=torch.bool),
+          seeded.fixed_fraction_grid(seed + 1, N, GH, GW, total // 2),
+          seeded.fixed_fraction_grid(seed + 2, N, GH, GW, 1),
+          seeded.fixed_fraction_grid(seed + 3, N, GH, GW, total - 1),
+          torch.zeros(N, 1, GH, GW, dtype=torch.bool),
+          seeded.fixed_fraction_grid(seed + 5, N, GH, GW, total // 4)]
+    return gs
+
+
+def gen_swiftnet(ref, tag, backbone, N, H, W, bs, n_frames, seed, store_frame_state):
+    grids = scenario_grids(N, H // bs, W // bs, seed)[:n_frames]
+    model, _ = build_ref_swiftnet(ref, backbone, bs, grids)
+    model.reset_temporal()
+    out = {"cfg": np.frombuffer(json.dumps(dict(backbone=backbone, N=N, H=H, W=W, block_size=bs, n_frames=n_frames,
+                                                frame_seed0=seed * 1000)).encode(), dtype=np.uint8)}
+    import warnings
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for t in range(n_frames):
+            x = seeded.synthetic_frame(seed * 1000 + t, (N, 3, H, W))
+            y = model(x)
+            out[f"grid{t}"] = grids[t].numpy()
+            out[f"logits{t}"] = y.detach().numpy().copy()
+            if store_frame_state:
+                out[f"frame_state{t}"] = model.policy_meta["frame_state"].detach().numpy().copy()
+    np.savez_compressed(os.path.join(GOLD, f"swiftnet_{tag}.npz"), **out)
+    print(f"swiftnet_{tag}.npz", {k: v.shape for k, v in out.items() if k.startswith("logits")})
+
+
+# ----------------------------------------------------------------------------- D. properties P1/P2/P3
+def check_properties(ref):
+    import warnings
+    props = {}
+    N, H, W, bs = 1, 256, 512, 64
+    GH, GW = H // bs, W // bs
+    # dense reference model (no wrapper), same weights, BN folded
+    with quiet():
+        bb = ref.resnet.resnet18(pretrained=False)
+        dense = ref.swiftnet.SwiftNet(backbone=bb, num_classes=19, num_features=128, use_spp=True)
+        dense.load_state_dict(seeded.name_seeded_state_dict(dense.state_dict()), strict=True)
+        dense.eval()
+        dense = ref.bn_fusion.fuse_bn_recursively(dense)
+    x0 = seeded.synthetic_frame(7, (N, 3, H, W))
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        dense_feats = dense.forward_down(x0)
+        dense_logits = dense(x0)
+        # P1: all-active block path == dense encoder
+        grids = [torch.ones(N, 1, GH, GW, dtype=torch.bool)]
+        blk, _ = build_ref_swiftnet(ref, "resnet18", bs, grids)
+        blk.reset_temporal()
+        xw = x0.as_subclass(ref.tw.TensorWrapper)
+        feats_obj = xw.process_temporal_features(None)
+        xb = xw.to_blocks(grids[0])
+        block_feats = blk.base_model.forward_down(xb)
+        p1 = []
+        for d, b in zip(dense_feats, block_feats):
+            full = b.combine().to_tensor()
+            p1.append(float((full - d).abs().max() / d.abs().max()))
+        props["P1_encoder_rel_maxabs_per_level"] = p1
+        assert max(p1) < 1e-5, p1  # levels 0-1 exact; deeper levels differ only by conv summation order
+        # P3: decoder differs from dense even at 100 % (no-halo per-tile bilinear upsample)
+        blk2, _ = build_ref_swiftnet(ref, "resnet18", bs, grids)
+        blk2.reset_temporal()
+        l_all = blk2(x0)
+        props["P3_logits_block_vs_dense_maxabs"] = float((l_all - dense_logits).abs().max())
+        props["logits_absmax"] = float(dense_logits.abs().max())
+        # P2: static clip, arbitrary masks -> logits identical to frame 0
+        gs = scenario_grids(N, GH, GW, 77)
+        blk3, _ = build_ref_swiftnet(ref, "resnet18", bs, gs)
+        blk3.reset_temporal()
+        l0 = blk3(x0).clone()
+        p2 = []
+        for t in range(1, len(gs)):
+            lt = blk3(x0)
+            p2.append(float((lt - l0).abs().max() / l0.abs().max()))
+        props["P2_static_clip_rel_maxabs_vs_frame0"] = p2
+        assert max(p2) < 1e-5, p2
+    with open(os.path.join(GOLD, "properties.json"), "w") as f:
+        json.dump(props, f, indent=1)
+    print("properties:", props)
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    ref = ref_loader.load_reference()
+    gen_index_tables(ref)
+    gen_ops(ref)
+    check_properties(ref)
+    gen_swiftnet(ref, "rn18_a", "resnet18", 1, 128, 256, 32, 6, 3, True)
+    gen_swiftnet(ref, "rn18_b", "resnet18", 1, 256, 512, 64, 4, 5, False)
+    gen_swiftnet(ref, "rn18_n2", "resnet18", 2, 128, 128, 32, 4, 9, False)
+    gen_swiftnet(ref, "rn50_a", "resnet50", 1, 128, 256, 32, 3, 4, False)
+
+
+if __name__ == "__main__":
+    main()
