@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Headline benchmark: frames/s of SwiftNet-RN18 through the block-copy engine on synthetic 1024x2048 clips at a fixed
+50 % execution mask (BASELINE.json config C2), plus the HBM roofline of the fused scatter+copy kernel and the host-CPU
+dense baseline.
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A *step* is one 20-frame clip (reset_temporal(); frame 0 executes all 128 tiles, frames 1..19 execute a seeded 64 of
+128) with every frame already resident in HBM.  fps = frames / wall, device-synchronised on both sides, exactly as the
+reference's driver measures it (semantic_segmentation/test_swiftnet.py:147-172).  Clips are independent, so N GPUs run
+N replicas with no collective on the data path (the barrier/all-reduce below only brackets the clock); scaling is weak.
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(ROOT, "blockcopy-video-processing-pytorch_amd"),):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+
+METRIC = "frames/sec SwiftNet-RN18 1024×2048 @ 50% active blocks, 1→8 GPU; scatter GB/s"
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+CLIP_LEN = 20
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5, help="timed clips per rank")
+    ap.add_argument("--warmup", type=int, default=2, help="untimed clips per rank")
+    ap.add_argument("--half", action="store_true", help="fp16 compute (reference speed configs use --half); default fp32")
+    ap.add_argument("--backbone", default="resnet18")
+    ap.add_argument("--height", type=int, default=1024)
+    ap.add_argument("--width", type=int, default=2048)
+    ap.add_argument("--block-size", type=int, default=128)
+    ap.add_argument("--target", type=float, default=0.5)
+    ap.add_argument("--engine", default="fused", choices=["fused", "reference"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dense", action="store_true", help="skip the dense-GPU comparison run")
+    ap.add_argument("--miopen-find", type=int, default=1, help="torch.backends.cudnn.benchmark during warm-up")
+    ap.add_argument("--cpu-frames", type=int, default=8)
+    return ap.parse_args()
+
+
+def dist_env():
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    return rank, world, local
+
+
+def barrier_sync(world, device):
+    torch.cuda.synchronize(device)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.cuda.synchronize(device)
+
+
+def cpu_dense_baseline(args, n_frames):
+    """'Reference on the host CPU cores, block execution disabled': dense SwiftNet fp32 through PyTorch CPU convs
+    (oneDNN) on all host cores, BN folded, no_grad; bounded sample."""
+    from bc_workloads import harness, seeded
+
+    cores = torch.get_num_threads()
+    model = harness.build_model(args.backbone, block_policy="static", device="cpu")
+    x = seeded.synthetic_frame(0, (1, 3, args.height, args.width))
+    with torch.no_grad():
+        model(x)   # warm-up (oneDNN primitive creation)
+        t0 = time.perf_counter()
+        done = 0
+        for _ in range(n_frames):
+            model(x)
+            done += 1
+            if time.perf_counter() - t0 > 30.0:
+                break
+        dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{done} dense (block-exec disabled) {args.backbone} frames 1x3x{args.height}x{args.width} fp32, "
+                      f"PyTorch CPU oneDNN conv, BN folded, after 1 warm-up frame ({dt:.1f} s)"}
+
+
+def main():
+    args = parse_args()
+    rank, world, local = dist_env()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
+    assert torch.cuda.is_available(), "bench.py needs the GPU"
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    if world > 1:
+        torch.distributed.init_process_group("nccl", device_id=device)
+
+    import blockcopy.backend as bk
+    from blockcopy.core import tensorwrapper as tw
+    from bc_workloads import harness
+
+    tw.set_engine(args.engine)
+    be = bk.get_backend()
+    dtype = torch.float16 if args.half else torch.float32
+    shape = (1, 3, args.height, args.width)
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)
+
+    model = harness.build_model(args.backbone, block_policy="fixed", block_size=args.block_size, block_target=args.target,
+                                device=device, dtype=dtype, seed=1000 * rank)
+    # per-rank clips (clip i of the job lives on rank i mod N); inputs resident in HBM before the clock starts
+    n_distinct = 2
+    clips = [harness.synthetic_clip(CLIP_LEN, shape, seed=(rank * n_distinct + c) * 100, device=device, dtype=dtype) for c in range(n_distinct)]
+
+    t_w0 = time.perf_counter()
+    for i in range(args.warmup):
+        harness.run_clip(model, clips[i % n_distinct])
+    torch.cuda.synchronize(device)
+    warm_s = time.perf_counter() - t_w0
+
+    be.prof_reset()
+    be.prof_enable(["combine_copy"])
+    barrier_sync(world, device)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        harness.run_clip(model, clips[i % n_distinct])
+    barrier_sync(world, device)
+    elapsed = time.perf_counter() - t0
+    be.prof_enable([])
+    cc = be.prof_read("combine_copy")
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    frames_total = world * args.steps * CLIP_LEN
+    fps = frames_total / elapsed
+    exec_frac = model.policy.stats.get_exec_percentage()
+
+    extra = {}
+    if rank == 0:
+        # halo-gather kernel statistics from one extra, untimed clip (events around all 21 launches per frame)
+        be.prof_reset()
+        be.prof_enable(["pad_ring", "split", "combine"])
+        harness.run_clip(model, clips[0])
+        torch.cuda.synchronize(device)
+        be.prof_enable([])
+        for op in ("pad_ring", "split", "combine"):
+            r = be.prof_read(op)
+            if r["launches"]:
+                extra[op] = {"launches_per_frame": r["launches"] / CLIP_LEN, "avg_us": 1e3 * r["total_ms"] / r["launches"],
+                             "GBps": r["total_bytes"] / (r["total_ms"] * 1e-3) / 1e9, "MB_per_frame": r["total_bytes"] / CLIP_LEN / 1e6}
+        if not args.no_dense and world == 1:
+            dense = harness.build_model(args.backbone, block_policy="static", device=device, dtype=dtype)
+            dfps, _, _ = harness.measure_fps(dense, clips[:1], n_clips=max(1, min(args.steps, 3)), warmup_clips=1, device=device)
+            extra["dense_gpu_fps"] = dfps
+            extra["speedup_vs_dense_gpu"] = fps / dfps
+            del dense
+
+    if rank == 0:
+        achieved = (cc["total_bytes"] / (cc["total_ms"] * 1e-3) / 1e9) if cc["total_ms"] > 0 else 0.0
+        out = {
+            "metric": METRIC, "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16" if args.half else "f32", "data": "synthetic",
+            "config": {"workload": f"C2: SwiftNet-{args.backbone} {shape[0]}x3x{args.height}x{args.width} synthetic clips of {CLIP_LEN} frames, "
+                                   f"block {args.block_size}, fixed {args.target:.0%} seeded mask (frame 0 of each clip all-active), "
+                                   f"{args.engine} engine, name-seeded weights, BN folded; step = 1 clip",
+                       "clips_per_rank": args.steps, "parallelism": f"{world} independent replica(s), no collective",
+                       "exec_fraction": exec_frac, "warmup_s": warm_s},
+            "roofline": {"kernel": "k_combine_copy (fused scatter+copy of the logits map)", "bound": "hbm", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "launches": cc["launches"], "avg_launch_us": (1e3 * cc["total_ms"] / cc["launches"]) if cc["launches"] else None,
+                         "algorithmic_bytes_per_launch": (cc["total_bytes"] / cc["launches"]) if cc["launches"] else None},
+            "kernels": extra,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_dense_baseline(args, args.cpu_frames)
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

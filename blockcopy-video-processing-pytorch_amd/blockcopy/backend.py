@@ -1,0 +1,246 @@
+"""Binding of the block ops to libblockcopy_hip.so (C ABI: include/blockcopy_hip.h) through ctypes.
+
+The product has exactly one compute backend: the gfx950 HIP library.  There is no CPU or eager-PyTorch
+fallback -- if the library is missing, or a tensor is not on the GPU, the ops raise (the reference is the
+same: "NVIDIA CUDA-capable GPU (no CPU support)", README.md:21; asserts in utils/cuda.py:42-48).
+
+``set_backend`` exists so that the *test-suite* can drive the host logic (state machine, op routing,
+index tables, ring-cache bookkeeping) on a machine without a GPU by injecting a checker backend built on
+the CPU oracle; nothing in this package ever does that by itself.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.environ.get("BLOCKCOPY_HIP_LIB", os.path.join(_PKG_ROOT, "lib", "libblockcopy_hip.so"))
+
+OP_SPLIT, OP_COMBINE, OP_TRANSFER, OP_PAD, OP_COMBINE_COPY, OP_PAD_RING, OP_GRID_TABLES = range(7)
+OP_NAMES = ("split", "combine", "transfer", "pad", "combine_copy", "pad_ring", "grid_tables")
+ABI_VERSION = 1
+
+
+class BlockCopyBackendError(RuntimeError):
+    pass
+
+
+def _ok(x: torch.Tensor, *dtypes) -> bool:
+    # same contract as the reference's cudaok(), utils/cuda.py:42-48
+    assert x.is_cuda, "blockcopy ops need GPU tensors (no CPU path)"
+    assert x.is_contiguous(), "blockcopy ops need contiguous NCHW tensors"
+    assert not dtypes or x.dtype in dtypes, (x.dtype, dtypes)
+    return True
+
+
+def load_library(path: str = None) -> ctypes.CDLL:
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise BlockCopyBackendError(
+            f"{path} not found: build it with `python blockcopy-video-processing-pytorch_amd/build.py` "
+            "(hipcc --offload-arch=gfx950).  There is no fallback backend.")
+    lib = ctypes.CDLL(path)
+    i, p, u = ctypes.c_int, ctypes.c_void_p, ctypes.c_uint
+    sig = {
+        "bc_split": [p, p, p] + [i] * 7 + [p],
+        "bc_combine": [p, p, p] + [i] * 7 + [p],
+        "bc_combine_copy": [p, p, p, p] + [i] * 6 + [p],
+        "bc_transfer": [p, p, p, p] + [i] * 8 + [p],
+        "bc_pad": [p, p, p, p, p] + [i] * 8 + [p],
+        "bc_pad_ring": [p, p, p, p, p] + [i] * 8 + [p],
+        "bc_grid_tables": [p, i, p, p, p, p, p, p],
+        "bc_grid_tables_host": [p, i, p, p, p, p],
+        "bc_abi_version": [],
+        "bc_prof_enable": [u],
+        "bc_prof_reset": [],
+        "bc_prof_read": [i, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)],
+    }
+    for name, argtypes in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = i
+    lib.bc_error_string.argtypes = [i]
+    lib.bc_error_string.restype = ctypes.c_char_p
+    lib.bc_op_name.argtypes = [i]
+    lib.bc_op_name.restype = ctypes.c_char_p
+    if lib.bc_abi_version() != ABI_VERSION:
+        raise BlockCopyBackendError(f"ABI mismatch: library {lib.bc_abi_version()} vs binding {ABI_VERSION}")
+    return lib
+
+
+class HipBackend:
+    """The product backend: raw device pointers into libblockcopy_hip.so on torch's current stream."""
+
+    name = "hip"
+
+    def __init__(self, path: str = None):
+        self.lib = load_library(path)
+
+    # -- helpers
+    def _check(self, rc: int, op: str):
+        if rc != 0:
+            raise BlockCopyBackendError(f"bc_{op} failed: {self.lib.bc_error_string(rc).decode()} (code {rc})")
+
+    @staticmethod
+    def _stream() -> int:
+        return torch.cuda.current_stream().cuda_stream
+
+    # -- A. reference operator boundary ---------------------------------------------------------------
+    def split(self, blocks, image, mapping_exec, grid_idx):
+        """blocks <- executed tiles of image.  reference: SplitFunction.forward, utils/block_funcs.py:12-49."""
+        assert _ok(blocks) and _ok(image, blocks.dtype) and _ok(mapping_exec, torch.int32) and _ok(grid_idx, torch.int32)
+        assert blocks.dim() == 4 and image.dim() == 4 and blocks.shape[2] == blocks.shape[3]
+        n_exec, C, bs, _ = blocks.shape
+        N, C_img, H, W = image.shape
+        _, _, GH, GW = grid_idx.shape
+        assert C == C_img and GH * bs == H and GW * bs == W, (blocks.shape, image.shape, grid_idx.shape)
+        assert n_exec == mapping_exec.numel()
+        if n_exec > 0:
+            with torch.cuda.device_of(blocks):
+                self._check(self.lib.bc_split(blocks.data_ptr(), image.data_ptr(), mapping_exec.data_ptr(), n_exec,
+                                              N, C, H, W, bs, blocks.element_size(), self._stream()), "split")
+        return blocks
+
+    def combine(self, blocks, out, grid_idx, mapping_exec):
+        """out[executed tiles] <- blocks, in place.  reference: CombineFunction.forward, utils/block_funcs.py:87-124."""
+        assert _ok(blocks) and _ok(out, blocks.dtype) and _ok(mapping_exec, torch.int32) and _ok(grid_idx, torch.int32)
+        N, C, H, W = out.shape
+        n_exec, Cb, bs, bs2 = blocks.shape
+        _, one, GH, GW = grid_idx.shape
+        assert bs >= 1 and bs == bs2 and one == 1 and grid_idx.size(0) == N and Cb == C
+        assert GH * bs == H and GW * bs == W
+        assert n_exec == mapping_exec.numel()
+        if n_exec > 0:
+            with torch.cuda.device_of(blocks):
+                self._check(self.lib.bc_combine(blocks.data_ptr(), out.data_ptr(), mapping_exec.data_ptr(), n_exec,
+                                                N, C, H, W, bs, blocks.element_size(), self._stream()), "combine")
+        return out
+
+    def transfer(self, out, prev_computed, prev_transfer, prev_grid_idx, transfer_idx, padding):
+        """border ring of non-executed tiles from the previous frame.  reference: TransferFunction.forward, :163-193."""
+        assert _ok(out) and _ok(prev_computed, out.dtype) and _ok(prev_transfer, out.dtype) and _ok(transfer_idx, torch.int32)
+        assert out.shape[1:] == prev_computed.shape[1:] == prev_transfer.shape[1:]
+        N, _, GH, GW = prev_grid_idx.shape
+        n_tr, C, bs, _ = out.shape
+        assert n_tr == transfer_idx.numel()
+        if n_tr > 0:
+            with torch.cuda.device_of(out):
+                self._check(self.lib.bc_transfer(out.data_ptr(),
+                                                 prev_computed.data_ptr() if prev_computed.numel() else None,
+                                                 prev_transfer.data_ptr() if prev_transfer.numel() else None,
+                                                 transfer_idx.data_ptr(), n_tr, N, C, GH, GW, bs, int(padding),
+                                                 out.element_size(), self._stream()), "transfer")
+        return out
+
+    def pad(self, data_exec, data_transfer, grid_idx, mapping_exec, pad):
+        """halo-padded packed batch.  reference: BlockPadFunction.forward, utils/blockpad.py:23-71 (allocates the output)."""
+        assert _ok(data_exec) and _ok(data_transfer, data_exec.dtype) and _ok(mapping_exec, torch.int32) and _ok(grid_idx, torch.int32)
+        assert data_exec.shape[1:] == data_transfer.shape[1:], (data_exec.shape, data_transfer.shape)
+        n_exec = mapping_exec.numel()
+        assert n_exec <= data_exec.shape[0]
+        assert grid_idx.numel() - n_exec <= data_transfer.shape[0], (grid_idx.numel(), n_exec, data_transfer.shape)
+        assert pad > 0
+        N, _, GH, GW = grid_idx.shape
+        B, C, bs, _ = data_exec.shape
+        out = torch.empty((B, C, bs + 2 * pad, bs + 2 * pad), device=data_exec.device, dtype=data_exec.dtype)
+        if n_exec > 0:
+            with torch.cuda.device_of(data_exec):
+                self._check(self.lib.bc_pad(out.data_ptr(), data_exec.data_ptr(),
+                                            data_transfer.data_ptr() if data_transfer.numel() else None,
+                                            grid_idx.data_ptr(), mapping_exec.data_ptr(), n_exec, N, C, GH, GW, bs, int(pad),
+                                            out.element_size(), self._stream()), "pad")
+        return out
+
+    # -- B. MI355X-first forms --------------------------------------------------------------------------
+    def combine_copy(self, blocks, prev, out, grid_idx):
+        """out <- blocks where executed else prev: fused scatter + copy, one pass over the dense map."""
+        assert _ok(blocks) and _ok(prev, blocks.dtype) and _ok(out, blocks.dtype) and _ok(grid_idx, torch.int32)
+        N, C, H, W = out.shape
+        _, Cb, bs, _ = blocks.shape
+        _, _, GH, GW = grid_idx.shape
+        assert prev.shape == out.shape and Cb == C and GH * bs == H and GW * bs == W and grid_idx.size(0) == N
+        assert out.data_ptr() != prev.data_ptr(), "combine_copy is out of place"
+        with torch.cuda.device_of(out):
+            self._check(self.lib.bc_combine_copy(blocks.data_ptr() if blocks.numel() else None, prev.data_ptr(), out.data_ptr(),
+                                                 grid_idx.data_ptr(), N, C, H, W, bs, out.element_size(), self._stream()),
+                        "combine_copy")
+        return out
+
+    def pad_ring(self, data_exec, ring, grid_idx, mapping_exec, pad):
+        """halo gather over the persistent ring cache (+ refresh of the executed tiles' rings)."""
+        assert _ok(data_exec) and _ok(ring, data_exec.dtype) and _ok(mapping_exec, torch.int32) and _ok(grid_idx, torch.int32)
+        N, _, GH, GW = grid_idx.shape
+        B, C, bs, _ = data_exec.shape
+        n_exec = mapping_exec.numel()
+        assert n_exec == B and pad > 0
+        assert tuple(ring.shape) == (N * GH * GW, C, bs, bs), (ring.shape, (N * GH * GW, C, bs, bs))
+        out = torch.empty((B, C, bs + 2 * pad, bs + 2 * pad), device=data_exec.device, dtype=data_exec.dtype)
+        if n_exec > 0:
+            with torch.cuda.device_of(data_exec):
+                self._check(self.lib.bc_pad_ring(out.data_ptr(), data_exec.data_ptr(), ring.data_ptr(), grid_idx.data_ptr(),
+                                                 mapping_exec.data_ptr(), n_exec, N, C, GH, GW, bs, int(pad),
+                                                 out.element_size(), self._stream()), "pad_ring")
+        return out
+
+    def grid_tables_device(self, grid, prev_grid_idx=None):
+        """index tables computed on the GPU (no host sync).  Returns (grid_idx, mapping_buf, transfer_buf, counts)
+        where mapping_buf / transfer_buf are full-length buffers whose valid prefix lengths are counts[0] / counts[1]."""
+        assert _ok(grid, torch.bool, torch.uint8)
+        n_total = grid.numel()
+        grid_idx = torch.empty(grid.shape, dtype=torch.int32, device=grid.device)
+        mapping = torch.empty(n_total, dtype=torch.int32, device=grid.device)
+        counts = torch.empty(2, dtype=torch.int32, device=grid.device)
+        transfer = torch.empty(n_total, dtype=torch.int32, device=grid.device) if prev_grid_idx is not None else None
+        with torch.cuda.device_of(grid):
+            self._check(self.lib.bc_grid_tables(grid.data_ptr(), n_total, grid_idx.data_ptr(), mapping.data_ptr(),
+                                                prev_grid_idx.data_ptr() if prev_grid_idx is not None else None,
+                                                transfer.data_ptr() if transfer is not None else None,
+                                                counts.data_ptr(), self._stream()), "grid_tables")
+        return grid_idx, mapping, transfer, counts
+
+    def grid_tables_host(self, grid_u8: np.ndarray, grid_idx: np.ndarray, mapping: np.ndarray,
+                         prev_grid_idx: np.ndarray = None, transfer: np.ndarray = None) -> int:
+        """host-side tables (C loop in the library) written straight into caller-provided (pinned) int32 arrays."""
+        rc = self.lib.bc_grid_tables_host(grid_u8.ctypes.data, grid_u8.size, grid_idx.ctypes.data, mapping.ctypes.data,
+                                          prev_grid_idx.ctypes.data if prev_grid_idx is not None else None,
+                                          transfer.ctypes.data if transfer is not None else None)
+        if rc < 0:
+            self._check(rc, "grid_tables_host")
+        return rc
+
+    # -- C. measurement -----------------------------------------------------------------------------------
+    def prof_enable(self, ops=()):
+        mask = 0
+        for op in ops:
+            mask |= 1 << (OP_NAMES.index(op) if isinstance(op, str) else int(op))
+        self._check(self.lib.bc_prof_enable(mask), "prof_enable")
+
+    def prof_reset(self):
+        self._check(self.lib.bc_prof_reset(), "prof_reset")
+
+    def prof_read(self, op):
+        op = OP_NAMES.index(op) if isinstance(op, str) else int(op)
+        n, ms, by = ctypes.c_longlong(0), ctypes.c_double(0), ctypes.c_double(0)
+        self._check(self.lib.bc_prof_read(op, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(by)), "prof_read")
+        return dict(op=OP_NAMES[op], launches=n.value, total_ms=ms.value, total_bytes=by.value)
+
+
+_backend = None
+
+
+def get_backend():
+    """The active backend; loads the HIP library on first use and fails loudly if that is impossible."""
+    global _backend
+    if _backend is None:
+        _backend = HipBackend()
+    return _backend
+
+
+def set_backend(backend):
+    """Install a backend object (test hook; see module docstring).  ``None`` restores lazy HIP loading."""
+    global _backend
+    prev, _backend = _backend, backend
+    return prev

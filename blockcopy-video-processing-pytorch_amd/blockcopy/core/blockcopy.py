@@ -1,0 +1,100 @@
+"""Per-frame block-copy manager: policy -> pack -> base model on packed tiles -> combine -> policy update.
+
+Same contract as the reference's ``BlockCopyModel`` / ``blockcopy_noblocks`` (core/blockcopy.py:7-122): same
+constructor, ``forward`` / ``reset_temporal`` / ``load_state_dict``, same ``policy_meta`` keys, same per-clip
+semantics (first frame of a clip executes every tile; ``num_exec == 0`` returns the cached output object)."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+import blockcopy
+
+from ..utils.profiler import timings
+
+
+class BlockCopyModel(nn.Module):
+    """Wrap ``base_model`` so that only the tiles chosen by the policy are recomputed on each frame.
+
+    settings: dict with the ``block_*`` keys of ``blockcopy.add_argparser_arguments``.
+    """
+
+    def __init__(self, base_model: nn.Module, settings: dict):
+        super().__init__()
+        self.is_blockcopy_manager = True   # marks the module that owns the temporal state
+        self.base_model = base_model
+        self.policy = blockcopy.build_policy_from_settings(settings)
+        self.block_temporal_features = None
+        self.train_interval = settings["block_train_interval"]
+        self.reset_temporal()
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        """Checkpoints are those of the base model (reference: core/blockcopy.py:30-32)."""
+        return self.base_model.load_state_dict(state_dict, strict=strict)
+
+    def reset_temporal(self):
+        """Forget all temporal state; call at the start of every clip."""
+        self.clip_length = 0
+        if self.block_temporal_features:
+            self.block_temporal_features.clear()
+        self.block_temporal_features = None
+        self.policy_meta = {"inputs": None, "outputs": None, "outputs_prev": None}
+        # NB: the reference also calls torch.cuda.empty_cache() here (:43).  Returning the whole caching
+        # allocator to the driver once per clip forces hipFree/hipMalloc round trips on the next clip's first
+        # frame; stale blocks are simply reused by the allocator, so it is not needed for correctness.
+
+    def forward(self, inputs, **kwargs):
+        return self._forward_blockcopy(inputs, **kwargs)
+
+    def _forward_blockcopy(self, inputs, **kwargs):
+        self.clip_length += 1
+
+        self.policy_meta["inputs"] = inputs
+        with timings.env("blockcopy/policy_forward", 3):
+            # the policy writes the execution grid into policy_meta['grid'] (+ optional CPU mirror 'grid_host')
+            self.policy_meta = self.policy(self.policy_meta)
+
+        with timings.env("blockcopy/model", 3):
+            x = blockcopy.to_tensorwrapper(inputs)
+            if self.policy_meta["num_exec"] == 0:
+                # nothing to execute: hand back the cached outputs
+                self.policy_meta = self.policy_meta.copy()
+                out = self.policy_meta["outputs"]
+            else:
+                self.block_temporal_features = x.process_temporal_features(self.block_temporal_features)
+                blocks = x.to_blocks(self.policy_meta["grid"], self.policy_meta.get("grid_host", None))
+                # frame state = most recently executed pixels of every tile
+                self.policy_meta["frame_state"] = blocks.combine_().to_tensor()
+                out = self.base_model(blocks, **kwargs)
+                out = out.combine().to_tensor()
+
+            self.policy_meta["outputs_prev"] = self.policy_meta["outputs"]
+            self.policy_meta["outputs"] = out
+
+        with timings.env("blockcopy/policy_optim", 3):
+            if self.policy is not None:
+                train_policy = self.clip_length % self.train_interval == 0
+                self.policy_meta = self.policy.optim(self.policy_meta, train=train_policy)
+        return out
+
+
+def blockcopy_noblocks(func):
+    """Decorator for a Module ``forward`` that needs the dense map (e.g. global pooling): combine the packed
+    input in place, run the module densely, re-pack the result with the same grid.
+
+        class GlobalContext(nn.Module):
+            @blockcopy_noblocks
+            def forward(self, x): ...
+    """
+
+    def noblocks(self, x, *args):
+        packed = isinstance(x, blockcopy.TensorWrapper)
+        if packed:
+            like = x
+            x = x.combine_().to_tensor()
+        x = func(self, x)
+        if packed:
+            x = blockcopy.to_tensorwrapper(x).to_blocks_like(like)
+        return x
+
+    return noblocks

@@ -1,0 +1,509 @@
+"""Block-sparse tensor representation with temporal feature propagation.
+
+Public surface mirrors the reference's ``core/tensorwrapper.py`` (``TensorWrapper``, ``BlockFeatures``,
+``to_tensorwrapper / to_tensor / is_block / is_tensorwrapper``) so model code written for the reference
+(`blockcopy.to_tensor(x)`, ``@blockcopy_noblocks``, ``x.combine_()``, ...) runs unchanged.  What differs is
+how the path is executed on MI355X:
+
+* index tables (``grid_idx``, ``mapping_exec``) are built by one C loop into a pinned staging buffer and
+  uploaded with a single asynchronous H->D copy; when the policy supplies a host mirror of its grid there is
+  **no** device->host synchronisation in the frame (the reference does two syncs + three uploads + a
+  GPU-tensor-by-CPU-mask index per frame, core/tensorwrapper.py:150-178);
+* ``ENGINE == "fused"`` (default): every padded layer owns a persistent **ring cache**; one ``pad_ring``
+  launch builds the halo-padded packed batch and refreshes the executed tiles' rings, so the reference's
+  per-layer ``transfer`` launch, its ``(computed, transfer)`` tensor pair and their FIFO disappear
+  (reference: _transfer_from_prev :445-476 + store_features :180-189 + pad);
+* non-in-place ``combine`` is ONE fused scatter+copy launch instead of ``clone()`` + scatter (:421-433);
+* ``ENGINE == "reference"`` keeps the reference's exact decomposition (split / transfer / pad / combine with
+  the FIFO of tensor pairs) on the same HIP library -- used for op-by-op parity checks.
+
+``__torch_function__`` is a classmethod (the instance-method form is deprecated in current PyTorch) and all
+handler bodies run with subclass dispatch disabled, so attribute reads such as ``x.shape`` inside the engine
+cost nothing extra.
+"""
+from __future__ import annotations
+
+import os
+import warnings
+from collections import deque
+from typing import Any, Callable, Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from ..backend import get_backend
+from ..utils.block_funcs import CombineCopyFunction, CombineFunction, SplitFunction, TransferFunction
+from ..utils.blockpad import pad, pad_ring
+from ..utils.profiler import timings
+
+VERBOSE = False                # debugging flag: print verbose statements
+BLOCKPAD_WITH_ZEROES = False   # debugging flag: zero halo instead of block padding (reference :14,:536)
+ENGINE = os.environ.get("BLOCKCOPY_ENGINE", "fused")   # "fused" | "reference"
+
+_NoDispatch = torch._C.DisableTorchFunctionSubclass
+
+
+def set_engine(name: str) -> str:
+    """Select the execution engine ("fused" or "reference"); returns the previous one."""
+    global ENGINE
+    assert name in ("fused", "reference"), name
+    prev, ENGINE = ENGINE, name
+    return prev
+
+
+def is_tensorwrapper(x) -> bool:
+    """True if x is a TensorWrapper."""
+    return isinstance(x, TensorWrapper)
+
+
+def is_block(x) -> bool:
+    """True if x is a TensorWrapper in packed (blocks) representation."""
+    return isinstance(x, TensorWrapper) and x.is_blocks
+
+
+def to_tensorwrapper(x: torch.Tensor) -> "TensorWrapper":
+    """View a tensor as a TensorWrapper (no copy)."""
+    # reference asserts x.is_cuda (core/tensorwrapper.py:35); here the GPU requirement is enforced by the HIP
+    # backend itself, which is the only backend the package can load on its own.
+    assert x.is_cuda or get_backend().name != "hip", "x must be on the GPU!"
+    with _NoDispatch():
+        return x.as_subclass(TensorWrapper)
+
+
+def to_tensor(x):
+    """TensorWrapper (or list / tuple / dict of them) -> torch.Tensor; packed tensors are combined first."""
+    if isinstance(x, TensorWrapper):
+        return x.to_tensor()
+    if isinstance(x, list):
+        return [to_tensor(z) for z in x]
+    if isinstance(x, tuple):
+        return tuple(to_tensor(z) for z in x)
+    if isinstance(x, dict):
+        return {k: to_tensor(v) for k, v in x.items()}
+    return x
+
+
+# Op classes of the reference's routing table (core/tensorwrapper.py:69-105).
+OPS = {
+    # ops with a spatial padding argument: the zero padding is replaced by a halo gathered from neighbours
+    "PADDED": {"conv2d", "max_pool2d", "avg_pool2d", "lp_pool2d", "fractional_max_pool2d"},
+    # resampling ops: executed per tile, without halo
+    "INTERPOLATE": {"interpolate", "upsample_bilinear"},
+    # ops whose statistics run over the batch axis, which here is the tile axis
+    "BATCHED": {"group_norm"},
+    # ops that need the whole dense tensor
+    "INCOMPATIBLE": {"adaptive_avg_pool2d", "adaptive_max_pool2d", "linear", "flip", "unsqueeze", "reshape", "view"},
+    # reductions that are only meaningful over the channel axis
+    "CHANNELONLY": {"mean", "sum", "max", "min,", "std", "var", "argmax", "count_nonzero", "nonzero"},
+    "WARNING": {""},
+}
+OPS_SPECIAL = set().union(*OPS.values())
+
+# positional index of `padding` for ops that reach __torch_function__ with positional arguments
+_PADDING_POS = {"conv2d": 4, "avg_pool2d": 3, "max_pool2d": 3}
+
+
+class BlockFeatures:
+    """Per-frame block state: the execution grid with its index tables, plus the temporal feature store.
+
+    fused engine     : ``rings`` -- one persistent (n_total,C,bs,bs) ring cache per padded op, in call order,
+                       handed from frame to frame;
+    reference engine : FIFO of (computed, transfer, padding) per padded op as in the reference (:131-232);
+    both             : FIFO of combined dense maps (``store_features_full``).
+    """
+
+    def __init__(self, device, engine: str = None):
+        self.device = torch.device(device)
+        self.engine = engine or ENGINE
+        self._grid = None            # bool (N,1,GH,GW): tiles executed this frame
+        self._grid_idx = None        # int32 (N,1,GH,GW): packed row of executed tiles; -n_total+k for the k-th skipped tile
+        self._mapping_exec = None    # int32 [n_exec]: flat grid position of each packed row
+        self._transfer_idx = None    # int32 [n_transfer]: previous frame's grid_idx at this frame's skipped tiles (reference engine)
+        self._grid_idx_host = None   # numpy mirror of _grid_idx (host copy kept for the next frame's transfer_idx)
+        self.n_exec = 0
+        self.n_total = 0
+
+        self._features_computed = deque()
+        self._features_transfer = deque()
+        self._features_full = deque()
+
+        self.rings = []              # fused engine: persistent ring caches (shared list object across frames)
+        self._ring_pos = 0
+
+    # ------------------------------------------------------------------ grid -> index tables
+    def _process_grid(self, grid: torch.Tensor, meta_prev: "BlockFeatures" = None, grid_host: torch.Tensor = None) -> None:
+        with timings.env("tensorwrapper/process_grid", 10):
+            assert grid.dim() == 4 and grid.shape[1] == 1, "grid must be (N,1,GH,GW)"
+            if grid_host is None:
+                # device-resident grid without host mirror: one D->H copy (the reference's path, :158)
+                grid_host = grid.to("cpu", dtype=torch.bool)
+            if grid_host.dtype != torch.bool:
+                grid_host = grid_host.to(torch.bool)
+            g8 = grid_host.contiguous().numpy().view(np.uint8).reshape(-1)
+            n_total = g8.size
+            on_gpu = self.device.type == "cuda"
+            staging = torch.empty(3 * n_total, dtype=torch.int32, pin_memory=on_gpu)
+            st = staging.numpy()
+            want_transfer = meta_prev is not None and self.engine == "reference"
+            n_exec = get_backend().grid_tables_host(
+                g8, st[:n_total], st[n_total:2 * n_total],
+                meta_prev._grid_idx_host if want_transfer else None,
+                st[2 * n_total:] if want_transfer else None)
+            if meta_prev is None:
+                assert n_exec == n_total, "No previous features known, first run should execute all blocks!"
+            else:
+                assert meta_prev.n_total == n_total, "grid size changed inside a clip"
+            dev = staging.to(self.device, non_blocking=True) if on_gpu else staging
+            self._grid = grid.to(self.device, dtype=torch.bool)
+            self._grid_idx = dev[:n_total].view(grid.shape)
+            self._mapping_exec = dev[n_total:n_total + n_exec]
+            if want_transfer:
+                self._transfer_idx = dev[2 * n_total:3 * n_total - n_exec]
+            self._grid_idx_host = st[:n_total]
+            self._staging = staging   # keeps the host mirror alive
+            self.n_exec, self.n_total = n_exec, n_total
+            if meta_prev is not None:
+                self.rings = meta_prev.rings   # ring caches persist across frames
+
+    # ------------------------------------------------------------------ fused engine: ring caches
+    def next_ring(self, data: torch.Tensor) -> torch.Tensor:
+        """Ring cache of the padded op being executed (ops must come in the same order every frame)."""
+        k = self._ring_pos
+        self._ring_pos += 1
+        _, C, bs, _ = data.shape
+        shape = (self.n_total, C, bs, bs)
+        if k == len(self.rings):
+            assert self.n_exec == self.n_total, "a new padded layer appeared after the first frame of the clip"
+            self.rings.append(torch.empty(shape, dtype=data.dtype, device=data.device))
+        ring = self.rings[k]
+        if tuple(ring.shape) != shape or ring.dtype != data.dtype:
+            raise AssertionError(f"padded op #{k}: expected tiles {tuple(ring.shape)}/{ring.dtype}, got {shape}/{data.dtype}; "
+                                 "the model must run the same op sequence every frame")
+        return ring
+
+    # ------------------------------------------------------------------ reference engine: FIFO of tensor pairs
+    def store_features(self, data_computed, data_transfer, padding: int = -1) -> None:
+        assert data_computed.shape[1:] == data_transfer.shape[1:], \
+            f"Number of channels must be equal, got {(data_computed.shape, data_transfer.shape)}"
+        self._features_computed.append((data_computed, padding))
+        self._features_transfer.append((data_transfer, padding))
+
+    def get_features(self):
+        if len(self._features_computed) == 0:
+            raise AssertionError("No computed features to pop from stack, something seems wrong in the model.")
+        return self._features_computed.popleft(), self._features_transfer.popleft()
+
+    # ------------------------------------------------------------------ combined dense maps
+    def store_features_full(self, data) -> None:
+        self._features_full.append(data)
+
+    def get_features_full(self):
+        if len(self._features_full) == 0:
+            raise AssertionError("No combined features to pop from stack, something seems wrong in the model.")
+        return self._features_full.popleft()
+
+    def clear(self):
+        self._features_computed.clear()
+        self._features_transfer.clear()
+        self._features_full.clear()
+        self.rings = []
+
+
+def _find_wrapper(items):
+    """First initialised TensorWrapper among (possibly nested) arguments."""
+    found = None
+    for a in items:
+        if isinstance(a, TensorWrapper):
+            if a.is_init:
+                return a
+            found = found or a
+        elif isinstance(a, (list, tuple)):
+            r = _find_wrapper(a)
+            if r is not None:
+                if r.is_init:
+                    return r
+                found = found or r
+    return found
+
+
+class TensorWrapper(torch.Tensor):
+    """torch.Tensor subclass carrying block metadata; packed tensors have shape (n_exec, C, bs, bs)."""
+
+    is_init = False
+
+    # ------------------------------------------------------------------ metadata
+    def _init_metadata(self, other=None):
+        if not self.is_init:
+            if other is None:
+                self._is_blocks = False
+                self._features = None
+                self._features_prev = None
+            else:
+                self._is_blocks = other._is_blocks
+                self._features = other._features
+                self._features_prev = other._features_prev
+            self.is_init = True
+        return self
+
+    def process_temporal_features(self, features_prev: BlockFeatures = None) -> BlockFeatures:
+        """Start a new frame: attach a fresh BlockFeatures, remember the previous frame's."""
+        self._init_metadata()
+        self._features_prev = features_prev
+        with _NoDispatch():
+            self._features = BlockFeatures(device=self.device)
+        return self._features
+
+    @property
+    def data_shape(self) -> torch.Size:
+        return self.shape
+
+    @property
+    def is_blocks(self) -> bool:
+        return self._is_blocks
+
+    @property
+    def block_size(self) -> int:
+        return self.data_shape[-1] if self.is_blocks else -1
+
+    def get_grid(self):
+        return self._features._grid
+
+    def get_grid_idx(self):
+        return self._features._grid_idx
+
+    def get_mapping_exec(self):
+        return self._features._mapping_exec
+
+    def get_features(self) -> BlockFeatures:
+        return self._features
+
+    def _plain(self) -> torch.Tensor:
+        with _NoDispatch():
+            return self.as_subclass(torch.Tensor)
+
+    @staticmethod
+    def _wrap_like(t: torch.Tensor, like: "TensorWrapper", is_blocks: bool) -> "TensorWrapper":
+        with _NoDispatch():
+            out = t.as_subclass(TensorWrapper)
+        out._init_metadata(like)
+        out._is_blocks = is_blocks
+        return out
+
+    # ------------------------------------------------------------------ dense -> packed
+    def to_blocks(self, grid: torch.Tensor, grid_host: torch.Tensor = None) -> "TensorWrapper":
+        """Pack the tiles selected by ``grid`` (bool, (N,1,GH,GW)).  ``grid_host`` is an optional CPU mirror of the
+        grid supplied by the policy; with it the frame needs no device->host synchronisation."""
+        assert not self.is_blocks
+        with _NoDispatch():
+            self._features._process_grid(grid, self._features_prev, grid_host)
+            assert grid.dim() == 4 and self.dim() == 4
+            assert self.shape[2] % grid.shape[2] == 0 and self.shape[3] % grid.shape[3] == 0
+            block_size = self.shape[2] // grid.shape[2]
+        return self._split(block_size)
+
+    def to_blocks_like(self, other: "TensorWrapper") -> "TensorWrapper":
+        """Pack with the same grid as ``other``."""
+        self._init_metadata(other)
+        self._is_blocks = False
+        with _NoDispatch():
+            block_size = self.shape[2] // self.get_grid().shape[2]
+        return self._split(block_size)
+
+    def _split(self, block_size: int) -> "TensorWrapper":
+        assert self.is_init, "need to call process_temporal_features before splitting in blocks!"
+        with timings.env("tensorwrapper/split", 10), _NoDispatch():
+            if self.is_blocks:
+                raise AttributeError("TensorWrapper: already split in blocks! Cannot split again.")
+            if self.dim() != 4:
+                raise AttributeError("TensorWrapper only supports 4D NCHW tensors!")
+            N, C, H, W = self.shape
+            if H % block_size != 0 or W % block_size != 0:
+                raise AttributeError(f"TensorWrapper: Shape ({self.shape}) not divisibile by given block size ({block_size})!")
+            grid_idx = self.get_grid_idx()
+            mapping_exec = self.get_mapping_exec()
+            block_size = W // grid_idx.shape[3]
+            n_exec = mapping_exec.numel()
+            dense = self.as_subclass(torch.Tensor)
+            if not dense.is_contiguous():
+                dense = dense.contiguous()
+            out = torch.empty((n_exec, C, block_size, block_size), dtype=dense.dtype, device=dense.device)
+            out = SplitFunction.apply(out, dense, mapping_exec, grid_idx)
+            return self._wrap_like(out, self, True)
+
+    # ------------------------------------------------------------------ packed -> dense
+    def to_tensor(self) -> torch.Tensor:
+        """Plain torch.Tensor view; packed tensors are combined (out of place) first."""
+        out = self.combine() if self.is_blocks else self
+        return out._plain()
+
+    def combine_(self) -> "TensorWrapper":
+        """In-place ``combine``: scatters into (and returns) the previous frame's dense map of this call site."""
+        return self.combine(inplace=True)
+
+    def combine(self, inplace: bool = False) -> "TensorWrapper":
+        """Packed -> dense.  Skipped tiles carry the previous frame's values (reference: :391-443)."""
+        with timings.env("tensorwrapper/combine", 4), _NoDispatch():
+            if not self.is_blocks:
+                raise AttributeError("TensorWrapper: Not split in blocks!")
+            grid_idx = self.get_grid_idx()
+            mapping_exec = self.get_mapping_exec()
+            _, C, BS, _ = self.shape
+            N, _, GH, GW = grid_idx.shape
+            out_shape = (N, C, GH * BS, GW * BS)
+            blocks = self.as_subclass(torch.Tensor)
+            if not blocks.is_contiguous():
+                blocks = blocks.contiguous()
+
+            if self._features_prev:
+                prev = self._features_prev.get_features_full()
+                assert out_shape == tuple(prev.shape), (out_shape, prev.shape)
+                if inplace:
+                    out = CombineFunction.apply(blocks, prev, grid_idx, mapping_exec)
+                elif self._features.engine == "fused":
+                    out = torch.empty(out_shape, dtype=blocks.dtype, device=blocks.device)
+                    out = CombineCopyFunction.apply(blocks, prev, out, grid_idx)
+                else:
+                    out = CombineFunction.apply(blocks, prev.clone(), grid_idx, mapping_exec)
+            else:
+                # first frame of the clip: every tile is executed
+                assert mapping_exec.numel() == grid_idx.numel()
+                out = torch.empty(out_shape, dtype=blocks.dtype, device=blocks.device)
+                out = CombineFunction.apply(blocks, out, grid_idx, mapping_exec)
+
+            self._features.store_features_full(out)
+            return self._wrap_like(out, self, False)
+
+    # ------------------------------------------------------------------ reference engine: transfer from previous frame
+    def _transfer_from_prev(self):
+        with timings.env("tensorwrapper/transfer", 10):
+            if self._features_prev is None:
+                return None
+            (prev_computed, prev_padding), (prev_transfer, _) = self._features_prev.get_features()
+            assert prev_transfer.shape[1:] == prev_computed.shape[1:]
+            _, C, H, W = prev_transfer.shape
+            transfer_idx = self._features._transfer_idx
+            out = torch.empty((transfer_idx.numel(), C, H, W), dtype=prev_transfer.dtype, device=prev_computed.device)
+            return TransferFunction.apply(out, prev_computed, prev_transfer, self._features_prev._grid_idx, transfer_idx, prev_padding)
+
+    # ------------------------------------------------------------------ op routing
+    @classmethod
+    def __torch_function__(cls, func: Callable, types: Tuple, args: Tuple = (), kwargs: Optional[Dict] = None) -> Any:
+        """Route every torch op: attribute reads and ordinary ops pass through on the packed batch; padded ops get
+        their halo from neighbours / the previous frame; batch-statistics ops are re-shaped; dense-only ops raise."""
+        if kwargs is None:
+            kwargs = {}
+        op = getattr(func, "__name__", "")
+        with _NoDispatch():
+            if op == "__get__":
+                ret = func(*args, **kwargs)
+                if not isinstance(ret, torch.Tensor):
+                    return ret   # shape / dtype / device / ... : nothing to wrap
+                self = _find_wrapper(args)
+                return cls._wrap_result(ret, self)
+
+            self = _find_wrapper(args)
+            if self is None:
+                self = _find_wrapper(tuple(kwargs.values()))
+            assert self is not None and self.is_init, "TensorWrapper used before process_temporal_features/to_blocks"
+
+            if self._is_blocks and op in OPS_SPECIAL:
+                if op in OPS["PADDED"]:
+                    ret = self._func_replace_padding(op, func, args, kwargs)
+                elif op in OPS["INTERPOLATE"]:
+                    ret = self._func_interpolate(func, args, kwargs)
+                elif op in OPS["BATCHED"]:
+                    ret = self._func_batched(func, args, kwargs)
+                elif op in OPS["CHANNELONLY"]:
+                    if kwargs.get("dim", None) != 1:
+                        print(f"Operation {op} might behave differently with TensorWrapper when dim != 1!")
+                    ret = func(*args, **kwargs)
+                elif op in OPS["INCOMPATIBLE"]:
+                    raise AttributeError(f"Operation {op} not supported for TensorWrapper!")
+                else:
+                    warnings.warn(f"Operation {op} might behave differently with TensorWrapper!")
+                    ret = func(*args, **kwargs)
+            else:
+                ret = func(*args, **kwargs)
+            return cls._wrap_result(ret, self)
+
+    @classmethod
+    def _wrap_result(cls, ret, like):
+        if isinstance(ret, torch.Tensor):
+            if not isinstance(ret, cls):
+                ret = ret.as_subclass(cls)
+            if like is not None and not ret.is_init:
+                ret._init_metadata(like)
+            return ret
+        if isinstance(ret, (tuple, list)):
+            return type(ret)(cls._wrap_result(r, like) for r in ret)
+        return ret
+
+    def _func_replace_padding(self, op, func, args, kwargs):
+        """Run a padded op on the packed batch with its zero padding replaced by a gathered halo."""
+        if BLOCKPAD_WITH_ZEROES:
+            return func(*args, **kwargs)
+        args = list(args)
+        pos = _PADDING_POS.get(op, None)
+        if "padding" in kwargs:
+            padding = kwargs["padding"]
+        elif pos is not None and len(args) > pos:
+            padding = args[pos]
+        else:
+            padding = 0
+        zeros = 0
+        if isinstance(padding, str):
+            if padding != "valid":
+                raise NotImplementedError(f"Only numeric paddings are supported, got {padding!r}")
+            padding = 0
+        elif isinstance(padding, (tuple, list)):
+            zeros = (0, 0)
+            if len(padding) == 1:
+                padding = (padding[0], padding[0])
+            if padding[0] != padding[1]:
+                raise NotImplementedError(f"Only support equal paddings, got {padding}")
+            padding = padding[0]
+        padding = int(padding)
+        if padding <= 0:
+            with timings.env("tensorwrapper/pad_func0", 11):
+                return func(*args, **kwargs)
+
+        data = args[0].as_subclass(torch.Tensor)
+        if not data.is_contiguous():
+            data = data.contiguous()
+        feats = self._features
+        grid_idx, mapping_exec = feats._grid_idx, feats._mapping_exec
+        if feats.engine == "fused":
+            ring = feats.next_ring(data)
+            with timings.env("tensorwrapper/pad", 10):
+                args[0] = pad_ring(data, ring, grid_idx, mapping_exec, padding)
+        else:
+            data_transfer = self._transfer_from_prev()
+            if data_transfer is None:
+                _, C, H, W = data.shape
+                data_transfer = torch.empty((0, C, H, W), dtype=data.dtype, device=data.device)
+            feats.store_features(data, data_transfer, padding)
+            with timings.env("tensorwrapper/pad", 10):
+                args[0] = pad(data, data_transfer, grid_idx, mapping_exec, padding)
+
+        if "padding" in kwargs:
+            kwargs = dict(kwargs, padding=zeros)
+        else:
+            args[pos] = zeros
+        with timings.env("tensorwrapper/pad_func", 11):
+            return func(*args, **kwargs)
+
+    def _func_interpolate(self, func, args, kwargs):
+        """Resampling runs per tile on the packed batch, i.e. WITHOUT halo: a tile's border pixels are
+        interpolated from the tile alone.  (The reference reaches the same arithmetic through a trilinear
+        re-expression on a (1,B,C,h,w) view, core/tensorwrapper.py:577-598 -- a cuDNN-era speed trick.)"""
+        return func(*args, **kwargs)
+
+    def _func_batched(self, func, args, kwargs):
+        """Ops with per-sample statistics (group_norm): fold the tile axis into the spatial axis so statistics
+        run over all executed tiles of the (batch-size-1) frame, as the reference does (:600-633)."""
+        args = list(args)
+        data = args[0].as_subclass(torch.Tensor)
+        B, C, H, W = data.shape
+        args[0] = data.permute(1, 0, 2, 3).reshape(1, C, B * H * W, 1)
+        out = func(*args, **kwargs)
+        return out.reshape(C, B, H, W).permute(1, 0, 2, 3).contiguous()

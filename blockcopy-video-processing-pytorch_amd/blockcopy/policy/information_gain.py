@@ -1,0 +1,111 @@
+"""Information-gain rewards for the RL policy (reference: policy/information_gain.py:22-160)."""
+from __future__ import annotations
+
+from typing import Dict
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class InformationGain(nn.Module):
+    def __init__(self, num_classes):
+        super().__init__()
+        self.num_classes = num_classes
+
+    def get_output_repr(self, policy_meta: Dict) -> torch.Tensor:
+        raise NotImplementedError
+
+    def forward(self, policy_meta: Dict) -> torch.Tensor:
+        raise NotImplementedError
+
+
+class InformationGainSemSeg(InformationGain):
+    """Per-pixel KL(prev || cur) of the quarter-scale softmaxed logits, averaged over classes (reference :22-41)."""
+
+    def __init__(self, num_classes):
+        super().__init__(num_classes)
+        self.scale_factor = 1 / 4
+
+    def get_output_repr(self, policy_meta: Dict) -> torch.Tensor:
+        out = policy_meta["outputs"]
+        assert out.size(1) == self.num_classes
+        return out
+
+    def forward(self, policy_meta: Dict) -> torch.Tensor:
+        assert policy_meta["outputs"] is not None and policy_meta["outputs_prev"] is not None
+        cur = F.log_softmax(F.interpolate(policy_meta["outputs"], scale_factor=self.scale_factor, mode="bilinear"), dim=1)
+        prev = F.log_softmax(F.interpolate(policy_meta["outputs_prev"], scale_factor=self.scale_factor, mode="bilinear"), dim=1)
+        # elementwise KL with log-space target: exp(prev) * (prev - cur)
+        return F.kl_div(input=cur, target=prev, reduction="none", log_target=True).mean(1, keepdim=True)
+
+
+def _as_int_boxes(arr: np.ndarray, div: int = 1) -> np.ndarray:
+    return (arr[:, :4] / div).astype(np.int32)
+
+
+def box_iou(a, b) -> float:
+    ax1, ay1, ax2, ay2 = a
+    bx1, by1, bx2, by2 = b
+    assert ax1 < ax2 and ay1 < ay2 and bx1 < bx2 and by1 < by2, (a, b)
+    xl, yt, xr, yb = max(ax1, bx1), max(ay1, by1), min(ax2, bx2), min(ay2, by2)
+    if xr < xl or yb < yt:
+        return 0.0
+    inter = (xr - xl) * (yb - yt)
+    return inter / float((ax2 - ax1) * (ay2 - ay1) + (bx2 - bx1) * (by2 - by1) - inter)
+
+
+def build_instance_mask(bbox_results, size, device="cpu") -> torch.Tensor:
+    """Dense score mask of the detections of image 0 (output representation fed to the policy net)."""
+    mask = torch.zeros(size, device=device)
+    for c in range(size[1]):
+        dets = bbox_results[0][c]
+        for (x1, y1, x2, y2), score in zip(_as_int_boxes(dets), dets[:, 4].tolist()):
+            mask[0, c, y1:y2, x1:x2] = torch.clamp(mask[0, 0, y1:y2, x1:x2], min=score)
+    return mask
+
+
+def build_instance_mask_iou_gain(bbox_results, bbox_results_prev, size, device="cpu", SUBSAMPLE=2) -> torch.Tensor:
+    """Detection information gain: (1 - IoU with the best-matching previous box) x score painted over both boxes;
+    unmatched previous boxes paint their own score (reference :68-108, batch size 1)."""
+    assert len(bbox_results) == 1, "only supports batch size 1"
+    mask = torch.zeros((size[0], size[1], size[2] // SUBSAMPLE, size[3] // SUBSAMPLE), device=device)
+
+    def paint(box, value):
+        x1, y1, x2, y2 = box
+        mask[0, 0, y1:y2, x1:x2] = torch.clamp(mask[0, 0, y1:y2, x1:x2], min=float(value))
+
+    for c in range(size[1]):
+        cur, prev = bbox_results[0][c], bbox_results_prev[0][c]
+        cur_boxes, prev_boxes = _as_int_boxes(cur, SUBSAMPLE), _as_int_boxes(prev, SUBSAMPLE)
+        cur_scores, prev_scores = cur[:, 4].tolist(), prev[:, 4].tolist()
+        matched = set()
+        for box, score in zip(cur_boxes, cur_scores):
+            best, best_j = 0.0, None
+            for j, pbox in enumerate(prev_boxes):
+                iou = box_iou(box, pbox)
+                if iou > best:
+                    best, best_j = iou, j
+            matched.add(best_j)
+            gain = 1.0 - best
+            paint(box, gain * score)
+            if best_j is not None:
+                paint(prev_boxes[best_j], gain * prev_scores[best_j])
+        for j, pbox in enumerate(prev_boxes):
+            if j not in matched:
+                paint(pbox, prev_scores[j])
+    if SUBSAMPLE > 1:
+        mask = F.interpolate(mask, scale_factor=SUBSAMPLE, mode="nearest")
+    return mask
+
+
+class InformationGainObjectDetection(InformationGain):
+    def get_output_repr(self, policy_meta: Dict) -> torch.Tensor:
+        N, C, H, W = policy_meta["inputs"].shape
+        return build_instance_mask(policy_meta["outputs"], (N, self.num_classes, H, W), device=policy_meta["inputs"].device)
+
+    def forward(self, policy_meta: Dict) -> torch.Tensor:
+        N, C, H, W = policy_meta["inputs"].shape
+        return build_instance_mask_iou_gain(policy_meta["outputs"], policy_meta["outputs_prev"],
+                                            (N, self.num_classes, H, W), device=policy_meta["inputs"].device)

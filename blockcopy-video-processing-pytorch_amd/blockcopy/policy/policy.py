@@ -1,0 +1,300 @@
+"""Execution policies: each frame they write ``policy_meta['grid']`` (bool, (N,1,GH,GW), on the frame's device)
+and the counters ``num_exec / num_total / perc_exec``.
+
+Contract and policy names follow the reference (policy/policy.py:14-370).  MI355X-first difference: every policy
+here decides its grid on the host (or pulls it to the host exactly once) and publishes that copy as
+``policy_meta['grid_host']``; the engine builds its index tables from it, so the block path itself never
+synchronises with the GPU (the reference syncs in ``int(grid.sum())`` :84, ``grid.cpu()`` :136 and twice more in
+``_process_grid``)."""
+from __future__ import annotations
+
+import abc
+import logging
+import random
+from abc import abstractmethod
+
+import torch
+import torch.nn.functional as F
+from torch.distributions import Bernoulli
+
+from blockcopy.policy.information_gain import InformationGain, InformationGainObjectDetection, InformationGainSemSeg
+from blockcopy.policy.net import PolicyNet, build_policy_net_from_settings
+from blockcopy.utils.profiler import timings
+
+
+def build_policy_from_settings(settings: dict):
+    """Policy object for ``settings['block_policy']`` in {all, none, random, fixed, rl_semseg, rl_objectdetection}."""
+    name = settings["block_policy"]
+    logging.info(f"> Policy: {name} with execution percentage target {settings['block_target']} and block size {settings['block_size']}")
+    quantize_number_exec = 1 / 16
+    common = dict(block_size=settings["block_size"], verbose=settings.get("block_policy_verbose", False))
+    if name == "all":
+        return PolicyAll(**common)
+    if name == "none":
+        return PolicyNone(**common)
+    if name == "random":
+        return PolicyRandom(quantize_number_exec=quantize_number_exec, **common)
+    if name == "fixed":
+        return PolicyFixed(block_target=settings["block_target"], seed=settings.get("block_seed", 0), **common)
+    if name.startswith("rl_"):
+        net = build_policy_net_from_settings(settings)
+        optimizer = build_policy_optimizer_from_settings(settings, net)
+        if name == "rl_semseg":
+            ig = InformationGainSemSeg(num_classes=settings["block_num_classes"])
+        elif name == "rl_objectdetection":
+            ig = InformationGainObjectDetection(num_classes=settings["block_num_classes"])
+        else:
+            raise AttributeError(f'Policy with name "{name}" not defined!')
+        return PolicyTrainRL(block_target=settings["block_target"], cost_momentum=settings["block_cost_momentum"],
+                             optimizer=optimizer, complexity_weight=settings["block_complexity_weight"],
+                             quantize_number_exec=quantize_number_exec, policy_net=net, information_gain=ig, **common)
+    raise NotImplementedError(f"Policy {name} not implemented")
+
+
+def build_policy_optimizer_from_settings(settings: dict, net: PolicyNet) -> torch.optim.Optimizer:
+    return torch.optim.RMSprop(net.parameters(), lr=settings["block_optim_lr"], weight_decay=settings["block_optim_wd"],
+                               centered=False, momentum=settings["block_optim_momentum"])
+
+
+class PolicyStats:
+    """Running fraction of executed tiles."""
+
+    def __init__(self):
+        self.count_images = 0
+        self.exec = 0
+        self.total = 0
+
+    def add_policy_meta(self, policy_meta: dict) -> dict:
+        grid = policy_meta["grid"]
+        host = policy_meta.get("grid_host", None)
+        # host mirror available -> count there; otherwise this is the one D->H sync of the frame
+        num_exec = int(host.sum()) if host is not None else int(grid.sum())
+        num_total = int(grid.numel())
+        policy_meta["num_exec"] = num_exec
+        policy_meta["num_total"] = num_total
+        policy_meta["perc_exec"] = float(num_exec) / num_total
+        self.count_images += grid.size(0)
+        self.exec += num_exec
+        self.total += num_total
+        return policy_meta
+
+    def get_exec_percentage(self):
+        return float(self.exec) / self.total
+
+    def __repr__(self) -> str:
+        return f"Policy stats: average exec percentage [0 - 1] : {self.get_exec_percentage():0.3f}"
+
+
+class Policy(torch.nn.Module, metaclass=abc.ABCMeta):
+    """Base class.  Subclasses implement ``forward(policy_meta) -> policy_meta``; ``optim`` is a no-op by default."""
+
+    def __init__(self, block_size, verbose=False, quantize_number_exec=0):
+        super().__init__()
+        self.block_size = block_size
+        self.net = None
+        self.optimizer = None
+        self.verbose = verbose
+        self.stats = PolicyStats()
+        self.fp16_enabled = False
+        self.quantize_number_exec = quantize_number_exec
+
+    def is_trainable(self):
+        return self.net is not None
+
+    def grid_shape(self, policy_meta):
+        N, C, H, W = policy_meta["inputs"].shape
+        assert H % self.block_size == 0, f"input height ({H}) not a multiple of block size {self.block_size}!"
+        assert W % self.block_size == 0, f"input width  ({W}) not a multiple of block size {self.block_size}!"
+        return (N, 1, H // self.block_size, W // self.block_size)
+
+    @staticmethod
+    def publish(policy_meta: dict, grid_host: torch.Tensor) -> dict:
+        """Store a host-decided bool grid as ``grid_host`` and its device copy as ``grid``."""
+        device = policy_meta["inputs"].device
+        grid_host = grid_host.to(torch.bool)
+        if device.type == "cuda":
+            pinned = torch.empty(grid_host.shape, dtype=torch.bool, pin_memory=True).copy_(grid_host)
+            policy_meta["grid"] = pinned.to(device, non_blocking=True)
+            policy_meta["grid_host"] = pinned
+        else:
+            policy_meta["grid"] = grid_host
+            policy_meta["grid_host"] = grid_host
+        return policy_meta
+
+    def quantize_number_exec_grid(self, grid: torch.Tensor) -> torch.Tensor:
+        """Round the number of executed tiles UP to a multiple of ``quantize_number_exec * total`` by switching on
+        randomly chosen skipped tiles, so the packed batch size takes few distinct values (one MIOpen solver
+        search / one captured graph per value).  Operates in place on a host bool grid (reference :124-144)."""
+        if self.quantize_number_exec > 0:
+            with timings.env("policy/quantize_number_exec", 3):
+                flat = grid.view(-1)
+                total = flat.numel()
+                idx_not_exec = torch.nonzero(~flat).squeeze(1).tolist()
+                num_exec = total - len(idx_not_exec)
+                multiple = max(1, int(total * self.quantize_number_exec))
+                num_exec_rounded = min(total, multiple * (1 + (num_exec - 1) // multiple))
+                idx = random.sample(idx_not_exec, num_exec_rounded - num_exec)
+                if idx:
+                    flat[idx] = True
+        return grid
+
+    @abstractmethod
+    def forward(self, policy_meta: dict) -> dict:
+        raise NotImplementedError
+
+    def optim(self, policy_meta, train=True, **kwargs):
+        return policy_meta
+
+
+class PolicyAll(Policy):
+    """Execute every tile."""
+
+    def forward(self, policy_meta: dict) -> dict:
+        self.publish(policy_meta, torch.ones(self.grid_shape(policy_meta), dtype=torch.bool))
+        return self.stats.add_policy_meta(policy_meta)
+
+
+class PolicyNone(Policy):
+    """Execute nothing once an ``outputs_prev`` exists (i.e. from the third frame of a clip on, as in the reference :188)."""
+
+    def forward(self, policy_meta: dict) -> dict:
+        first = policy_meta.get("outputs_prev", None) is None
+        self.publish(policy_meta, torch.full(self.grid_shape(policy_meta), bool(first), dtype=torch.bool))
+        return self.stats.add_policy_meta(policy_meta)
+
+
+class PolicyRandom(Policy):
+    """Each tile executed with probability 1/2, count rounded up to the quantisation step (reference :195-216)."""
+
+    def forward(self, policy_meta: dict) -> dict:
+        shape = self.grid_shape(policy_meta)
+        if policy_meta.get("outputs_prev", None) is None:
+            grid = torch.ones(shape, dtype=torch.bool)
+        else:
+            grid = torch.randn(shape) > 0
+        grid = self.quantize_number_exec_grid(grid)
+        self.publish(policy_meta, grid)
+        return self.stats.add_policy_meta(policy_meta)
+
+
+class PolicyFixed(Policy):
+    """Exactly ``round(block_target * total)`` tiles per frame, chosen by a seeded permutation (frame f of a clip
+    uses seed ``seed + f``); the first frame of a clip executes everything.  Reproducible stand-in for `random`
+    used by the benchmarks."""
+
+    def __init__(self, block_size, block_target, seed=0, verbose=False):
+        super().__init__(block_size, verbose)
+        self.block_target = block_target
+        self.seed = seed
+        self._frame = 0
+
+    def forward(self, policy_meta: dict) -> dict:
+        shape = self.grid_shape(policy_meta)
+        total = shape[0] * shape[2] * shape[3]
+        if policy_meta["outputs"] is None:
+            self._frame = 0
+            grid = torch.ones(shape, dtype=torch.bool)
+        else:
+            self._frame += 1
+            g = torch.Generator(device="cpu")
+            g.manual_seed(self.seed + self._frame)
+            grid = torch.zeros(total, dtype=torch.bool)
+            grid[torch.randperm(total, generator=g)[:int(round(self.block_target * total))]] = True
+            grid = grid.view(shape)
+        self.publish(policy_meta, grid)
+        return self.stats.add_policy_meta(policy_meta)
+
+
+class PolicyTrainRL(Policy, metaclass=abc.ABCMeta):
+    """REINFORCE policy trained online: reward = information gain + gamma * signed squared deviation of the running
+    execution rate from ``block_target`` (reference :219-370)."""
+
+    def __init__(self, block_size: int, block_target: float, optimizer: torch.optim.Optimizer, complexity_weight: float,
+                 policy_net: PolicyNet, information_gain: InformationGain, cost_momentum: float = 0.9,
+                 at_least_one: bool = False, quantize_number_exec: float = 0, verbose: bool = False):
+        super().__init__(block_size, verbose, quantize_number_exec)
+        assert 0 <= block_target <= 1
+        self.block_target = block_target
+        self.information_gain = information_gain
+        self.momentum = cost_momentum
+        self.running_cost = None
+        self.net = policy_net
+        self.complexity_weight_gamma = complexity_weight
+        self.optimizer = optimizer
+        self.at_least_one = at_least_one
+
+    def forward(self, policy_meta: dict):
+        shape = self.grid_shape(policy_meta)
+        if policy_meta["outputs"] is None:
+            # no temporal history: execute everything
+            self.publish(policy_meta, torch.ones(shape, dtype=torch.bool))
+        else:
+            with torch.enable_grad():
+                with timings.env("policy/net", 3):
+                    assert self.net.training
+                    grid_logits = self.net(policy_meta)
+                with timings.env("policy/sample", 3):
+                    m = Bernoulli(logits=grid_logits)
+                    sample = m.sample()
+                    # the single D->H transfer of the frame: sampled grid (+ a NaN flag for the logits)
+                    packed = torch.cat([sample.reshape(-1), torch.isnan(grid_logits).any().reshape(1).to(sample.dtype)]).cpu()
+                    assert packed[-1] == 0, "Policy net returned NaN's, maybe optimization problem?"
+                    grid_host = packed[:-1].reshape(shape) > 0
+                if self.at_least_one and not grid_host.any():
+                    grid_host[0, 0, 0, 0] = True
+                grid_host = self.quantize_number_exec_grid(grid_host)
+                self.publish(policy_meta, grid_host)
+                grid_f = policy_meta["grid"].to(grid_logits.dtype)
+                policy_meta["grid_log_probs"] = m.log_prob(grid_f)
+                policy_meta["grid_probs"] = m.probs
+        return self.stats.add_policy_meta(policy_meta)
+
+    def _get_information_gain(self, policy_meta: dict) -> torch.Tensor:
+        with timings.env("policy/information_gain", 3):
+            ig = self.information_gain(policy_meta)
+            assert ig.dim() == 4
+            return ig
+
+    def _get_reward_complexity(self, policy_meta: dict) -> float:
+        r = -float(self.running_cost - self.block_target)
+        return r * abs(r)
+
+    def optim(self, policy_meta: dict, train=True) -> dict:
+        policy_meta["output_repr"] = self.information_gain.get_output_repr(policy_meta)
+        grid = policy_meta["grid"]
+        assert grid.dim() == 4
+        block_use = policy_meta["perc_exec"]
+        if self.running_cost is None:
+            self.running_cost = block_use
+        self.running_cost = self.running_cost * self.momentum + (1 - self.momentum) * block_use
+
+        if policy_meta["outputs_prev"] is not None and train:
+            with torch.enable_grad():
+                ig = self._get_information_gain(policy_meta)
+                policy_meta["information_gain"] = ig
+                reward_complexity_weighted = self._get_reward_complexity(policy_meta) * self.complexity_weight_gamma
+                reward = ig + reward_complexity_weighted
+                assert reward.dim() == 4
+                log_probs = policy_meta["grid_log_probs"]
+                reward = F.adaptive_max_pool2d(reward, output_size=log_probs.shape[2:])
+                reward = torch.where(grid, reward, -reward)   # skipped tiles are rewarded for LOW gain
+                loss_policy = (-log_probs * reward.detach()).mean()
+                with timings.env("policy/optimizer_backward", 3):
+                    loss_policy.backward()
+                with timings.env("policy/optimizer_step", 3):
+                    self.optimizer.step()
+                    self.optimizer.zero_grad(set_to_none=True)
+                policy_meta["loss_policy"] = loss_policy.detach()
+
+                if self.verbose:
+                    assert not torch.isnan(loss_policy)
+                    probs = policy_meta["grid_probs"]
+                    exec_mean, skip_mean = probs[grid].mean(), probs[~grid].mean()
+                    print(f"BLOCKS/running_cost: {self.running_cost: 0.3f} \nBLOCKS/block_use: {block_use:0.3f} \n"
+                          f"BLOCKS/information_gain_max: {ig.max()} \nBLOCKS/information_gain_min: {ig.min()} \n"
+                          f"BLOCKS/reward_complexity_weighted: {reward_complexity_weighted} \n"
+                          f"BLOCKS/avg_prob_exec: {exec_mean:0.3f} \nBLOCKS/avg_prob_skip: {skip_mean:0.3f} \n")
+                    print(self.stats)
+                    if self.stats.count_images > 300 and exec_mean - skip_mean < 0.3:
+                        print("Warning: Block execution policy seems not well trained yet.")
+        return policy_meta

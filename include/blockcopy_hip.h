@@ -1,0 +1,126 @@
+/*
+ * blockcopy_hip.h -- C ABI of libblockcopy_hip.so, the MI355X (gfx950) implementation of the
+ * block-copy operator boundary.
+ *
+ * Plain pointers and sizes only: no torch / HIP types in any signature.  `stream` is a
+ * hipStream_t passed as void* (NULL = the default stream).  All device pointers are raw HBM
+ * addresses of contiguous NCHW tensors; `elem_size` is the payload element size in bytes
+ * (4 = float, 2 = half/bf16; 1 and 8 also accepted -- the ops are pure copies).
+ * Every function enqueues asynchronously on `stream`, never allocates or frees device memory,
+ * never synchronises, and returns BC_OK (0), a negative BC_ERR_* code for rejected arguments
+ * (the reference raises Python asserts for the same conditions, utils/cuda.py:42-48,
+ * utils/block_funcs.py:16-30,88-104,164-170, utils/blockpad.py:24-36), or a positive hipError_t.
+ *
+ * Section A mirrors, one for one, the four kernels the reference launches through CuPy
+ * (its "FFI" for this path); section B is the MI355X-first form of the same path used by the
+ * engine (fused scatter+copy, halo gather over a persistent ring cache, device-side index tables).
+ *
+ * Reference citations are relative to blockcopy/blockcopy/ in the reference tree.
+ */
+#ifndef BLOCKCOPY_HIP_H
+#define BLOCKCOPY_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BC_ABI_VERSION 1
+
+enum {
+    BC_OK = 0,
+    BC_ERR_NULL = -1,      /* required pointer is NULL */
+    BC_ERR_SHAPE = -2,     /* non-positive dim, H or W not a multiple of bs, pad < 1 or pad > bs */
+    BC_ERR_ELEM = -3,      /* elem_size not in {1,2,4,8} */
+    BC_ERR_RANGE = -4,     /* element offsets would not fit the reference's 31-bit index space */
+    BC_ERR_ALIGN = -5      /* pointer not aligned to elem_size */
+};
+
+/* ---------------------------------------------------------------------------------------------
+ * A. Reference operator boundary (drop-in for the four CuPy kernels)
+ * ------------------------------------------------------------------------------------------- */
+
+/* gather.  replaces split_kernel + SplitFunction.forward launch, utils/block_funcs.py:10-83.
+ * blocks[b,c,h,w] = image[gn,c,gh*bs+h,gw*bs+w], (gn,gh,gw) = unravel(mapping_exec[b], (N,H/bs,W/bs)).
+ * blocks: (n_exec,C,bs,bs) caller-allocated; image: (N,C,H,W); mapping_exec: int32[n_exec] on device. */
+int bc_split(void *blocks, const void *image, const int32_t *mapping_exec, int n_exec,
+             int N, int C, int H, int W, int bs, int elem_size, void *stream);
+
+/* scatter in place.  replaces combine_kernel + CombineFunction.forward, utils/block_funcs.py:85-158.
+ * out[gn,c,gh*bs+h,gw*bs+w] = blocks[b,c,h,w]; tiles not in mapping_exec keep their previous contents. */
+int bc_combine(const void *blocks, void *out, const int32_t *mapping_exec, int n_exec,
+               int N, int C, int H, int W, int bs, int elem_size, void *stream);
+
+/* border-ring transfer.  replaces transfer_kernel + TransferFunction.forward, utils/block_funcs.py:161-237.
+ * out[b] (ring of width `padding` only; interior untouched = don't-care) = transfer_idx[b] >= 0 ?
+ * prev_computed[transfer_idx[b]] : prev_transfer[transfer_idx[b] + N*GH*GW].  padding < 0 copies whole tiles. */
+int bc_transfer(void *out, const void *prev_computed, const void *prev_transfer,
+                const int32_t *transfer_idx, int n_transfer,
+                int N, int C, int GH, int GW, int bs, int padding, int elem_size, void *stream);
+
+/* halo gather.  replaces repad_kernel + BlockPadFunction.forward, utils/blockpad.py:21-156.
+ * out: (n_exec,C,bs+2*pad,bs+2*pad) caller-allocated (the reference allocates it inside, blockpad.py:45-46;
+ * the binding does that with the torch caching allocator).  Interior from features[b]; halo from the
+ * neighbouring tile: features[grid_idx[g']] if >= 0 else transfer[grid_idx[g'] + N*GH*GW]; zeros beyond
+ * the image border. */
+int bc_pad(void *out, const void *features, const void *transfer, const int32_t *grid_idx,
+           const int32_t *mapping_exec, int n_exec,
+           int N, int C, int GH, int GW, int bs, int pad, int elem_size, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * B. MI355X-first forms of the same path
+ * ------------------------------------------------------------------------------------------- */
+
+/* fused scatter + copy: ONE pass that writes the whole dense map `out` (N,C,H,W), taking each tile from
+ * `blocks` when grid_idx[tile] >= 0 and from `prev` (previous frame's dense map, same shape) otherwise.
+ * Equals prev.clone() followed by bc_combine (core/tensorwrapper.py:421-433) in one kernel and with
+ * 2*N*C*H*W*elem_size bytes of traffic instead of 2x that plus the executed tiles.  out must not alias
+ * prev.  prev may be NULL only if every tile is executed. */
+int bc_combine_copy(const void *blocks, const void *prev, void *out, const int32_t *grid_idx,
+                    int N, int C, int H, int W, int bs, int elem_size, void *stream);
+
+/* halo gather over a persistent ring cache.  `ring` is a (N*GH*GW, C, bs, bs) device buffer owned by the
+ * caller and kept across frames for one padded layer; only its border ring of width `pad` is ever read or
+ * written.  Same output as bc_transfer + bc_pad of the reference decomposition, but non-executed
+ * neighbours are read from ring[g'] (indexed by grid position, no per-frame compaction) and every executed
+ * tile refreshes ring[g] with its own border in the same launch -- the transfer kernel and its tensors
+ * disappear. */
+int bc_pad_ring(void *out, const void *features, void *ring, const int32_t *grid_idx,
+                const int32_t *mapping_exec, int n_exec,
+                int N, int C, int GH, int GW, int bs, int pad, int elem_size, void *stream);
+
+/* index tables on device.  replaces get_grid_mappings (core/tensorwrapper.py:108-128) and the
+ * prev_grid_idx[~grid] lookup (:176-178), which the reference runs on the CPU behind two D->H syncs.
+ * grid: uint8/bool[n_total] on device.  Writes grid_idx int32[n_total], mapping_exec int32[<= n_total],
+ * counts[0] = n_exec, counts[1] = n_transfer; if prev_grid_idx != NULL also transfer_idx int32[<= n_total].
+ * One workgroup; no host synchronisation. */
+int bc_grid_tables(const uint8_t *grid, int n_total, int32_t *grid_idx, int32_t *mapping_exec,
+                   const int32_t *prev_grid_idx, int32_t *transfer_idx, int32_t *counts, void *stream);
+
+/* the same tables on the host (for policies whose grid is already host-resident).  Returns n_exec. */
+int bc_grid_tables_host(const uint8_t *grid, int n_total, int32_t *grid_idx, int32_t *mapping_exec,
+                        const int32_t *prev_grid_idx, int32_t *transfer_idx);
+
+/* ---------------------------------------------------------------------------------------------
+ * C. Introspection / measurement
+ * ------------------------------------------------------------------------------------------- */
+
+enum { BC_OP_SPLIT = 0, BC_OP_COMBINE = 1, BC_OP_TRANSFER = 2, BC_OP_PAD = 3,
+       BC_OP_COMBINE_COPY = 4, BC_OP_PAD_RING = 5, BC_OP_GRID_TABLES = 6, BC_OP_COUNT = 7 };
+
+int bc_abi_version(void);
+const char *bc_error_string(int code);
+const char *bc_op_name(int op);
+
+/* Per-op device timing with hipEvent pairs recorded on the launch stream around each kernel of the
+ * selected ops (bit i of op_mask = op i).  bc_prof_read synchronises the recorded events and returns the
+ * number of launches, their summed device time (ms) and summed algorithmic bytes since the last reset. */
+int bc_prof_enable(unsigned op_mask);
+int bc_prof_reset(void);
+int bc_prof_read(int op, long long *launches, double *total_ms, double *total_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BLOCKCOPY_HIP_H */

@@ -232,9 +232,22 @@ def check_properties(ref):
     print("properties:", props)
 
 
+def gen_keys(ref):
+    """Parameter names/shapes of the reference SwiftNet (pins state_dict compatibility of bc_workloads.swiftnet)."""
+    out = {}
+    for bb in ("resnet18", "resnet50"):
+        with quiet():
+            m = ref.swiftnet.SwiftNet(backbone=getattr(ref.resnet, bb)(pretrained=False), num_classes=19, num_features=128, use_spp=True)
+        out[bb] = {k: list(v.shape) for k, v in m.state_dict().items()}
+    with open(os.path.join(GOLD, "swiftnet_keys.json"), "w") as f:
+        json.dump(out, f)
+    print("swiftnet_keys.json", {k: len(v) for k, v in out.items()})
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     ref = ref_loader.load_reference()
+    gen_keys(ref)
     gen_index_tables(ref)
     gen_ops(ref)
     check_properties(ref)

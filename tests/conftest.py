@@ -1,0 +1,44 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "blockcopy-video-processing-pytorch_amd")
+for p in (PKG, os.path.join(ROOT, "oracle"), os.path.dirname(os.path.abspath(__file__)), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built_library():
+    """The C-ABI library must exist for every test tier (hipcc cross-compiles without a GPU)."""
+    import build as bc_build  # blockcopy-video-processing-pytorch_amd/build.py
+
+    bc_build.build_hip_library()
+    import oracle
+
+    oracle.build()
+    yield
+
+
+@pytest.fixture()
+def oracle_backend():
+    """Inject the CPU-oracle checker backend for host-logic tests; restored afterwards."""
+    import blockcopy.backend as bk
+    from oracle_backend import OracleBackend
+
+    prev = bk.set_backend(OracleBackend())
+    yield
+    bk.set_backend(prev)

@@ -1,0 +1,66 @@
+"""Checker backend for CPU tests: the block-op interface of ``blockcopy.backend.HipBackend`` implemented with the
+CPU oracle (oracle/oracle.py).  TEST INFRASTRUCTURE ONLY -- lets the host logic (state machine, op routing, index
+tables, ring-cache bookkeeping) be exercised against the golden fixtures on a machine without a GPU.  The fused ops
+are expressed through the oracle's reference decomposition, which is exactly the equivalence the GPU tests assert
+for the HIP kernels."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+import oracle as O
+
+
+class OracleBackend:
+    name = "oracle-cpu"
+
+    def split(self, blocks, image, mapping_exec, grid_idx):
+        if mapping_exec.numel():
+            O.c_split(blocks, image.contiguous(), mapping_exec)
+        return blocks
+
+    def combine(self, blocks, out, grid_idx, mapping_exec):
+        if mapping_exec.numel():
+            O.c_combine(blocks.contiguous(), out, mapping_exec)
+        return out
+
+    def transfer(self, out, prev_computed, prev_transfer, prev_grid_idx, transfer_idx, padding):
+        out.fill_(float("nan"))   # make the don't-care interior loud
+        if transfer_idx.numel():
+            O.c_transfer(out, prev_computed.contiguous(), prev_transfer.contiguous(), tuple(prev_grid_idx.shape), transfer_idx, padding)
+        return out
+
+    def pad(self, data_exec, data_transfer, grid_idx, mapping_exec, pad):
+        B, C, bs, _ = data_exec.shape
+        out = torch.empty((B, C, bs + 2 * pad, bs + 2 * pad), dtype=data_exec.dtype)
+        if mapping_exec.numel():
+            O.c_repad(out, data_exec.contiguous(), data_transfer.contiguous(), grid_idx, mapping_exec, pad)
+        return out
+
+    def combine_copy(self, blocks, prev, out, grid_idx):
+        out.copy_(prev)   # clone + scatter == the reference's non-in-place combine
+        mapping = torch.nonzero(grid_idx.reshape(-1) >= 0).squeeze(1).to(torch.int32)
+        if mapping.numel():
+            O.c_combine(blocks.contiguous(), out, mapping)
+        return out
+
+    def pad_ring(self, data_exec, ring, grid_idx, mapping_exec, pad):
+        gi = grid_idx.reshape(-1)
+        skipped = torch.nonzero(gi < 0).squeeze(1)
+        transfer = ring[skipped].contiguous()   # compacted in raster order == row (grid_idx + n_total)
+        out = self.pad(data_exec, transfer, grid_idx, mapping_exec, pad)
+        bs = data_exec.shape[2]
+        m = torch.from_numpy(O.ring_mask(bs, pad))
+        sel = ring[mapping_exec.long()]
+        sel[:, :, m] = data_exec[:, :, m]
+        ring[mapping_exec.long()] = sel
+        return out
+
+    def grid_tables_host(self, grid_u8, grid_idx, mapping, prev_grid_idx=None, transfer=None):
+        gi, m = O.c_grid_mappings(grid_u8.astype(bool).reshape(1, 1, 1, -1))
+        grid_idx[:] = gi.reshape(-1)
+        mapping[:len(m)] = m
+        if prev_grid_idx is not None:
+            t = O.c_transfer_idx(prev_grid_idx, grid_u8.astype(bool))
+            transfer[:len(t)] = t
+        return len(m)

@@ -1,0 +1,234 @@
+"""GPU parity tests proper: every entry point of the C ABI (through the ctypes binding) against the CPU oracle on the
+same seeded inputs, bit-exact (the ops are pure copies).  Run with -m gpu on a real MI355X."""
+import itertools
+
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.float16]
+# (N, C, GH, GW, bs, pad)
+CASES = [
+    (1, 3, 2, 4, 8, 1),      # small, pow2
+    (2, 5, 3, 3, 4, 2),      # batch 2, odd C, pad == bs/2
+    (1, 4, 4, 4, 2, 1),      # tiny tiles (C4 layer4 regime), pad == bs/2
+    (1, 7, 3, 5, 1, 1),      # 1x1 tiles, pad == bs
+    (2, 2, 2, 3, 6, 3),      # non power-of-two tile, pad 3
+    (1, 3, 1, 1, 16, 3),     # single tile: everything beyond the border
+    (1, 3, 1, 6, 12, 1),     # one row of tiles
+    (1, 64, 4, 8, 32, 1),    # SwiftNet layer1-like
+    (1, 19, 8, 16, 32, 1),   # C2 logits geometry (256x512 map)
+    (1, 3, 2, 3, 128, 3),    # network-input geometry (conv1 k7 p3)
+]
+
+
+def _dev(x):
+    return (torch.from_numpy(x) if isinstance(x, np.ndarray) else x).cuda()
+
+
+def _grids(N, GH, GW, n_frames, seed):
+    rng = np.random.default_rng(seed)
+    total = N * GH * GW
+    out = [np.ones((N, 1, GH, GW), bool)]
+    for t in range(1, n_frames):
+        kind = t % 4
+        g = np.zeros(total, bool)
+        if kind == 1:
+            g = rng.random(total) < 0.5
+        elif kind == 2:
+            g[rng.integers(total)] = True
+        elif kind == 3:
+            g[:] = True
+            g[rng.integers(total)] = False
+        else:
+            g = rng.random(total) < 0.25
+        if not g.any():
+            g[0] = True
+        out.append(g.reshape(N, 1, GH, GW))
+    return out
+
+
+@pytest.fixture(scope="module")
+def be():
+    import blockcopy.backend as bk
+
+    bk.set_backend(None)
+    b = bk.get_backend()
+    assert b.name == "hip"
+    return b
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CASES)
+def test_split_combine_combine_copy(be, case, dtype):
+    N, C, GH, GW, bs, _ = case
+    H, W = GH * bs, GW * bs
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    for grid in _grids(N, GH, GW, 5, 7):
+        gi, m = O.c_grid_mappings(grid)
+        image = torch.randn((N, C, H, W), generator=g).to(dtype)
+        want = torch.empty((len(m), C, bs, bs), dtype=dtype)
+        O.c_split(want, image, m)
+        got = torch.full((len(m), C, bs, bs), -7.0, dtype=dtype).cuda()
+        be.split(got, _dev(image), _dev(m), _dev(gi))
+        assert torch.equal(got.cpu(), want)
+
+        blocks = torch.randn((len(m), C, bs, bs), generator=g).to(dtype)
+        prev = torch.randn((N, C, H, W), generator=g).to(dtype)
+        want_out = prev.clone()
+        O.c_combine(blocks, want_out, m)
+        got_out = _dev(prev.clone())
+        be.combine(_dev(blocks), got_out, _dev(gi), _dev(m))
+        assert torch.equal(got_out.cpu(), want_out)
+
+        fused = torch.full((N, C, H, W), 5.0, dtype=dtype).cuda()
+        be.combine_copy(_dev(blocks), _dev(prev), fused, _dev(gi))
+        assert torch.equal(fused.cpu(), want_out)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CASES)
+def test_transfer_pad_and_ring_chain(be, case, dtype):
+    """Multi-frame chain: reference decomposition (transfer -> pad) and the ring-cache form must both equal the oracle."""
+    N, C, GH, GW, bs, p = case
+    g = torch.Generator().manual_seed(1 + hash(case) % 1000)
+    n_total = N * GH * GW
+    ring = torch.full((n_total, C, bs, bs), float("nan"), dtype=dtype).cuda()
+    mask = torch.from_numpy(O.ring_mask(bs, p))
+    prev = None
+    for grid in _grids(N, GH, GW, 7, 11):
+        gi, m = O.c_grid_mappings(grid)
+        feats = torch.randn((len(m), C, bs, bs), generator=g).to(dtype)
+        if prev is None:
+            tr_want = torch.empty((0, C, bs, bs), dtype=dtype)
+            tr_got = tr_want.cuda()
+        else:
+            pf, ptr_want, ptr_got, pgi = prev
+            tidx = O.c_transfer_idx(pgi, grid)
+            tr_want = torch.zeros((len(tidx), C, bs, bs), dtype=dtype)
+            O.c_transfer(tr_want, pf, ptr_want, grid.shape, tidx, p)
+            tr_got = torch.zeros((len(tidx), C, bs, bs), dtype=dtype).cuda()
+            be.transfer(tr_got, _dev(pf), ptr_got, _dev(pgi), _dev(tidx), p)
+            # only the border ring is defined (interior = don't care, reference block_funcs.py:218-224)
+            assert torch.equal(tr_got.cpu()[:, :, mask], tr_want[:, :, mask])
+        want = torch.empty((len(m), C, bs + 2 * p, bs + 2 * p), dtype=dtype)
+        O.c_repad(want, feats, tr_want, gi, m, p)
+        got = be.pad(_dev(feats), tr_got, _dev(gi), _dev(m), p)
+        assert torch.equal(got.cpu(), want)
+        got_ring = be.pad_ring(_dev(feats), ring, _dev(gi), _dev(m), p)
+        assert torch.equal(got_ring.cpu(), want)
+        prev = (feats, tr_want, tr_got, gi)
+
+
+def test_other_element_sizes(be):
+    """1- and 8-byte payloads go through the same kernels."""
+    N, C, GH, GW, bs, p = 1, 3, 2, 3, 4, 1
+    grid = _grids(N, GH, GW, 2, 3)[1]
+    gi, m = O.c_grid_mappings(grid)
+    for dtype in (torch.uint8, torch.float64):
+        image = (torch.rand((N, C, GH * bs, GW * bs)) * 200).to(dtype)
+        want = torch.empty((len(m), C, bs, bs), dtype=dtype)
+        O.c_split(want, image, m)
+        got = torch.zeros_like(want).cuda()
+        be.split(got, _dev(image), _dev(m), _dev(gi))
+        assert torch.equal(got.cpu(), want)
+        tr = (torch.rand((grid.size - len(m), C, bs, bs)) * 200).to(dtype)
+        wp = torch.empty((len(m), C, bs + 2 * p, bs + 2 * p), dtype=dtype)
+        O.c_repad(wp, want, tr, gi, m, p)
+        assert torch.equal(be.pad(got, _dev(tr), _dev(gi), _dev(m), p).cpu(), wp)
+
+
+def test_misaligned_views_fall_back_to_narrow_vectors(be):
+    """A storage offset of one element breaks 16-byte alignment; results must not change."""
+    N, C, GH, GW, bs = 1, 3, 2, 2, 8
+    grid = _grids(N, GH, GW, 2, 5)[1]
+    gi, m = O.c_grid_mappings(grid)
+    image = torch.randn((N, C, GH * bs, GW * bs))
+    want = torch.empty((len(m), C, bs, bs))
+    O.c_split(want, image, m)
+    buf = torch.zeros(image.numel() + 1).cuda()
+    img_dev = buf[1:].view(image.shape)
+    img_dev.copy_(image)
+    assert img_dev.data_ptr() % 16 != 0 and img_dev.is_contiguous()
+    got = torch.zeros_like(want).cuda()
+    be.split(got, img_dev, _dev(m), _dev(gi))
+    assert torch.equal(got.cpu(), want)
+    out_buf = torch.zeros(image.numel() + 1).cuda()
+    out_dev = out_buf[1:].view(image.shape)
+    be.combine_copy(got, img_dev, out_dev, _dev(gi))
+    assert torch.equal(out_dev.cpu(), image)
+
+
+def test_grid_tables_device(be, golden_dir):
+    import json
+    import os
+
+    G = np.load(os.path.join(golden_dir, "index_tables.npz"))
+    for c in json.loads(bytes(G["meta"]).decode()):
+        prev = None
+        for f in range(c["frames"]):
+            k = f"c{c['case']}_f{f}"
+            grid = torch.from_numpy(G[k + "_grid"]).cuda()
+            gi, mp, tr, counts = be.grid_tables_device(grid, prev)
+            n_exec, n_tr = counts.cpu().tolist()
+            assert np.array_equal(gi.cpu().numpy(), G[k + "_grid_idx"])
+            assert np.array_equal(mp[:n_exec].cpu().numpy(), G[k + "_mapping_exec"])
+            assert n_exec + n_tr == grid.numel()
+            if prev is not None:
+                assert np.array_equal(tr[:n_tr].cpu().numpy(), G[k + "_transfer_idx"])
+            prev = gi
+
+
+def test_empty_and_error_paths(be):
+    z = torch.zeros((0, 3, 4, 4)).cuda()
+    img = torch.zeros((1, 3, 8, 8)).cuda()
+    gi = torch.zeros((1, 1, 2, 2), dtype=torch.int32).cuda()
+    m0 = torch.zeros(0, dtype=torch.int32).cuda()
+    assert be.split(z, img, m0, gi) is z            # n_exec == 0: no launch
+    assert be.combine(z, img, gi, m0) is img
+    lib = be.lib
+    assert lib.bc_split(None, None, None, 1, 1, 3, 8, 8, 4, 4, None) == -1      # BC_ERR_NULL
+    assert lib.bc_split(None, None, None, 1, 1, 3, 8, 9, 4, 4, None) == -2      # W not a multiple of bs
+    assert lib.bc_split(None, None, None, 1, 1, 3, 8, 8, 4, 3, None) == -3      # elem size
+    assert lib.bc_pad(None, None, None, None, None, 1, 1, 3, 2, 2, 4, 0, 4, None) == -2   # pad < 1
+    assert lib.bc_pad(None, None, None, None, None, 1, 1, 3, 2, 2, 4, 5, 4, None) == -2   # pad > bs
+    with pytest.raises(AssertionError):
+        be.split(torch.zeros((1, 3, 4, 4)), img, m0, gi)   # CPU tensor: no CPU path
+
+
+def test_large_c2_shapes_roundtrip(be):
+    """BASELINE config C2 sizes: size-independent properties instead of the (slow) oracle.
+    split -> combine_copy over an all-skipped/all-executed mix reproduces the image; halo interior equals the tile."""
+    N, C, GH, GW, bs = 1, 19, 8, 16, 32
+    H, W = GH * bs, GW * bs
+    grid = torch.zeros(N * GH * GW, dtype=torch.bool)
+    grid[torch.randperm(N * GH * GW, generator=torch.Generator().manual_seed(0))[:64]] = True
+    gi, m = O.c_grid_mappings(grid.view(N, 1, GH, GW).numpy())
+    image = torch.randn((N, C, H, W), generator=torch.Generator().manual_seed(1)).cuda()
+    prev = torch.randn((N, C, H, W), generator=torch.Generator().manual_seed(2)).cuda()
+    blocks = torch.empty((64, C, bs, bs)).cuda()
+    be.split(blocks, image, _dev(m), _dev(gi))
+    out = torch.empty_like(image)
+    be.combine_copy(blocks, prev, out, _dev(gi))
+    sel = grid.view(1, 1, GH, GW).repeat_interleave(bs, 2).repeat_interleave(bs, 3).cuda()
+    assert torch.equal(out, torch.where(sel, image, prev))
+    # idempotence: combining the tiles split from `out` back into `out` changes nothing
+    blocks2 = torch.empty_like(blocks)
+    be.split(blocks2, out, _dev(m), _dev(gi))
+    out2 = out.clone()
+    be.combine(blocks2, out2, _dev(gi), _dev(m))
+    assert torch.equal(out2, out)
+    # all-executed halo gather == zero-padded unfold of the dense map
+    gi1, m1 = O.c_grid_mappings(np.ones((N, 1, GH, GW), bool))
+    allb = torch.empty((GH * GW, C, bs, bs)).cuda()
+    be.split(allb, image, _dev(m1), _dev(gi1))
+    ring = torch.empty((GH * GW, C, bs, bs)).cuda()
+    padded = be.pad_ring(allb, ring, _dev(gi1), _dev(m1), 1)
+    dense = torch.nn.functional.pad(image, (1, 1, 1, 1))
+    want = dense.unfold(2, bs + 2, bs).unfold(3, bs + 2, bs)           # N,C,GH,GW,bs+2,bs+2
+    want = want.permute(0, 2, 3, 1, 4, 5).reshape(GH * GW, C, bs + 2, bs + 2)
+    assert torch.equal(padded, want)

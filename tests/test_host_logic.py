@@ -1,0 +1,241 @@
+"""CPU tests of the host side of the engine (state machine, op routing, index tables, ring-cache bookkeeping, policies)
+against the golden fixtures produced by the REFERENCE Python.  The block ops are served by the injected oracle
+backend (tests/oracle_backend.py); the product itself has no CPU path (see test_no_cpu_fallback)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from common import load_golden, make_forced_policy, run_golden_clip
+
+
+class TinyNet(torch.nn.Module):
+    """Same tiny conv/pool net as oracle/gen_golden.py::TinyNet (pads 1 and 2, tiles 8 -> 4 -> 2)."""
+
+    def __init__(self):
+        super().__init__()
+        self.c1 = torch.nn.Conv2d(3, 4, 3, padding=1)
+        self.c2 = torch.nn.Conv2d(4, 5, 5, padding=2)
+        self.c3 = torch.nn.Conv2d(5, 6, 3, stride=2, padding=1)
+
+    def forward(self, x):
+        x = torch.relu(self.c1(x))
+        x = torch.nn.functional.max_pool2d(x, 3, 2, 1)
+        x = torch.relu(self.c2(x))
+        return self.c3(x)
+
+
+def tiny_grids():
+    from bc_workloads import seeded
+
+    N, GH, GW = 2, 2, 3
+    gs = [torch.ones(N, 1, GH, GW, dtype=torch.bool)]
+    for s, n in ((11, 6), (12, 3), (13, 1), (14, 11)):
+        gs.append(seeded.fixed_fraction_grid(s, N, GH, GW, n))
+    return gs
+
+
+def test_index_tables_match_reference(golden_dir, oracle_backend):
+    """BlockFeatures._process_grid vs the reference's get_grid_mappings / transfer_idx (core/tensorwrapper.py:108-178)."""
+    from blockcopy.core.tensorwrapper import BlockFeatures
+
+    G = np.load(os.path.join(golden_dir, "index_tables.npz"))
+    for c in json.loads(bytes(G["meta"]).decode()):
+        prev = None
+        for f in range(c["frames"]):
+            k = f"c{c['case']}_f{f}"
+            grid = torch.from_numpy(G[k + "_grid"])
+            bf = BlockFeatures("cpu", engine="reference")
+            bf._process_grid(grid, prev, grid)
+            assert np.array_equal(bf._grid_idx.numpy(), G[k + "_grid_idx"])
+            assert np.array_equal(bf._mapping_exec.numpy(), G[k + "_mapping_exec"])
+            if prev is not None:
+                assert np.array_equal(bf._transfer_idx.numpy(), G[k + "_transfer_idx"])
+            prev = bf
+
+
+def test_product_grid_tables_host_matches_reference(golden_dir):
+    """The library's host-side table builder (bc_grid_tables_host) against the same fixtures -- no GPU needed."""
+    import blockcopy.backend as bk
+
+    lib_backend = bk.HipBackend()
+    G = np.load(os.path.join(golden_dir, "index_tables.npz"))
+    for c in json.loads(bytes(G["meta"]).decode()):
+        prev = None
+        for f in range(c["frames"]):
+            k = f"c{c['case']}_f{f}"
+            g8 = G[k + "_grid"].astype(np.uint8).reshape(-1)
+            n = g8.size
+            gi, mp, tr = np.empty(n, np.int32), np.empty(n, np.int32), np.empty(n, np.int32)
+            n_exec = lib_backend.grid_tables_host(g8, gi, mp, prev, tr if prev is not None else None)
+            assert np.array_equal(gi.reshape(G[k + "_grid_idx"].shape), G[k + "_grid_idx"])
+            assert np.array_equal(mp[:n_exec], G[k + "_mapping_exec"])
+            if prev is not None:
+                assert np.array_equal(tr[:n - n_exec], G[k + "_transfer_idx"])
+            prev = gi
+
+
+@pytest.mark.parametrize("engine", ["fused", "reference"])
+def test_tinynet_matches_reference(golden_dir, oracle_backend, engine):
+    import blockcopy
+    from blockcopy.core import tensorwrapper as tw
+    from blockcopy.core.argparser import default_settings
+    from bc_workloads import seeded
+
+    G = np.load(os.path.join(golden_dir, "ops_tinynet.npz"))
+    tw.set_engine(engine)
+    try:
+        net = TinyNet()
+        net.load_state_dict(seeded.name_seeded_state_dict(net.state_dict()))
+        model = blockcopy.BlockCopyModel(net.eval(), default_settings(block_policy="all", block_size=8))
+        grids = tiny_grids()
+        model.policy = make_forced_policy(8, grids)
+        model.reset_temporal()
+        with torch.no_grad():
+            for t in range(len(grids)):
+                y = model(seeded.synthetic_frame(100 + t, (2, 3, 16, 24)))
+                assert torch.equal(y, torch.from_numpy(G[f"net_out{t}"])), (engine, t)
+    finally:
+        tw.set_engine("fused")
+
+
+@pytest.mark.parametrize("engine", ["fused", "reference"])
+@pytest.mark.parametrize("name", ["swiftnet_rn18_a.npz", "swiftnet_rn18_n2.npz", "swiftnet_rn50_a.npz"])
+def test_swiftnet_matches_reference_on_cpu(golden_dir, oracle_backend, name, engine):
+    """Whole SwiftNet clip through OUR BlockCopyModel/TensorWrapper/SwiftNet/BN-fold vs the reference's logits.
+    Includes an all-skipped frame (num_exec == 0 returns the cached output) and single-tile / all-but-one masks."""
+    from blockcopy.core import tensorwrapper as tw
+
+    G, cfg = load_golden(golden_dir, name)
+    try:
+        errs, fs_errs = run_golden_clip(G, cfg, "cpu", engine)
+    finally:
+        tw.set_engine("fused")
+    assert max(errs) <= 2e-5, errs          # same oneDNN convs; tiny differences from bilinear vs trilinear and fold order
+    assert all(e == 0.0 for e in fs_errs)   # frame_state: pure copies
+
+
+def test_state_dict_keys_match_reference(golden_dir):
+    """Our SwiftNet restatement exposes exactly the reference's parameter names and shapes."""
+    from bc_workloads.swiftnet import build_swiftnet
+
+    with open(os.path.join(golden_dir, "swiftnet_keys.json")) as f:
+        want = json.load(f)
+    for backbone in ("resnet18", "resnet50"):
+        sd = build_swiftnet(backbone).state_dict()
+        got = {k: list(v.shape) for k, v in sd.items()}
+        assert got == want[backbone]
+        assert list(got) == list(want[backbone])   # same order too
+
+
+def test_num_exec_zero_returns_cached_output_object(oracle_backend):
+    import blockcopy
+    from blockcopy.core.argparser import default_settings
+
+    net = TinyNet().eval()
+    model = blockcopy.BlockCopyModel(net, default_settings(block_policy="none", block_size=8))
+    x = torch.randn(1, 3, 16, 16)
+    with torch.no_grad():
+        y0 = model(x)
+        y1 = model(x)   # PolicyNone still executes frame 2 (outputs_prev is None until then, reference policy.py:188)
+        y2 = model(x)
+    assert model.policy_meta["num_exec"] == 0
+    assert y2 is y1 and y1 is not y0
+
+
+def test_first_frame_must_execute_everything(oracle_backend):
+    import blockcopy
+
+    x = blockcopy.to_tensorwrapper(torch.randn(1, 3, 16, 16))
+    x.process_temporal_features(None)
+    grid = torch.zeros(1, 1, 2, 2, dtype=torch.bool)
+    grid[0, 0, 0, 0] = True
+    with pytest.raises(AssertionError, match="first run should execute all blocks"):
+        x.to_blocks(grid, grid)
+
+
+def test_routing_errors_and_flags(oracle_backend):
+    import blockcopy
+
+    x = blockcopy.to_tensorwrapper(torch.randn(1, 4, 16, 16))
+    x.process_temporal_features(None)
+    grid = torch.ones(1, 1, 2, 2, dtype=torch.bool)
+    b = x.to_blocks(grid, grid)
+    assert blockcopy.is_block(b) and blockcopy.is_tensorwrapper(b) and b.block_size == 8 and b.shape == (4, 4, 8, 8)
+    assert not blockcopy.is_block(x) and x.block_size == -1
+    with pytest.raises(AttributeError, match="not supported"):
+        torch.nn.functional.adaptive_avg_pool2d(b, 1)
+    with pytest.raises(AttributeError, match="not supported"):
+        b.view(-1)
+    with pytest.raises(NotImplementedError, match="equal paddings"):
+        torch.nn.functional.conv2d(b, torch.randn(4, 4, 3, 3), None, 1, (1, 2))
+    with pytest.raises(AttributeError, match="already split"):
+        b._split(8)
+    with pytest.raises(AttributeError, match="Not split"):
+        x.combine()
+    y = torch.relu(b) + 1
+    assert blockcopy.is_block(y) and y.get_grid_idx() is b.get_grid_idx()
+    d = blockcopy.to_tensor({"a": [y], "b": (y, 3)})
+    assert type(d["a"][0]) is torch.Tensor and d["a"][0].shape == (1, 4, 16, 16) and d["b"][1] == 3
+    # group_norm statistics run over all executed tiles of the frame
+    gn = torch.nn.functional.group_norm(b, 2)
+    dense_gn = torch.nn.functional.group_norm(b.combine().to_tensor(), 2)
+    assert torch.allclose(blockcopy.to_tensor(gn), dense_gn, atol=1e-5)
+
+
+def test_op_order_divergence_is_detected(oracle_backend):
+    import blockcopy
+
+    def frame(channels):
+        x = blockcopy.to_tensorwrapper(torch.randn(1, channels, 16, 16))
+        return x
+
+    x = frame(4)
+    feats = x.process_temporal_features(None)
+    grid = torch.ones(1, 1, 2, 2, dtype=torch.bool)
+    torch.nn.functional.conv2d(x.to_blocks(grid, grid), torch.randn(4, 4, 3, 3), padding=1)
+    x2 = frame(5)
+    x2.process_temporal_features(feats)
+    with pytest.raises(AssertionError, match="same op sequence"):
+        torch.nn.functional.conv2d(x2.to_blocks(grid, grid), torch.randn(5, 5, 3, 3), padding=1)
+
+
+def test_policies(oracle_backend):
+    import random
+
+    from blockcopy.core.argparser import default_settings
+    from blockcopy.policy.policy import build_policy_from_settings
+
+    x = torch.randn(1, 3, 64, 128)
+    meta = {"inputs": x, "outputs": None, "outputs_prev": None}
+    pol = build_policy_from_settings(default_settings(block_policy="fixed", block_size=16, block_target=0.5))
+    m = pol(dict(meta))
+    assert m["num_exec"] == m["num_total"] == 32 and m["grid"].dtype == torch.bool and m["grid"].shape == (1, 1, 4, 8)
+    m2 = pol(dict(meta, outputs=torch.zeros(1)))
+    assert m2["num_exec"] == 16 and torch.equal(m2["grid"], m2["grid_host"])
+    random.seed(0)
+    torch.manual_seed(0)
+    pol = build_policy_from_settings(default_settings(block_policy="random", block_size=16))
+    m3 = pol(dict(meta, outputs=torch.zeros(1), outputs_prev=torch.zeros(1)))
+    assert m3["num_exec"] % 2 == 0 and 0 < m3["num_exec"] <= 32   # quantised to total/16 = 2
+    assert abs(pol.stats.get_exec_percentage() - m3["perc_exec"]) < 1e-9
+    with pytest.raises(AssertionError, match="not a multiple of block size"):
+        pol(dict(meta, inputs=torch.randn(1, 3, 60, 128)))
+
+
+def test_no_cpu_fallback():
+    """Without an injected checker the package's only backend is the HIP library, which refuses CPU tensors."""
+    import blockcopy.backend as bk
+
+    prev = bk.set_backend(None)
+    try:
+        be = bk.get_backend()
+        assert be.name == "hip"
+        with pytest.raises(AssertionError, match="GPU"):
+            be.split(torch.zeros(1, 3, 4, 4), torch.zeros(1, 3, 8, 8), torch.zeros(1, dtype=torch.int32), torch.zeros(1, 1, 2, 2, dtype=torch.int32))
+        with pytest.raises(bk.BlockCopyBackendError, match="no fallback"):
+            bk.load_library("/nonexistent/libblockcopy_hip.so")
+    finally:
+        bk.set_backend(prev)
