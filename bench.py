@@ -153,6 +153,13 @@ def main():
             if r["launches"]:
                 extra[op] = {"launches_per_frame": r["launches"] / CLIP_LEN, "avg_us": 1e3 * r["total_ms"] / r["launches"],
                              "GBps": r["total_bytes"] / (r["total_ms"] * 1e-3) / 1e9, "MB_per_frame": r["total_bytes"] / CLIP_LEN / 1e6}
+        # host-side enqueue cost of one clip (no sync inside): tells whether the frame is CPU- or GPU-bound
+        torch.cuda.synchronize(device)
+        th = time.perf_counter()
+        harness.run_clip(model, clips[0])
+        host_s = time.perf_counter() - th
+        torch.cuda.synchronize(device)
+        extra["host_enqueue_ms_per_frame"] = 1e3 * host_s / CLIP_LEN
         if not args.no_dense and world == 1:
             dense = harness.build_model(args.backbone, block_policy="static", device=device, dtype=dtype)
             dfps, _, _ = harness.measure_fps(dense, clips[:1], n_clips=max(1, min(args.steps, 3)), warmup_clips=1, device=device)

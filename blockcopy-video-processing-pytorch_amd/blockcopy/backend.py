@@ -19,8 +19,9 @@ import torch
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("BLOCKCOPY_HIP_LIB", os.path.join(_PKG_ROOT, "lib", "libblockcopy_hip.so"))
 
-OP_SPLIT, OP_COMBINE, OP_TRANSFER, OP_PAD, OP_COMBINE_COPY, OP_PAD_RING, OP_GRID_TABLES = range(7)
-OP_NAMES = ("split", "combine", "transfer", "pad", "combine_copy", "pad_ring", "grid_tables")
+OP_SPLIT, OP_COMBINE, OP_TRANSFER, OP_PAD, OP_COMBINE_COPY, OP_PAD_RING, OP_GRID_TABLES, OP_INTERP = range(8)
+OP_NAMES = ("split", "combine", "transfer", "pad", "combine_copy", "pad_ring", "grid_tables", "interp")
+_DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 ABI_VERSION = 1
 
 
@@ -53,6 +54,7 @@ def load_library(path: str = None) -> ctypes.CDLL:
         "bc_pad_ring": [p, p, p, p, p] + [i] * 8 + [p],
         "bc_grid_tables": [p, i, p, p, p, p, p, p],
         "bc_grid_tables_host": [p, i, p, p, p, p],
+        "bc_interp_bilinear": [p, p, ctypes.c_longlong, i, i, i, i, i, ctypes.c_float, ctypes.c_float, i, p],
         "bc_abi_version": [],
         "bc_prof_enable": [u],
         "bc_prof_reset": [],
@@ -184,6 +186,20 @@ class HipBackend:
                                                  mapping_exec.data_ptr(), n_exec, N, C, GH, GW, bs, int(pad),
                                                  out.element_size(), self._stream()), "pad_ring")
         return out
+
+    def interp_bilinear(self, data, out_h, out_w, align_corners, rh, rw):
+        """per-tile bilinear resampling (planes = all leading dims); arithmetic of torch's upsample_bilinear2d."""
+        assert _ok(data, *_DTYPE_CODE) and data.dim() == 4
+        B, C, h, w = data.shape
+        out = torch.empty((B, C, out_h, out_w), device=data.device, dtype=data.dtype)
+        if out.numel() > 0:
+            with torch.cuda.device_of(data):
+                self._check(self.lib.bc_interp_bilinear(out.data_ptr(), data.data_ptr(), B * C, h, w, out_h, out_w,
+                                                        int(bool(align_corners)), float(rh), float(rw),
+                                                        _DTYPE_CODE[data.dtype], self._stream()), "interp_bilinear")
+        return out
+
+    supports_interp_dtypes = tuple(_DTYPE_CODE)
 
     def grid_tables_device(self, grid, prev_grid_idx=None):
         """index tables computed on the GPU (no host sync).  Returns (grid_idx, mapping_buf, transfer_buf, counts)

@@ -493,10 +493,41 @@ class TensorWrapper(torch.Tensor):
             return func(*args, **kwargs)
 
     def _func_interpolate(self, func, args, kwargs):
-        """Resampling runs per tile on the packed batch, i.e. WITHOUT halo: a tile's border pixels are
-        interpolated from the tile alone.  (The reference reaches the same arithmetic through a trilinear
-        re-expression on a (1,B,C,h,w) view, core/tensorwrapper.py:577-598 -- a cuDNN-era speed trick.)"""
-        return func(*args, **kwargs)
+        """Resampling runs per tile on the packed batch, i.e. WITHOUT halo: a tile's border pixels are interpolated
+        from the tile alone.  (The reference reaches the same arithmetic through a trilinear re-expression on a
+        (1,B,C,h,w) view, core/tensorwrapper.py:577-598, because the stock bilinear kernel loops over tiles x
+        channels inside each thread.)  Bilinear goes to the library's fully parallel per-tile kernel; every other
+        mode runs as the stock op on the packed batch."""
+        data = args[0].as_subclass(torch.Tensor)
+        mode = kwargs.get("mode", args[3] if len(args) > 3 else "nearest")
+        if func.__name__ == "upsample_bilinear":
+            mode, kwargs = "bilinear", dict(kwargs, align_corners=True)
+        be = get_backend()
+        if (mode != "bilinear" or data.dim() != 4 or kwargs.get("antialias", False)
+                or data.dtype not in getattr(be, "supports_interp_dtypes", ())):
+            return func(*args, **kwargs)
+        size = kwargs.get("size", args[1] if len(args) > 1 else None)
+        scale = kwargs.get("scale_factor", args[2] if len(args) > 2 else None)
+        align = bool(kwargs.get("align_corners", False))
+        recompute = bool(kwargs.get("recompute_scale_factor", False))
+        h, w = data.shape[2], data.shape[3]
+        if size is not None:
+            H, W = (int(size), int(size)) if isinstance(size, int) else (int(size[0]), int(size[1]))
+            sh = sw = None
+        else:
+            sh, sw = (float(scale), float(scale)) if not isinstance(scale, (tuple, list)) else (float(scale[0]), float(scale[1]))
+            H, W = int(h * sh), int(w * sw)   # floor, as torch
+            if recompute:
+                sh = sw = None
+
+        def resolved(in_size, out_size, s):
+            if align:
+                return np.float32(in_size - 1) / np.float32(out_size - 1) if out_size > 1 else np.float32(0)
+            return np.float32(1.0 / s) if (s is not None and s > 0) else np.float32(in_size) / np.float32(out_size)
+
+        if not data.is_contiguous():
+            data = data.contiguous()
+        return be.interp_bilinear(data, H, W, align, resolved(h, H, sh), resolved(w, W, sw))
 
     def _func_batched(self, func, args, kwargs):
         """Ops with per-sample statistics (group_norm): fold the tile axis into the spatial axis so statistics

@@ -12,6 +12,8 @@
 //   * 64-wide wavefronts, 256-thread workgroups, no LDS needed except the 3x3 neighbour table of the halo
 //     gather.
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <hip/hip_bfloat16.h>
 #include <stdint.h>
 #include <string.h>
 
@@ -307,6 +309,76 @@ __global__ __launch_bounds__(1024) void k_grid_tables(const uint8_t *__restrict_
     if (threadIdx.x == 0) { counts[0] = carry; counts[1] = n_total - carry; }
 }
 
+// ------------------------------------------------------------------------------------------ per-tile bilinear resampling
+template <typename T> struct Cvt;
+template <> struct Cvt<float> {
+    static __device__ __forceinline__ float ld(const float *p) { return *p; }
+    static __device__ __forceinline__ float st(float v) { return v; }
+};
+template <> struct Cvt<__half> {
+    static __device__ __forceinline__ float ld(const __half *p) { return __half2float(*p); }
+    static __device__ __forceinline__ __half st(float v) { return __float2half(v); }
+};
+template <> struct Cvt<hip_bfloat16> {
+    static __device__ __forceinline__ float ld(const hip_bfloat16 *p) { return (float)(*p); }
+    static __device__ __forceinline__ hip_bfloat16 st(float v) { return hip_bfloat16(v); }
+};
+
+struct InterpGeom {
+    FastDiv Wq, H;        // output quads per row, output height
+    uint32_t h, w, W;
+    uint32_t total;       // planes*H*Wq work items
+    float rh, rw;
+    int align;
+};
+
+__device__ __forceinline__ void src_index(float scale, uint32_t dst, int align, uint32_t size, uint32_t &i0, uint32_t &ip, float &l1)
+{
+    float s = align ? scale * (float)dst : fmaxf(scale * ((float)dst + 0.5f) - 0.5f, 0.0f);
+    i0 = (uint32_t)s;
+    if (i0 > size - 1) i0 = size - 1;
+    ip = (i0 < size - 1) ? 1u : 0u;
+    l1 = s - (float)i0;
+}
+
+// One work item = Q horizontally adjacent outputs of one plane row (Q*sizeof(T) = 16 B store when W % Q == 0);
+// all planes/rows/columns in parallel (the stock kernel loops over planes inside each thread).
+template <typename T, int Q>
+__global__ __launch_bounds__(WG) void k_interp_bilinear(T *__restrict__ out, const T *__restrict__ in, InterpGeom g)
+{
+    const uint32_t stride = gridDim.x * WG;
+    for (uint32_t i = blockIdx.x * WG + threadIdx.x; i < g.total; i += stride) {
+        uint32_t r, q, plane, oy;
+        fd_divmod(i, g.Wq, r, q);
+        fd_divmod(r, g.H, plane, oy);
+        uint32_t y0, yp; float ly1;
+        src_index(g.rh, oy, g.align, g.h, y0, yp, ly1);
+        const float ly0 = 1.0f - ly1;
+        const T *__restrict__ row0 = in + ((size_t)plane * g.h + y0) * g.w;
+        const T *__restrict__ row1 = row0 + (size_t)yp * g.w;
+        T res[Q];
+#pragma unroll
+        for (int k = 0; k < Q; ++k) {
+            const uint32_t ox = q * Q + k;
+            uint32_t x0, xp; float lx1;
+            src_index(g.rw, ox < g.W ? ox : g.W - 1, g.align, g.w, x0, xp, lx1);
+            const float lx0 = 1.0f - lx1;
+            const float v = ly0 * (lx0 * Cvt<T>::ld(row0 + x0) + lx1 * Cvt<T>::ld(row0 + x0 + xp)) +
+                            ly1 * (lx0 * Cvt<T>::ld(row1 + x0) + lx1 * Cvt<T>::ld(row1 + x0 + xp));
+            res[k] = Cvt<T>::st(v);
+        }
+        T *__restrict__ dst = out + ((size_t)plane * g.H.d + oy) * g.W + (size_t)q * Q;
+        if (Q > 1 && (g.W % Q) == 0) {
+            typedef typename VecOf<sizeof(T) * Q>::type V;
+            *reinterpret_cast<V *>(dst) = *reinterpret_cast<const V *>(res);
+        } else {
+#pragma unroll
+            for (int k = 0; k < Q; ++k)
+                if (q * Q + k < g.W) dst[k] = res[k];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ host helpers
 int pick_vb(size_t row_bytes, std::initializer_list<const void *> ptrs)
 {
@@ -466,7 +538,7 @@ BC_EXPORT const char *bc_error_string(int code)
 
 BC_EXPORT const char *bc_op_name(int op)
 {
-    static const char *names[BC_OP_COUNT] = {"split", "combine", "transfer", "pad", "combine_copy", "pad_ring", "grid_tables"};
+    static const char *names[BC_OP_COUNT] = {"split", "combine", "transfer", "pad", "combine_copy", "pad_ring", "grid_tables", "interp"};
     return (op >= 0 && op < BC_OP_COUNT) ? names[op] : "?";
 }
 
@@ -587,6 +659,35 @@ BC_EXPORT int bc_pad_ring(void *out, const void *features, void *ring, const int
     ProfScope ps(BC_OP_PAD_RING, (hipStream_t)stream, halo_bytes(n_exec, C, bs, pad, E));
     return launch_halo<true>(out, features, ring, ring, grid_idx, mapping_exec, n_exec, N, C, GH, GW, bs, pad, E,
                              (hipStream_t)stream);
+}
+
+BC_EXPORT int bc_interp_bilinear(void *out, const void *in, long long planes, int h, int w, int H, int W,
+                                 int align_corners, float rh, float rw, int dtype, void *stream)
+{
+    if (dtype < BC_F32 || dtype > BC_BF16) return BC_ERR_ELEM;
+    if (planes < 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return BC_ERR_SHAPE;
+    if (planes == 0) return BC_OK;
+    if (!out || !in) return BC_ERR_NULL;
+    const int E = dtype == BC_F32 ? 4 : 2;
+    if ((uint64_t)planes * H * W >= (1ull << 31) || (uint64_t)planes * h * w >= (1ull << 31)) return BC_ERR_RANGE;
+    if (!aligned(out, E) || !aligned(in, E)) return BC_ERR_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    const int Q = 16 / E;
+    // vector stores need a 16-byte aligned base and W % Q == 0 (otherwise the kernel stores element-wise)
+    const bool vec = (W % Q) == 0 && aligned(out, 16);
+    InterpGeom g;
+    const uint32_t q = vec ? Q : 1;
+    g.Wq = make_fd((W + q - 1) / q); g.H = make_fd(H);
+    g.h = h; g.w = w; g.W = W; g.rh = rh; g.rw = rw; g.align = align_corners;
+    g.total = (uint32_t)((uint64_t)planes * H * g.Wq.d);
+    const int grid = grid_for(g.total, 1);
+    ProfScope ps(BC_OP_INTERP, st, ((double)planes * h * w + (double)planes * H * W) * E);
+#define BC_IP(T_, Q_) hipLaunchKernelGGL((k_interp_bilinear<T_, Q_>), dim3(grid), dim3(WG), 0, st, (T_ *)out, (const T_ *)in, g)
+    if (dtype == BC_F32) { if (vec) BC_IP(float, 4); else BC_IP(float, 1); }
+    else if (dtype == BC_F16) { if (vec) BC_IP(__half, 8); else BC_IP(__half, 1); }
+    else { if (vec) BC_IP(hip_bfloat16, 8); else BC_IP(hip_bfloat16, 1); }
+#undef BC_IP
+    return launch_status();
 }
 
 BC_EXPORT int bc_grid_tables(const uint8_t *grid, int n_total, int32_t *grid_idx, int32_t *mapping_exec,

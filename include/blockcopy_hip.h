@@ -102,12 +102,23 @@ int bc_grid_tables(const uint8_t *grid, int n_total, int32_t *grid_idx, int32_t 
 int bc_grid_tables_host(const uint8_t *grid, int n_total, int32_t *grid_idx, int32_t *mapping_exec,
                         const int32_t *prev_grid_idx, int32_t *transfer_idx);
 
+/* per-tile bilinear resampling of a packed batch: in (planes, h, w) -> out (planes, H, W), planes = n_exec*C.
+ * Replaces the reference's INTERPOLATE route (core/tensorwrapper.py:577-598: bilinear re-expressed as trilinear
+ * on a (1,B,C,h,w) view because the stock bilinear kernel serialises over tiles x channels -- on MI355X it costs
+ * 1.1 ms per call at SwiftNet's decoder shapes).  No halo: a tile's border is interpolated from the tile alone,
+ * exactly as in the reference.  Arithmetic = PyTorch's upsample_bilinear2d (source index scale*(dst+0.5)-0.5
+ * clamped at 0, or scale*dst with align_corners; fp32 accumulation; rh/rw are the already-resolved
+ * input/output scales).  dtype: 0 = float32, 1 = float16, 2 = bfloat16. */
+enum { BC_F32 = 0, BC_F16 = 1, BC_BF16 = 2 };
+int bc_interp_bilinear(void *out, const void *in, long long planes, int h, int w, int H, int W,
+                       int align_corners, float rh, float rw, int dtype, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * C. Introspection / measurement
  * ------------------------------------------------------------------------------------------- */
 
 enum { BC_OP_SPLIT = 0, BC_OP_COMBINE = 1, BC_OP_TRANSFER = 2, BC_OP_PAD = 3,
-       BC_OP_COMBINE_COPY = 4, BC_OP_PAD_RING = 5, BC_OP_GRID_TABLES = 6, BC_OP_COUNT = 7 };
+       BC_OP_COMBINE_COPY = 4, BC_OP_PAD_RING = 5, BC_OP_GRID_TABLES = 6, BC_OP_INTERP = 7, BC_OP_COUNT = 8 };
 
 int bc_abi_version(void);
 const char *bc_error_string(int code);

@@ -56,6 +56,12 @@ class OracleBackend:
         ring[mapping_exec.long()] = sel
         return out
 
+    supports_interp_dtypes = (torch.float32,)
+
+    def interp_bilinear(self, data, out_h, out_w, align_corners, rh, rw):
+        # floating-point op: the checker is stock PyTorch on the packed batch (per tile, no halo)
+        return torch.nn.functional.interpolate(data, size=(out_h, out_w), mode="bilinear", align_corners=align_corners)
+
     def grid_tables_host(self, grid_u8, grid_idx, mapping, prev_grid_idx=None, transfer=None):
         gi, m = O.c_grid_mappings(grid_u8.astype(bool).reshape(1, 1, 1, -1))
         grid_idx[:] = gi.reshape(-1)

@@ -232,3 +232,46 @@ def test_large_c2_shapes_roundtrip(be):
     want = dense.unfold(2, bs + 2, bs).unfold(3, bs + 2, bs)           # N,C,GH,GW,bs+2,bs+2
     want = want.permute(0, 2, 3, 1, 4, 5).reshape(GH * GW, C, bs + 2, bs + 2)
     assert torch.equal(padded, want)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.float16, 2e-3), (torch.bfloat16, 2e-2)])
+def test_interp_bilinear_matches_torch(be, dtype, tol):
+    """Floating-point kernel: compared with stock PyTorch (fp32 CPU reference of the same op), tolerance per dtype."""
+    import torch.nn.functional as F
+
+    g = torch.Generator().manual_seed(0)
+    for (B, C, h, w), kw in [((64, 128, 4, 4), dict(size=(8, 8))), ((3, 5, 8, 16), dict(size=(16, 32))),
+                             ((2, 3, 7, 5), dict(size=(13, 11))), ((2, 4, 6, 6), dict(scale_factor=2.0)),
+                             ((2, 4, 6, 6), dict(scale_factor=1.5)), ((2, 2, 5, 9), dict(size=(10, 18), align_corners=True)),
+                             ((1, 2, 8, 8), dict(size=(4, 4))), ((2, 2, 1, 1), dict(size=(2, 2)))]:
+        x = torch.randn((B, C, h, w), generator=g)
+        size, scale, align = kw.get("size"), kw.get("scale_factor"), kw.get("align_corners", False)
+        if size is not None:
+            H, W = size
+            rh = np.float32(h - 1) / np.float32(H - 1) if align else np.float32(h) / np.float32(H)
+            rw = np.float32(w - 1) / np.float32(W - 1) if align else np.float32(w) / np.float32(W)
+        else:
+            H, W = int(h * scale), int(w * scale)
+            rh = rw = np.float32(1.0 / scale)
+        got = be.interp_bilinear(x.to(dtype).cuda(), H, W, align, rh, rw)
+        want = F.interpolate(x.to(dtype).float(), mode="bilinear", **kw)   # same rounded inputs, fp32 arithmetic
+        assert got.shape == want.shape and got.dtype == dtype
+        assert float((got.float().cpu() - want).abs().max()) <= tol * max(1.0, float(want.abs().max())), (dtype, kw)
+
+
+def test_interpolate_routing_on_packed_tiles(be):
+    """F.interpolate on a packed TensorWrapper == stock bilinear applied per tile (no halo)."""
+    import blockcopy
+    import torch.nn.functional as F
+
+    x = torch.randn(1, 6, 32, 64).cuda()
+    xw = blockcopy.to_tensorwrapper(x)
+    xw.process_temporal_features(None)
+    grid = torch.ones(1, 1, 2, 4, dtype=torch.bool)
+    b = xw.to_blocks(grid.cuda(), grid)
+    up = F.interpolate(b, (32, 32), mode="bilinear")
+    assert blockcopy.is_block(up) and up.shape == (8, 6, 32, 32)
+    want = F.interpolate(b.as_subclass(torch.Tensor), (32, 32), mode="bilinear")
+    assert float((up.as_subclass(torch.Tensor) - want).abs().max()) <= 2e-6
+    nearest = F.interpolate(b, scale_factor=2, mode="nearest")
+    assert torch.equal(nearest.as_subclass(torch.Tensor), F.interpolate(b.as_subclass(torch.Tensor), scale_factor=2, mode="nearest"))

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 --kernel-trace CSV of bench.py: per-frame kernel time inside the timed clips.
+
+usage: trace_summary.py <kernel_trace.csv> <frames_in_window> [skip_last_frames]
+The window is delimited by the gather (k_tiles<.., true>) launches: two per frame (network input + SPP output)."""
+import collections
+import csv
+import sys
+
+
+def main():
+    path, n_frames = sys.argv[1], int(sys.argv[2])
+    skip = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    rows = list(csv.DictReader(open(path)))
+    ks = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows)
+    marks = [s for s, e, n in ks if "k_tiles<" in n and "true>" in n]
+    per_frame = 2
+    fe = marks[-per_frame * skip] if skip else ks[-1][1] + 1
+    fs = marks[-per_frame * (skip + n_frames)]
+    sel = [(s, e, n) for s, e, n in ks if fs <= s < fe]
+    busy = sum(e - s for s, e, n in sel)
+    print(f"window: {n_frames} frames, wall {(fe - fs) / 1e6 / n_frames:.3f} ms/frame, GPU busy {busy / 1e6 / n_frames:.3f} ms/frame, "
+          f"{len(sel) / n_frames:.1f} launches/frame")
+    agg = collections.defaultdict(lambda: [0, 0])
+    for s, e, n in sel:
+        a = agg[n[:100]]
+        a[0] += e - s
+        a[1] += 1
+    print(f"{'kernel':100s} {'ms/frame':>9s} {'calls/frm':>9s} {'avg_us':>8s}")
+    for n, (t, c) in sorted(agg.items(), key=lambda x: -x[1][0])[:40]:
+        print(f"{n:100s} {t / 1e6 / n_frames:9.3f} {c / n_frames:9.1f} {t / c / 1e3:8.1f}")
+
+
+if __name__ == "__main__":
+    main()
