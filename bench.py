@@ -47,6 +47,7 @@ def parse_args():
     ap.add_argument("--no-dense", action="store_true", help="skip the dense-GPU comparison run")
     ap.add_argument("--miopen-find", type=int, default=1, help="torch.backends.cudnn.benchmark during warm-up")
     ap.add_argument("--cpu-frames", type=int, default=8)
+    ap.add_argument("--graph", type=int, default=1, help="hipGraph replay of the packed pipeline (0 = eager launches)")
     return ap.parse_args()
 
 
@@ -110,7 +111,8 @@ def main():
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
 
     model = harness.build_model(args.backbone, block_policy="fixed", block_size=args.block_size, block_target=args.target,
-                                device=device, dtype=dtype, seed=1000 * rank)
+                                device=device, dtype=dtype, seed=1000 * rank,
+                                block_graph=args.graph)
     # per-rank clips (clip i of the job lives on rank i mod N); inputs resident in HBM before the clock starts
     n_distinct = 2
     clips = [harness.synthetic_clip(CLIP_LEN, shape, seed=(rank * n_distinct + c) * 100, device=device, dtype=dtype) for c in range(n_distinct)]
@@ -145,6 +147,7 @@ def main():
         # halo-gather kernel statistics from one extra, untimed clip (events around all 21 launches per frame)
         be.prof_reset()
         be.prof_enable(["pad_ring", "split", "combine"])
+        use_graph, model.use_graph = model.use_graph, False   # per-launch events need eager launches
         harness.run_clip(model, clips[0])
         torch.cuda.synchronize(device)
         be.prof_enable([])
@@ -154,6 +157,13 @@ def main():
                 extra[op] = {"launches_per_frame": r["launches"] / CLIP_LEN, "avg_us": 1e3 * r["total_ms"] / r["launches"],
                              "GBps": r["total_bytes"] / (r["total_ms"] * 1e-3) / 1e9, "MB_per_frame": r["total_bytes"] / CLIP_LEN / 1e6}
         # host-side enqueue cost of one clip (no sync inside): tells whether the frame is CPU- or GPU-bound
+        torch.cuda.synchronize(device)
+        th = time.perf_counter()
+        harness.run_clip(model, clips[0])
+        host_s = time.perf_counter() - th
+        torch.cuda.synchronize(device)
+        extra["eager_host_enqueue_ms_per_frame"] = 1e3 * host_s / CLIP_LEN
+        model.use_graph = use_graph
         torch.cuda.synchronize(device)
         th = time.perf_counter()
         harness.run_clip(model, clips[0])
@@ -175,7 +185,7 @@ def main():
             "dtype": "f16" if args.half else "f32", "data": "synthetic",
             "config": {"workload": f"C2: SwiftNet-{args.backbone} {shape[0]}x3x{args.height}x{args.width} synthetic clips of {CLIP_LEN} frames, "
                                    f"block {args.block_size}, fixed {args.target:.0%} seeded mask (frame 0 of each clip all-active), "
-                                   f"{args.engine} engine, name-seeded weights, BN folded; step = 1 clip",
+                                   f"{args.engine} engine{' + hipGraph replay' if args.graph else ''}, name-seeded weights, BN folded; step = 1 clip",
                        "clips_per_rank": args.steps, "parallelism": f"{world} independent replica(s), no collective",
                        "exec_fraction": exec_frac, "warmup_s": warm_s},
             "roofline": {"kernel": "k_combine_copy (fused scatter+copy of the logits map)", "bound": "hbm", "achieved": achieved,

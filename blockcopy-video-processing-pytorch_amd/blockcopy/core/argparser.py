@@ -15,6 +15,7 @@ _FLAGS = [
     ("--block-train-interval", dict(type=int, default=4, help="optimize the policy every N frames")),
     ("--block-cost-momentum", dict(type=float, default=0.9, help="cost momentum")),
     ("--block-policy-verbose", dict(action="store_true", help="print debug info for policy training")),
+    ("--block-graph", dict(type=int, default=0, help="1: replay the packed pipeline as a hipGraph per executed-tile count")),
     ("--block-seed", dict(type=int, default=0, help="seed of the `fixed` policy's tile choice")),
 ]
 

@@ -103,6 +103,43 @@ OPS_SPECIAL = set().union(*OPS.values())
 _PADDING_POS = {"conv2d": 4, "avg_pool2d": 3, "max_pool2d": 3}
 
 
+class PersistentState:
+    """Temporal state with fixed HBM addresses, for the graph-captured frame pipeline (core/graphs.py).
+
+    Holds, in call order, one ring cache per padded op and one dense map per combine call site.  Unlike the
+    per-frame FIFO hand-over of the eager engine, these buffers survive ``reset_temporal()`` (an all-active first
+    frame overwrites them completely), so a hipGraph captured over them stays valid for the life of the model."""
+
+    def __init__(self):
+        self.rings = []
+        self.maps = []
+        self.ring_pos = 0
+        self.map_pos = 0
+        self.frozen = False   # set once a graph has been captured: no new buffers may appear
+
+    def rewind(self):
+        self.ring_pos = 0
+        self.map_pos = 0
+
+    def _next(self, store, pos, shape, dtype, device, what):
+        if pos == len(store):
+            assert not self.frozen, f"a new {what} appeared after graph capture; the model must run the same op sequence every frame"
+            store.append(torch.empty(shape, dtype=dtype, device=device))
+        buf = store[pos]
+        if tuple(buf.shape) != tuple(shape) or buf.dtype != dtype:
+            raise AssertionError(f"{what} #{pos}: expected {tuple(buf.shape)}/{buf.dtype}, got {tuple(shape)}/{dtype}; "
+                                 "the model must run the same op sequence every frame")
+        return buf
+
+    def next_ring(self, shape, dtype, device):
+        self.ring_pos += 1
+        return self._next(self.rings, self.ring_pos - 1, shape, dtype, device, "padded op")
+
+    def next_map(self, shape, dtype, device):
+        self.map_pos += 1
+        return self._next(self.maps, self.map_pos - 1, shape, dtype, device, "combine call site")
+
+
 class BlockFeatures:
     """Per-frame block state: the execution grid with its index tables, plus the temporal feature store.
 
@@ -129,6 +166,7 @@ class BlockFeatures:
 
         self.rings = []              # fused engine: persistent ring caches (shared list object across frames)
         self._ring_pos = 0
+        self.persistent = None       # PersistentState when running as a graph-capturable body (core/graphs.py)
 
     # ------------------------------------------------------------------ grid -> index tables
     def _process_grid(self, grid: torch.Tensor, meta_prev: "BlockFeatures" = None, grid_host: torch.Tensor = None) -> None:
@@ -168,10 +206,12 @@ class BlockFeatures:
     # ------------------------------------------------------------------ fused engine: ring caches
     def next_ring(self, data: torch.Tensor) -> torch.Tensor:
         """Ring cache of the padded op being executed (ops must come in the same order every frame)."""
-        k = self._ring_pos
-        self._ring_pos += 1
         _, C, bs, _ = data.shape
         shape = (self.n_total, C, bs, bs)
+        if self.persistent is not None:
+            return self.persistent.next_ring(shape, data.dtype, data.device)
+        k = self._ring_pos
+        self._ring_pos += 1
         if k == len(self.rings):
             assert self.n_exec == self.n_total, "a new padded layer appeared after the first frame of the clip"
             self.rings.append(torch.empty(shape, dtype=data.dtype, device=data.device))
@@ -353,6 +393,16 @@ class TensorWrapper(torch.Tensor):
             blocks = self.as_subclass(torch.Tensor)
             if not blocks.is_contiguous():
                 blocks = blocks.contiguous()
+
+            ps = self._features.persistent
+            if ps is not None:
+                # graph-capturable body: scatter into the call site's persistent map (fixed address); an
+                # out-of-place combine then snapshots it (values identical to clone + scatter).
+                buf = ps.next_map(out_shape, blocks.dtype, blocks.device)
+                out = CombineFunction.apply(blocks, buf, grid_idx, mapping_exec)
+                if not inplace:
+                    out = out.clone()
+                return self._wrap_like(out, self, False)
 
             if self._features_prev:
                 prev = self._features_prev.get_features_full()

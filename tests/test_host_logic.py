@@ -239,3 +239,13 @@ def test_no_cpu_fallback():
             bk.load_library("/nonexistent/libblockcopy_hip.so")
     finally:
         bk.set_backend(prev)
+
+
+@pytest.mark.parametrize("name", ["swiftnet_rn18_a.npz", "swiftnet_rn18_n2.npz"])
+def test_persistent_state_pipeline_matches_reference_on_cpu(golden_dir, oracle_backend, name):
+    """The graph-capturable body (persistent ring caches / dense maps, static index tables) run eagerly on CPU:
+    same logits as the reference over two consecutive clips that share the persistent buffers."""
+    G, cfg = load_golden(golden_dir, name)
+    errs, fs_errs = run_golden_clip(G, cfg, "cpu", "fused", graph=1, repeats=2)
+    assert len(errs) == 2 * cfg["n_frames"] and max(errs) <= 2e-5, errs
+    assert all(e == 0.0 for e in fs_errs)
