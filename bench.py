@@ -88,6 +88,43 @@ def cpu_dense_baseline(args, n_frames):
                       f"PyTorch CPU oneDNN conv, BN folded, after 1 warm-up frame ({dt:.1f} s)"}
 
 
+def scatter_copy_large(be, device, iters=20):
+    """The same fused scatter+copy kernel at the largest map of the configs (C5 detector head, (1,256,256,512) fp32,
+    block 32, 64 of 128 tiles = 268 MB of traffic, beyond the 256 MiB Infinity Cache): the HBM-bound figure."""
+    N, C, H, W, bs, n_exec = 1, 256, 256, 512, 32, 64
+    GH, GW = H // bs, W // bs
+    g = torch.zeros(GH * GW, dtype=torch.bool)
+    g[torch.randperm(GH * GW, generator=torch.Generator().manual_seed(0))[:n_exec]] = True
+    gi = torch.where(g, g.cumsum(0) - 1, (~g).cumsum(0) - 1 - GH * GW).to(torch.int32).view(N, 1, GH, GW).to(device)
+    blocks = torch.randn((n_exec, C, bs, bs), device=device)
+    prev = torch.randn((N, C, H, W), device=device)
+    out = torch.empty_like(prev)
+    for _ in range(3):
+        be.combine_copy(blocks, prev, out, gi)
+    be.prof_reset()
+    be.prof_enable(["combine_copy"])
+    for _ in range(iters):
+        be.combine_copy(blocks, prev, out, gi)
+    torch.cuda.synchronize(device)
+    be.prof_enable([])
+    r = be.prof_read("combine_copy")
+    gbps = r["total_bytes"] / (r["total_ms"] * 1e-3) / 1e9
+    return {"kernel": "k_combine_copy", "shape": "(1,256,256,512) f32, block 32, 64/128 tiles executed", "launches": r["launches"],
+            "avg_launch_us": 1e3 * r["total_ms"] / r["launches"], "algorithmic_bytes_per_launch": r["total_bytes"] / r["launches"],
+            "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBS}
+
+
+def pmc_traffic():
+    """HBM traffic per launch of the roofline kernel from a separate rocprofv3 --pmc run of this same command
+    (tools/pmc_traffic.py writes profiles/traffic_latest.json); None when no such measurement is committed."""
+    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if not os.path.exists(path):
+        return None, None
+    with open(path) as f:
+        t = json.load(f)
+    return t.get("k_combine_copy_bytes_per_launch"), t.get("source")
+
+
 def main():
     args = parse_args()
     rank, world, local = dist_env()
@@ -170,6 +207,7 @@ def main():
         host_s = time.perf_counter() - th
         torch.cuda.synchronize(device)
         extra["host_enqueue_ms_per_frame"] = 1e3 * host_s / CLIP_LEN
+        extra["roofline_large"] = scatter_copy_large(be, device)
         if not args.no_dense and world == 1:
             dense = harness.build_model(args.backbone, block_policy="static", device=device, dtype=dtype)
             dfps, _, _ = harness.measure_fps(dense, clips[:1], n_clips=max(1, min(args.steps, 3)), warmup_clips=1, device=device)
@@ -179,6 +217,7 @@ def main():
 
     if rank == 0:
         achieved = (cc["total_bytes"] / (cc["total_ms"] * 1e-3) / 1e9) if cc["total_ms"] > 0 else 0.0
+        traffic, traffic_src = pmc_traffic()
         out = {
             "metric": METRIC, "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -189,7 +228,8 @@ def main():
                        "clips_per_rank": args.steps, "parallelism": f"{world} independent replica(s), no collective",
                        "exec_fraction": exec_frac, "warmup_s": warm_s},
             "roofline": {"kernel": "k_combine_copy (fused scatter+copy of the logits map)", "bound": "hbm", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "launches": cc["launches"], "avg_launch_us": (1e3 * cc["total_ms"] / cc["launches"]) if cc["launches"] else None,
                          "algorithmic_bytes_per_launch": (cc["total_bytes"] / cc["launches"]) if cc["launches"] else None},
             "kernels": extra,

@@ -12,9 +12,11 @@
 //   * 64-wide wavefronts, 256-thread workgroups, no LDS needed except the 3x3 neighbour table of the halo
 //     gather.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <hip/hip_fp16.h>
 #include <hip/hip_bfloat16.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -74,21 +76,10 @@ struct TileGeom {
     uint32_t total;              // number of packed vectors = n_exec*C*bs*vpr
 };
 
-// dense vector index of packed vector v
-__device__ __forceinline__ uint32_t dense_index(uint32_t v, const TileGeom &g, const int32_t *__restrict__ mapping_exec)
-{
-    uint32_t r, xv, r2, h, b, c;
-    fd_divmod(v, g.vpr, r, xv);
-    fd_divmod(r, g.bs, r2, h);
-    fd_divmod(r2, g.C, b, c);
-    const uint32_t ig = (uint32_t)mapping_exec[b];
-    uint32_t t, gw, n, gh;
-    fd_divmod(ig, g.GW, t, gw);
-    fd_divmod(t, g.GH, n, gh);
-    return ((n * g.C.d + c) * g.H + gh * g.bsz + h) * g.vprW + gw * g.vpr.d + xv;
-}
-
 // TO_PACKED: packed[v] = dense[dense_index(v)]   (split);   else dense[dense_index(v)] = packed[v]   (combine)
+// Each lane moves UNROLL vectors that are gridDim*WG apart (every memory instruction of a wave stays contiguous).
+// All index loads are issued first, then all payload loads, then the stores: no branch sits between a load and
+// its use, so the UNROLL requests of a lane are in flight together (tail lanes clamp their index).
 template <int VB, bool TO_PACKED>
 __global__ __launch_bounds__(WG) void k_tiles(typename VecOf<VB>::type *__restrict__ packed_w,
                                               const typename VecOf<VB>::type *__restrict__ packed_r,
@@ -98,25 +89,37 @@ __global__ __launch_bounds__(WG) void k_tiles(typename VecOf<VB>::type *__restri
 {
     typedef typename VecOf<VB>::type V;
     const uint32_t stride = gridDim.x * WG;
-    for (uint32_t v0 = blockIdx.x * WG + threadIdx.x; v0 < g.total; v0 += stride * UNROLL) {
-        V val[UNROLL];
-        uint32_t di[UNROLL];
+    const uint32_t v0 = blockIdx.x * WG + threadIdx.x;
+    const uint32_t last = g.total - 1;
+    uint32_t vc[UNROLL], rem[UNROLL], b[UNROLL], ig[UNROLL], di[UNROLL];
+    V val[UNROLL];
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            const uint32_t v = v0 + u * stride;
-            if (v < g.total) {
-                di[u] = dense_index(v, g, mapping_exec);
-                val[u] = TO_PACKED ? dense_r[di[u]] : packed_r[v];
-            }
-        }
+    for (int u = 0; u < UNROLL; ++u) {
+        const uint32_t v = v0 + u * stride;
+        vc[u] = v < last ? v : last;
+        uint32_t r, xv, r2, h, c;
+        fd_divmod(vc[u], g.vpr, r, xv);
+        fd_divmod(r, g.bs, r2, h);
+        fd_divmod(r2, g.C, b[u], c);
+        rem[u] = (c * g.H + h) * g.vprW + xv;   // part of the dense index that does not depend on the tile position
+    }
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            const uint32_t v = v0 + u * stride;
-            if (v < g.total) {
-                if (TO_PACKED) packed_w[v] = val[u];
-                else dense_w[di[u]] = val[u];
-            }
-        }
+    for (int u = 0; u < UNROLL; ++u) ig[u] = (uint32_t)mapping_exec[b[u]];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+        uint32_t t, gw, n, gh;
+        fd_divmod(ig[u], g.GW, t, gw);
+        fd_divmod(t, g.GH, n, gh);
+        di[u] = rem[u] + (n * g.C.d * g.H + gh * g.bsz) * g.vprW + gw * g.vpr.d;
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) val[u] = TO_PACKED ? dense_r[di[u]] : packed_r[vc[u]];
+    // tail lanes carry the clamped (last) vector and store it again: same value to the same address, so the
+    // stores need no predicate (a predicate here makes the compiler sink each load into its store's branch).
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+        if (TO_PACKED) packed_w[vc[u]] = val[u];
+        else dense_w[di[u]] = val[u];
     }
 }
 
@@ -129,35 +132,42 @@ struct DenseGeom {
 
 template <int VB>
 __global__ __launch_bounds__(WG) void k_combine_copy(const typename VecOf<VB>::type *__restrict__ blocks,
-                                                     const typename VecOf<VB>::type *__restrict__ prev,
+                                                     long long prev_delta,   // (prev - blocks) in vectors
                                                      typename VecOf<VB>::type *__restrict__ out,
                                                      const int32_t *__restrict__ grid_idx, DenseGeom g)
 {
+    // Both sources are addressed from ONE base (blocks + signed offset): with two base pointers selected per lane
+    // the compiler loses the no-alias information against `out` and serialises load -> store -> load.
     typedef typename VecOf<VB>::type V;
     const uint32_t stride = gridDim.x * WG;
-    for (uint32_t v0 = blockIdx.x * WG + threadIdx.x; v0 < g.total; v0 += stride * UNROLL) {
-        V val[UNROLL];
+    const uint32_t v0 = blockIdx.x * WG + threadIdx.x;
+    const uint32_t last = g.total - 1;
+    uint32_t vc[UNROLL], tile[UNROLL], inner[UNROLL];
+    int32_t idx[UNROLL];
+    V val[UNROLL];
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            const uint32_t v = v0 + u * stride;
-            if (v < g.total) {
-                uint32_t r, xw, r2, y, n, c, gw, xv, gh, h;
-                fd_divmod(v, g.vprW, r, xw);
-                fd_divmod(r, g.H, r2, y);
-                fd_divmod(r2, g.C, n, c);
-                fd_divmod(xw, g.vpr, gw, xv);
-                fd_divmod(y, g.bs, gh, h);
-                const int32_t idx = grid_idx[(n * g.GH + gh) * g.GW + gw];
-                const V *src = idx >= 0 ? blocks + (((uint32_t)idx * g.C.d + c) * g.bs.d + h) * g.vpr.d + xv : prev + v;
-                val[u] = *src;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            const uint32_t v = v0 + u * stride;
-            if (v < g.total) out[v] = val[u];
-        }
+    for (int u = 0; u < UNROLL; ++u) {
+        const uint32_t v = v0 + u * stride;
+        vc[u] = v < last ? v : last;
+        uint32_t r, xw, r2, y, n, c, gw, xv, gh, h;
+        fd_divmod(vc[u], g.vprW, r, xw);
+        fd_divmod(r, g.H, r2, y);
+        fd_divmod(r2, g.C, n, c);
+        fd_divmod(xw, g.vpr, gw, xv);
+        fd_divmod(y, g.bs, gh, h);
+        tile[u] = (n * g.GH + gh) * g.GW + gw;
+        inner[u] = (c * g.bs.d + h) * g.vpr.d + xv;   // vector offset inside a packed tile
     }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) idx[u] = grid_idx[tile[u]];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+        const long long off = idx[u] >= 0 ? (long long)((uint32_t)idx[u] * g.C.d * g.bs.d * g.vpr.d + inner[u])
+                                          : prev_delta + (long long)vc[u];
+        val[u] = blocks[off];
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) out[vc[u]] = val[u];   // clamped duplicates rewrite the same value (see k_tiles)
 }
 
 // ------------------------------------------------------------------------------------------ border-ring transfer
@@ -262,6 +272,288 @@ __global__ __launch_bounds__(WG) void k_halo(T *__restrict__ out, const T *__res
         out_t[f] = val;
         if (RING && s == 4 && (hs < p || hs >= bs - p || ws < p || ws >= bs - p))
             ring_w[(size_t)own_g * (g.C * plane) + in_tile] = val;
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------ halo gather, LDS staged
+// The padded row (bs+2p elements) is never 16-byte aligned with respect to its source row, so a register-only copy is
+// stuck with element-wide accesses on one side.  Here a workgroup owns a CONTIGUOUS range of L output elements of one
+// tile's padded output (C planes of (bs+2p)^2, back to back) and assembles it in LDS:
+//   fill  : source rows are read with aligned VE-element vector loads (interior rows from the tile itself, top/bottom
+//           halo rows from the vertical neighbours), the 2p edge elements per row with scalar loads; everything is
+//           written to the LDS image at its final position (ds_write per element does the sub-vector shift);
+//   drain : the image is read back as aligned 16-byte vectors and stored fully coalesced.  The image is placed in LDS
+//           with the same 16-byte phase as the global range, so aligned LDS vectors map to aligned global vectors.
+// Loads and LDS writes are unconditional (tail items are clamped, out-of-range elements go to a dummy LDS slot) so that
+// each lane keeps all of its requests in flight at once.  RING: see k_halo.
+struct HaloLdsGeom {
+    FastDiv BSP, vpr, P2, GW, GH;   // padded row length, source vectors per row, 2*pad, grid dims
+    uint32_t C, bs, pad, n_total;
+    uint32_t per_tile;              // C*(bs+2p)^2
+    uint32_t L;                     // output elements per workgroup
+    uint32_t plane;                 // bs*bs
+};
+
+constexpr int HALO_UM = 4;          // middle-run vectors per lane
+constexpr int HALO_UE = 2;          // edge elements per lane
+constexpr int HALO_TBL = 128;       // bytes reserved at the start of dynamic LDS for the 3x3 neighbour table
+
+template <typename T, int VE, bool RING>
+__global__ __launch_bounds__(WG) void k_halo_lds(T *__restrict__ out, const T *__restrict__ features, long long other_delta,
+                                                 T *__restrict__ ring_w, const int32_t *__restrict__ grid_idx,
+                                                 const int32_t *__restrict__ mapping_exec, HaloLdsGeom g)
+{
+    typedef typename VecOf<VE * sizeof(T)>::type SV;   // source vector
+    constexpr int DE = 16 / sizeof(T);                 // elements per drain vector
+    extern __shared__ uint4 smem[];
+    long long *nb_base = reinterpret_cast<long long *>(smem);            // element offset from `features`, 9 entries
+    int32_t *nb_zero = reinterpret_cast<int32_t *>(smem) + 18;           // 1 = beyond the image border
+    uint32_t *own_g = reinterpret_cast<uint32_t *>(smem) + 27;
+    T *img = reinterpret_cast<T *>(reinterpret_cast<char *>(smem) + HALO_TBL);
+
+    const uint32_t b = blockIdx.y;
+    const uint32_t tile_elems = g.C * g.plane;
+    if (threadIdx.x < 9) {
+        const uint32_t ig = (uint32_t)mapping_exec[b];
+        uint32_t t, gw, n, gh;
+        fd_divmod(ig, g.GW, t, gw);
+        fd_divmod(t, g.GH, n, gh);
+        const int dy = (int)(threadIdx.x / 3) - 1, dx = (int)(threadIdx.x % 3) - 1;
+        const int nh = (int)gh + dy, nw = (int)gw + dx;
+        long long base = 0;
+        int zero = 0;
+        if (nh < 0 || nh >= (int)g.GH.d || nw < 0 || nw >= (int)g.GW.d) zero = 1;
+        else if (dy == 0 && dx == 0) base = (long long)b * tile_elems;
+        else {
+            const uint32_t g_in = (uint32_t)((int)ig + dx + (int)g.GW.d * dy);
+            const int32_t idx = grid_idx[g_in];
+            if (idx >= 0) base = (long long)idx * tile_elems;
+            else base = other_delta + (long long)(RING ? g_in : (uint32_t)(idx + (int32_t)g.n_total)) * tile_elems;
+        }
+        nb_base[threadIdx.x] = base;
+        nb_zero[threadIdx.x] = zero;
+        if (threadIdx.x == 4) *own_g = ig;
+    }
+    __syncthreads();
+
+    const uint32_t bs = g.bs, p = g.pad, BSP = g.BSP.d;
+    const uint32_t f0 = blockIdx.x * g.L;
+    const uint32_t f1 = min(f0 + g.L, g.per_tile);
+    const uint32_t n = f1 - f0;
+    T *__restrict__ out_t = out + (size_t)b * g.per_tile;
+    const uint32_t ph = (uint32_t)((reinterpret_cast<uintptr_t>(out_t + f0) & 15u) / sizeof(T));
+    const uint32_t dummy = ph + g.L;                 // scratch slot behind the image
+    const uint32_t r_lo = fd_div(f0, g.BSP), r_hi = fd_div(f1 - 1, g.BSP);
+    const uint32_t nrows = r_hi - r_lo + 1;
+    const long long ring_base = RING ? (long long)(*own_g) * tile_elems : 0;
+
+    // ---- fill, ONE batch: the host sizes L so that a range spans at most HALO_UM*WG middle vectors and HALO_UE*WG
+    // edge elements; every lane issues all its loads (HALO_UM vectors + HALO_UE scalars) before the first LDS write,
+    // so the workgroup's critical path is: neighbour table -> one global round trip -> LDS -> stores.
+    SV vec[HALO_UM];
+    T edge[HALO_UE];
+    uint32_t fm[HALO_UM], zm[HALO_UM], rsel[HALO_UM], fe[HALO_UE], ze[HALO_UE];
+    long long roff[HALO_UM];
+    {
+        const uint32_t nitems = nrows * g.vpr.d;
+#pragma unroll
+        for (int u = 0; u < HALO_UM; ++u) {
+            const uint32_t it = min(threadIdx.x + u * WG, nitems - 1);
+            uint32_t ri, xv, c, hp;
+            fd_divmod(it, g.vpr, ri, xv);
+            const uint32_t r = r_lo + ri;
+            fd_divmod(r, g.BSP, c, hp);
+            const uint32_t sy = hp < p ? 0u : (hp >= p + bs ? 2u : 1u);
+            const uint32_t hs = hp - p + bs - sy * bs;
+            const uint32_t s = sy * 3 + 1;
+            const uint32_t in_tile = c * g.plane + hs * bs + xv * VE;
+            zm[u] = (uint32_t)nb_zero[s];
+            const long long src = zm[u] ? 0 : nb_base[s] + in_tile;
+            vec[u] = *reinterpret_cast<const SV *>(features + src);
+            fm[u] = r * BSP + p + xv * VE;
+            roff[u] = ring_base + in_tile;
+            rsel[u] = RING && sy == 1 && (hs < p || hs >= bs - p || xv * VE < p || xv * VE + VE > bs - p);
+        }
+    }
+    {
+        const uint32_t nitems = nrows * g.P2.d;
+#pragma unroll
+        for (int u = 0; u < HALO_UE; ++u) {
+            const uint32_t it = min(threadIdx.x + u * WG, nitems - 1);
+            uint32_t ri, e, c, hp;
+            fd_divmod(it, g.P2, ri, e);
+            const uint32_t r = r_lo + ri;
+            fd_divmod(r, g.BSP, c, hp);
+            const uint32_t sy = hp < p ? 0u : (hp >= p + bs ? 2u : 1u);
+            const uint32_t hs = hp - p + bs - sy * bs;
+            const bool right = e >= p;
+            const uint32_t s = sy * 3 + (right ? 2u : 0u);
+            const uint32_t ws = right ? e - p : bs - p + e;
+            const uint32_t wp = right ? bs + e : e;        // p + bs + (e - p)
+            ze[u] = (uint32_t)nb_zero[s];
+            const long long src = ze[u] ? 0 : nb_base[s] + (c * g.plane + hs * bs + ws);
+            edge[u] = features[src];
+            fe[u] = r * BSP + wp;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < HALO_UM; ++u) {
+        const T *e = reinterpret_cast<const T *>(&vec[u]);
+#pragma unroll
+        for (int k = 0; k < VE; ++k) {
+            const uint32_t f = fm[u] + k;
+            const uint32_t j = (f >= f0 && f < f1) ? ph + (f - f0) : dummy;
+            img[j] = zm[u] ? (T)0 : e[k];
+        }
+        if (RING && rsel[u]) *reinterpret_cast<SV *>(ring_w + roff[u]) = vec[u];
+    }
+#pragma unroll
+    for (int u = 0; u < HALO_UE; ++u) {
+        const uint32_t f = fe[u];
+        const uint32_t j = (f >= f0 && f < f1) ? ph + (f - f0) : dummy;
+        img[j] = ze[u] ? (T)0 : edge[u];
+    }
+    __syncthreads();
+
+    // ---- drain: aligned 16-byte vectors (element-wise at the two ragged ends of the range)
+    {
+        const uint32_t nv = (ph + n + DE - 1) / DE;
+        const uint4 *__restrict__ img_v = reinterpret_cast<const uint4 *>(img);
+        uint4 *__restrict__ dst_v = reinterpret_cast<uint4 *>(reinterpret_cast<uintptr_t>(out_t + f0) & ~(uintptr_t)15);
+        for (uint32_t i = threadIdx.x; i < nv; i += WG) {
+            const uint32_t lo = i * DE;
+            if (lo >= ph && lo + DE <= ph + n) {
+                dst_v[i] = img_v[i];
+            } else {
+#pragma unroll
+                for (int k = 0; k < DE; ++k) {
+                    const uint32_t j = lo + k;
+                    if (j >= ph && j < ph + n) out_t[f0 + (j - ph)] = img[j];
+                }
+            }
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------ halo gather, row vectors
+// Register-only form.  A padded row = [p edge | bs middle | p edge].  The middle run is a whole row of some tile
+// (the tile itself, or its upper/lower neighbour for the 2p halo rows), so it is read with ALIGNED VE-element vector
+// loads; its destination is shifted by p elements, so it is written with UNDER-ALIGNED vector stores of the same
+// width (gfx950 global memory runs in unaligned-access mode: a dwordx4 store only needs element alignment; one
+// wavefront still covers one contiguous run of addresses).  The 2p edge elements per row move as scalars.
+// The 3x3 neighbour table is wave-uniform (it depends on blockIdx.y only): mapping_exec[b] and the eight grid_idx
+// entries are scalar loads into SGPRs -- no LDS, no barrier, and nothing between a lane and its HALO_UM + HALO_UE
+// independent requests.
+struct HaloRowsGeom {
+    FastDiv BSP, vpr, P2, GW, GH;
+    uint32_t C, bs, pad, n_total, plane, per_tile;
+    uint32_t mid_items;     // C*BSP*vpr   source vectors per tile
+    uint32_t edge_items;    // C*BSP*2p    edge elements per tile
+    uint32_t edge_per_wg;
+};
+
+template <typename T, int VE> struct RowVec {
+    typedef T aligned_t __attribute__((ext_vector_type(VE)));
+    typedef T packed_t __attribute__((ext_vector_type(VE), aligned(sizeof(T))));
+};
+template <typename T> struct RowVec<T, 1> {
+    typedef T aligned_t;
+    typedef T packed_t;
+};
+
+template <typename T, int VE, bool RING>
+__global__ __launch_bounds__(WG) void k_halo_rows(T *__restrict__ out, const T *__restrict__ features, long long other_delta,
+                                                  T *__restrict__ ring_w, const int32_t *__restrict__ grid_idx,
+                                                  const int32_t *__restrict__ mapping_exec, HaloRowsGeom g)
+{
+    typedef typename RowVec<T, VE>::aligned_t SV;
+    typedef typename RowVec<T, VE>::packed_t SVU;
+    const uint32_t b = blockIdx.y;
+    const uint32_t tile_elems = g.C * g.plane;
+    const uint32_t bs = g.bs, p = g.pad, BSP = g.BSP.d;
+
+    // ---- wave-uniform 3x3 neighbour table (scalar loads)
+    const uint32_t ig = (uint32_t)mapping_exec[b];
+    uint32_t t0, gw, n0, gh;
+    fd_divmod(ig, g.GW, t0, gw);
+    fd_divmod(t0, g.GH, n0, gh);
+    long long nbb[9];
+    bool nbz[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int dy = k / 3 - 1, dx = k % 3 - 1;
+        const int nh = (int)gh + dy, nw = (int)gw + dx;
+        nbz[k] = nh < 0 || nh >= (int)g.GH.d || nw < 0 || nw >= (int)g.GW.d;
+        nbb[k] = 0;
+        if (k == 4) nbb[k] = (long long)b * tile_elems;
+        else if (!nbz[k]) {
+            const uint32_t g_in = (uint32_t)((int)ig + dx + (int)g.GW.d * dy);
+            const int32_t idx = grid_idx[g_in];
+            nbb[k] = idx >= 0 ? (long long)idx * tile_elems
+                              : other_delta + (long long)(RING ? g_in : (uint32_t)(idx + (int32_t)g.n_total)) * tile_elems;
+        }
+    }
+    const long long ring_base = (long long)ig * tile_elems;
+    T *__restrict__ out_t = out + (size_t)b * g.per_tile;
+
+    // ---- middle runs
+    {
+        SV vec[HALO_UM];
+        uint32_t dst[HALO_UM], in_tile[HALO_UM];
+        bool zero[HALO_UM], rsel[HALO_UM];
+#pragma unroll
+        for (int u = 0; u < HALO_UM; ++u) {
+            const uint32_t it = min((blockIdx.x * HALO_UM + u) * WG + threadIdx.x, g.mid_items - 1);
+            uint32_t rr, xv, c, hp;
+            fd_divmod(it, g.vpr, rr, xv);
+            fd_divmod(rr, g.BSP, c, hp);
+            const bool top = hp < p, bot = hp >= p + bs;
+            const uint32_t hs = top ? hp + bs - p : (bot ? hp - p - bs : hp - p);
+            in_tile[u] = c * g.plane + hs * bs + xv * VE;
+            zero[u] = top ? nbz[1] : (bot ? nbz[7] : false);
+            const long long base = top ? nbb[1] : (bot ? nbb[7] : nbb[4]);
+            vec[u] = *reinterpret_cast<const SV *>(features + (zero[u] ? 0 : base + in_tile[u]));
+            dst[u] = rr * BSP + p + xv * VE;
+            rsel[u] = RING && !top && !bot && (hs < p || hs >= bs - p || xv * VE < p || xv * VE + VE > bs - p);
+        }
+#pragma unroll
+        for (int u = 0; u < HALO_UM; ++u) {
+            const SV v = zero[u] ? (SV)0 : vec[u];
+            *reinterpret_cast<SVU *>(out_t + dst[u]) = v;
+            if (RING && rsel[u]) *reinterpret_cast<SV *>(ring_w + ring_base + in_tile[u]) = v;
+        }
+    }
+    // ---- edge elements (left/right neighbours and the four corners)
+    {
+        const uint32_t e0 = blockIdx.x * g.edge_per_wg;
+        const uint32_t e1 = min(e0 + g.edge_per_wg, g.edge_items);
+        for (uint32_t base_it = e0; base_it < e1; base_it += WG * HALO_UE) {
+            T val[HALO_UE];
+            uint32_t dst[HALO_UE];
+            bool zero[HALO_UE];
+#pragma unroll
+            for (int u = 0; u < HALO_UE; ++u) {
+                const uint32_t it = min(base_it + u * WG + threadIdx.x, e1 - 1);
+                uint32_t rr, e, c, hp;
+                fd_divmod(it, g.P2, rr, e);
+                fd_divmod(rr, g.BSP, c, hp);
+                const bool top = hp < p, bot = hp >= p + bs, right = e >= p;
+                const uint32_t hs = top ? hp + bs - p : (bot ? hp - p - bs : hp - p);
+                const uint32_t ws = right ? e - p : bs - p + e;
+                const long long bl = top ? nbb[0] : (bot ? nbb[6] : nbb[3]);
+                const long long br = top ? nbb[2] : (bot ? nbb[8] : nbb[5]);
+                const bool zl = top ? nbz[0] : (bot ? nbz[6] : nbz[3]);
+                const bool zr = top ? nbz[2] : (bot ? nbz[8] : nbz[5]);
+                zero[u] = right ? zr : zl;
+                const long long src = (right ? br : bl) + (c * g.plane + hs * bs + ws);
+                val[u] = features[zero[u] ? 0 : src];
+                dst[u] = rr * BSP + (right ? bs + e : e);
+            }
+#pragma unroll
+            for (int u = 0; u < HALO_UE; ++u) out_t[dst[u]] = zero[u] ? (T)0 : val[u];
+        }
     }
 }
 
@@ -401,6 +693,13 @@ int grid_for(uint64_t items, int per_thread)
     return (int)(wgs < 1 ? 1 : (wgs > MAX_WG ? MAX_WG : wgs));
 }
 
+// exact cover: every lane handles `per_thread` items, no grid-stride loop (items < 2^31 => grid < 2^23)
+int grid_exact(uint64_t items, int per_thread)
+{
+    const uint64_t wgs = (items + (uint64_t)WG * per_thread - 1) / ((uint64_t)WG * per_thread);
+    return (int)(wgs < 1 ? 1 : wgs);
+}
+
 // ---- per-op event timing (bench.py roofline: device time of exactly these launches, on their stream)
 struct ProfState {
     std::mutex mu;
@@ -413,13 +712,16 @@ struct ProfState {
     double bytes[BC_OP_COUNT] = {0};
 } g_prof;
 
+// When an op is being profiled its kernel is launched with hipExtLaunchKernelGGL, which attaches the start/stop events
+// to the dispatch packet itself: the elapsed time is the kernel's own execution time (what rocprofv3 reports), not the
+// launch bracket of two separately recorded events (which adds ~4 us of dispatch latency to a 5 us kernel).
 struct ProfScope {
     int op;
-    hipStream_t st;
     bool on;
     ProfState::Rec rec;
-    ProfScope(int op_, hipStream_t st_, double bytes) : op(op_), st(st_), on(false)
+    ProfScope(int op_, double bytes) : op(op_), on(false)
     {
+        rec.a = rec.b = nullptr;
         if (!(g_prof.mask & (1u << op))) return;
         std::lock_guard<std::mutex> lk(g_prof.mu);
         if (!g_prof.pool.empty()) { rec = g_prof.pool.back(); g_prof.pool.pop_back(); }
@@ -429,16 +731,20 @@ struct ProfScope {
         }
         g_prof.bytes[op] += bytes;
         on = true;
-        (void)hipEventRecord(rec.a, st);
     }
     ~ProfScope()
     {
         if (!on) return;
-        (void)hipEventRecord(rec.b, st);
         std::lock_guard<std::mutex> lk(g_prof.mu);
         g_prof.pending[op].push_back(rec);
     }
 };
+
+#define BC_LAUNCH(ps_, kernel_, grid_, block_, lds_, st_, ...)                                                     \
+    do {                                                                                                           \
+        if ((ps_).on) hipExtLaunchKernelGGL(kernel_, grid_, block_, lds_, st_, (ps_).rec.a, (ps_).rec.b, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kernel_, grid_, block_, lds_, st_, __VA_ARGS__);                                   \
+    } while (0)
 
 int launch_status()
 {
@@ -455,7 +761,7 @@ int check_dense(int N, int C, int H, int W, int bs, int E)
 }
 
 template <bool TO_PACKED>
-int launch_tiles(void *packed, void *dense, const int32_t *mapping_exec, int n_exec,
+int launch_tiles(ProfScope &ps, void *packed, void *dense, const int32_t *mapping_exec, int n_exec,
                  int N, int C, int H, int W, int bs, int E, hipStream_t st)
 {
     const int vb = pick_vb((size_t)bs * E, {packed, dense});
@@ -464,10 +770,10 @@ int launch_tiles(void *packed, void *dense, const int32_t *mapping_exec, int n_e
     g.vpr = make_fd(vpr); g.bs = make_fd(bs); g.C = make_fd(C); g.GW = make_fd(W / bs); g.GH = make_fd(H / bs);
     g.H = H; g.bsz = bs; g.vprW = (uint32_t)((size_t)W * E / vb);
     g.total = (uint32_t)((uint64_t)n_exec * C * bs * vpr);
-    const int grid = grid_for(g.total, UNROLL);
+    const int grid = grid_exact(g.total, UNROLL);
 #define BC_TILES(VB_)                                                                                          \
     case VB_:                                                                                                  \
-        hipLaunchKernelGGL((k_tiles<VB_, TO_PACKED>), dim3(grid), dim3(WG), 0, st,                             \
+        BC_LAUNCH(ps, (k_tiles<VB_, TO_PACKED>), dim3(grid), dim3(WG), 0, st,                             \
                            (VecOf<VB_>::type *)packed, (const VecOf<VB_>::type *)packed,                       \
                            (VecOf<VB_>::type *)dense, (const VecOf<VB_>::type *)dense, mapping_exec, g);       \
         break;
@@ -477,9 +783,9 @@ int launch_tiles(void *packed, void *dense, const int32_t *mapping_exec, int n_e
 }
 
 template <bool RING>
-int launch_halo(void *out, const void *features, const void *other_r, void *ring_w, const int32_t *grid_idx,
-                const int32_t *mapping_exec, int n_exec, int N, int C, int GH, int GW, int bs, int pad, int E,
-                hipStream_t st)
+int launch_halo_simple(ProfScope &ps, void *out, const void *features, const void *other_r, void *ring_w, const int32_t *grid_idx,
+                       const int32_t *mapping_exec, int n_exec, int N, int C, int GH, int GW, int bs, int pad, int E,
+                       hipStream_t st)
 {
     HaloGeom g;
     const uint32_t bsp = bs + 2 * pad;
@@ -487,12 +793,11 @@ int launch_halo(void *out, const void *features, const void *other_r, void *ring
     g.C = C; g.bs = bs; g.pad = pad; g.n_total = (uint32_t)N * GH * GW;
     g.per_tile = (uint32_t)C * bsp * bsp;
     uint64_t gx = ((uint64_t)g.per_tile + WG * 4 - 1) / (WG * 4);
-    // keep the launch at >= ~2048 workgroups when there are few tiles, <= 64 column chunks per tile
     if (gx > 64) gx = 64;
     if (gx < 1) gx = 1;
     const dim3 grid((unsigned)gx, (unsigned)n_exec);
 #define BC_HALO(T_)                                                                                            \
-    hipLaunchKernelGGL((k_halo<T_, RING>), grid, dim3(WG), 0, st, (T_ *)out, (const T_ *)features,             \
+    BC_LAUNCH(ps, (k_halo<T_, RING>), grid, dim3(WG), 0, st, (T_ *)out, (const T_ *)features,             \
                        (const T_ *)other_r, (T_ *)ring_w, grid_idx, mapping_exec, g)
     switch (E) {
     case 1: BC_HALO(uint8_t); break;
@@ -501,6 +806,96 @@ int launch_halo(void *out, const void *features, const void *other_r, void *ring
     default: BC_HALO(uint64_t); break;
     }
 #undef BC_HALO
+    return launch_status();
+}
+
+// Which halo-gather kernel a launch uses.  Measured on MI355X (profiles/r01/kbench_*.txt): below ~30 MB of traffic
+// the launch is a single wave of workgroups and the register-only row kernel has the shortest critical path
+// (6-8 us); above it the LDS-staged kernel's aligned stores win (3.7-4.4 TB/s vs 2.4-2.8 TB/s).
+// BC_HALO_KERNEL = auto (default) | rows | lds | simple overrides the choice for A/B measurements.
+enum { HALO_AUTO = -1, HALO_ROWS = 0, HALO_LDS = 1, HALO_SIMPLE = 2 };
+int halo_kernel_override()
+{
+    static const int v = [] {
+        const char *e = getenv("BC_HALO_KERNEL");
+        if (!e) return (int)HALO_AUTO;
+        return e[0] == 'r' ? (int)HALO_ROWS : (e[0] == 'l' ? (int)HALO_LDS : (e[0] == 's' ? (int)HALO_SIMPLE : (int)HALO_AUTO));
+    }();
+    return v;
+}
+int halo_kernel_choice(double bytes)
+{
+    const int o = halo_kernel_override();
+    return o != HALO_AUTO ? o : (bytes < 30e6 ? HALO_ROWS : HALO_LDS);
+}
+
+template <bool RING>
+int launch_halo(ProfScope &ps, void *out, const void *features, const void *other_r, void *ring_w, const int32_t *grid_idx,
+                const int32_t *mapping_exec, int n_exec, int N, int C, int GH, int GW, int bs, int pad, int E,
+                hipStream_t st)
+{
+    const int choice = halo_kernel_choice(2.0 * n_exec * C * (double)(bs + 2 * pad) * (bs + 2 * pad) * E);
+    if ((E != 2 && E != 4) || choice == HALO_SIMPLE)
+        return launch_halo_simple<RING>(ps, out, features, other_r, ring_w, grid_idx, mapping_exec, n_exec, N, C, GH, GW, bs, pad, E, st);
+    const int vb = pick_vb((size_t)bs * E, {features, other_r, ring_w});
+    if (choice == HALO_ROWS) {
+        HaloRowsGeom g;
+        const uint32_t bsp = bs + 2 * pad, vpr = (uint32_t)((size_t)bs * E / vb);
+        g.BSP = make_fd(bsp); g.vpr = make_fd(vpr); g.P2 = make_fd(2 * pad); g.GW = make_fd(GW); g.GH = make_fd(GH);
+        g.C = C; g.bs = bs; g.pad = pad; g.n_total = (uint32_t)N * GH * GW; g.plane = (uint32_t)bs * bs;
+        g.per_tile = (uint32_t)C * bsp * bsp;
+        g.mid_items = (uint32_t)C * bsp * vpr;
+        g.edge_items = (uint32_t)C * bsp * 2 * pad;
+        const uint32_t gx = (g.mid_items + WG * HALO_UM - 1) / (WG * HALO_UM);
+        g.edge_per_wg = (g.edge_items + gx - 1) / gx;
+        const dim3 grid(gx, (unsigned)n_exec);
+        const long long delta = ((const char *)other_r - (const char *)features) / E;
+#define BC_HR(T_, VE_)                                                                                         \
+        BC_LAUNCH(ps, (k_halo_rows<T_, VE_, RING>), grid, dim3(WG), 0, st, (T_ *)out, (const T_ *)features, \
+                           delta, (T_ *)ring_w, grid_idx, mapping_exec, g)
+        const int ve = vb / E;
+        if (E == 4) {
+            if (ve >= 4) BC_HR(uint32_t, 4); else if (ve == 2) BC_HR(uint32_t, 2); else BC_HR(uint32_t, 1);
+        } else {
+            if (ve >= 8) BC_HR(uint16_t, 8); else if (ve == 4) BC_HR(uint16_t, 4); else if (ve == 2) BC_HR(uint16_t, 2); else BC_HR(uint16_t, 1);
+        }
+#undef BC_HR
+        return launch_status();
+    }
+    HaloLdsGeom g;
+    const uint32_t bsp = bs + 2 * pad;
+    g.BSP = make_fd(bsp); g.vpr = make_fd((uint32_t)((size_t)bs * E / vb)); g.P2 = make_fd(2 * pad);
+    g.GW = make_fd(GW); g.GH = make_fd(GH);
+    g.C = C; g.bs = bs; g.pad = pad; g.n_total = (uint32_t)N * GH * GW;
+    g.per_tile = (uint32_t)C * bsp * bsp;
+    g.plane = (uint32_t)bs * bs;
+    // range length L: (1) a range of L elements spans at most L/BSP + 1 padded rows, and one batch covers
+    // HALO_UM*WG middle vectors and HALO_UE*WG edge elements; (2) aim at >= ~2048 workgroups per launch.
+    const uint64_t rows_mid = (uint64_t)HALO_UM * WG / g.vpr.d, rows_edge = (uint64_t)HALO_UE * WG / (2 * pad);
+    const uint64_t rows_max = rows_mid < rows_edge ? rows_mid : rows_edge;
+    if (rows_max < 2)
+        return launch_halo_simple<RING>(ps, out, features, other_r, ring_w, grid_idx, mapping_exec, n_exec, N, C, GH, GW, bs, pad, E, st);
+    uint64_t L = (rows_max - 1) * bsp;
+    const uint64_t total = (uint64_t)g.per_tile * n_exec;
+    const uint64_t want = (total + 2047) / 2048, Lmin = 2048 / E;
+    if (L > want) L = want < Lmin ? (Lmin < L ? Lmin : L) : want;
+    if (L > 32768 / (uint64_t)E) L = 32768 / E;
+    if (L > g.per_tile) L = g.per_tile;
+    g.L = (uint32_t)L;
+    const uint32_t chunks = (g.per_tile + g.L - 1) / g.L;
+    const size_t lds = HALO_TBL + ((size_t)(g.L + 16 / E + 1) * E + 15) / 16 * 16;
+    const dim3 grid(chunks, (unsigned)n_exec);
+    const long long delta = ((const char *)other_r - (const char *)features) / E;
+#define BC_HL(T_, VE_)                                                                                         \
+    BC_LAUNCH(ps, (k_halo_lds<T_, VE_, RING>), grid, dim3(WG), lds, st, (T_ *)out, (const T_ *)features,  \
+                       delta, (T_ *)ring_w, grid_idx, mapping_exec, g)
+    const int ve = vb / E;
+    if (E == 4) {
+        if (ve >= 4) BC_HL(uint32_t, 4); else if (ve == 2) BC_HL(uint32_t, 2); else BC_HL(uint32_t, 1);
+    } else {
+        if (ve >= 8) BC_HL(uint16_t, 8); else if (ve == 4) BC_HL(uint16_t, 4); else if (ve == 2) BC_HL(uint16_t, 2); else BC_HL(uint16_t, 1);
+    }
+#undef BC_HL
     return launch_status();
 }
 
@@ -551,8 +946,8 @@ BC_EXPORT int bc_split(void *blocks, const void *image, const int32_t *mapping_e
     if (n_exec == 0) return BC_OK;
     if (!blocks || !image || !mapping_exec) return BC_ERR_NULL;
     if (!aligned(blocks, E) || !aligned(image, E)) return BC_ERR_ALIGN;
-    ProfScope ps(BC_OP_SPLIT, (hipStream_t)stream, 2.0 * n_exec * C * bs * bs * E);
-    return launch_tiles<true>(blocks, const_cast<void *>(image), mapping_exec, n_exec, N, C, H, W, bs, E, (hipStream_t)stream);
+    ProfScope ps(BC_OP_SPLIT, 2.0 * n_exec * C * bs * bs * E);
+    return launch_tiles<true>(ps, blocks, const_cast<void *>(image), mapping_exec, n_exec, N, C, H, W, bs, E, (hipStream_t)stream);
 }
 
 BC_EXPORT int bc_combine(const void *blocks, void *out, const int32_t *mapping_exec, int n_exec,
@@ -564,8 +959,8 @@ BC_EXPORT int bc_combine(const void *blocks, void *out, const int32_t *mapping_e
     if (n_exec == 0) return BC_OK;
     if (!blocks || !out || !mapping_exec) return BC_ERR_NULL;
     if (!aligned(blocks, E) || !aligned(out, E)) return BC_ERR_ALIGN;
-    ProfScope ps(BC_OP_COMBINE, (hipStream_t)stream, 2.0 * n_exec * C * bs * bs * E);
-    return launch_tiles<false>(const_cast<void *>(blocks), out, mapping_exec, n_exec, N, C, H, W, bs, E, (hipStream_t)stream);
+    ProfScope ps(BC_OP_COMBINE, 2.0 * n_exec * C * bs * bs * E);
+    return launch_tiles<false>(ps, const_cast<void *>(blocks), out, mapping_exec, n_exec, N, C, H, W, bs, E, (hipStream_t)stream);
 }
 
 BC_EXPORT int bc_combine_copy(const void *blocks, const void *prev, void *out, const int32_t *grid_idx,
@@ -585,12 +980,13 @@ BC_EXPORT int bc_combine_copy(const void *blocks, const void *prev, void *out, c
     g.vprW = make_fd(vprW); g.H = make_fd(H); g.C = make_fd(C); g.vpr = make_fd(vpr); g.bs = make_fd(bs);
     g.GH = H / bs; g.GW = W / bs;
     g.total = (uint32_t)((uint64_t)N * C * H * vprW);
-    const int grid = grid_for(g.total, UNROLL);
-    ProfScope ps(BC_OP_COMBINE_COPY, st, 2.0 * N * C * H * W * E);
+    const int grid = grid_exact(g.total, UNROLL);
+    ProfScope ps(BC_OP_COMBINE_COPY, 2.0 * N * C * H * W * E);
 #define BC_CC(VB_)                                                                                             \
     case VB_:                                                                                                  \
-        hipLaunchKernelGGL((k_combine_copy<VB_>), dim3(grid), dim3(WG), 0, st, (const VecOf<VB_>::type *)bl,   \
-                           (const VecOf<VB_>::type *)pv, (VecOf<VB_>::type *)out, grid_idx, g);                \
+        BC_LAUNCH(ps, (k_combine_copy<VB_>), dim3(grid), dim3(WG), 0, st, (const VecOf<VB_>::type *)bl,   \
+                           (long long)(((const char *)pv - (const char *)bl) / VB_), (VecOf<VB_>::type *)out,  \
+                           grid_idx, g);                                                                       \
         break;
     switch (vb) { BC_CC(16) BC_CC(8) BC_CC(4) BC_CC(2) BC_CC(1) }
 #undef BC_CC
@@ -618,10 +1014,10 @@ BC_EXPORT int bc_transfer(void *out, const void *prev_computed, const void *prev
     g.total = (uint32_t)((uint64_t)n_transfer * C * bs * vpr);
     const int grid = grid_for(g.total, 1);
     const double ring = padding < 0 || bs <= 2 * padding ? (double)bs * bs : (double)bs * bs - (double)(bs - 2 * padding) * (bs - 2 * padding);
-    ProfScope ps(BC_OP_TRANSFER, st, 2.0 * n_transfer * C * ring * E);
+    ProfScope ps(BC_OP_TRANSFER, 2.0 * n_transfer * C * ring * E);
 #define BC_TR(VB_)                                                                                             \
     case VB_:                                                                                                  \
-        hipLaunchKernelGGL((k_transfer<VB_>), dim3(grid), dim3(WG), 0, st, (VecOf<VB_>::type *)out,            \
+        BC_LAUNCH(ps, (k_transfer<VB_>), dim3(grid), dim3(WG), 0, st, (VecOf<VB_>::type *)out,            \
                            (const VecOf<VB_>::type *)pc, (const VecOf<VB_>::type *)pt, transfer_idx, g);       \
         break;
     switch (vb) { BC_TR(16) BC_TR(8) BC_TR(4) BC_TR(2) BC_TR(1) }
@@ -642,9 +1038,9 @@ BC_EXPORT int bc_pad(void *out, const void *features, const void *transfer, cons
     int rc = check_halo(out, features, grid_idx, mapping_exec, n_exec, N, C, GH, GW, bs, pad, E);
     if (rc != BC_OK || n_exec == 0) return rc;
     if (!aligned(transfer, E)) return BC_ERR_ALIGN;
-    ProfScope ps(BC_OP_PAD, (hipStream_t)stream, halo_bytes(n_exec, C, bs, pad, E));
+    ProfScope ps(BC_OP_PAD, halo_bytes(n_exec, C, bs, pad, E));
     // transfer may be NULL/empty when every tile is executed (first frame): it is then never dereferenced
-    return launch_halo<false>(out, features, transfer ? transfer : features, nullptr, grid_idx, mapping_exec, n_exec,
+    return launch_halo<false>(ps, out, features, transfer ? transfer : features, nullptr, grid_idx, mapping_exec, n_exec,
                               N, C, GH, GW, bs, pad, E, (hipStream_t)stream);
 }
 
@@ -656,8 +1052,8 @@ BC_EXPORT int bc_pad_ring(void *out, const void *features, void *ring, const int
     if (rc != BC_OK || n_exec == 0) return rc;
     if (!ring) return BC_ERR_NULL;
     if (!aligned(ring, E)) return BC_ERR_ALIGN;
-    ProfScope ps(BC_OP_PAD_RING, (hipStream_t)stream, halo_bytes(n_exec, C, bs, pad, E));
-    return launch_halo<true>(out, features, ring, ring, grid_idx, mapping_exec, n_exec, N, C, GH, GW, bs, pad, E,
+    ProfScope ps(BC_OP_PAD_RING, halo_bytes(n_exec, C, bs, pad, E));
+    return launch_halo<true>(ps, out, features, ring, ring, grid_idx, mapping_exec, n_exec, N, C, GH, GW, bs, pad, E,
                              (hipStream_t)stream);
 }
 
@@ -681,8 +1077,8 @@ BC_EXPORT int bc_interp_bilinear(void *out, const void *in, long long planes, in
     g.h = h; g.w = w; g.W = W; g.rh = rh; g.rw = rw; g.align = align_corners;
     g.total = (uint32_t)((uint64_t)planes * H * g.Wq.d);
     const int grid = grid_for(g.total, 1);
-    ProfScope ps(BC_OP_INTERP, st, ((double)planes * h * w + (double)planes * H * W) * E);
-#define BC_IP(T_, Q_) hipLaunchKernelGGL((k_interp_bilinear<T_, Q_>), dim3(grid), dim3(WG), 0, st, (T_ *)out, (const T_ *)in, g)
+    ProfScope ps(BC_OP_INTERP, ((double)planes * h * w + (double)planes * H * W) * E);
+#define BC_IP(T_, Q_) BC_LAUNCH(ps, (k_interp_bilinear<T_, Q_>), dim3(grid), dim3(WG), 0, st, (T_ *)out, (const T_ *)in, g)
     if (dtype == BC_F32) { if (vec) BC_IP(float, 4); else BC_IP(float, 1); }
     else if (dtype == BC_F16) { if (vec) BC_IP(__half, 8); else BC_IP(__half, 1); }
     else { if (vec) BC_IP(hip_bfloat16, 8); else BC_IP(hip_bfloat16, 1); }
@@ -696,8 +1092,8 @@ BC_EXPORT int bc_grid_tables(const uint8_t *grid, int n_total, int32_t *grid_idx
     if (n_total <= 0) return BC_ERR_SHAPE;
     if (!grid || !grid_idx || !mapping_exec || !counts) return BC_ERR_NULL;
     if (prev_grid_idx && !transfer_idx) return BC_ERR_NULL;
-    ProfScope ps(BC_OP_GRID_TABLES, (hipStream_t)stream, 9.0 * n_total);
-    hipLaunchKernelGGL(k_grid_tables, dim3(1), dim3(1024), 0, (hipStream_t)stream, grid, n_total, grid_idx,
+    ProfScope ps(BC_OP_GRID_TABLES, 9.0 * n_total);
+    BC_LAUNCH(ps, k_grid_tables, dim3(1), dim3(1024), 0, (hipStream_t)stream, grid, n_total, grid_idx,
                        mapping_exec, prev_grid_idx, transfer_idx, counts);
     return launch_status();
 }

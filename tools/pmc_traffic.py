@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Per-launch HBM traffic of the block-copy kernels from two rocprofv3 --pmc runs (FETCH_SIZE and WRITE_SIZE cannot
+share a pass: MI355X_MICROARCH.md 'rocprofv3 PMC slots').
+
+usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> [out.json]
+Corrections for gfx950 as the guide prescribes: counter unit = KiB; FETCH_SIZE reports exactly half of the bytes of a
+wide coalesced read stream, so it is doubled; WRITE_SIZE is exact for 16-byte-per-lane stores."""
+import collections
+import csv
+import json
+import re
+import sys
+
+
+def per_kernel(path, counter):
+    acc = collections.defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(path)):
+        if r.get("Counter_Name") != counter:
+            continue
+        a = acc[(r["Kernel_Name"], int(r["Grid_Size"]))]
+        a[0] += float(r["Counter_Value"])
+        a[1] += 1
+    return acc
+
+
+def main():
+    fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
+    write = per_kernel(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    for key in sorted(set(fetch) | set(write)):
+        name, grid = key
+        m = re.search(r"\(anonymous namespace\)::(k_\w+(?:<[^(]*>)?)\(", name)
+        if not m:
+            continue
+        short = m.group(1) + f" grid={grid}"
+        f, fn = fetch.get(key, [0, 0])
+        w, wn = write.get(key, [0, 0])
+        n = max(fn, wn, 1)
+        rd, wr = 2.0 * f * 1024 / max(fn, 1), w * 1024 / max(wn, 1)
+        out[short] = dict(launches=n, read_bytes_per_launch=rd, write_bytes_per_launch=wr, hbm_bytes_per_launch=rd + wr)
+        print(f"{short:40s} launches {n:6d}  read {rd / 1e6:9.2f} MB  write {wr / 1e6:9.2f} MB  total {(rd + wr) / 1e6:9.2f} MB per launch")
+    if len(sys.argv) > 3:
+        # bench.py's roofline kernel: the C2 logits map (1,19,256,512) f32 = 622592 16-byte vectors, 4 per lane
+        cc = next((v for k, v in out.items() if k.startswith("k_combine_copy") and k.endswith("grid=155648")), None)
+        with open(sys.argv[3], "w") as fjson:
+            json.dump({"k_combine_copy_bytes_per_launch": cc["hbm_bytes_per_launch"] if cc else None,
+                       "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of tools/pmc_driver.py (same kernel, same shape as bench.py's); FETCH_SIZE x2 (gfx950), KiB units",
+                       "kernels": out}, fjson, indent=1)
+
+
+if __name__ == "__main__":
+    main()
