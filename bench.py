@@ -51,20 +51,6 @@ def parse_args():
     return ap.parse_args()
 
 
-def dist_env():
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    return rank, world, local
-
-
-def barrier_sync(world, device):
-    torch.cuda.synchronize(device)
-    if world > 1:
-        torch.distributed.barrier()
-        torch.cuda.synchronize(device)
-
-
 def cpu_dense_baseline(args, n_frames):
     """'Reference on the host CPU cores, block execution disabled': dense SwiftNet fp32 through PyTorch CPU convs
     (oneDNN) on all host cores, BN folded, no_grad; bounded sample."""
@@ -126,8 +112,10 @@ def pmc_traffic():
 
 
 def main():
+    from bc_workloads import replicas
+
     args = parse_args()
-    rank, world, local = dist_env()
+    rank, world, local = replicas.dist_env()
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
@@ -162,21 +150,17 @@ def main():
 
     be.prof_reset()
     be.prof_enable(["combine_copy"])
-    barrier_sync(world, device)
+    replicas.barrier(world, device)
     t0 = time.perf_counter()
     for i in range(args.steps):
         harness.run_clip(model, clips[i % n_distinct])
-    barrier_sync(world, device)
+    replicas.barrier(world, device)
     elapsed = time.perf_counter() - t0
     be.prof_enable([])
     cc = be.prof_read("combine_copy")
 
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
-    frames_total = world * args.steps * CLIP_LEN
-    fps = frames_total / elapsed
+    # whole-job throughput: all ranks' frames / slowest rank's time (no collective on the data path)
+    fps, elapsed, frames_total = replicas.job_throughput(args.steps * CLIP_LEN, elapsed, world, device)
     exec_frac = model.policy.stats.get_exec_percentage()
 
     extra = {}

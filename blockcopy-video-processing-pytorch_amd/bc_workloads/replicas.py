@@ -1,0 +1,42 @@
+"""Clip-parallel replicas: the only multi-GPU form of this path.
+
+A clip is the unit of temporal state (``reset_temporal()`` per clip, reference test_swiftnet.py:181-182) and clips share
+nothing but read-only weights, so N GPUs run N independent replicas: clip i of a job goes to rank i mod N, there is no
+collective on the data path, and the job's throughput is (all frames) / (slowest rank's time).  ``torch.distributed``
+is used only to bracket the clock (barrier + MAX all-reduce of one scalar)."""
+from __future__ import annotations
+
+import os
+from typing import List
+
+import torch
+
+
+def dist_env():
+    """(rank, world_size, local_rank) from the torchrun environment (1 process when absent)."""
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def clips_for_rank(n_clips: int, rank: int, world: int) -> List[int]:
+    """Indices of the job's clips processed by ``rank`` (round-robin)."""
+    return [i for i in range(n_clips) if i % world == rank]
+
+
+def barrier(world: int, device=None):
+    if device is not None and torch.device(device).type == "cuda":
+        torch.cuda.synchronize(device)
+    if world > 1:
+        torch.distributed.barrier()
+        if device is not None and torch.device(device).type == "cuda":
+            torch.cuda.synchronize(device)
+
+
+def job_throughput(frames_local: int, elapsed_local: float, world: int, device="cpu"):
+    """(frames/s of the whole job, slowest rank's seconds, total frames): SUM of frames over ranks / MAX of time."""
+    if world == 1:
+        return frames_local / elapsed_local, elapsed_local, frames_local
+    t = torch.tensor([elapsed_local], dtype=torch.float64, device=device)
+    f = torch.tensor([float(frames_local)], dtype=torch.float64, device=device)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    torch.distributed.all_reduce(f, op=torch.distributed.ReduceOp.SUM)
+    return float(f.item()) / float(t.item()), float(t.item()), int(f.item())
