@@ -42,6 +42,9 @@ def parse_args():
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--block-size", type=int, default=128)
     ap.add_argument("--target", type=float, default=0.5)
+    ap.add_argument("--policy", default="fixed", choices=["fixed", "random", "all", "rl_semseg"],
+                    help="fixed = seeded fixed-fraction mask (config C2, the headline); rl_semseg = online-trained policy (C3)")
+    ap.add_argument("--train-interval", type=int, default=3)
     ap.add_argument("--engine", default="fused", choices=["fused", "reference"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense", action="store_true", help="skip the dense-GPU comparison run")
@@ -135,9 +138,9 @@ def main():
     shape = (1, 3, args.height, args.width)
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
 
-    model = harness.build_model(args.backbone, block_policy="fixed", block_size=args.block_size, block_target=args.target,
+    model = harness.build_model(args.backbone, block_policy=args.policy, block_size=args.block_size, block_target=args.target,
                                 device=device, dtype=dtype, seed=1000 * rank,
-                                block_graph=args.graph)
+                                block_graph=args.graph, block_train_interval=args.train_interval)
     # per-rank clips (clip i of the job lives on rank i mod N); inputs resident in HBM before the clock starts
     n_distinct = 2
     clips = [harness.synthetic_clip(CLIP_LEN, shape, seed=(rank * n_distinct + c) * 100, device=device, dtype=dtype) for c in range(n_distinct)]
@@ -206,8 +209,8 @@ def main():
             "metric": METRIC, "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16" if args.half else "f32", "data": "synthetic",
-            "config": {"workload": f"C2: SwiftNet-{args.backbone} {shape[0]}x3x{args.height}x{args.width} synthetic clips of {CLIP_LEN} frames, "
-                                   f"block {args.block_size}, fixed {args.target:.0%} seeded mask (frame 0 of each clip all-active), "
+            "config": {"workload": f"{'C2' if args.policy == 'fixed' else 'C3' if args.policy == 'rl_semseg' else args.policy}: SwiftNet-{args.backbone} {shape[0]}x3x{args.height}x{args.width} synthetic clips of {CLIP_LEN} frames, "
+                                   f"block {args.block_size}, policy {args.policy} target {args.target:.0%} (frame 0 of each clip all-active), "
                                    f"{args.engine} engine{' + hipGraph replay' if args.graph else ''}, name-seeded weights, BN folded; step = 1 clip",
                        "clips_per_rank": args.steps, "parallelism": f"{world} independent replica(s), no collective",
                        "exec_fraction": exec_frac, "warmup_s": warm_s},

@@ -244,10 +244,55 @@ def gen_keys(ref):
     print("swiftnet_keys.json", {k: len(v) for k, v in out.items()})
 
 
+# ----------------------------------------------------------------------------- E. one online-RL policy run (config C3)
+def gen_rl(ref):
+    """4 frames of SwiftNet-RN18 under the reference's rl_semseg policy (PolicyTrainRL + PolicyNet +
+    InformationGainSemSeg + RMSprop), train_interval 2.  Seeds: torch/random = 0 right before the first frame; the
+    policy net gets name-seeded weights so the fixture does not depend on constructor RNG order."""
+    import random
+    import warnings
+
+    N, H, W, bs = 1, 128, 256, 32
+    with quiet():
+        bb = ref.resnet.resnet18(pretrained=False)
+        model = ref.swiftnet.SwiftNet(backbone=bb, num_classes=19, num_features=128, use_spp=True)
+        model.load_state_dict(seeded.name_seeded_state_dict(model.state_dict()), strict=True)
+        model.eval()
+        st = dict(SETTINGS, block_policy="rl_semseg", block_size=bs, block_target=0.4, block_train_interval=2)
+        wrapped = ref.bc.BlockCopyModel(model, st)
+        wrapped.policy.net.load_state_dict(seeded.name_seeded_state_dict(wrapped.policy.net.state_dict()))
+        wrapped = ref.bn_fusion.fuse_bn_recursively(wrapped)
+    assert wrapped.policy.net.training
+    torch.manual_seed(0)
+    random.seed(0)
+    wrapped.reset_temporal()
+    out = {"cfg": np.frombuffer(json.dumps(dict(N=N, H=H, W=W, block_size=bs, n_frames=4, block_target=0.4, train_interval=2,
+                                                frame_seed0=4242)).encode(), dtype=np.uint8)}
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for t in range(4):
+            x = seeded.synthetic_frame(4242 + t, (N, 3, H, W))
+            y = wrapped(x)
+            pm = wrapped.policy_meta
+            out[f"grid{t}"] = pm["grid"].numpy().copy()
+            out[f"logits{t}"] = y.detach().numpy().copy()
+            if t > 0:
+                out[f"grid_probs{t}"] = pm["grid_probs"].detach().numpy().copy()
+            if "information_gain" in pm and wrapped.clip_length % 2 == 0:
+                out[f"information_gain{t}"] = pm["information_gain"].detach().numpy().copy()
+            out[f"running_cost{t}"] = np.float64(wrapped.policy.running_cost)
+    sd = wrapped.policy.net.state_dict()
+    out["policy_abs_sum_after"] = np.float64(sum(float(v.double().abs().sum()) for k, v in sd.items() if v.dtype.is_floating_point))
+    out["policy_conv1_after"] = sd["backbone.conv1.weight"].numpy().copy()
+    np.savez_compressed(os.path.join(GOLD, "rl_semseg_run.npz"), **out)
+    print("rl_semseg_run.npz exec per frame:", [int(out[f"grid{t}"].sum()) for t in range(4)], "running_cost", float(out["running_cost3"]))
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     ref = ref_loader.load_reference()
     gen_keys(ref)
+    gen_rl(ref)
     gen_index_tables(ref)
     gen_ops(ref)
     check_properties(ref)

@@ -249,3 +249,60 @@ def test_persistent_state_pipeline_matches_reference_on_cpu(golden_dir, oracle_b
     errs, fs_errs = run_golden_clip(G, cfg, "cpu", "fused", graph=1, repeats=2)
     assert len(errs) == 2 * cfg["n_frames"] and max(errs) <= 2e-5, errs
     assert all(e == 0.0 for e in fs_errs)
+
+
+def _rl_model(cfg, device, graph=0):
+    import blockcopy
+    from blockcopy.core.argparser import default_settings
+    from bc_workloads import seeded
+    from bc_workloads.bn_fold import fold_batchnorm
+    from bc_workloads.swiftnet import build_swiftnet
+
+    net = build_swiftnet("resnet18")
+    net.load_state_dict(seeded.name_seeded_state_dict(net.state_dict()), strict=True)
+    net.eval()
+    st = default_settings(block_policy="rl_semseg", block_size=cfg["block_size"], block_target=cfg["block_target"],
+                          block_train_interval=cfg["train_interval"], block_graph=graph)
+    model = blockcopy.BlockCopyModel(net, st)
+    model.policy.net.load_state_dict(seeded.name_seeded_state_dict(model.policy.net.state_dict()))
+    model = fold_batchnorm(model.to(device))
+    assert model.policy.net.training   # the policy net trains online; only the base model is in eval mode
+    return model
+
+
+def test_rl_policy_loop_matches_reference(golden_dir, oracle_backend):
+    """Config C3 plumbing: PolicyTrainRL + PolicyNet + InformationGainSemSeg + RMSprop for 4 frames with the reference's
+    seeds reproduce its sampled grids, probabilities, information gain, running cost and weight update.
+
+    RMSprop's first steps are sign-like (step ~ lr / sqrt(1 - alpha) whatever the gradient magnitude), so weights whose
+    gradient is ~0 may step the other way under 1e-6 input noise: after the first update the comparison is on the
+    update direction (cosine / sign agreement) and on loose probabilities; before it, everything is tight."""
+    import random
+
+    from bc_workloads import seeded
+
+    G, cfg = load_golden(golden_dir, "rl_semseg_run.npz")
+    model = _rl_model(cfg, "cpu")
+    w0 = model.policy.net.state_dict()["backbone.conv1.weight"].clone()
+    torch.manual_seed(0)
+    random.seed(0)
+    model.reset_temporal()
+    with torch.no_grad():
+        for t in range(cfg["n_frames"]):
+            y = model(seeded.synthetic_frame(cfg["frame_seed0"] + t, (cfg["N"], 3, cfg["H"], cfg["W"])))
+            pm = model.policy_meta
+            assert np.array_equal(pm["grid"].numpy(), G[f"grid{t}"]), t          # same Bernoulli samples + quantisation
+            assert float((y - torch.from_numpy(G[f"logits{t}"])).abs().max()) <= 2e-5
+            if t > 0:
+                tight = t == 1   # no optimiser step has happened yet
+                assert np.allclose(pm["grid_probs"].detach().numpy(), G[f"grid_probs{t}"], rtol=2e-3 if tight else 0, atol=1e-6 if tight else 0.05)
+            if f"information_gain{t}" in G.files:
+                assert np.allclose(pm["information_gain"].detach().numpy(), G[f"information_gain{t}"], rtol=1e-3, atol=1e-6)
+            assert abs(model.policy.running_cost - float(G[f"running_cost{t}"])) < 1e-12
+    w1 = model.policy.net.state_dict()["backbone.conv1.weight"]
+    d_me, d_ref = (w1 - w0).numpy().ravel(), (G["policy_conv1_after"] - w0.numpy()).ravel()
+    assert np.linalg.norm(d_ref) > 0.05   # the policy did train (two RMSprop steps)
+    assert float(d_me @ d_ref / np.linalg.norm(d_me) / np.linalg.norm(d_ref)) > 0.95
+    assert float(np.mean(np.sign(d_me) == np.sign(d_ref))) > 0.98
+    assert set(pm) >= {"frame_state", "grid", "grid_log_probs", "grid_probs", "information_gain", "inputs", "num_exec", "num_total",
+                       "output_repr", "outputs", "outputs_prev", "perc_exec"}
