@@ -19,8 +19,8 @@ import torch
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("BLOCKCOPY_HIP_LIB", os.path.join(_PKG_ROOT, "lib", "libblockcopy_hip.so"))
 
-OP_SPLIT, OP_COMBINE, OP_TRANSFER, OP_PAD, OP_COMBINE_COPY, OP_PAD_RING, OP_GRID_TABLES, OP_INTERP = range(8)
-OP_NAMES = ("split", "combine", "transfer", "pad", "combine_copy", "pad_ring", "grid_tables", "interp")
+OP_SPLIT, OP_COMBINE, OP_TRANSFER, OP_PAD, OP_COMBINE_COPY, OP_PAD_RING, OP_GRID_TABLES, OP_INTERP, OP_AFFINE = range(9)
+OP_NAMES = ("split", "combine", "transfer", "pad", "combine_copy", "pad_ring", "grid_tables", "interp", "affine")
 _DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 ABI_VERSION = 1
 
@@ -55,6 +55,8 @@ def load_library(path: str = None) -> ctypes.CDLL:
         "bc_grid_tables": [p, i, p, p, p, p, p, p],
         "bc_grid_tables_host": [p, i, p, p, p, p],
         "bc_interp_bilinear": [p, p, ctypes.c_longlong, i, i, i, i, i, ctypes.c_float, ctypes.c_float, i, p],
+        "bc_pad_ring_act": [p, p, p, p, p] + [i] * 8 + [p, p, i, p],
+        "bc_affine_act": [p, p, p, p, p, i, ctypes.c_longlong, i, ctypes.c_longlong, i, p],
         "bc_abi_version": [],
         "bc_prof_enable": [u],
         "bc_prof_reset": [],
@@ -171,8 +173,9 @@ class HipBackend:
                         "combine_copy")
         return out
 
-    def pad_ring(self, data_exec, ring, grid_idx, mapping_exec, pad):
-        """halo gather over the persistent ring cache (+ refresh of the executed tiles' rings)."""
+    def pad_ring(self, data_exec, ring, grid_idx, mapping_exec, pad, prologue=None):
+        """halo gather over the persistent ring cache (+ refresh of the executed tiles' rings).
+        prologue = (scale, shift, relu): per-channel fp32 affine + ReLU fused into the gather (ring keeps raw values)."""
         assert _ok(data_exec) and _ok(ring, data_exec.dtype) and _ok(mapping_exec, torch.int32) and _ok(grid_idx, torch.int32)
         N, _, GH, GW = grid_idx.shape
         B, C, bs, _ = data_exec.shape
@@ -182,10 +185,39 @@ class HipBackend:
         out = torch.empty((B, C, bs + 2 * pad, bs + 2 * pad), device=data_exec.device, dtype=data_exec.dtype)
         if n_exec > 0:
             with torch.cuda.device_of(data_exec):
-                self._check(self.lib.bc_pad_ring(out.data_ptr(), data_exec.data_ptr(), ring.data_ptr(), grid_idx.data_ptr(),
-                                                 mapping_exec.data_ptr(), n_exec, N, C, GH, GW, bs, int(pad),
-                                                 out.element_size(), self._stream()), "pad_ring")
+                if prologue is None:
+                    self._check(self.lib.bc_pad_ring(out.data_ptr(), data_exec.data_ptr(), ring.data_ptr(), grid_idx.data_ptr(),
+                                                     mapping_exec.data_ptr(), n_exec, N, C, GH, GW, bs, int(pad),
+                                                     out.element_size(), self._stream()), "pad_ring")
+                else:
+                    scale, shift, relu = prologue
+                    for v in (scale, shift):
+                        assert v is None or (_ok(v, torch.float32) and v.numel() == C)
+                    self._check(self.lib.bc_pad_ring_act(out.data_ptr(), data_exec.data_ptr(), ring.data_ptr(), grid_idx.data_ptr(),
+                                                         mapping_exec.data_ptr(), n_exec, N, C, GH, GW, bs, int(pad),
+                                                         _DTYPE_CODE[data_exec.dtype],
+                                                         scale.data_ptr() if scale is not None else None,
+                                                         shift.data_ptr() if shift is not None else None, int(bool(relu)),
+                                                         self._stream()), "pad_ring_act")
         return out
+
+    def affine_act(self, data, scale=None, shift=None, add=None, relu=False):
+        """relu?(data*scale[c] + shift[c] + add) on a packed (B,C,h,w) tensor in one pass (fp32 arithmetic)."""
+        assert _ok(data, *_DTYPE_CODE) and data.dim() == 4
+        B, C, h, w = data.shape
+        for v in (scale, shift):
+            assert v is None or (_ok(v, torch.float32) and v.numel() == C)
+        assert add is None or (_ok(add, data.dtype) and add.shape == data.shape)
+        out = torch.empty_like(data)
+        if data.numel() > 0:
+            with torch.cuda.device_of(data):
+                self._check(self.lib.bc_affine_act(out.data_ptr(), data.data_ptr(), add.data_ptr() if add is not None else None,
+                                                   scale.data_ptr() if scale is not None else None,
+                                                   shift.data_ptr() if shift is not None else None, int(bool(relu)),
+                                                   B, C, h * w, _DTYPE_CODE[data.dtype], self._stream()), "affine_act")
+        return out
+
+    supports_fusion_dtypes = tuple(_DTYPE_CODE)
 
     def interp_bilinear(self, data, out_h, out_w, align_corners, rh, rw):
         """per-tile bilinear resampling (planes = all leading dims); arithmetic of torch's upsample_bilinear2d."""

@@ -1,0 +1,126 @@
+"""Pending elementwise work on a packed tensor (SURVEY.md section 8(f)-3 "fused per-block ops around the convs").
+
+Between two convs a CNN runs bias add / batch-norm / residual add / ReLU as separate launches; on the packed batch each
+of them is a 5-7 us kernel that re-reads and re-writes the whole activation (~75 launches and ~0.6 ms per SwiftNet-RN18
+frame at C2).  The engine instead records them on the TensorWrapper as
+
+        value = relu?( raw * scale[c] + shift[c] + add )
+
+and folds the record into the next consumer: the halo gather of a padded op applies (scale, shift, relu) to the values
+it gathers (``bc_pad_ring_act``), anything else triggers ONE fused pass (``bc_affine_act``).  Inference only: the
+per-channel vectors are derived from module parameters once and cached.
+"""
+from __future__ import annotations
+
+import os
+import weakref
+
+import torch
+
+ENABLED = os.environ.get("BLOCKCOPY_FUSE", "1") != "0"
+
+
+def set_enabled(flag: bool) -> bool:
+    global ENABLED
+    prev, ENABLED = ENABLED, bool(flag)
+    return prev
+
+
+class Pending:
+    __slots__ = ("scale", "shift", "add", "relu")
+
+    def __init__(self, scale=None, shift=None, add=None, relu=False):
+        self.scale, self.shift, self.add, self.relu = scale, shift, add, relu
+
+    def copy(self):
+        return Pending(self.scale, self.shift, self.add, self.relu)
+
+    @property
+    def affine_only(self):
+        return self.add is None and not self.relu
+
+
+_cache = {}
+
+
+def clear_cache():
+    """Forget derived per-channel vectors (call after changing weights of a wrapped model in place)."""
+    _cache.clear()
+
+
+def _key(*tensors):
+    # identity + storage address + version: a freed model's parameters may hand their addresses to a new model
+    return tuple((id(t), t.data_ptr(), t._version) if t is not None else None for t in tensors)
+
+
+def _lookup(k, tensors):
+    hit = _cache.get(k)
+    if hit is None:
+        return None
+    value, refs = hit
+    for r, t in zip(refs, tensors):
+        if (r is None) != (t is None) or (r is not None and r() is not t):
+            del _cache[k]      # stale: an id was recycled
+            return None
+    return value
+
+
+def _store(k, tensors, value):
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        return value   # memory of a graph's private pool must not outlive the capture as a cached constant
+    if len(_cache) > 4096:
+        _cache.clear()
+    _cache[k] = (value, tuple(weakref.ref(t) if t is not None else None for t in tensors))
+    return value
+
+
+def channel_vector(t: torch.Tensor) -> torch.Tensor:
+    """fp32 contiguous copy of a per-channel parameter, derived once per parameter object."""
+    k = ("vec",) + _key(t)
+    v = _lookup(k, (t,))
+    if v is None:
+        with torch.no_grad():
+            v = _store(k, (t,), t.detach().float().contiguous().clone() if t.dtype != torch.float32 else t.detach().contiguous())
+    return v
+
+
+def batchnorm_affine(running_mean, running_var, weight, bias, eps):
+    """Eval-mode batch norm as y = x*scale + shift."""
+    ts = (running_mean, running_var, weight, bias)
+    k = ("bn", float(eps)) + _key(*ts)
+    v = _lookup(k, ts)
+    if v is None:
+        with torch.no_grad():
+            inv = torch.rsqrt(running_var.detach().float() + eps)
+            scale = inv if weight is None else weight.detach().float() * inv
+            shift = -running_mean.detach().float() * scale
+            if bias is not None:
+                shift = shift + bias.detach().float()
+        v = _store(k, ts, (scale.contiguous(), shift.contiguous()))
+    return v
+
+
+def compose_affine(p_scale, p_shift, scale, shift):
+    """(x*p_scale + p_shift)*scale + shift  ->  (x*S + T); operands are cached vectors, so the result is cached too."""
+    ts = (p_scale, p_shift, scale, shift)
+    k = ("cmp",) + _key(*ts)
+    v = _lookup(k, ts)
+    if v is None:
+        with torch.no_grad():
+            S = scale if p_scale is None else p_scale * scale
+            T = shift if p_shift is None else p_shift * scale + shift
+        v = _store(k, ts, (S.contiguous(), T.contiguous()))
+    return v
+
+
+def add_shifts(a, b):
+    if a is None:
+        return b
+    if b is None:
+        return a
+    k = ("add",) + _key(a, b)
+    v = _lookup(k, (a, b))
+    if v is None:
+        with torch.no_grad():
+            v = _store(k, (a, b), (a + b).contiguous())
+    return v

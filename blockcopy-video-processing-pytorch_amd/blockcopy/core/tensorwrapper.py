@@ -31,6 +31,7 @@ from typing import Any, Callable, Dict, Optional, Tuple
 import numpy as np
 import torch
 
+from . import fusion
 from ..backend import get_backend
 from ..utils.block_funcs import CombineCopyFunction, CombineFunction, SplitFunction, TransferFunction
 from ..utils.blockpad import pad, pad_ring
@@ -249,6 +250,19 @@ class BlockFeatures:
         self.rings = []
 
 
+_FUSABLE = {"relu", "relu_", "batch_norm", "add", "add_", "__add__", "__iadd__"}
+
+
+def _materialize_args(items):
+    """Execute pending work of every TensorWrapper among (possibly nested) arguments."""
+    for a in items:
+        if isinstance(a, TensorWrapper):
+            if a._pending is not None:
+                a._materialize()
+        elif isinstance(a, (list, tuple)):
+            _materialize_args(a)
+
+
 def _find_wrapper(items):
     """First initialised TensorWrapper among (possibly nested) arguments."""
     found = None
@@ -270,6 +284,7 @@ class TensorWrapper(torch.Tensor):
     """torch.Tensor subclass carrying block metadata; packed tensors have shape (n_exec, C, bs, bs)."""
 
     is_init = False
+    _pending = None    # fusion.Pending: elementwise work recorded but not yet executed (packed tensors only)
 
     # ------------------------------------------------------------------ metadata
     def _init_metadata(self, other=None):
@@ -318,8 +333,53 @@ class TensorWrapper(torch.Tensor):
         return self._features
 
     def _plain(self) -> torch.Tensor:
+        """Plain-tensor view of the VALUE (pending elementwise work is executed first)."""
+        if self._pending is not None:
+            self._materialize()
         with _NoDispatch():
             return self.as_subclass(torch.Tensor)
+
+    def _raw(self) -> torch.Tensor:
+        """Plain-tensor view of the stored data, ignoring pending work."""
+        with _NoDispatch():
+            return self.as_subclass(torch.Tensor)
+
+    def _materialize(self) -> "TensorWrapper":
+        """Execute the pending affine/add/ReLU in ONE fused pass into a new buffer and rebind this tensor to it
+        (the raw buffer is left intact: other tensors may still refer to it)."""
+        P = self._pending
+        if P is None:
+            return self
+        self._pending = None
+        with _NoDispatch():
+            raw = self.as_subclass(torch.Tensor)
+            if not raw.is_contiguous():
+                raw = raw.contiguous()
+            add = P.add
+            if add is not None and not add.is_contiguous():
+                add = add.contiguous()
+            be = get_backend()
+            if raw.dtype in getattr(be, "supports_fusion_dtypes", ()):
+                out = be.affine_act(raw, P.scale, P.shift, add, P.relu)
+            else:   # exotic dtype: the same arithmetic with stock ops
+                out = raw.float()
+                if P.scale is not None:
+                    out = out * P.scale.view(1, -1, 1, 1)
+                if P.shift is not None:
+                    out = out + P.shift.view(1, -1, 1, 1)
+                if add is not None:
+                    out = out + add.float()
+                out = (torch.relu(out) if P.relu else out).to(raw.dtype)
+            self.data = out
+        return self
+
+    def _sibling(self, pending) -> "TensorWrapper":
+        """New TensorWrapper over the same stored data with its own pending record."""
+        with _NoDispatch():
+            out = self.as_subclass(torch.Tensor).as_subclass(TensorWrapper)
+        out._init_metadata(self)
+        out._pending = pending
+        return out
 
     @staticmethod
     def _wrap_like(t: torch.Tensor, like: "TensorWrapper", is_blocks: bool) -> "TensorWrapper":
@@ -390,6 +450,8 @@ class TensorWrapper(torch.Tensor):
             _, C, BS, _ = self.shape
             N, _, GH, GW = grid_idx.shape
             out_shape = (N, C, GH * BS, GW * BS)
+            if self._pending is not None:
+                self._materialize()
             blocks = self.as_subclass(torch.Tensor)
             if not blocks.is_contiguous():
                 blocks = blocks.contiguous()
@@ -456,9 +518,23 @@ class TensorWrapper(torch.Tensor):
                 self = _find_wrapper(tuple(kwargs.values()))
             assert self is not None and self.is_init, "TensorWrapper used before process_temporal_features/to_blocks"
 
+            pend = None
+            if self._is_blocks and fusion.ENABLED and self._features.engine == "fused" and op in _FUSABLE:
+                ret, pend, done = self._func_fused(op, func, args, kwargs)
+                if done:
+                    if isinstance(ret, TensorWrapper):
+                        return ret
+                    out = cls._wrap_result(ret, self)
+                    out._pending = pend
+                    return out
+            if op not in OPS["PADDED"]:
+                _materialize_args(args)
+                if kwargs:
+                    _materialize_args(tuple(kwargs.values()))
+
             if self._is_blocks and op in OPS_SPECIAL:
                 if op in OPS["PADDED"]:
-                    ret = self._func_replace_padding(op, func, args, kwargs)
+                    ret, pend = self._func_replace_padding(op, func, args, kwargs)
                 elif op in OPS["INTERPOLATE"]:
                     ret = self._func_interpolate(func, args, kwargs)
                 elif op in OPS["BATCHED"]:
@@ -473,8 +549,67 @@ class TensorWrapper(torch.Tensor):
                     warnings.warn(f"Operation {op} might behave differently with TensorWrapper!")
                     ret = func(*args, **kwargs)
             else:
+                if op in OPS["PADDED"]:
+                    _materialize_args(args)
                 ret = func(*args, **kwargs)
-            return cls._wrap_result(ret, self)
+            out = cls._wrap_result(ret, self)
+            if pend is not None:
+                out._pending = pend
+            return out
+
+    # ------------------------------------------------------------------ lazily fused elementwise ops
+    def _func_fused(self, op, func, args, kwargs):
+        """relu / eval batch-norm / residual add on packed tensors: record instead of launching.
+        Returns (result, pending, handled)."""
+        be = get_backend()
+        x = args[0]
+        if not isinstance(x, TensorWrapper) or x.dim() != 4 or x.dtype not in getattr(be, "supports_fusion_dtypes", ()):
+            return None, None, False
+        if op in ("relu", "relu_"):
+            inplace = op == "relu_" or bool(kwargs.get("inplace", args[1] if len(args) > 1 else False))
+            if inplace:
+                if x._pending is None:
+                    x._pending = fusion.Pending(relu=True)
+                else:
+                    x._pending.relu = True
+                return x, None, True
+            P = x._pending.copy() if x._pending is not None else fusion.Pending()
+            P.relu = True
+            return x._sibling(P), None, True
+        if op == "batch_norm":
+            # F.batch_norm(input, running_mean, running_var, weight=None, bias=None, training=False, momentum, eps)
+            rm = kwargs.get("running_mean", args[1] if len(args) > 1 else None)
+            rv = kwargs.get("running_var", args[2] if len(args) > 2 else None)
+            w = kwargs.get("weight", args[3] if len(args) > 3 else None)
+            b = kwargs.get("bias", args[4] if len(args) > 4 else None)
+            training = kwargs.get("training", args[5] if len(args) > 5 else False)
+            eps = kwargs.get("eps", args[7] if len(args) > 7 else 1e-5)
+            if training or rm is None or rv is None:
+                return None, None, False
+            scale, shift = fusion.batchnorm_affine(rm, rv, w, b, eps)
+            if x._pending is not None and not x._pending.affine_only:
+                x._materialize()
+            if x._pending is not None:
+                scale, shift = fusion.compose_affine(x._pending.scale, x._pending.shift, scale, shift)
+            return x._sibling(fusion.Pending(scale=scale, shift=shift)), None, True
+        # residual add:  x (+)= y
+        y = args[1] if len(args) > 1 else kwargs.get("other", None)
+        alpha = kwargs.get("alpha", args[2] if len(args) > 2 else 1)
+        inplace = op in ("add_", "__iadd__")
+        if (alpha != 1 or not isinstance(y, torch.Tensor) or y.shape != x.shape or y.dtype != x.dtype
+                or x._pending is None or not x._pending.affine_only):
+            return None, None, False
+        P = x._pending if inplace else x._pending.copy()
+        if isinstance(y, TensorWrapper) and y._pending is not None:
+            q = y._pending
+            if q.scale is None and q.affine_only:      # (raw_y + shift_y): fold the shift, add the raw tensor
+                P.shift = fusion.add_shifts(P.shift, q.shift)
+                P.add = y._raw()
+            else:
+                P.add = y._plain()
+        else:
+            P.add = y._raw() if isinstance(y, TensorWrapper) else y
+        return (x if inplace else x._sibling(P)), None, True
 
     @classmethod
     def _wrap_result(cls, ret, like):
@@ -489,10 +624,25 @@ class TensorWrapper(torch.Tensor):
         return ret
 
     def _func_replace_padding(self, op, func, args, kwargs):
-        """Run a padded op on the packed batch with its zero padding replaced by a gathered halo."""
-        if BLOCKPAD_WITH_ZEROES:
-            return func(*args, **kwargs)
+        """Run a padded op on the packed batch with its zero padding replaced by a gathered halo.
+        Returns (result, pending-for-the-result)."""
+        fuse = fusion.ENABLED and self._features.engine == "fused" and not BLOCKPAD_WITH_ZEROES
         args = list(args)
+        x = args[0]
+        pend_out = None
+        if fuse and op == "conv2d":
+            # conv bias -> pending per-channel shift on the result (folded into whatever consumes it)
+            bias = kwargs["bias"] if "bias" in kwargs else (args[2] if len(args) > 2 else None)
+            be = get_backend()
+            if bias is not None and isinstance(x, TensorWrapper) and x.dtype in getattr(be, "supports_fusion_dtypes", ()):
+                pend_out = fusion.Pending(shift=fusion.channel_vector(bias))
+                if "bias" in kwargs:
+                    kwargs = dict(kwargs, bias=None)
+                else:
+                    args[2] = None
+        if BLOCKPAD_WITH_ZEROES:
+            _materialize_args(args)
+            return func(*args, **kwargs), pend_out
         pos = _PADDING_POS.get(op, None)
         if "padding" in kwargs:
             padding = kwargs["padding"]
@@ -514,18 +664,27 @@ class TensorWrapper(torch.Tensor):
             padding = padding[0]
         padding = int(padding)
         if padding <= 0:
+            _materialize_args(args)
             with timings.env("tensorwrapper/pad_func0", 11):
-                return func(*args, **kwargs)
+                return func(*args, **kwargs), pend_out
 
-        data = args[0].as_subclass(torch.Tensor)
+        feats = self._features
+        prologue = None
+        if isinstance(x, TensorWrapper) and x._pending is not None:
+            P = x._pending
+            if fuse and P.add is None:
+                prologue = (P.scale, P.shift, P.relu)     # folded into the halo gather; x itself stays pending
+            else:
+                x._materialize()
+        _materialize_args(args[1:])
+        data = x._raw() if isinstance(x, TensorWrapper) else x
         if not data.is_contiguous():
             data = data.contiguous()
-        feats = self._features
         grid_idx, mapping_exec = feats._grid_idx, feats._mapping_exec
         if feats.engine == "fused":
             ring = feats.next_ring(data)
             with timings.env("tensorwrapper/pad", 10):
-                args[0] = pad_ring(data, ring, grid_idx, mapping_exec, padding)
+                args[0] = pad_ring(data, ring, grid_idx, mapping_exec, padding, prologue)
         else:
             data_transfer = self._transfer_from_prev()
             if data_transfer is None:
@@ -540,7 +699,7 @@ class TensorWrapper(torch.Tensor):
         else:
             args[pos] = zeros
         with timings.env("tensorwrapper/pad_func", 11):
-            return func(*args, **kwargs)
+            return func(*args, **kwargs), pend_out
 
     def _func_interpolate(self, func, args, kwargs):
         """Resampling runs per tile on the packed batch, i.e. WITHOUT halo: a tile's border pixels are interpolated

@@ -20,9 +20,10 @@ def pad(features, transfer, grid_idx, exec_map, pad=1):
     return BlockPadFunction.apply(features, transfer, grid_idx, exec_map, pad)
 
 
-def pad_ring(features, ring, grid_idx, exec_map, pad=1):
-    """Same result as transfer + pad of the reference, over a persistent per-layer ring cache."""
-    return BlockPadRingFunction.apply(features, ring, grid_idx, exec_map, pad)
+def pad_ring(features, ring, grid_idx, exec_map, pad=1, prologue=None):
+    """Same result as transfer + pad of the reference, over a persistent per-layer ring cache.
+    ``prologue`` = (scale, shift, relu) fuses a pending per-channel affine + ReLU into the gather."""
+    return BlockPadRingFunction.apply(features, ring, grid_idx, exec_map, pad, prologue)
 
 
 class BlockPadFunction(Function):
@@ -39,10 +40,10 @@ class BlockPadFunction(Function):
 
 class BlockPadRingFunction(Function):
     @staticmethod
-    def forward(ctx, data_exec, ring, grid_idx, mapping_exec, pad):
+    def forward(ctx, data_exec, ring, grid_idx, mapping_exec, pad, prologue=None):
         _warn_tiny(data_exec.shape[2])
         with timings.env("block/pad_kernel", 20):
-            return get_backend().pad_ring(data_exec, ring, grid_idx, mapping_exec, pad)
+            return get_backend().pad_ring(data_exec, ring, grid_idx, mapping_exec, pad, prologue)
 
     @staticmethod
     def backward(ctx, grad_x):

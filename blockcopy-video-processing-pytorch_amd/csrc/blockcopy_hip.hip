@@ -206,6 +206,55 @@ __global__ __launch_bounds__(WG) void k_transfer(typename VecOf<VB>::type *__res
     }
 }
 
+// ------------------------------------------------------------------------------------------ fused activation prologue
+// Optional per-channel affine + ReLU applied to every gathered REAL value inside the halo gather
+// (y = relu?(x*scale[c] + shift[c]), fp32 arithmetic): the BN->ReLU prologue of a pre-activation conv or the
+// bias+ReLU epilogue of the producing conv, fused into the copy.  Zeros written beyond the image border stay zero
+// (the padded op pads the ACTIVATED tensor) and the ring cache keeps RAW values, so the same transform applies to
+// values gathered in later frames.  DT: 0 = none (pure copy, bit-exact), 1 = f32, 2 = f16, 3 = bf16.
+struct Prologue {
+    const float *scale;   // may be null (= 1)
+    const float *shift;   // may be null (= 0)
+    int relu;
+};
+
+template <int DT, typename T> struct ActCvt;
+template <typename T> struct ActCvt<0, T> {
+    static __device__ __forceinline__ T apply(T v, float, float, int) { return v; }
+};
+template <> struct ActCvt<1, uint32_t> {
+    static __device__ __forceinline__ uint32_t apply(uint32_t v, float s, float t, int relu)
+    {
+        float x = __uint_as_float(v) * s + t;
+        if (relu) x = fmaxf(x, 0.0f);
+        return __float_as_uint(x);
+    }
+};
+template <> struct ActCvt<2, uint16_t> {
+    static __device__ __forceinline__ uint16_t apply(uint16_t v, float s, float t, int relu)
+    {
+        float x = __half2float(__ushort_as_half(v)) * s + t;
+        if (relu) x = fmaxf(x, 0.0f);
+        return __half_as_ushort(__float2half(x));
+    }
+};
+template <> struct ActCvt<3, uint16_t> {
+    static __device__ __forceinline__ uint16_t apply(uint16_t v, float s, float t, int relu)
+    {
+        float x = __uint_as_float((uint32_t)v << 16) * s + t;
+        if (relu) x = fmaxf(x, 0.0f);
+        hip_bfloat16 b(x);
+        return *reinterpret_cast<uint16_t *>(&b);
+    }
+};
+
+template <int DT> __device__ __forceinline__ void pro_coeffs(const Prologue &pr, uint32_t c, float &s, float &t)
+{
+    if (DT == 0) { s = 1.0f; t = 0.0f; return; }
+    s = pr.scale ? pr.scale[c] : 1.0f;
+    t = pr.shift ? pr.shift[c] : 0.0f;
+}
+
 // ------------------------------------------------------------------------------------------ halo gather
 struct HaloGeom {
     FastDiv PP, BSP, GW, GH;  // padded plane (bs+2p)^2, padded row bs+2p, grid dims
@@ -299,10 +348,10 @@ constexpr int HALO_UM = 4;          // middle-run vectors per lane
 constexpr int HALO_UE = 2;          // edge elements per lane
 constexpr int HALO_TBL = 128;       // bytes reserved at the start of dynamic LDS for the 3x3 neighbour table
 
-template <typename T, int VE, bool RING>
+template <typename T, int VE, bool RING, int DT>
 __global__ __launch_bounds__(WG) void k_halo_lds(T *__restrict__ out, const T *__restrict__ features, long long other_delta,
                                                  T *__restrict__ ring_w, const int32_t *__restrict__ grid_idx,
-                                                 const int32_t *__restrict__ mapping_exec, HaloLdsGeom g)
+                                                 const int32_t *__restrict__ mapping_exec, HaloLdsGeom g, Prologue pr)
 {
     typedef typename VecOf<VE * sizeof(T)>::type SV;   // source vector
     constexpr int DE = 16 / sizeof(T);                 // elements per drain vector
@@ -354,6 +403,7 @@ __global__ __launch_bounds__(WG) void k_halo_lds(T *__restrict__ out, const T *_
     SV vec[HALO_UM];
     T edge[HALO_UE];
     uint32_t fm[HALO_UM], zm[HALO_UM], rsel[HALO_UM], fe[HALO_UE], ze[HALO_UE];
+    float psm[HALO_UM], ptm[HALO_UM], pse[HALO_UE], pte[HALO_UE];
     long long roff[HALO_UM];
     {
         const uint32_t nitems = nrows * g.vpr.d;
@@ -364,6 +414,7 @@ __global__ __launch_bounds__(WG) void k_halo_lds(T *__restrict__ out, const T *_
             fd_divmod(it, g.vpr, ri, xv);
             const uint32_t r = r_lo + ri;
             fd_divmod(r, g.BSP, c, hp);
+            pro_coeffs<DT>(pr, c, psm[u], ptm[u]);
             const uint32_t sy = hp < p ? 0u : (hp >= p + bs ? 2u : 1u);
             const uint32_t hs = hp - p + bs - sy * bs;
             const uint32_t s = sy * 3 + 1;
@@ -385,6 +436,7 @@ __global__ __launch_bounds__(WG) void k_halo_lds(T *__restrict__ out, const T *_
             fd_divmod(it, g.P2, ri, e);
             const uint32_t r = r_lo + ri;
             fd_divmod(r, g.BSP, c, hp);
+            pro_coeffs<DT>(pr, c, pse[u], pte[u]);
             const uint32_t sy = hp < p ? 0u : (hp >= p + bs ? 2u : 1u);
             const uint32_t hs = hp - p + bs - sy * bs;
             const bool right = e >= p;
@@ -404,15 +456,15 @@ __global__ __launch_bounds__(WG) void k_halo_lds(T *__restrict__ out, const T *_
         for (int k = 0; k < VE; ++k) {
             const uint32_t f = fm[u] + k;
             const uint32_t j = (f >= f0 && f < f1) ? ph + (f - f0) : dummy;
-            img[j] = zm[u] ? (T)0 : e[k];
+            img[j] = zm[u] ? (T)0 : ActCvt<DT, T>::apply(e[k], psm[u], ptm[u], pr.relu);
         }
-        if (RING && rsel[u]) *reinterpret_cast<SV *>(ring_w + roff[u]) = vec[u];
+        if (RING && rsel[u]) *reinterpret_cast<SV *>(ring_w + roff[u]) = vec[u];   // ring keeps RAW values
     }
 #pragma unroll
     for (int u = 0; u < HALO_UE; ++u) {
         const uint32_t f = fe[u];
         const uint32_t j = (f >= f0 && f < f1) ? ph + (f - f0) : dummy;
-        img[j] = ze[u] ? (T)0 : edge[u];
+        img[j] = ze[u] ? (T)0 : ActCvt<DT, T>::apply(edge[u], pse[u], pte[u], pr.relu);
     }
     __syncthreads();
 
@@ -463,10 +515,10 @@ template <typename T> struct RowVec<T, 1> {
     typedef T packed_t;
 };
 
-template <typename T, int VE, bool RING>
+template <typename T, int VE, bool RING, int DT>
 __global__ __launch_bounds__(WG) void k_halo_rows(T *__restrict__ out, const T *__restrict__ features, long long other_delta,
                                                   T *__restrict__ ring_w, const int32_t *__restrict__ grid_idx,
-                                                  const int32_t *__restrict__ mapping_exec, HaloRowsGeom g)
+                                                  const int32_t *__restrict__ mapping_exec, HaloRowsGeom g, Prologue pr)
 {
     typedef typename RowVec<T, VE>::aligned_t SV;
     typedef typename RowVec<T, VE>::packed_t SVU;
@@ -503,12 +555,14 @@ __global__ __launch_bounds__(WG) void k_halo_rows(T *__restrict__ out, const T *
         SV vec[HALO_UM];
         uint32_t dst[HALO_UM], in_tile[HALO_UM];
         bool zero[HALO_UM], rsel[HALO_UM];
+        float ps[HALO_UM], pt[HALO_UM];
 #pragma unroll
         for (int u = 0; u < HALO_UM; ++u) {
             const uint32_t it = min((blockIdx.x * HALO_UM + u) * WG + threadIdx.x, g.mid_items - 1);
             uint32_t rr, xv, c, hp;
             fd_divmod(it, g.vpr, rr, xv);
             fd_divmod(rr, g.BSP, c, hp);
+            pro_coeffs<DT>(pr, c, ps[u], pt[u]);
             const bool top = hp < p, bot = hp >= p + bs;
             const uint32_t hs = top ? hp + bs - p : (bot ? hp - p - bs : hp - p);
             in_tile[u] = c * g.plane + hs * bs + xv * VE;
@@ -520,9 +574,15 @@ __global__ __launch_bounds__(WG) void k_halo_rows(T *__restrict__ out, const T *
         }
 #pragma unroll
         for (int u = 0; u < HALO_UM; ++u) {
-            const SV v = zero[u] ? (SV)0 : vec[u];
+            SV v = vec[u];
+            if (RING && rsel[u]) *reinterpret_cast<SV *>(ring_w + ring_base + in_tile[u]) = v;   // ring keeps RAW values
+            if (DT != 0) {
+                T *e = reinterpret_cast<T *>(&v);
+#pragma unroll
+                for (int k = 0; k < VE; ++k) e[k] = ActCvt<DT, T>::apply(e[k], ps[u], pt[u], pr.relu);
+            }
+            if (zero[u]) v = (SV)0;
             *reinterpret_cast<SVU *>(out_t + dst[u]) = v;
-            if (RING && rsel[u]) *reinterpret_cast<SV *>(ring_w + ring_base + in_tile[u]) = v;
         }
     }
     // ---- edge elements (left/right neighbours and the four corners)
@@ -533,12 +593,14 @@ __global__ __launch_bounds__(WG) void k_halo_rows(T *__restrict__ out, const T *
             T val[HALO_UE];
             uint32_t dst[HALO_UE];
             bool zero[HALO_UE];
+            float ps[HALO_UE], pt[HALO_UE];
 #pragma unroll
             for (int u = 0; u < HALO_UE; ++u) {
                 const uint32_t it = min(base_it + u * WG + threadIdx.x, e1 - 1);
                 uint32_t rr, e, c, hp;
                 fd_divmod(it, g.P2, rr, e);
                 fd_divmod(rr, g.BSP, c, hp);
+                pro_coeffs<DT>(pr, c, ps[u], pt[u]);
                 const bool top = hp < p, bot = hp >= p + bs, right = e >= p;
                 const uint32_t hs = top ? hp + bs - p : (bot ? hp - p - bs : hp - p);
                 const uint32_t ws = right ? e - p : bs - p + e;
@@ -552,7 +614,7 @@ __global__ __launch_bounds__(WG) void k_halo_rows(T *__restrict__ out, const T *
                 dst[u] = rr * BSP + (right ? bs + e : e);
             }
 #pragma unroll
-            for (int u = 0; u < HALO_UE; ++u) out_t[dst[u]] = zero[u] ? (T)0 : val[u];
+            for (int u = 0; u < HALO_UE; ++u) out_t[dst[u]] = zero[u] ? (T)0 : ActCvt<DT, T>::apply(val[u], ps[u], pt[u], pr.relu);
         }
     }
 }
@@ -669,6 +731,42 @@ __global__ __launch_bounds__(WG) void k_interp_bilinear(T *__restrict__ out, con
                 if (q * Q + k < g.W) dst[k] = res[k];
         }
     }
+}
+
+
+// ------------------------------------------------------------------------------------------ fused elementwise epilogue
+// out = relu?(in * scale[c] + shift[c] + add) over a packed (B, C, h, w) tensor, fp32 arithmetic: replaces the separate
+// bias-add / batch-norm / residual-add / ReLU launches between two convs with ONE pass.
+struct AffineGeom {
+    FastDiv hwq, C;     // vectors per plane, channels
+    uint32_t total;     // B*C*hwq
+};
+
+template <typename T, int Q>
+__global__ __launch_bounds__(WG) void k_affine_act(T *__restrict__ out, const T *__restrict__ in, const T *__restrict__ add,
+                                                   const float *__restrict__ scale, const float *__restrict__ shift,
+                                                   int relu, AffineGeom g)
+{
+    typedef typename VecOf<sizeof(T) * Q>::type V;
+    const uint32_t i = blockIdx.x * WG + threadIdx.x;
+    if (i >= g.total) return;
+    uint32_t pl, q, b, c;
+    fd_divmod(i, g.hwq, pl, q);
+    fd_divmod(pl, g.C, b, c);
+    const float s = scale ? scale[c] : 1.0f, t = shift ? shift[c] : 0.0f;
+    V vi = reinterpret_cast<const V *>(in)[i];
+    V va = vi;
+    if (add) va = reinterpret_cast<const V *>(add)[i];
+    const T *xi = reinterpret_cast<const T *>(&vi), *xa = reinterpret_cast<const T *>(&va);
+    T res[Q];
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+        float x = Cvt<T>::ld(xi + k) * s + t;
+        if (add) x += Cvt<T>::ld(xa + k);
+        if (relu) x = fmaxf(x, 0.0f);
+        res[k] = Cvt<T>::st(x);
+    }
+    reinterpret_cast<V *>(out)[i] = *reinterpret_cast<const V *>(res);
 }
 
 // ------------------------------------------------------------------------------------------ host helpers
@@ -829,12 +927,14 @@ int halo_kernel_choice(double bytes)
     return o != HALO_AUTO ? o : (bytes < 30e6 ? HALO_ROWS : HALO_LDS);
 }
 
+// dt: 0 = pure copy, BC_F32+1 / BC_F16+1 / BC_BF16+1 = fused activation prologue in that dtype (ring form only)
 template <bool RING>
 int launch_halo(ProfScope &ps, void *out, const void *features, const void *other_r, void *ring_w, const int32_t *grid_idx,
                 const int32_t *mapping_exec, int n_exec, int N, int C, int GH, int GW, int bs, int pad, int E,
-                hipStream_t st)
+                hipStream_t st, int dt = 0, Prologue pr = Prologue{nullptr, nullptr, 0})
 {
-    const int choice = halo_kernel_choice(2.0 * n_exec * C * (double)(bs + 2 * pad) * (bs + 2 * pad) * E);
+    int choice = halo_kernel_choice(2.0 * n_exec * C * (double)(bs + 2 * pad) * (bs + 2 * pad) * E);
+    if (dt != 0 && choice == HALO_SIMPLE) choice = HALO_ROWS;   // the element-wise fallback has no prologue
     if ((E != 2 && E != 4) || choice == HALO_SIMPLE)
         return launch_halo_simple<RING>(ps, out, features, other_r, ring_w, grid_idx, mapping_exec, n_exec, N, C, GH, GW, bs, pad, E, st);
     const int vb = pick_vb((size_t)bs * E, {features, other_r, ring_w});
@@ -850,15 +950,17 @@ int launch_halo(ProfScope &ps, void *out, const void *features, const void *othe
         g.edge_per_wg = (g.edge_items + gx - 1) / gx;
         const dim3 grid(gx, (unsigned)n_exec);
         const long long delta = ((const char *)other_r - (const char *)features) / E;
-#define BC_HR(T_, VE_)                                                                                         \
-        BC_LAUNCH(ps, (k_halo_rows<T_, VE_, RING>), grid, dim3(WG), 0, st, (T_ *)out, (const T_ *)features, \
-                           delta, (T_ *)ring_w, grid_idx, mapping_exec, g)
+#define BC_HR(T_, VE_, DT_)                                                                                    \
+        BC_LAUNCH(ps, (k_halo_rows<T_, VE_, RING, DT_>), grid, dim3(WG), 0, st, (T_ *)out, (const T_ *)features, \
+                  delta, (T_ *)ring_w, grid_idx, mapping_exec, g, pr)
+#define BC_HR4(DT_) do { if (ve >= 4) BC_HR(uint32_t, 4, DT_); else if (ve == 2) BC_HR(uint32_t, 2, DT_); else BC_HR(uint32_t, 1, DT_); } while (0)
+#define BC_HR2(DT_) do { if (ve >= 8) BC_HR(uint16_t, 8, DT_); else if (ve == 4) BC_HR(uint16_t, 4, DT_);       \
+                         else if (ve == 2) BC_HR(uint16_t, 2, DT_); else BC_HR(uint16_t, 1, DT_); } while (0)
         const int ve = vb / E;
-        if (E == 4) {
-            if (ve >= 4) BC_HR(uint32_t, 4); else if (ve == 2) BC_HR(uint32_t, 2); else BC_HR(uint32_t, 1);
-        } else {
-            if (ve >= 8) BC_HR(uint16_t, 8); else if (ve == 4) BC_HR(uint16_t, 4); else if (ve == 2) BC_HR(uint16_t, 2); else BC_HR(uint16_t, 1);
-        }
+        if (E == 4) { if (RING && dt == 1) BC_HR4(1); else BC_HR4(0); }
+        else { if (RING && dt == 2) BC_HR2(2); else if (RING && dt == 3) BC_HR2(3); else BC_HR2(0); }
+#undef BC_HR2
+#undef BC_HR4
 #undef BC_HR
         return launch_status();
     }
@@ -873,6 +975,7 @@ int launch_halo(ProfScope &ps, void *out, const void *features, const void *othe
     // HALO_UM*WG middle vectors and HALO_UE*WG edge elements; (2) aim at >= ~2048 workgroups per launch.
     const uint64_t rows_mid = (uint64_t)HALO_UM * WG / g.vpr.d, rows_edge = (uint64_t)HALO_UE * WG / (2 * pad);
     const uint64_t rows_max = rows_mid < rows_edge ? rows_mid : rows_edge;
+    if (rows_max < 2 && dt != 0) return BC_ERR_SHAPE;
     if (rows_max < 2)
         return launch_halo_simple<RING>(ps, out, features, other_r, ring_w, grid_idx, mapping_exec, n_exec, N, C, GH, GW, bs, pad, E, st);
     uint64_t L = (rows_max - 1) * bsp;
@@ -886,15 +989,17 @@ int launch_halo(ProfScope &ps, void *out, const void *features, const void *othe
     const size_t lds = HALO_TBL + ((size_t)(g.L + 16 / E + 1) * E + 15) / 16 * 16;
     const dim3 grid(chunks, (unsigned)n_exec);
     const long long delta = ((const char *)other_r - (const char *)features) / E;
-#define BC_HL(T_, VE_)                                                                                         \
-    BC_LAUNCH(ps, (k_halo_lds<T_, VE_, RING>), grid, dim3(WG), lds, st, (T_ *)out, (const T_ *)features,  \
-                       delta, (T_ *)ring_w, grid_idx, mapping_exec, g)
+#define BC_HL(T_, VE_, DT_)                                                                                    \
+    BC_LAUNCH(ps, (k_halo_lds<T_, VE_, RING, DT_>), grid, dim3(WG), lds, st, (T_ *)out, (const T_ *)features,  \
+              delta, (T_ *)ring_w, grid_idx, mapping_exec, g, pr)
+#define BC_HL4(DT_) do { if (ve >= 4) BC_HL(uint32_t, 4, DT_); else if (ve == 2) BC_HL(uint32_t, 2, DT_); else BC_HL(uint32_t, 1, DT_); } while (0)
+#define BC_HL2(DT_) do { if (ve >= 8) BC_HL(uint16_t, 8, DT_); else if (ve == 4) BC_HL(uint16_t, 4, DT_);       \
+                         else if (ve == 2) BC_HL(uint16_t, 2, DT_); else BC_HL(uint16_t, 1, DT_); } while (0)
     const int ve = vb / E;
-    if (E == 4) {
-        if (ve >= 4) BC_HL(uint32_t, 4); else if (ve == 2) BC_HL(uint32_t, 2); else BC_HL(uint32_t, 1);
-    } else {
-        if (ve >= 8) BC_HL(uint16_t, 8); else if (ve == 4) BC_HL(uint16_t, 4); else if (ve == 2) BC_HL(uint16_t, 2); else BC_HL(uint16_t, 1);
-    }
+    if (E == 4) { if (RING && dt == 1) BC_HL4(1); else BC_HL4(0); }
+    else { if (RING && dt == 2) BC_HL2(2); else if (RING && dt == 3) BC_HL2(3); else BC_HL2(0); }
+#undef BC_HL2
+#undef BC_HL4
 #undef BC_HL
     return launch_status();
 }
@@ -933,7 +1038,7 @@ BC_EXPORT const char *bc_error_string(int code)
 
 BC_EXPORT const char *bc_op_name(int op)
 {
-    static const char *names[BC_OP_COUNT] = {"split", "combine", "transfer", "pad", "combine_copy", "pad_ring", "grid_tables", "interp"};
+    static const char *names[BC_OP_COUNT] = {"split", "combine", "transfer", "pad", "combine_copy", "pad_ring", "grid_tables", "interp", "affine"};
     return (op >= 0 && op < BC_OP_COUNT) ? names[op] : "?";
 }
 
@@ -1055,6 +1160,52 @@ BC_EXPORT int bc_pad_ring(void *out, const void *features, void *ring, const int
     ProfScope ps(BC_OP_PAD_RING, halo_bytes(n_exec, C, bs, pad, E));
     return launch_halo<true>(ps, out, features, ring, ring, grid_idx, mapping_exec, n_exec, N, C, GH, GW, bs, pad, E,
                              (hipStream_t)stream);
+}
+
+BC_EXPORT int bc_pad_ring_act(void *out, const void *features, void *ring, const int32_t *grid_idx,
+                              const int32_t *mapping_exec, int n_exec, int N, int C, int GH, int GW, int bs, int pad,
+                              int dtype, const float *scale, const float *shift, int relu, void *stream)
+{
+    if (dtype < BC_F32 || dtype > BC_BF16) return BC_ERR_ELEM;
+    const int E = dtype == BC_F32 ? 4 : 2;
+    int rc = check_halo(out, features, grid_idx, mapping_exec, n_exec, N, C, GH, GW, bs, pad, E);
+    if (rc != BC_OK || n_exec == 0) return rc;
+    if (!ring) return BC_ERR_NULL;
+    if (!aligned(ring, E)) return BC_ERR_ALIGN;
+    ProfScope ps(BC_OP_PAD_RING, halo_bytes(n_exec, C, bs, pad, E));
+    Prologue pr{scale, shift, relu};
+    const int dt = (scale || shift || relu) ? dtype + 1 : 0;
+    return launch_halo<true>(ps, out, features, ring, ring, grid_idx, mapping_exec, n_exec, N, C, GH, GW, bs, pad, E,
+                             (hipStream_t)stream, dt, pr);
+}
+
+BC_EXPORT int bc_affine_act(void *out, const void *in, const void *add, const float *scale, const float *shift, int relu,
+                            long long B, int C, long long hw, int dtype, void *stream)
+{
+    if (dtype < BC_F32 || dtype > BC_BF16) return BC_ERR_ELEM;
+    if (B < 0 || C <= 0 || hw <= 0) return BC_ERR_SHAPE;
+    if (B == 0) return BC_OK;
+    if (!out || !in) return BC_ERR_NULL;
+    const int E = dtype == BC_F32 ? 4 : 2;
+    if ((uint64_t)B * C * hw >= (1ull << 31)) return BC_ERR_RANGE;
+    if (!aligned(out, E) || !aligned(in, E) || !aligned(add, E)) return BC_ERR_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    int q = 16 / E;
+    while (q > 1 && ((hw % q) != 0 || !aligned(out, q * E) || !aligned(in, q * E) || !aligned(add, q * E))) q >>= 1;
+    AffineGeom g;
+    g.hwq = make_fd((uint32_t)(hw / q)); g.C = make_fd(C);
+    g.total = (uint32_t)((uint64_t)B * C * (hw / q));
+    const int grid = grid_exact(g.total, 1);
+    ProfScope ps(BC_OP_AFFINE, (add ? 3.0 : 2.0) * B * C * hw * E);
+#define BC_AF(T_, Q_) BC_LAUNCH(ps, (k_affine_act<T_, Q_>), dim3(grid), dim3(WG), 0, st, (T_ *)out, (const T_ *)in, (const T_ *)add, scale, shift, relu, g)
+#define BC_AFQ(T_, QMAX_) do { if (q == QMAX_) BC_AF(T_, QMAX_); else if (q == QMAX_ / 2) BC_AF(T_, QMAX_ / 2); \
+                               else if (QMAX_ >= 8 && q == 2) BC_AF(T_, 2); else BC_AF(T_, 1); } while (0)
+    if (dtype == BC_F32) BC_AFQ(float, 4);
+    else if (dtype == BC_F16) BC_AFQ(__half, 8);
+    else BC_AFQ(hip_bfloat16, 8);
+#undef BC_AFQ
+#undef BC_AF
+    return launch_status();
 }
 
 BC_EXPORT int bc_interp_bilinear(void *out, const void *in, long long planes, int h, int w, int H, int W,

@@ -113,12 +113,28 @@ enum { BC_F32 = 0, BC_F16 = 1, BC_BF16 = 2 };
 int bc_interp_bilinear(void *out, const void *in, long long planes, int h, int w, int H, int W,
                        int align_corners, float rh, float rw, int dtype, void *stream);
 
+/* fused per-block ops around the convs.  The reference runs bias / batch-norm / ReLU /
+ * residual add as separate PyTorch launches on the packed batch (core/tensorwrapper.py:478-527 passes them through);
+ * here the engine keeps them pending and folds them into these two entry points.
+ *
+ * bc_pad_ring_act = bc_pad_ring with an activation PROLOGUE: every gathered real value x of channel c becomes
+ * relu?(x*scale[c] + shift[c]) (fp32 arithmetic; scale/shift are float32[C] device vectors, either may be NULL),
+ * zeros beyond the image border stay zero, the ring cache keeps raw values.  With scale = shift = NULL and relu = 0
+ * it is the pure copy.
+ * bc_affine_act: out = relu?(in*scale[c] + shift[c] + add) over a packed (B,C,hw) tensor; add may be NULL; out may
+ * alias in. */
+int bc_pad_ring_act(void *out, const void *features, void *ring, const int32_t *grid_idx,
+                    const int32_t *mapping_exec, int n_exec, int N, int C, int GH, int GW, int bs, int pad,
+                    int dtype, const float *scale, const float *shift, int relu, void *stream);
+int bc_affine_act(void *out, const void *in, const void *add, const float *scale, const float *shift, int relu,
+                  long long B, int C, long long hw, int dtype, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * C. Introspection / measurement
  * ------------------------------------------------------------------------------------------- */
 
 enum { BC_OP_SPLIT = 0, BC_OP_COMBINE = 1, BC_OP_TRANSFER = 2, BC_OP_PAD = 3,
-       BC_OP_COMBINE_COPY = 4, BC_OP_PAD_RING = 5, BC_OP_GRID_TABLES = 6, BC_OP_INTERP = 7, BC_OP_COUNT = 8 };
+       BC_OP_COMBINE_COPY = 4, BC_OP_PAD_RING = 5, BC_OP_GRID_TABLES = 6, BC_OP_INTERP = 7, BC_OP_AFFINE = 8, BC_OP_COUNT = 9 };
 
 int bc_abi_version(void);
 const char *bc_error_string(int code);

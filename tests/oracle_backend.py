@@ -44,7 +44,7 @@ class OracleBackend:
             O.c_combine(blocks.contiguous(), out, mapping)
         return out
 
-    def pad_ring(self, data_exec, ring, grid_idx, mapping_exec, pad):
+    def pad_ring(self, data_exec, ring, grid_idx, mapping_exec, pad, prologue=None):
         gi = grid_idx.reshape(-1)
         skipped = torch.nonzero(gi < 0).squeeze(1)
         transfer = ring[skipped].contiguous()   # compacted in raster order == row (grid_idx + n_total)
@@ -53,8 +53,34 @@ class OracleBackend:
         m = torch.from_numpy(O.ring_mask(bs, pad))
         sel = ring[mapping_exec.long()]
         sel[:, :, m] = data_exec[:, :, m]
-        ring[mapping_exec.long()] = sel
+        ring[mapping_exec.long()] = sel       # the ring cache keeps RAW values
+        if prologue is not None:
+            # which padded positions hold real data (not image-border zeros)?  gather a tensor of ones the same way
+            real = self.pad(torch.ones_like(data_exec), torch.ones_like(transfer), grid_idx, mapping_exec, pad) == 1
+            scale, shift, relu = prologue
+            y = out.float()
+            if scale is not None:
+                y = y * scale.view(1, -1, 1, 1)
+            if shift is not None:
+                y = y + shift.view(1, -1, 1, 1)
+            if relu:
+                y = torch.relu(y)
+            out = torch.where(real, y.to(out.dtype), torch.zeros_like(out))
         return out
+
+    supports_fusion_dtypes = (torch.float32,)
+
+    def affine_act(self, data, scale=None, shift=None, add=None, relu=False):
+        y = data.float()
+        if scale is not None:
+            y = y * scale.view(1, -1, 1, 1)
+        if shift is not None:
+            y = y + shift.view(1, -1, 1, 1)
+        if add is not None:
+            y = y + add.float()
+        if relu:
+            y = torch.relu(y)
+        return y.to(data.dtype)
 
     supports_interp_dtypes = (torch.float32,)
 

@@ -275,3 +275,49 @@ def test_interpolate_routing_on_packed_tiles(be):
     assert float((up.as_subclass(torch.Tensor) - want).abs().max()) <= 2e-6
     nearest = F.interpolate(b, scale_factor=2, mode="nearest")
     assert torch.equal(nearest.as_subclass(torch.Tensor), F.interpolate(b.as_subclass(torch.Tensor), scale_factor=2, mode="nearest"))
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.float16, 2e-3), (torch.bfloat16, 2e-2)])
+def test_affine_act_matches_torch(be, dtype, tol):
+    """Fused epilogue kernel (floating point): relu?(x*scale[c] + shift[c] + add) vs stock PyTorch in fp32."""
+    from oracle_backend import OracleBackend
+
+    chk = OracleBackend()
+    g = torch.Generator().manual_seed(0)
+    for (B, C, h, w) in [(64, 64, 32, 32), (5, 7, 4, 4), (3, 5, 1, 1), (2, 3, 2, 2), (2, 4, 3, 5)]:
+        x = torch.randn((B, C, h, w), generator=g).to(dtype)
+        add = torch.randn((B, C, h, w), generator=g).to(dtype)
+        scale, shift = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+        for kw in (dict(scale=scale, shift=shift, relu=True), dict(shift=shift, add=add, relu=True), dict(shift=shift),
+                   dict(relu=True), dict(scale=scale, shift=shift, add=add, relu=False)):
+            want = chk.affine_act(x, **kw).float()
+            dev = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in kw.items()}
+            got = be.affine_act(x.cuda(), **dev)
+            assert got.dtype == dtype and got.shape == x.shape
+            assert float((got.float().cpu() - want).abs().max()) <= tol * max(1.0, float(want.abs().max())), (dtype, (B, C, h, w), list(kw))
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.float16, 2e-3)])
+def test_pad_ring_with_activation_prologue(be, dtype, tol):
+    """Halo gather with the fused affine+ReLU prologue over a 5-frame chain: gathered real values are transformed,
+    image-border zeros stay zero, the ring cache keeps raw values (so later frames transform them the same way)."""
+    from oracle_backend import OracleBackend
+
+    chk = OracleBackend()
+    g = torch.Generator().manual_seed(3)
+    # the last geometry is > 30 MB of traffic, i.e. it runs the LDS-staged kernel; the others the row kernel
+    for (N, C, GH, GW, bs, p) in [(1, 6, 3, 4, 8, 1), (2, 5, 2, 3, 4, 2), (1, 16, 2, 2, 32, 1), (1, 4, 3, 3, 2, 1), (1, 64, 4, 8, 64, 1)]:
+        scale, shift = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.5
+        ring_dev = torch.zeros((N * GH * GW, C, bs, bs), dtype=dtype).cuda()
+        ring_cpu = torch.zeros((N * GH * GW, C, bs, bs), dtype=dtype)
+        for grid in _grids(N, GH, GW, 5, 21):
+            gi, m = O.c_grid_mappings(grid)
+            feats = torch.randn((len(m), C, bs, bs), generator=g).to(dtype)
+            pro = (scale, shift, True)
+            want = chk.pad_ring(feats, ring_cpu, torch.from_numpy(gi), torch.from_numpy(m), p, pro)
+            got = be.pad_ring(_dev(feats), ring_dev, _dev(gi), _dev(m), p, (scale.cuda(), shift.cuda(), True))
+            assert float((got.float().cpu() - want.float()).abs().max()) <= tol * max(1.0, float(want.float().abs().max()))
+            # border zeros are exact zeros, and the ring holds raw (untransformed) values bit for bit
+            assert torch.equal(got.cpu() == 0, want == 0) or float(((got.cpu() == 0) != (want == 0)).float().mean()) < 1e-3
+            mask = torch.from_numpy(O.ring_mask(bs, p))
+            assert torch.equal(ring_dev.cpu()[:, :, mask], ring_cpu[:, :, mask])
