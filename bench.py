@@ -77,6 +77,16 @@ def cpu_dense_baseline(args, n_frames):
                       f"PyTorch CPU oneDNN conv, BN folded, after 1 warm-up frame ({dt:.1f} s)"}
 
 
+def config_name(args):
+    """Which BASELINE.json config the arguments correspond to."""
+    base = (args.backbone, args.height, args.width, args.block_size)
+    if base == ("resnet18", 1024, 2048, 128):
+        return "C2" if args.policy == "fixed" and args.target == 0.5 else ("C3" if args.policy == "rl_semseg" else "C2-variant")
+    if base == ("resnet50", 2048, 4096, 64) and args.policy == "fixed" and args.target == 0.25:
+        return "C4"
+    return "custom"
+
+
 def scatter_copy_large(be, device, iters=20):
     """The same fused scatter+copy kernel at the largest map of the configs (C5 detector head, (1,256,256,512) fp32,
     block 32, 64 of 128 tiles = 268 MB of traffic, beyond the 256 MiB Infinity Cache): the HBM-bound figure."""
@@ -209,7 +219,7 @@ def main():
             "metric": METRIC, "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16" if args.half else "f32", "data": "synthetic",
-            "config": {"workload": f"{'C2' if args.policy == 'fixed' else 'C3' if args.policy == 'rl_semseg' else args.policy}: SwiftNet-{args.backbone} {shape[0]}x3x{args.height}x{args.width} synthetic clips of {CLIP_LEN} frames, "
+            "config": {"workload": f"{config_name(args)}: SwiftNet-{args.backbone} {shape[0]}x3x{args.height}x{args.width} synthetic clips of {CLIP_LEN} frames, "
                                    f"block {args.block_size}, policy {args.policy} target {args.target:.0%} (frame 0 of each clip all-active), "
                                    f"{args.engine} engine{' + hipGraph replay' if args.graph else ''}, name-seeded weights, BN folded; step = 1 clip",
                        "clips_per_rank": args.steps, "parallelism": f"{world} independent replica(s), no collective",
