@@ -68,6 +68,7 @@ template <> struct VecOf<1> { typedef uint8_t type; };
 constexpr int WG = 256;          // 4 wavefronts
 constexpr int MAX_WG = 256 * 8;  // 8 resident workgroups per CU on 256 CUs
 constexpr int UNROLL = 4;
+constexpr uint32_t SMALL_LAUNCH_VECTORS = 256u * 8u * 256u * 2u;   // < 2 vectors per resident lane of the chip
 
 // ------------------------------------------------------------------------------------------ gather / scatter
 struct TileGeom {
@@ -80,7 +81,7 @@ struct TileGeom {
 // Each lane moves UNROLL vectors that are gridDim*WG apart (every memory instruction of a wave stays contiguous).
 // All index loads are issued first, then all payload loads, then the stores: no branch sits between a load and
 // its use, so the UNROLL requests of a lane are in flight together (tail lanes clamp their index).
-template <int VB, bool TO_PACKED>
+template <int VB, bool TO_PACKED, int U>
 __global__ __launch_bounds__(WG) void k_tiles(typename VecOf<VB>::type *__restrict__ packed_w,
                                               const typename VecOf<VB>::type *__restrict__ packed_r,
                                               typename VecOf<VB>::type *__restrict__ dense_w,
@@ -91,10 +92,10 @@ __global__ __launch_bounds__(WG) void k_tiles(typename VecOf<VB>::type *__restri
     const uint32_t stride = gridDim.x * WG;
     const uint32_t v0 = blockIdx.x * WG + threadIdx.x;
     const uint32_t last = g.total - 1;
-    uint32_t vc[UNROLL], rem[UNROLL], b[UNROLL], ig[UNROLL], di[UNROLL];
-    V val[UNROLL];
+    uint32_t vc[U], rem[U], b[U], ig[U], di[U];
+    V val[U];
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
+    for (int u = 0; u < U; ++u) {
         const uint32_t v = v0 + u * stride;
         vc[u] = v < last ? v : last;
         uint32_t r, xv, r2, h, c;
@@ -104,20 +105,20 @@ __global__ __launch_bounds__(WG) void k_tiles(typename VecOf<VB>::type *__restri
         rem[u] = (c * g.H + h) * g.vprW + xv;   // part of the dense index that does not depend on the tile position
     }
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) ig[u] = (uint32_t)mapping_exec[b[u]];
+    for (int u = 0; u < U; ++u) ig[u] = (uint32_t)mapping_exec[b[u]];
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
+    for (int u = 0; u < U; ++u) {
         uint32_t t, gw, n, gh;
         fd_divmod(ig[u], g.GW, t, gw);
         fd_divmod(t, g.GH, n, gh);
         di[u] = rem[u] + (n * g.C.d * g.H + gh * g.bsz) * g.vprW + gw * g.vpr.d;
     }
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) val[u] = TO_PACKED ? dense_r[di[u]] : packed_r[vc[u]];
+    for (int u = 0; u < U; ++u) val[u] = TO_PACKED ? dense_r[di[u]] : packed_r[vc[u]];
     // tail lanes carry the clamped (last) vector and store it again: same value to the same address, so the
     // stores need no predicate (a predicate here makes the compiler sink each load into its store's branch).
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
+    for (int u = 0; u < U; ++u) {
         if (TO_PACKED) packed_w[vc[u]] = val[u];
         else dense_w[di[u]] = val[u];
     }
@@ -130,7 +131,7 @@ struct DenseGeom {
     uint32_t total;               // N*C*H*vprW
 };
 
-template <int VB>
+template <int VB, int U>
 __global__ __launch_bounds__(WG) void k_combine_copy(const typename VecOf<VB>::type *__restrict__ blocks,
                                                      long long prev_delta,   // (prev - blocks) in vectors
                                                      typename VecOf<VB>::type *__restrict__ out,
@@ -142,11 +143,11 @@ __global__ __launch_bounds__(WG) void k_combine_copy(const typename VecOf<VB>::t
     const uint32_t stride = gridDim.x * WG;
     const uint32_t v0 = blockIdx.x * WG + threadIdx.x;
     const uint32_t last = g.total - 1;
-    uint32_t vc[UNROLL], tile[UNROLL], inner[UNROLL];
-    int32_t idx[UNROLL];
-    V val[UNROLL];
+    uint32_t vc[U], tile[U], inner[U];
+    int32_t idx[U];
+    V val[U];
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
+    for (int u = 0; u < U; ++u) {
         const uint32_t v = v0 + u * stride;
         vc[u] = v < last ? v : last;
         uint32_t r, xw, r2, y, n, c, gw, xv, gh, h;
@@ -159,15 +160,15 @@ __global__ __launch_bounds__(WG) void k_combine_copy(const typename VecOf<VB>::t
         inner[u] = (c * g.bs.d + h) * g.vpr.d + xv;   // vector offset inside a packed tile
     }
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) idx[u] = grid_idx[tile[u]];
+    for (int u = 0; u < U; ++u) idx[u] = grid_idx[tile[u]];
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
+    for (int u = 0; u < U; ++u) {
         const long long off = idx[u] >= 0 ? (long long)((uint32_t)idx[u] * g.C.d * g.bs.d * g.vpr.d + inner[u])
                                           : prev_delta + (long long)vc[u];
         val[u] = blocks[off];
     }
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) out[vc[u]] = val[u];   // clamped duplicates rewrite the same value (see k_tiles)
+    for (int u = 0; u < U; ++u) out[vc[u]] = val[u];   // clamped duplicates rewrite the same value (see k_tiles)
 }
 
 // ------------------------------------------------------------------------------------------ border-ring transfer
@@ -868,10 +869,18 @@ int launch_tiles(ProfScope &ps, void *packed, void *dense, const int32_t *mappin
     g.vpr = make_fd(vpr); g.bs = make_fd(bs); g.C = make_fd(C); g.GW = make_fd(W / bs); g.GH = make_fd(H / bs);
     g.H = H; g.bsz = bs; g.vprW = (uint32_t)((size_t)W * E / vb);
     g.total = (uint32_t)((uint64_t)n_exec * C * bs * vpr);
-    const int grid = grid_exact(g.total, UNROLL);
+    // small launches are one wave of workgroups: one vector per lane gives the shortest critical path;
+    // large ones amortise index math and keep UNROLL requests per lane in flight
+    const bool small = g.total < SMALL_LAUNCH_VECTORS;
+    const int grid = grid_exact(g.total, small ? 1 : UNROLL);
 #define BC_TILES(VB_)                                                                                          \
     case VB_:                                                                                                  \
-        BC_LAUNCH(ps, (k_tiles<VB_, TO_PACKED>), dim3(grid), dim3(WG), 0, st,                             \
+        if (small)                                                                                             \
+            BC_LAUNCH(ps, (k_tiles<VB_, TO_PACKED, 1>), dim3(grid), dim3(WG), 0, st,                           \
+                      (VecOf<VB_>::type *)packed, (const VecOf<VB_>::type *)packed,                            \
+                      (VecOf<VB_>::type *)dense, (const VecOf<VB_>::type *)dense, mapping_exec, g);            \
+        else                                                                                                   \
+        BC_LAUNCH(ps, (k_tiles<VB_, TO_PACKED, UNROLL>), dim3(grid), dim3(WG), 0, st,                     \
                            (VecOf<VB_>::type *)packed, (const VecOf<VB_>::type *)packed,                       \
                            (VecOf<VB_>::type *)dense, (const VecOf<VB_>::type *)dense, mapping_exec, g);       \
         break;
@@ -1085,11 +1094,17 @@ BC_EXPORT int bc_combine_copy(const void *blocks, const void *prev, void *out, c
     g.vprW = make_fd(vprW); g.H = make_fd(H); g.C = make_fd(C); g.vpr = make_fd(vpr); g.bs = make_fd(bs);
     g.GH = H / bs; g.GW = W / bs;
     g.total = (uint32_t)((uint64_t)N * C * H * vprW);
-    const int grid = grid_exact(g.total, UNROLL);
+    const bool small = g.total < SMALL_LAUNCH_VECTORS;
+    const int grid = grid_exact(g.total, small ? 1 : UNROLL);
     ProfScope ps(BC_OP_COMBINE_COPY, 2.0 * N * C * H * W * E);
 #define BC_CC(VB_)                                                                                             \
     case VB_:                                                                                                  \
-        BC_LAUNCH(ps, (k_combine_copy<VB_>), dim3(grid), dim3(WG), 0, st, (const VecOf<VB_>::type *)bl,   \
+        if (small)                                                                                             \
+            BC_LAUNCH(ps, (k_combine_copy<VB_, 1>), dim3(grid), dim3(WG), 0, st, (const VecOf<VB_>::type *)bl, \
+                      (long long)(((const char *)pv - (const char *)bl) / VB_), (VecOf<VB_>::type *)out,       \
+                      grid_idx, g);                                                                            \
+        else                                                                                                   \
+        BC_LAUNCH(ps, (k_combine_copy<VB_, UNROLL>), dim3(grid), dim3(WG), 0, st, (const VecOf<VB_>::type *)bl,   \
                            (long long)(((const char *)pv - (const char *)bl) / VB_), (VecOf<VB_>::type *)out,  \
                            grid_idx, g);                                                                       \
         break;
