@@ -181,7 +181,7 @@ class HipBackend:
         B, C, bs, _ = data_exec.shape
         n_exec = mapping_exec.numel()
         assert n_exec == B and pad > 0
-        assert tuple(ring.shape) == (N * GH * GW, C, bs, bs), (ring.shape, (N * GH * GW, C, bs, bs))
+        assert tuple(ring.shape) == (N * GH * GW, C, 4 * pad * bs), (ring.shape, (N * GH * GW, C, 4 * pad * bs))
         out = torch.empty((B, C, bs + 2 * pad, bs + 2 * pad), device=data_exec.device, dtype=data_exec.dtype)
         if n_exec > 0:
             with torch.cuda.device_of(data_exec):

@@ -144,7 +144,7 @@ class PersistentState:
 class BlockFeatures:
     """Per-frame block state: the execution grid with its index tables, plus the temporal feature store.
 
-    fused engine     : ``rings`` -- one persistent (n_total,C,bs,bs) ring cache per padded op, in call order,
+    fused engine     : ``rings`` -- one persistent (n_total,C,4*p*bs) compact ring cache per padded op, in call order,
                        handed from frame to frame;
     reference engine : FIFO of (computed, transfer, padding) per padded op as in the reference (:131-232);
     both             : FIFO of combined dense maps (``store_features_full``).
@@ -205,10 +205,11 @@ class BlockFeatures:
                 self.rings = meta_prev.rings   # ring caches persist across frames
 
     # ------------------------------------------------------------------ fused engine: ring caches
-    def next_ring(self, data: torch.Tensor) -> torch.Tensor:
-        """Ring cache of the padded op being executed (ops must come in the same order every frame)."""
+    def next_ring(self, data: torch.Tensor, padding: int) -> torch.Tensor:
+        """Ring cache of the padded op being executed (ops must come in the same order every frame).
+        Compact layout: per grid position and channel [top p rows | bottom p rows | left p cols | right p cols]."""
         _, C, bs, _ = data.shape
-        shape = (self.n_total, C, bs, bs)
+        shape = (self.n_total, C, 4 * padding * bs)
         if self.persistent is not None:
             return self.persistent.next_ring(shape, data.dtype, data.device)
         k = self._ring_pos
@@ -682,7 +683,7 @@ class TensorWrapper(torch.Tensor):
             data = data.contiguous()
         grid_idx, mapping_exec = feats._grid_idx, feats._mapping_exec
         if feats.engine == "fused":
-            ring = feats.next_ring(data)
+            ring = feats.next_ring(data, padding)
             with timings.env("tensorwrapper/pad", 10):
                 args[0] = pad_ring(data, ring, grid_idx, mapping_exec, padding, prologue)
         else:

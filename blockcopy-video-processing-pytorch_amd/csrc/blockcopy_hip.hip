@@ -257,6 +257,34 @@ template <int DT> __device__ __forceinline__ void pro_coeffs(const Prologue &pr,
 }
 
 // ------------------------------------------------------------------------------------------ halo gather
+// ------------------------------------------------------------------------------------------ compact ring cache layout
+// Per (grid position, channel) the ring cache stores only what a neighbour can ever need, as four contiguous segments
+// (RS = 4*p*bs elements):   T = rows [0,p)        at 0            (row-major, bs wide)
+//                           B = rows [bs-p,bs)    at p*bs
+//                           L = cols [0,p)        at 2*p*bs       (row-major, p wide)
+//                           R = cols [bs-p,bs)    at 2*p*bs+bs*p
+// so an executed tile refreshes its ring with full-line contiguous stores (a dense (bs,bs) ring layout made every
+// left/right column element its own partial cache line: +47 % write traffic by PMC), and a reader's halo column
+// becomes a contiguous run.  Source element (hs, ws) of a ring-resident neighbour in direction (sy, sx)
+// (0 = above/left, 1 = same row/col, 2 = below/right of the reader):
+__device__ __forceinline__ uint32_t ring_elem(uint32_t sy, uint32_t sx, uint32_t hs, uint32_t ws, uint32_t bs, uint32_t p)
+{
+    if (sy == 0) return p * bs + (hs - (bs - p)) * bs + ws;      // reader's top halo  <- neighbour's B rows
+    if (sy == 2) return hs * bs + ws;                            // reader's bottom halo <- neighbour's T rows
+    if (sx == 0) return 2 * p * bs + bs * p + hs * p + (ws - (bs - p));   // left halo  <- neighbour's R cols
+    return 2 * p * bs + hs * p + ws;                             // right halo <- neighbour's L cols
+}
+
+// refresh of the executed tile's own ring record from one of its elements (hs, ws); rec = ring + (g*C + c)*RS
+template <typename T>
+__device__ __forceinline__ void ring_store_elem(T *__restrict__ rec, uint32_t hs, uint32_t ws, uint32_t bs, uint32_t p, T v)
+{
+    if (hs < p) rec[hs * bs + ws] = v;
+    if (hs >= bs - p) rec[p * bs + (hs - (bs - p)) * bs + ws] = v;
+    if (ws < p) rec[2 * p * bs + hs * p + ws] = v;
+    if (ws >= bs - p) rec[2 * p * bs + bs * p + hs * p + (ws - (bs - p))] = v;
+}
+
 struct HaloGeom {
     FastDiv PP, BSP, GW, GH;  // padded plane (bs+2p)^2, padded row bs+2p, grid dims
     uint32_t C, bs, pad, n_total;
@@ -267,7 +295,7 @@ struct HaloGeom {
 // (C planes of (bs+2p)^2 elements).  The 3x3 neighbour table (which tensor, which row of it, or zero) is
 // resolved once per workgroup into LDS.  RING=false: reference repad semantics (neighbour rows of the
 // compacted `other` = transfer tensor).  RING=true: `other` is the persistent ring cache indexed by grid
-// position, and the tile's own border ring is written back to it.
+// position (compact layout above), and the tile's own border ring is written back to it.
 template <typename T, bool RING>
 __global__ __launch_bounds__(WG) void k_halo(T *__restrict__ out, const T *__restrict__ features,
                                              const T *__restrict__ other_r, T *__restrict__ ring_w,
@@ -314,14 +342,15 @@ __global__ __launch_bounds__(WG) void k_halo(T *__restrict__ out, const T *__res
         const uint32_t hs = hp - p + bs - sy * bs;  // sy=0: bs-p+hp ; 1: hp-p ; 2: hp-p-bs
         const uint32_t ws = wp - p + bs - sx * bs;
         const uint32_t in_tile = c * plane + hs * bs + ws;
+        const uint32_t RS = 4 * p * bs;
         T val = 0;
-        if (kind != 2) {
-            const T *src = kind == 0 ? features : other_r;
-            val = src[(size_t)(uint32_t)nb_row[s] * (g.C * plane) + in_tile];
+        if (kind == 0) val = features[(size_t)(uint32_t)nb_row[s] * (g.C * plane) + in_tile];
+        else if (kind == 1) {
+            if (RING) val = other_r[((size_t)(uint32_t)nb_row[s] * g.C + c) * RS + ring_elem(sy, sx, hs, ws, bs, p)];
+            else val = other_r[(size_t)(uint32_t)nb_row[s] * (g.C * plane) + in_tile];
         }
         out_t[f] = val;
-        if (RING && s == 4 && (hs < p || hs >= bs - p || ws < p || ws >= bs - p))
-            ring_w[(size_t)own_g * (g.C * plane) + in_tile] = val;
+        if (RING && s == 4) ring_store_elem(ring_w + ((size_t)own_g * g.C + c) * RS, hs, ws, bs, p, val);
     }
 }
 
@@ -358,7 +387,7 @@ __global__ __launch_bounds__(WG) void k_halo_lds(T *__restrict__ out, const T *_
     constexpr int DE = 16 / sizeof(T);                 // elements per drain vector
     extern __shared__ uint4 smem[];
     long long *nb_base = reinterpret_cast<long long *>(smem);            // element offset from `features`, 9 entries
-    int32_t *nb_zero = reinterpret_cast<int32_t *>(smem) + 18;           // 1 = beyond the image border
+    int32_t *nb_zero = reinterpret_cast<int32_t *>(smem) + 18;           // 1 = beyond image border, 2 = ring-cache record
     uint32_t *own_g = reinterpret_cast<uint32_t *>(smem) + 27;
     T *img = reinterpret_cast<T *>(reinterpret_cast<char *>(smem) + HALO_TBL);
 
@@ -379,7 +408,8 @@ __global__ __launch_bounds__(WG) void k_halo_lds(T *__restrict__ out, const T *_
             const uint32_t g_in = (uint32_t)((int)ig + dx + (int)g.GW.d * dy);
             const int32_t idx = grid_idx[g_in];
             if (idx >= 0) base = (long long)idx * tile_elems;
-            else base = other_delta + (long long)(RING ? g_in : (uint32_t)(idx + (int32_t)g.n_total)) * tile_elems;
+            else if (RING) { base = other_delta + (long long)g_in * g.C * (4 * g.pad * g.bs); zero = 2; }
+            else base = other_delta + (long long)(uint32_t)(idx + (int32_t)g.n_total) * tile_elems;
         }
         nb_base[threadIdx.x] = base;
         nb_zero[threadIdx.x] = zero;
@@ -396,14 +426,15 @@ __global__ __launch_bounds__(WG) void k_halo_lds(T *__restrict__ out, const T *_
     const uint32_t dummy = ph + g.L;                 // scratch slot behind the image
     const uint32_t r_lo = fd_div(f0, g.BSP), r_hi = fd_div(f1 - 1, g.BSP);
     const uint32_t nrows = r_hi - r_lo + 1;
-    const long long ring_base = RING ? (long long)(*own_g) * tile_elems : 0;
+    const uint32_t RS = 4 * p * bs;
+    const long long ring_base = RING ? (long long)(*own_g) * g.C * RS : 0;
 
     // ---- fill, ONE batch: the host sizes L so that a range spans at most HALO_UM*WG middle vectors and HALO_UE*WG
     // edge elements; every lane issues all its loads (HALO_UM vectors + HALO_UE scalars) before the first LDS write,
     // so the workgroup's critical path is: neighbour table -> one global round trip -> LDS -> stores.
     SV vec[HALO_UM];
     T edge[HALO_UE];
-    uint32_t fm[HALO_UM], zm[HALO_UM], rsel[HALO_UM], fe[HALO_UE], ze[HALO_UE];
+    uint32_t fm[HALO_UM], zm[HALO_UM], rsel[HALO_UM], fe[HALO_UE], ze[HALO_UE], rhs[HALO_UM], rws[HALO_UM];
     float psm[HALO_UM], ptm[HALO_UM], pse[HALO_UE], pte[HALO_UE];
     long long roff[HALO_UM];
     {
@@ -420,12 +451,14 @@ __global__ __launch_bounds__(WG) void k_halo_lds(T *__restrict__ out, const T *_
             const uint32_t hs = hp - p + bs - sy * bs;
             const uint32_t s = sy * 3 + 1;
             const uint32_t in_tile = c * g.plane + hs * bs + xv * VE;
-            zm[u] = (uint32_t)nb_zero[s];
-            const long long src = zm[u] ? 0 : nb_base[s] + in_tile;
+            const uint32_t z = (uint32_t)nb_zero[s];
+            zm[u] = z == 1;
+            const long long src = z == 1 ? 0 : nb_base[s] + (z == 2 ? c * RS + ring_elem(sy, 1, hs, xv * VE, bs, p) : in_tile);
             vec[u] = *reinterpret_cast<const SV *>(features + src);
             fm[u] = r * BSP + p + xv * VE;
-            roff[u] = ring_base + in_tile;
+            roff[u] = ring_base + (long long)c * RS;
             rsel[u] = RING && sy == 1 && (hs < p || hs >= bs - p || xv * VE < p || xv * VE + VE > bs - p);
+            rhs[u] = hs; rws[u] = xv * VE;
         }
     }
     {
@@ -444,8 +477,10 @@ __global__ __launch_bounds__(WG) void k_halo_lds(T *__restrict__ out, const T *_
             const uint32_t s = sy * 3 + (right ? 2u : 0u);
             const uint32_t ws = right ? e - p : bs - p + e;
             const uint32_t wp = right ? bs + e : e;        // p + bs + (e - p)
-            ze[u] = (uint32_t)nb_zero[s];
-            const long long src = ze[u] ? 0 : nb_base[s] + (c * g.plane + hs * bs + ws);
+            const uint32_t z = (uint32_t)nb_zero[s];
+            ze[u] = z == 1;
+            const long long src = z == 1 ? 0 : nb_base[s] + (z == 2 ? c * RS + ring_elem(sy, right ? 2u : 0u, hs, ws, bs, p)
+                                                                       : c * g.plane + hs * bs + ws);
             edge[u] = features[src];
             fe[u] = r * BSP + wp;
         }
@@ -459,7 +494,17 @@ __global__ __launch_bounds__(WG) void k_halo_lds(T *__restrict__ out, const T *_
             const uint32_t j = (f >= f0 && f < f1) ? ph + (f - f0) : dummy;
             img[j] = zm[u] ? (T)0 : ActCvt<DT, T>::apply(e[k], psm[u], ptm[u], pr.relu);
         }
-        if (RING && rsel[u]) *reinterpret_cast<SV *>(ring_w + roff[u]) = vec[u];   // ring keeps RAW values
+        if (RING && rsel[u]) {   // refresh the tile's own compact ring record; the ring keeps RAW values
+            T *rec = ring_w + roff[u];
+            if (rhs[u] < p) *reinterpret_cast<SV *>(rec + rhs[u] * bs + rws[u]) = vec[u];
+            if (rhs[u] >= bs - p) *reinterpret_cast<SV *>(rec + p * bs + (rhs[u] - (bs - p)) * bs + rws[u]) = vec[u];
+#pragma unroll
+            for (int k = 0; k < VE; ++k) {
+                const uint32_t w = rws[u] + k;
+                if (w < p) rec[2 * p * bs + rhs[u] * p + w] = e[k];
+                if (w >= bs - p) rec[2 * p * bs + bs * p + rhs[u] * p + (w - (bs - p))] = e[k];
+            }
+        }
     }
 #pragma unroll
     for (int u = 0; u < HALO_UE; ++u) {
@@ -532,29 +577,32 @@ __global__ __launch_bounds__(WG) void k_halo_rows(T *__restrict__ out, const T *
     uint32_t t0, gw, n0, gh;
     fd_divmod(ig, g.GW, t0, gw);
     fd_divmod(t0, g.GH, n0, gh);
+    const uint32_t RS = 4 * p * bs;
     long long nbb[9];
-    bool nbz[9];
+    bool nbz[9], nbr[9];     // beyond the image border / ring-cache record (compact layout)
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
         const int dy = k / 3 - 1, dx = k % 3 - 1;
         const int nh = (int)gh + dy, nw = (int)gw + dx;
         nbz[k] = nh < 0 || nh >= (int)g.GH.d || nw < 0 || nw >= (int)g.GW.d;
+        nbr[k] = false;
         nbb[k] = 0;
         if (k == 4) nbb[k] = (long long)b * tile_elems;
         else if (!nbz[k]) {
             const uint32_t g_in = (uint32_t)((int)ig + dx + (int)g.GW.d * dy);
             const int32_t idx = grid_idx[g_in];
-            nbb[k] = idx >= 0 ? (long long)idx * tile_elems
-                              : other_delta + (long long)(RING ? g_in : (uint32_t)(idx + (int32_t)g.n_total)) * tile_elems;
+            if (idx >= 0) nbb[k] = (long long)idx * tile_elems;
+            else if (RING) { nbb[k] = other_delta + (long long)g_in * g.C * RS; nbr[k] = true; }
+            else nbb[k] = other_delta + (long long)(uint32_t)(idx + (int32_t)g.n_total) * tile_elems;
         }
     }
-    const long long ring_base = (long long)ig * tile_elems;
+    const long long ring_base = (long long)ig * g.C * RS;
     T *__restrict__ out_t = out + (size_t)b * g.per_tile;
 
     // ---- middle runs
     {
         SV vec[HALO_UM];
-        uint32_t dst[HALO_UM], in_tile[HALO_UM];
+        uint32_t dst[HALO_UM], rc[HALO_UM], rhs[HALO_UM], rws[HALO_UM];
         bool zero[HALO_UM], rsel[HALO_UM];
         float ps[HALO_UM], pt[HALO_UM];
 #pragma unroll
@@ -566,17 +614,31 @@ __global__ __launch_bounds__(WG) void k_halo_rows(T *__restrict__ out, const T *
             pro_coeffs<DT>(pr, c, ps[u], pt[u]);
             const bool top = hp < p, bot = hp >= p + bs;
             const uint32_t hs = top ? hp + bs - p : (bot ? hp - p - bs : hp - p);
-            in_tile[u] = c * g.plane + hs * bs + xv * VE;
+            const uint32_t in_tile = c * g.plane + hs * bs + xv * VE;
             zero[u] = top ? nbz[1] : (bot ? nbz[7] : false);
+            const bool from_ring = top ? nbr[1] : (bot ? nbr[7] : false);
             const long long base = top ? nbb[1] : (bot ? nbb[7] : nbb[4]);
-            vec[u] = *reinterpret_cast<const SV *>(features + (zero[u] ? 0 : base + in_tile[u]));
+            const uint32_t off = from_ring ? c * RS + ring_elem(top ? 0u : 2u, 1, hs, xv * VE, bs, p) : in_tile;
+            vec[u] = *reinterpret_cast<const SV *>(features + (zero[u] ? 0 : base + off));
             dst[u] = rr * BSP + p + xv * VE;
             rsel[u] = RING && !top && !bot && (hs < p || hs >= bs - p || xv * VE < p || xv * VE + VE > bs - p);
+            rc[u] = c; rhs[u] = hs; rws[u] = xv * VE;
         }
 #pragma unroll
         for (int u = 0; u < HALO_UM; ++u) {
             SV v = vec[u];
-            if (RING && rsel[u]) *reinterpret_cast<SV *>(ring_w + ring_base + in_tile[u]) = v;   // ring keeps RAW values
+            if (RING && rsel[u]) {   // refresh the tile's own compact ring record; the ring keeps RAW values
+                T *rec = ring_w + ring_base + (long long)rc[u] * RS;
+                if (rhs[u] < p) *reinterpret_cast<SV *>(rec + rhs[u] * bs + rws[u]) = v;
+                if (rhs[u] >= bs - p) *reinterpret_cast<SV *>(rec + p * bs + (rhs[u] - (bs - p)) * bs + rws[u]) = v;
+                const T *e = reinterpret_cast<const T *>(&v);
+#pragma unroll
+                for (int k = 0; k < VE; ++k) {
+                    const uint32_t w = rws[u] + k;
+                    if (w < p) rec[2 * p * bs + rhs[u] * p + w] = e[k];
+                    if (w >= bs - p) rec[2 * p * bs + bs * p + rhs[u] * p + (w - (bs - p))] = e[k];
+                }
+            }
             if (DT != 0) {
                 T *e = reinterpret_cast<T *>(&v);
 #pragma unroll
@@ -609,8 +671,13 @@ __global__ __launch_bounds__(WG) void k_halo_rows(T *__restrict__ out, const T *
                 const long long br = top ? nbb[2] : (bot ? nbb[8] : nbb[5]);
                 const bool zl = top ? nbz[0] : (bot ? nbz[6] : nbz[3]);
                 const bool zr = top ? nbz[2] : (bot ? nbz[8] : nbz[5]);
+                const bool rl = top ? nbr[0] : (bot ? nbr[6] : nbr[3]);
+                const bool rr_ = top ? nbr[2] : (bot ? nbr[8] : nbr[5]);
                 zero[u] = right ? zr : zl;
-                const long long src = (right ? br : bl) + (c * g.plane + hs * bs + ws);
+                const bool from_ring = right ? rr_ : rl;
+                const uint32_t off = from_ring ? c * RS + ring_elem(top ? 0u : (bot ? 2u : 1u), right ? 2u : 0u, hs, ws, bs, p)
+                                               : c * g.plane + hs * bs + ws;
+                const long long src = (right ? br : bl) + off;
                 val[u] = features[zero[u] ? 0 : src];
                 dst[u] = rr * BSP + (right ? bs + e : e);
             }

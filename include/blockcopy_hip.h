@@ -80,9 +80,10 @@ int bc_pad(void *out, const void *features, const void *transfer, const int32_t 
 int bc_combine_copy(const void *blocks, const void *prev, void *out, const int32_t *grid_idx,
                     int N, int C, int H, int W, int bs, int elem_size, void *stream);
 
-/* halo gather over a persistent ring cache.  `ring` is a (N*GH*GW, C, bs, bs) device buffer owned by the
- * caller and kept across frames for one padded layer; only its border ring of width `pad` is ever read or
- * written.  Same output as bc_transfer + bc_pad of the reference decomposition, but non-executed
+/* halo gather over a persistent ring cache.  `ring` is a (N*GH*GW, C, 4*pad*bs) device buffer owned by the
+ * caller and kept across frames for one padded layer: per grid position and channel the four contiguous segments
+ * [top pad rows | bottom pad rows | left pad cols | right pad cols] of the tile most recently executed there
+ * (row-major; everything a neighbour's halo of width `pad` can need, nothing else).  Same output as bc_transfer + bc_pad of the reference decomposition, but non-executed
  * neighbours are read from ring[g'] (indexed by grid position, no per-frame compaction) and every executed
  * tile refreshes ring[g] with its own border in the same launch -- the transfer kernel and its tensors
  * disappear. */

@@ -11,6 +11,24 @@ import torch
 import oracle as O
 
 
+def ring_to_tiles(ring, bs, p):
+    """compact ring records (n, C, 4*p*bs) -> (n, C, bs, bs) tiles whose border ring is filled (interior NaN)."""
+    n, C, _ = ring.shape
+    t = torch.full((n, C, bs, bs), float("nan"), dtype=ring.dtype) if ring.dtype.is_floating_point else torch.zeros((n, C, bs, bs), dtype=ring.dtype)
+    T, B, L, R = ring.split([p * bs, p * bs, bs * p, bs * p], dim=2)
+    t[:, :, :, :p] = L.reshape(n, C, bs, p)
+    t[:, :, :, bs - p:] = R.reshape(n, C, bs, p)
+    t[:, :, :p, :] = T.reshape(n, C, p, bs)
+    t[:, :, bs - p:, :] = B.reshape(n, C, p, bs)
+    return t
+
+
+def tiles_to_ring(tiles, p):
+    n, C, bs, _ = tiles.shape
+    return torch.cat([tiles[:, :, :p, :].reshape(n, C, -1), tiles[:, :, bs - p:, :].reshape(n, C, -1),
+                      tiles[:, :, :, :p].reshape(n, C, -1), tiles[:, :, :, bs - p:].reshape(n, C, -1)], dim=2)
+
+
 class OracleBackend:
     name = "oracle-cpu"
 
@@ -46,14 +64,12 @@ class OracleBackend:
 
     def pad_ring(self, data_exec, ring, grid_idx, mapping_exec, pad, prologue=None):
         gi = grid_idx.reshape(-1)
-        skipped = torch.nonzero(gi < 0).squeeze(1)
-        transfer = ring[skipped].contiguous()   # compacted in raster order == row (grid_idx + n_total)
-        out = self.pad(data_exec, transfer, grid_idx, mapping_exec, pad)
         bs = data_exec.shape[2]
-        m = torch.from_numpy(O.ring_mask(bs, pad))
-        sel = ring[mapping_exec.long()]
-        sel[:, :, m] = data_exec[:, :, m]
-        ring[mapping_exec.long()] = sel       # the ring cache keeps RAW values
+        skipped = torch.nonzero(gi < 0).squeeze(1)
+        # skipped tiles, compacted in raster order == row (grid_idx + n_total) of the reference's transfer tensor
+        transfer = ring_to_tiles(ring[skipped], bs, pad).contiguous()
+        out = self.pad(data_exec, transfer, grid_idx, mapping_exec, pad)
+        ring[mapping_exec.long()] = tiles_to_ring(data_exec, pad)      # the ring cache keeps RAW values
         if prologue is not None:
             # which padded positions hold real data (not image-border zeros)?  gather a tensor of ones the same way
             real = self.pad(torch.ones_like(data_exec), torch.ones_like(transfer), grid_idx, mapping_exec, pad) == 1

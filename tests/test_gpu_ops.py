@@ -97,7 +97,7 @@ def test_transfer_pad_and_ring_chain(be, case, dtype):
     N, C, GH, GW, bs, p = case
     g = torch.Generator().manual_seed(1 + hash(case) % 1000)
     n_total = N * GH * GW
-    ring = torch.full((n_total, C, bs, bs), float("nan"), dtype=dtype).cuda()
+    ring = torch.full((n_total, C, 4 * p * bs), float("nan"), dtype=dtype).cuda()
     mask = torch.from_numpy(O.ring_mask(bs, p))
     prev = None
     for grid in _grids(N, GH, GW, 7, 11):
@@ -226,7 +226,7 @@ def test_large_c2_shapes_roundtrip(be):
     gi1, m1 = O.c_grid_mappings(np.ones((N, 1, GH, GW), bool))
     allb = torch.empty((GH * GW, C, bs, bs)).cuda()
     be.split(allb, image, _dev(m1), _dev(gi1))
-    ring = torch.empty((GH * GW, C, bs, bs)).cuda()
+    ring = torch.empty((GH * GW, C, 4 * bs)).cuda()
     padded = be.pad_ring(allb, ring, _dev(gi1), _dev(m1), 1)
     dense = torch.nn.functional.pad(image, (1, 1, 1, 1))
     want = dense.unfold(2, bs + 2, bs).unfold(3, bs + 2, bs)           # N,C,GH,GW,bs+2,bs+2
@@ -308,8 +308,8 @@ def test_pad_ring_with_activation_prologue(be, dtype, tol):
     # the last geometry is > 30 MB of traffic, i.e. it runs the LDS-staged kernel; the others the row kernel
     for (N, C, GH, GW, bs, p) in [(1, 6, 3, 4, 8, 1), (2, 5, 2, 3, 4, 2), (1, 16, 2, 2, 32, 1), (1, 4, 3, 3, 2, 1), (1, 64, 4, 8, 64, 1)]:
         scale, shift = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.5
-        ring_dev = torch.zeros((N * GH * GW, C, bs, bs), dtype=dtype).cuda()
-        ring_cpu = torch.zeros((N * GH * GW, C, bs, bs), dtype=dtype)
+        ring_dev = torch.zeros((N * GH * GW, C, 4 * p * bs), dtype=dtype).cuda()
+        ring_cpu = torch.zeros((N * GH * GW, C, 4 * p * bs), dtype=dtype)
         for grid in _grids(N, GH, GW, 5, 21):
             gi, m = O.c_grid_mappings(grid)
             feats = torch.randn((len(m), C, bs, bs), generator=g).to(dtype)
@@ -319,5 +319,4 @@ def test_pad_ring_with_activation_prologue(be, dtype, tol):
             assert float((got.float().cpu() - want.float()).abs().max()) <= tol * max(1.0, float(want.float().abs().max()))
             # border zeros are exact zeros, and the ring holds raw (untransformed) values bit for bit
             assert torch.equal(got.cpu() == 0, want == 0) or float(((got.cpu() == 0) != (want == 0)).float().mean()) < 1e-3
-            mask = torch.from_numpy(O.ring_mask(bs, p))
-            assert torch.equal(ring_dev.cpu()[:, :, mask], ring_cpu[:, :, mask])
+            assert torch.equal(ring_dev.cpu(), ring_cpu)

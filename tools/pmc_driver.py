@@ -37,7 +37,7 @@ def main():
     # halo gathers (layer1 and max-pool input shapes)
     for (C, bs, p) in [(64, 32, 1), (64, 64, 1)]:
         feats = torch.randn((64, C, bs, bs), device="cuda")
-        ring = torch.randn((128, C, bs, bs), device="cuda")
+        ring = torch.randn((128, C, 4 * p * bs), device="cuda")
         for _ in range(reps):
             be.pad_ring(feats, ring, gi, m, p)
     torch.cuda.synchronize()

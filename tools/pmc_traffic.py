@@ -40,8 +40,8 @@ def main():
         out[short] = dict(launches=n, read_bytes_per_launch=rd, write_bytes_per_launch=wr, hbm_bytes_per_launch=rd + wr)
         print(f"{short:40s} launches {n:6d}  read {rd / 1e6:9.2f} MB  write {wr / 1e6:9.2f} MB  total {(rd + wr) / 1e6:9.2f} MB per launch")
     if len(sys.argv) > 3:
-        # bench.py's roofline kernel: the C2 logits map (1,19,256,512) f32 = 622592 16-byte vectors, 4 per lane
-        cc = next((v for k, v in out.items() if k.startswith("k_combine_copy") and k.endswith("grid=155648")), None)
+        # bench.py's roofline kernel: the C2 logits map (1,19,256,512) f32 = 622592 16-byte vectors, one per lane
+        cc = next((v for k, v in out.items() if k.startswith("k_combine_copy") and k.endswith("grid=622592")), None)
         with open(sys.argv[3], "w") as fjson:
             json.dump({"k_combine_copy_bytes_per_launch": cc["hbm_bytes_per_launch"] if cc else None,
                        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of tools/pmc_driver.py (same kernel, same shape as bench.py's); FETCH_SIZE x2 (gfx950), KiB units",
