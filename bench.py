@@ -45,6 +45,7 @@ def parse_args():
     ap.add_argument("--policy", default="fixed", choices=["fixed", "random", "all", "rl_semseg"],
                     help="fixed = seeded fixed-fraction mask (config C2, the headline); rl_semseg = online-trained policy (C3)")
     ap.add_argument("--train-interval", type=int, default=3)
+    ap.add_argument("--timings", type=int, default=0, help="profiler section level (blockcopy.utils.profiler); report goes to stderr")
     ap.add_argument("--engine", default="fused", choices=["fused", "reference"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense", action="store_true", help="skip the dense-GPU comparison run")
@@ -161,6 +162,9 @@ def main():
     torch.cuda.synchronize(device)
     warm_s = time.perf_counter() - t_w0
 
+    from blockcopy.utils.profiler import timings
+    timings.set_level(args.timings)
+    timings.reset()
     be.prof_reset()
     be.prof_enable(["combine_copy"])
     replicas.barrier(world, device)
@@ -171,6 +175,10 @@ def main():
     elapsed = time.perf_counter() - t0
     be.prof_enable([])
     cc = be.prof_read("combine_copy")
+    if args.timings and rank == 0:
+        timings.add_cnt(args.steps * CLIP_LEN)
+        print(timings, file=sys.stderr)
+    timings.set_level(0)
 
     # whole-job throughput: all ranks' frames / slowest rank's time (no collective on the data path)
     fps, elapsed, frames_total = replicas.job_throughput(args.steps * CLIP_LEN, elapsed, world, device)

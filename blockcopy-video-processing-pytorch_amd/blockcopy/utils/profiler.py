@@ -38,6 +38,8 @@ class Timings:
 
     def start(self, name: str, level: int = 0):
         if level <= self.level:
+            if self._gpu() and torch.cuda.is_current_stream_capturing():
+                return   # sections inside a hipGraph capture cannot be timed (they replay without Python)
             if self._gpu():
                 ev = torch.cuda.Event(enable_timing=True)
                 ev.record()
@@ -63,7 +65,10 @@ class Timings:
         torch.cuda.synchronize()
         for name, pairs in self._pending.items():
             for a, b in pairs:
-                self.records[name] += a.elapsed_time(b) * 1e-3
+                try:
+                    self.records[name] += a.elapsed_time(b) * 1e-3
+                except RuntimeError:
+                    pass   # an event that never executed
             pairs.clear()
 
     def __repr__(self):
