@@ -45,6 +45,8 @@ def parse_args():
     ap.add_argument("--policy", default="fixed", choices=["fixed", "random", "all", "rl_semseg"],
                     help="fixed = seeded fixed-fraction mask (config C2, the headline); rl_semseg = online-trained policy (C3)")
     ap.add_argument("--train-interval", type=int, default=3)
+    ap.add_argument("--channels-last", type=int, default=1,
+                    help="1 (default): channels-last weights/activations -> NHWC packed tiles, MIOpen's preferred layout; 0: NCHW")
     ap.add_argument("--timings", type=int, default=0, help="profiler section level (blockcopy.utils.profiler); report goes to stderr")
     ap.add_argument("--engine", default="fused", choices=["fused", "reference"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -151,7 +153,8 @@ def main():
 
     model = harness.build_model(args.backbone, block_policy=args.policy, block_size=args.block_size, block_target=args.target,
                                 device=device, dtype=dtype, seed=1000 * rank,
-                                block_graph=args.graph, block_train_interval=args.train_interval)
+                                block_graph=args.graph, block_train_interval=args.train_interval,
+                                channels_last=bool(args.channels_last))
     # per-rank clips (clip i of the job lives on rank i mod N); inputs resident in HBM before the clock starts
     n_distinct = 2
     clips = [harness.synthetic_clip(CLIP_LEN, shape, seed=(rank * n_distinct + c) * 100, device=device, dtype=dtype) for c in range(n_distinct)]
@@ -214,7 +217,8 @@ def main():
         extra["host_enqueue_ms_per_frame"] = 1e3 * host_s / CLIP_LEN
         extra["roofline_large"] = scatter_copy_large(be, device)
         if not args.no_dense and world == 1:
-            dense = harness.build_model(args.backbone, block_policy="static", device=device, dtype=dtype)
+            dense = harness.build_model(args.backbone, block_policy="static", device=device, dtype=dtype,
+                                        channels_last=bool(args.channels_last))
             dfps, _, _ = harness.measure_fps(dense, clips[:1], n_clips=max(1, min(args.steps, 3)), warmup_clips=1, device=device)
             extra["dense_gpu_fps"] = dfps
             extra["speedup_vs_dense_gpu"] = fps / dfps
@@ -229,7 +233,7 @@ def main():
             "dtype": "f16" if args.half else "f32", "data": "synthetic",
             "config": {"workload": f"{config_name(args)}: SwiftNet-{args.backbone} {shape[0]}x3x{args.height}x{args.width} synthetic clips of {CLIP_LEN} frames, "
                                    f"block {args.block_size}, policy {args.policy} target {args.target:.0%} (frame 0 of each clip all-active), "
-                                   f"{args.engine} engine{' + hipGraph replay' if args.graph else ''}, name-seeded weights, BN folded; step = 1 clip",
+                                   f"{args.engine} engine{' + hipGraph replay' if args.graph else ''}{', channels-last' if args.channels_last else ''}, name-seeded weights, BN folded; step = 1 clip",
                        "clips_per_rank": args.steps, "parallelism": f"{world} independent replica(s), no collective",
                        "exec_fraction": exec_frac, "warmup_s": warm_s},
             "roofline": {"kernel": "k_combine_copy (fused scatter+copy of the logits map)", "bound": "hbm", "achieved": achieved,

@@ -18,7 +18,7 @@ from .swiftnet import build_swiftnet
 
 
 def build_model(backbone="resnet18", block_policy="fixed", block_size=128, block_target=0.5, device="cuda",
-                dtype=torch.float32, fold_bn=True, seed=0, **settings_overrides):
+                dtype=torch.float32, fold_bn=True, seed=0, channels_last=False, **settings_overrides):
     """SwiftNet with name-seeded weights, optionally wrapped in BlockCopyModel (``block_policy='static'`` = dense)."""
     net = build_swiftnet(backbone)
     net.load_state_dict(seeded.name_seeded_state_dict(net.state_dict()), strict=True)
@@ -31,6 +31,10 @@ def build_model(backbone="resnet18", block_policy="fixed", block_size=128, block
     model = model.to(device)
     if fold_bn:
         model = fold_batchnorm(model)
+    if channels_last:
+        # weights in channels-last: MIOpen then produces channels-last activations and the engine's packed tiles,
+        # ring caches and dense maps follow (every halo access becomes an aligned vector)
+        model = model.to(memory_format=torch.channels_last)
     if dtype != torch.float32:
         model = model.to(dtype)
         if block_policy != "static" and model.policy.net is not None:

@@ -168,9 +168,12 @@ class SpatialPyramidPooling(nn.Module):
             ar = size[1] / size[0]
             x = self.spp[0](x)
             levels = [x]
+            # adaptive pooling of a channels-last map is ~5x slower than of an NCHW one on ROCm; the map is tiny
+            # (stride 32), so pool from one NCHW copy (values are identical)
+            x_pool = x if x.is_contiguous() else x.contiguous()
             for i in range(1, len(self.spp) - 1):
                 g = self.grids[i - 1]
-                pooled = F.adaptive_avg_pool2d(x, (g, max(1, round(ar * g))))
+                pooled = F.adaptive_avg_pool2d(x_pool, (g, max(1, round(ar * g))))
                 levels.append(F.interpolate(self.spp[i](pooled), size, mode="bilinear"))
             return self.spp[-1](torch.cat(levels, 1))
 

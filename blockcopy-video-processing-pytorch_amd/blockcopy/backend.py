@@ -29,10 +29,27 @@ class BlockCopyBackendError(RuntimeError):
     pass
 
 
+def is_nhwc(x: torch.Tensor) -> bool:
+    """True for a 4-D tensor whose memory is channels-last (and not also plain-contiguous, e.g. C == 1)."""
+    return x.dim() == 4 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
+
+
+def dense_layout(x: torch.Tensor) -> torch.Tensor:
+    """x itself if it is NCHW- or channels-last-contiguous, else a contiguous copy."""
+    if x.is_contiguous() or (x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)):
+        return x
+    return x.contiguous()
+
+
+def empty_like_layout(shape, like: torch.Tensor) -> torch.Tensor:
+    fmt = torch.channels_last if is_nhwc(like) else torch.contiguous_format
+    return torch.empty(shape, dtype=like.dtype, device=like.device, memory_format=fmt)
+
+
 def _ok(x: torch.Tensor, *dtypes) -> bool:
-    # same contract as the reference's cudaok(), utils/cuda.py:42-48
+    # same contract as the reference's cudaok(), utils/cuda.py:42-48 (plus channels-last as a second dense layout)
     assert x.is_cuda, "blockcopy ops need GPU tensors (no CPU path)"
-    assert x.is_contiguous(), "blockcopy ops need contiguous NCHW tensors"
+    assert x.is_contiguous() or is_nhwc(x), "blockcopy ops need contiguous NCHW or channels-last tensors"
     assert not dtypes or x.dtype in dtypes, (x.dtype, dtypes)
     return True
 
@@ -56,6 +73,9 @@ def load_library(path: str = None) -> ctypes.CDLL:
         "bc_grid_tables_host": [p, i, p, p, p, p],
         "bc_interp_bilinear": [p, p, ctypes.c_longlong, i, i, i, i, i, ctypes.c_float, ctypes.c_float, i, p],
         "bc_pad_ring_act": [p, p, p, p, p] + [i] * 8 + [p, p, i, p],
+        "bc_pad_ring_nhwc": [p, p, p, p, p] + [i] * 9 + [p, p, i, p],
+        "bc_affine_act_nhwc": [p, p, p, p, p, i, ctypes.c_longlong, i, i, p],
+        "bc_interp_bilinear_nhwc": [p, p, ctypes.c_longlong, i, i, i, i, i, i, ctypes.c_float, ctypes.c_float, i, p],
         "bc_affine_act": [p, p, p, p, p, i, ctypes.c_longlong, i, ctypes.c_longlong, i, p],
         "bc_abi_version": [],
         "bc_prof_enable": [u],
@@ -102,10 +122,13 @@ class HipBackend:
         _, _, GH, GW = grid_idx.shape
         assert C == C_img and GH * bs == H and GW * bs == W, (blocks.shape, image.shape, grid_idx.shape)
         assert n_exec == mapping_exec.numel()
+        # (1x1 tiles and single-channel maps have the same bytes in both layouts)
+        assert is_nhwc(blocks) == is_nhwc(image) or C == 1 or bs == 1, "packed and dense tensors must share the memory layout"
+        Ck, Ek = (1, C * blocks.element_size()) if is_nhwc(image) else (C, blocks.element_size())   # channels-last: fat elements
         if n_exec > 0:
             with torch.cuda.device_of(blocks):
                 self._check(self.lib.bc_split(blocks.data_ptr(), image.data_ptr(), mapping_exec.data_ptr(), n_exec,
-                                              N, C, H, W, bs, blocks.element_size(), self._stream()), "split")
+                                              N, Ck, H, W, bs, Ek, self._stream()), "split")
         return blocks
 
     def combine(self, blocks, out, grid_idx, mapping_exec):
@@ -117,16 +140,19 @@ class HipBackend:
         assert bs >= 1 and bs == bs2 and one == 1 and grid_idx.size(0) == N and Cb == C
         assert GH * bs == H and GW * bs == W
         assert n_exec == mapping_exec.numel()
+        assert is_nhwc(blocks) == is_nhwc(out) or C == 1 or bs == 1, "packed and dense tensors must share the memory layout"
+        Ck, Ek = (1, C * blocks.element_size()) if is_nhwc(out) else (C, blocks.element_size())
         if n_exec > 0:
             with torch.cuda.device_of(blocks):
                 self._check(self.lib.bc_combine(blocks.data_ptr(), out.data_ptr(), mapping_exec.data_ptr(), n_exec,
-                                                N, C, H, W, bs, blocks.element_size(), self._stream()), "combine")
+                                                N, Ck, H, W, bs, Ek, self._stream()), "combine")
         return out
 
     def transfer(self, out, prev_computed, prev_transfer, prev_grid_idx, transfer_idx, padding):
         """border ring of non-executed tiles from the previous frame.  reference: TransferFunction.forward, :163-193."""
         assert _ok(out) and _ok(prev_computed, out.dtype) and _ok(prev_transfer, out.dtype) and _ok(transfer_idx, torch.int32)
         assert out.shape[1:] == prev_computed.shape[1:] == prev_transfer.shape[1:]
+        assert not (is_nhwc(out) or is_nhwc(prev_computed) or is_nhwc(prev_transfer)), "the reference decomposition is NCHW only"
         N, _, GH, GW = prev_grid_idx.shape
         n_tr, C, bs, _ = out.shape
         assert n_tr == transfer_idx.numel()
@@ -143,6 +169,7 @@ class HipBackend:
         """halo-padded packed batch.  reference: BlockPadFunction.forward, utils/blockpad.py:23-71 (allocates the output)."""
         assert _ok(data_exec) and _ok(data_transfer, data_exec.dtype) and _ok(mapping_exec, torch.int32) and _ok(grid_idx, torch.int32)
         assert data_exec.shape[1:] == data_transfer.shape[1:], (data_exec.shape, data_transfer.shape)
+        assert not (is_nhwc(data_exec) or is_nhwc(data_transfer)), "the reference decomposition is NCHW only"
         n_exec = mapping_exec.numel()
         assert n_exec <= data_exec.shape[0]
         assert grid_idx.numel() - n_exec <= data_transfer.shape[0], (grid_idx.numel(), n_exec, data_transfer.shape)
@@ -167,9 +194,12 @@ class HipBackend:
         _, _, GH, GW = grid_idx.shape
         assert prev.shape == out.shape and Cb == C and GH * bs == H and GW * bs == W and grid_idx.size(0) == N
         assert out.data_ptr() != prev.data_ptr(), "combine_copy is out of place"
+        assert is_nhwc(out) == is_nhwc(prev) and (is_nhwc(out) == is_nhwc(blocks) or C == 1 or bs == 1), \
+            "blocks / prev / out must share the memory layout"
+        Ck, Ek = (1, C * out.element_size()) if is_nhwc(out) else (C, out.element_size())
         with torch.cuda.device_of(out):
             self._check(self.lib.bc_combine_copy(blocks.data_ptr() if blocks.numel() else None, prev.data_ptr(), out.data_ptr(),
-                                                 grid_idx.data_ptr(), N, C, H, W, bs, out.element_size(), self._stream()),
+                                                 grid_idx.data_ptr(), N, Ck, H, W, bs, Ek, self._stream()),
                         "combine_copy")
         return out
 
@@ -182,8 +212,19 @@ class HipBackend:
         n_exec = mapping_exec.numel()
         assert n_exec == B and pad > 0
         assert tuple(ring.shape) == (N * GH * GW, C, 4 * pad * bs), (ring.shape, (N * GH * GW, C, 4 * pad * bs))
-        out = torch.empty((B, C, bs + 2 * pad, bs + 2 * pad), device=data_exec.device, dtype=data_exec.dtype)
-        if n_exec > 0:
+        out = empty_like_layout((B, C, bs + 2 * pad, bs + 2 * pad), data_exec)
+        if n_exec > 0 and is_nhwc(data_exec):
+            scale, shift, relu = prologue if prologue is not None else (None, None, False)
+            for v in (scale, shift):
+                assert v is None or (_ok(v, torch.float32) and v.numel() == C)
+            with torch.cuda.device_of(data_exec):
+                self._check(self.lib.bc_pad_ring_nhwc(out.data_ptr(), data_exec.data_ptr(), ring.data_ptr(), grid_idx.data_ptr(),
+                                                      mapping_exec.data_ptr(), n_exec, N, C, GH, GW, bs, int(pad),
+                                                      data_exec.element_size(), _DTYPE_CODE.get(data_exec.dtype, -1),
+                                                      scale.data_ptr() if scale is not None else None,
+                                                      shift.data_ptr() if shift is not None else None, int(bool(relu)),
+                                                      self._stream()), "pad_ring_nhwc")
+        elif n_exec > 0:
             with torch.cuda.device_of(data_exec):
                 if prologue is None:
                     self._check(self.lib.bc_pad_ring(out.data_ptr(), data_exec.data_ptr(), ring.data_ptr(), grid_idx.data_ptr(),
@@ -208,8 +249,16 @@ class HipBackend:
         for v in (scale, shift):
             assert v is None or (_ok(v, torch.float32) and v.numel() == C)
         assert add is None or (_ok(add, data.dtype) and add.shape == data.shape)
-        out = torch.empty_like(data)
-        if data.numel() > 0:
+        out = torch.empty_like(data)   # preserves the memory format
+        if add is not None and is_nhwc(add) != is_nhwc(data):
+            add = add.contiguous(memory_format=torch.channels_last if is_nhwc(data) else torch.contiguous_format)
+        if data.numel() > 0 and is_nhwc(data):
+            with torch.cuda.device_of(data):
+                self._check(self.lib.bc_affine_act_nhwc(out.data_ptr(), data.data_ptr(), add.data_ptr() if add is not None else None,
+                                                        scale.data_ptr() if scale is not None else None,
+                                                        shift.data_ptr() if shift is not None else None, int(bool(relu)),
+                                                        B * h * w, C, _DTYPE_CODE[data.dtype], self._stream()), "affine_act_nhwc")
+        elif data.numel() > 0:
             with torch.cuda.device_of(data):
                 self._check(self.lib.bc_affine_act(out.data_ptr(), data.data_ptr(), add.data_ptr() if add is not None else None,
                                                    scale.data_ptr() if scale is not None else None,
@@ -223,8 +272,13 @@ class HipBackend:
         """per-tile bilinear resampling (planes = all leading dims); arithmetic of torch's upsample_bilinear2d."""
         assert _ok(data, *_DTYPE_CODE) and data.dim() == 4
         B, C, h, w = data.shape
-        out = torch.empty((B, C, out_h, out_w), device=data.device, dtype=data.dtype)
-        if out.numel() > 0:
+        out = empty_like_layout((B, C, out_h, out_w), data)
+        if out.numel() > 0 and is_nhwc(data):
+            with torch.cuda.device_of(data):
+                self._check(self.lib.bc_interp_bilinear_nhwc(out.data_ptr(), data.data_ptr(), B, C, h, w, out_h, out_w,
+                                                             int(bool(align_corners)), float(rh), float(rw),
+                                                             _DTYPE_CODE[data.dtype], self._stream()), "interp_bilinear_nhwc")
+        elif out.numel() > 0:
             with torch.cuda.device_of(data):
                 self._check(self.lib.bc_interp_bilinear(out.data_ptr(), data.data_ptr(), B * C, h, w, out_h, out_w,
                                                         int(bool(align_corners)), float(rh), float(rw),

@@ -20,7 +20,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-from ..backend import get_backend
+from ..backend import empty_like_layout, get_backend
 from .tensorwrapper import BlockFeatures, PersistentState, TensorWrapper, _NoDispatch
 
 WARM_RUNS = 1   # eager runs of a new executed-tile count before it is captured (MIOpen solver search, lazy module loads)
@@ -112,7 +112,7 @@ class GraphedFrame:
         be = get_backend()
         n_exec, C, bs, _ = out_blocks.shape
         N, _, GH, GW = self.grid_shape
-        out = torch.empty((N, C, GH * bs, GW * bs), dtype=out_blocks.dtype, device=out_blocks.device)
+        out = empty_like_layout((N, C, GH * bs, GW * bs), out_blocks)
         if self.prev_out is None:
             be.combine(out_blocks, out, self.grid_idx, self.tables[self.n_total:self.n_total + n_exec])
         else:

@@ -32,7 +32,7 @@ import numpy as np
 import torch
 
 from . import fusion
-from ..backend import get_backend
+from ..backend import dense_layout, empty_like_layout, get_backend, is_nhwc
 from ..utils.block_funcs import CombineCopyFunction, CombineFunction, SplitFunction, TransferFunction
 from ..utils.blockpad import pad, pad_ring
 from ..utils.profiler import timings
@@ -122,12 +122,13 @@ class PersistentState:
         self.ring_pos = 0
         self.map_pos = 0
 
-    def _next(self, store, pos, shape, dtype, device, what):
+    def _next(self, store, pos, shape, dtype, device, what, nhwc=False):
         if pos == len(store):
             assert not self.frozen, f"a new {what} appeared after graph capture; the model must run the same op sequence every frame"
-            store.append(torch.empty(shape, dtype=dtype, device=device))
+            fmt = torch.channels_last if nhwc and len(shape) == 4 else torch.contiguous_format
+            store.append(torch.empty(shape, dtype=dtype, device=device, memory_format=fmt))
         buf = store[pos]
-        if tuple(buf.shape) != tuple(shape) or buf.dtype != dtype:
+        if tuple(buf.shape) != tuple(shape) or buf.dtype != dtype or (len(shape) == 4 and shape[1] > 1 and is_nhwc(buf) != bool(nhwc)):
             raise AssertionError(f"{what} #{pos}: expected {tuple(buf.shape)}/{buf.dtype}, got {tuple(shape)}/{dtype}; "
                                  "the model must run the same op sequence every frame")
         return buf
@@ -136,9 +137,9 @@ class PersistentState:
         self.ring_pos += 1
         return self._next(self.rings, self.ring_pos - 1, shape, dtype, device, "padded op")
 
-    def next_map(self, shape, dtype, device):
+    def next_map(self, shape, dtype, device, nhwc=False):
         self.map_pos += 1
-        return self._next(self.maps, self.map_pos - 1, shape, dtype, device, "combine call site")
+        return self._next(self.maps, self.map_pos - 1, shape, dtype, device, "combine call site", nhwc)
 
 
 class BlockFeatures:
@@ -353,12 +354,10 @@ class TensorWrapper(torch.Tensor):
             return self
         self._pending = None
         with _NoDispatch():
-            raw = self.as_subclass(torch.Tensor)
-            if not raw.is_contiguous():
-                raw = raw.contiguous()
+            raw = dense_layout(self.as_subclass(torch.Tensor))
             add = P.add
-            if add is not None and not add.is_contiguous():
-                add = add.contiguous()
+            if add is not None:
+                add = dense_layout(add)
             be = get_backend()
             if raw.dtype in getattr(be, "supports_fusion_dtypes", ()):
                 out = be.affine_act(raw, P.scale, P.shift, add, P.relu)
@@ -424,10 +423,8 @@ class TensorWrapper(torch.Tensor):
             mapping_exec = self.get_mapping_exec()
             block_size = W // grid_idx.shape[3]
             n_exec = mapping_exec.numel()
-            dense = self.as_subclass(torch.Tensor)
-            if not dense.is_contiguous():
-                dense = dense.contiguous()
-            out = torch.empty((n_exec, C, block_size, block_size), dtype=dense.dtype, device=dense.device)
+            dense = dense_layout(self.as_subclass(torch.Tensor))
+            out = empty_like_layout((n_exec, C, block_size, block_size), dense)   # packed tiles keep the dense map's layout
             out = SplitFunction.apply(out, dense, mapping_exec, grid_idx)
             return self._wrap_like(out, self, True)
 
@@ -453,15 +450,13 @@ class TensorWrapper(torch.Tensor):
             out_shape = (N, C, GH * BS, GW * BS)
             if self._pending is not None:
                 self._materialize()
-            blocks = self.as_subclass(torch.Tensor)
-            if not blocks.is_contiguous():
-                blocks = blocks.contiguous()
+            blocks = dense_layout(self.as_subclass(torch.Tensor))
 
             ps = self._features.persistent
             if ps is not None:
                 # graph-capturable body: scatter into the call site's persistent map (fixed address); an
                 # out-of-place combine then snapshots it (values identical to clone + scatter).
-                buf = ps.next_map(out_shape, blocks.dtype, blocks.device)
+                buf = ps.next_map(out_shape, blocks.dtype, blocks.device, is_nhwc(blocks))
                 out = CombineFunction.apply(blocks, buf, grid_idx, mapping_exec)
                 if not inplace:
                     out = out.clone()
@@ -470,17 +465,19 @@ class TensorWrapper(torch.Tensor):
             if self._features_prev:
                 prev = self._features_prev.get_features_full()
                 assert out_shape == tuple(prev.shape), (out_shape, prev.shape)
+                if is_nhwc(prev) != is_nhwc(blocks) and C > 1:
+                    raise AssertionError("the memory layout of a combined map changed between frames")
                 if inplace:
                     out = CombineFunction.apply(blocks, prev, grid_idx, mapping_exec)
                 elif self._features.engine == "fused":
-                    out = torch.empty(out_shape, dtype=blocks.dtype, device=blocks.device)
+                    out = empty_like_layout(out_shape, blocks)
                     out = CombineCopyFunction.apply(blocks, prev, out, grid_idx)
                 else:
                     out = CombineFunction.apply(blocks, prev.clone(), grid_idx, mapping_exec)
             else:
                 # first frame of the clip: every tile is executed
                 assert mapping_exec.numel() == grid_idx.numel()
-                out = torch.empty(out_shape, dtype=blocks.dtype, device=blocks.device)
+                out = empty_like_layout(out_shape, blocks)
                 out = CombineFunction.apply(blocks, out, grid_idx, mapping_exec)
 
             self._features.store_features_full(out)
@@ -678,9 +675,9 @@ class TensorWrapper(torch.Tensor):
             else:
                 x._materialize()
         _materialize_args(args[1:])
-        data = x._raw() if isinstance(x, TensorWrapper) else x
-        if not data.is_contiguous():
-            data = data.contiguous()
+        data = dense_layout(x._raw() if isinstance(x, TensorWrapper) else x)
+        if feats.engine != "fused" and is_nhwc(data):
+            data = data.contiguous()    # the reference decomposition is NCHW only
         grid_idx, mapping_exec = feats._grid_idx, feats._mapping_exec
         if feats.engine == "fused":
             ring = feats.next_ring(data, padding)
@@ -735,9 +732,7 @@ class TensorWrapper(torch.Tensor):
                 return np.float32(in_size - 1) / np.float32(out_size - 1) if out_size > 1 else np.float32(0)
             return np.float32(1.0 / s) if (s is not None and s > 0) else np.float32(in_size) / np.float32(out_size)
 
-        if not data.is_contiguous():
-            data = data.contiguous()
-        return be.interp_bilinear(data, H, W, align, resolved(h, H, sh), resolved(w, W, sw))
+        return be.interp_bilinear(dense_layout(data), H, W, align, resolved(h, H, sh), resolved(w, W, sw))
 
     def _func_batched(self, func, args, kwargs):
         """Ops with per-sample statistics (group_norm): fold the tile axis into the spatial axis so statistics

@@ -837,6 +837,194 @@ __global__ __launch_bounds__(WG) void k_affine_act(T *__restrict__ out, const T 
     reinterpret_cast<V *>(out)[i] = *reinterpret_cast<const V *>(res);
 }
 
+// VE consecutive per-channel coefficients starting at channel c0 (c0 % VE == 0): float4 loads when VE is a multiple of 4
+template <int VE>
+__device__ __forceinline__ void load_coeffs(const float *__restrict__ p, uint32_t c0, float fill, float (&v)[VE])
+{
+    if (p == nullptr) {
+#pragma unroll
+        for (int j = 0; j < VE; ++j) v[j] = fill;
+    } else if (VE % 4 == 0) {
+#pragma unroll
+        for (int j = 0; j < VE / 4; ++j) {
+            const float4 q = reinterpret_cast<const float4 *>(p + c0)[j];
+            v[4 * j] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < VE; ++j) v[j] = p[c0 + j];
+    }
+}
+
+// ========================================================================================== channels-last (NHWC) forms
+// In channels-last memory a pixel is one contiguous run of C*E bytes ("fat pixel" = K vectors of VB bytes), a tile row is
+// bs fat pixels, a packed tile is fully contiguous, and the halo shift p*C*E is a whole number of vectors: every access of
+// the halo gather is an ALIGNED vector and there is no middle/edge distinction.  (MIOpen's fastest fp16 conv kernels are
+// NHWC too: the packed 3x3 conv runs in 14 us instead of 39 us.)  Gather / scatter / scatter+copy need no new kernel: a
+// channels-last (N,C,H,W) map is an NCHW (N,1,H,W) map of fat elements, which the kernels above already handle.
+struct HaloNhwcGeom {
+    FastDiv K, BSP, GW, GH;   // vectors per fat pixel, padded row length (pixels), grid dims
+    uint32_t C, bs, pad, n_total;
+    uint32_t per_tile;        // BSP*BSP*K output vectors per executed tile
+    uint32_t epv;             // elements per vector
+};
+
+template <int VB, typename T, bool RING, int DT>
+__global__ __launch_bounds__(WG) void k_halo_nhwc(typename VecOf<VB>::type *__restrict__ out,
+                                                  const typename VecOf<VB>::type *__restrict__ features, long long other_delta,
+                                                  typename VecOf<VB>::type *__restrict__ ring_w,
+                                                  const int32_t *__restrict__ grid_idx, const int32_t *__restrict__ mapping_exec,
+                                                  HaloNhwcGeom g, Prologue pr)
+{
+    typedef typename VecOf<VB>::type V;
+    constexpr int VE = VB / (int)sizeof(T);
+    const uint32_t b = blockIdx.y;
+    const uint32_t bs = g.bs, p = g.pad, BSP = g.BSP.d, K = g.K.d;
+    const uint32_t tile_vecs = bs * bs * K;          // vectors per packed tile
+    const uint32_t RSV = 4 * p * bs * K;             // vectors per compact ring record (fat pixels x K)
+
+    // wave-uniform 3x3 neighbour table (scalar loads), as in k_halo_rows
+    const uint32_t ig = (uint32_t)mapping_exec[b];
+    uint32_t t0, gw, n0, gh;
+    fd_divmod(ig, g.GW, t0, gw);
+    fd_divmod(t0, g.GH, n0, gh);
+    long long nbb[9];
+    bool nbz[9], nbr[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int dy = k / 3 - 1, dx = k % 3 - 1;
+        const int nh = (int)gh + dy, nw = (int)gw + dx;
+        nbz[k] = nh < 0 || nh >= (int)g.GH.d || nw < 0 || nw >= (int)g.GW.d;
+        nbr[k] = false;
+        nbb[k] = 0;
+        if (k == 4) nbb[k] = (long long)b * tile_vecs;
+        else if (!nbz[k]) {
+            const uint32_t g_in = (uint32_t)((int)ig + dx + (int)g.GW.d * dy);
+            const int32_t idx = grid_idx[g_in];
+            if (idx >= 0) nbb[k] = (long long)idx * tile_vecs;
+            else if (RING) { nbb[k] = other_delta + (long long)g_in * RSV; nbr[k] = true; }
+            else nbb[k] = other_delta + (long long)(uint32_t)(idx + (int32_t)g.n_total) * tile_vecs;
+        }
+    }
+    V *__restrict__ out_t = out + (size_t)b * g.per_tile;
+    V *__restrict__ rec = RING ? ring_w + (long long)ig * RSV : nullptr;
+
+    V vec[UNROLL];
+    uint32_t fo[UNROLL], kk[UNROLL], hs_[UNROLL], ws_[UNROLL];
+    bool zero[UNROLL], own[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+        const uint32_t f = min((blockIdx.x * UNROLL + u) * WG + threadIdx.x, g.per_tile - 1);
+        uint32_t pix, k, hp, wp;
+        fd_divmod(f, g.K, pix, k);
+        fd_divmod(pix, g.BSP, hp, wp);
+        const uint32_t sy = hp < p ? 0u : (hp >= p + bs ? 2u : 1u);
+        const uint32_t sx = wp < p ? 0u : (wp >= p + bs ? 2u : 1u);
+        const uint32_t hs = hp - p + bs - sy * bs, ws = wp - p + bs - sx * bs;
+        // 3x3 select of wave-uniform values
+        const long long b0 = sx == 0 ? nbb[0] : (sx == 1 ? nbb[1] : nbb[2]);
+        const long long b1 = sx == 0 ? nbb[3] : (sx == 1 ? nbb[4] : nbb[5]);
+        const long long b2 = sx == 0 ? nbb[6] : (sx == 1 ? nbb[7] : nbb[8]);
+        const bool z0 = sx == 0 ? nbz[0] : (sx == 1 ? nbz[1] : nbz[2]);
+        const bool z1 = sx == 0 ? nbz[3] : (sx == 1 ? false : nbz[5]);
+        const bool z2 = sx == 0 ? nbz[6] : (sx == 1 ? nbz[7] : nbz[8]);
+        const bool r0 = sx == 0 ? nbr[0] : (sx == 1 ? nbr[1] : nbr[2]);
+        const bool r1 = sx == 0 ? nbr[3] : (sx == 1 ? false : nbr[5]);
+        const bool r2 = sx == 0 ? nbr[6] : (sx == 1 ? nbr[7] : nbr[8]);
+        const long long base = sy == 0 ? b0 : (sy == 1 ? b1 : b2);
+        zero[u] = sy == 0 ? z0 : (sy == 1 ? z1 : z2);
+        const bool from_ring = sy == 0 ? r0 : (sy == 1 ? r1 : r2);
+        const uint32_t off = (from_ring ? ring_elem(sy, sx, hs, ws, bs, p) : hs * bs + ws) * K + k;
+        vec[u] = features[zero[u] ? 0 : base + off];
+        fo[u] = f; kk[u] = k; hs_[u] = hs; ws_[u] = ws;
+        own[u] = sy == 1 && sx == 1;
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+        V v = vec[u];
+        if (RING && own[u]) {   // refresh the tile's own compact ring record (raw values), aligned vector stores
+            const uint32_t hs = hs_[u], ws = ws_[u], k = kk[u];
+            if (hs < p) rec[(hs * bs + ws) * K + k] = v;
+            if (hs >= bs - p) rec[(p * bs + (hs - (bs - p)) * bs + ws) * K + k] = v;
+            if (ws < p) rec[(2 * p * bs + hs * p + ws) * K + k] = v;
+            if (ws >= bs - p) rec[(2 * p * bs + bs * p + hs * p + (ws - (bs - p))) * K + k] = v;
+        }
+        if (DT != 0) {
+            T *e = reinterpret_cast<T *>(&v);
+            float sc[VE], sh[VE];
+            load_coeffs<VE>(pr.scale, kk[u] * VE, 1.0f, sc);
+            load_coeffs<VE>(pr.shift, kk[u] * VE, 0.0f, sh);
+#pragma unroll
+            for (int j = 0; j < VE; ++j) e[j] = ActCvt<DT, T>::apply(e[j], sc[j], sh[j], pr.relu);
+        }
+        if (zero[u]) v = V{};
+        out_t[fo[u]] = v;
+    }
+}
+
+// channels-last fused epilogue: channel index runs fastest
+template <typename T, int Q>
+__global__ __launch_bounds__(WG) void k_affine_act_nhwc(T *__restrict__ out, const T *__restrict__ in, const T *__restrict__ add,
+                                                        const float *__restrict__ scale, const float *__restrict__ shift,
+                                                        int relu, FastDiv Cq, uint32_t total)
+{
+    typedef typename VecOf<sizeof(T) * Q>::type V;
+    const uint32_t i = blockIdx.x * WG + threadIdx.x;
+    if (i >= total) return;
+    uint32_t pix, q;
+    fd_divmod(i, Cq, pix, q);
+    V vi = reinterpret_cast<const V *>(in)[i];
+    V va = vi;
+    if (add) va = reinterpret_cast<const V *>(add)[i];
+    const T *xi = reinterpret_cast<const T *>(&vi), *xa = reinterpret_cast<const T *>(&va);
+    T res[Q];
+    float sc[Q], sh[Q];
+    load_coeffs<Q>(scale, q * Q, 1.0f, sc);
+    load_coeffs<Q>(shift, q * Q, 0.0f, sh);
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+        float x = Cvt<T>::ld(xi + k) * sc[k] + sh[k];
+        if (add) x += Cvt<T>::ld(xa + k);
+        if (relu) x = fmaxf(x, 0.0f);
+        res[k] = Cvt<T>::st(x);
+    }
+    reinterpret_cast<V *>(out)[i] = *reinterpret_cast<const V *>(res);
+}
+
+// channels-last per-tile bilinear resampling: one lane = Q channels of one output pixel
+struct InterpNhwcGeom {
+    FastDiv Cq, W, H;
+    uint32_t h, w, total;
+    float rh, rw;
+    int align;
+};
+
+template <typename T, int Q>
+__global__ __launch_bounds__(WG) void k_interp_bilinear_nhwc(T *__restrict__ out, const T *__restrict__ in, InterpNhwcGeom g)
+{
+    typedef typename VecOf<sizeof(T) * Q>::type V;
+    const uint32_t i = blockIdx.x * WG + threadIdx.x;
+    if (i >= g.total) return;
+    uint32_t r, q, r2, ox, plane, oy;
+    fd_divmod(i, g.Cq, r, q);
+    fd_divmod(r, g.W, r2, ox);
+    fd_divmod(r2, g.H, plane, oy);
+    uint32_t y0, yp, x0, xp; float ly1, lx1;
+    src_index(g.rh, oy, g.align, g.h, y0, yp, ly1);
+    src_index(g.rw, ox, g.align, g.w, x0, xp, lx1);
+    const float ly0 = 1.0f - ly1, lx0 = 1.0f - lx1;
+    const V *base = reinterpret_cast<const V *>(in) + (size_t)plane * g.h * g.w * g.Cq.d + q;
+    const V v00 = base[((size_t)y0 * g.w + x0) * g.Cq.d], v01 = base[((size_t)y0 * g.w + x0 + xp) * g.Cq.d];
+    const V v10 = base[((size_t)(y0 + yp) * g.w + x0) * g.Cq.d], v11 = base[((size_t)(y0 + yp) * g.w + x0 + xp) * g.Cq.d];
+    const T *a = reinterpret_cast<const T *>(&v00), *bq = reinterpret_cast<const T *>(&v01);
+    const T *c = reinterpret_cast<const T *>(&v10), *d = reinterpret_cast<const T *>(&v11);
+    T res[Q];
+#pragma unroll
+    for (int k = 0; k < Q; ++k)
+        res[k] = Cvt<T>::st(ly0 * (lx0 * Cvt<T>::ld(a + k) + lx1 * Cvt<T>::ld(bq + k)) + ly1 * (lx0 * Cvt<T>::ld(c + k) + lx1 * Cvt<T>::ld(d + k)));
+    reinterpret_cast<V *>(out)[i] = *reinterpret_cast<const V *>(res);
+}
+
 // ------------------------------------------------------------------------------------------ host helpers
 int pick_vb(size_t row_bytes, std::initializer_list<const void *> ptrs)
 {
@@ -849,9 +1037,16 @@ int pick_vb(size_t row_bytes, std::initializer_list<const void *> ptrs)
     return vb;
 }
 
-bool elem_ok(int e) { return e == 1 || e == 2 || e == 4 || e == 8; }
+// copy kernels: any unit size (1..2^20 bytes): a channels-last map is an NCHW map of C*E-byte "fat" elements
+bool elem_ok(int e) { return e >= 1 && e <= (1 << 20); }
 
-bool aligned(const void *p, int e) { return (reinterpret_cast<uintptr_t>(p) % (uintptr_t)e) == 0; }
+// alignment demanded of a pointer for unit size e: the largest power of two dividing e, at most 16
+bool aligned(const void *p, int e)
+{
+    int a = 1;
+    while (a < 16 && (e % (a * 2)) == 0) a *= 2;
+    return (reinterpret_cast<uintptr_t>(p) % (uintptr_t)a) == 0;
+}
 
 int grid_for(uint64_t items, int per_thread)
 {
@@ -1083,7 +1278,7 @@ int launch_halo(ProfScope &ps, void *out, const void *features, const void *othe
 int check_halo(const void *out, const void *features, const int32_t *grid_idx, const int32_t *mapping_exec,
                int n_exec, int N, int C, int GH, int GW, int bs, int pad, int E)
 {
-    if (!elem_ok(E)) return BC_ERR_ELEM;
+    if (E != 1 && E != 2 && E != 4 && E != 8) return BC_ERR_ELEM;   // NCHW halo kernels are element-typed
     if (n_exec < 0 || N <= 0 || C <= 0 || GH <= 0 || GW <= 0 || bs <= 0 || pad < 1 || pad > bs) return BC_ERR_SHAPE;
     if (n_exec == 0) return BC_OK;
     if (!out || !features || !grid_idx || !mapping_exec) return BC_ERR_NULL;
@@ -1316,6 +1511,103 @@ BC_EXPORT int bc_interp_bilinear(void *out, const void *in, long long planes, in
     else if (dtype == BC_F16) { if (vec) BC_IP(__half, 8); else BC_IP(__half, 1); }
     else { if (vec) BC_IP(hip_bfloat16, 8); else BC_IP(hip_bfloat16, 1); }
 #undef BC_IP
+    return launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------- channels-last entry points
+BC_EXPORT int bc_pad_ring_nhwc(void *out, const void *features, void *ring, const int32_t *grid_idx,
+                               const int32_t *mapping_exec, int n_exec, int N, int C, int GH, int GW, int bs, int pad,
+                               int elem_size, int dtype, const float *scale, const float *shift, int relu, void *stream)
+{
+    const int E = elem_size;
+    if (E != 1 && E != 2 && E != 4 && E != 8) return BC_ERR_ELEM;
+    const bool act = scale || shift || relu;
+    if (act && (dtype < BC_F32 || dtype > BC_BF16 || E != (dtype == BC_F32 ? 4 : 2))) return BC_ERR_ELEM;
+    if (n_exec < 0 || N <= 0 || C <= 0 || GH <= 0 || GW <= 0 || bs <= 0 || pad < 1 || pad > bs) return BC_ERR_SHAPE;
+    if (n_exec == 0) return BC_OK;
+    if (!out || !features || !ring || !grid_idx || !mapping_exec) return BC_ERR_NULL;
+    const uint64_t bsp = (uint64_t)bs + 2 * pad;
+    if ((uint64_t)n_exec * C * bsp * bsp >= (1ull << 31) || (uint64_t)N * GH * GW * C * bs * bs >= (1ull << 31)) return BC_ERR_RANGE;
+    const int vb = pick_vb((size_t)C * E, {out, features, ring});
+    if (vb < 2 || (act && vb < E)) return BC_ERR_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    HaloNhwcGeom g;
+    const uint32_t K = (uint32_t)((size_t)C * E / vb);
+    g.K = make_fd(K); g.BSP = make_fd((uint32_t)bsp); g.GW = make_fd(GW); g.GH = make_fd(GH);
+    g.C = C; g.bs = bs; g.pad = pad; g.n_total = (uint32_t)N * GH * GW;
+    g.per_tile = (uint32_t)(bsp * bsp * K);
+    g.epv = vb / E;
+    const dim3 grid((g.per_tile + WG * UNROLL - 1) / (WG * UNROLL), (unsigned)n_exec);
+    const long long delta = ((const char *)ring - (const char *)features) / vb;
+    Prologue pr{scale, shift, relu};
+    ProfScope ps(BC_OP_PAD_RING, halo_bytes(n_exec, C, bs, pad, E));
+#define BC_HN(VB_, T_, DT_)                                                                                        \
+    BC_LAUNCH(ps, (k_halo_nhwc<VB_, T_, true, DT_>), grid, dim3(WG), 0, st, (VecOf<VB_>::type *)out,                \
+              (const VecOf<VB_>::type *)features, delta, (VecOf<VB_>::type *)ring, grid_idx, mapping_exec, g, pr)
+#define BC_HNV(T_, DT_) do { if (vb == 16) BC_HN(16, T_, DT_); else if (vb == 8) BC_HN(8, T_, DT_);               \
+                             else if (vb == 4) BC_HN(4, T_, DT_); else BC_HN(2, uint16_t, 0); } while (0)
+    if (!act) BC_HNV(uint16_t, 0);
+    else if (dtype == BC_F32) { if (vb == 16) BC_HN(16, uint32_t, 1); else if (vb == 8) BC_HN(8, uint32_t, 1); else BC_HN(4, uint32_t, 1); }
+    else if (dtype == BC_F16) { if (vb == 16) BC_HN(16, uint16_t, 2); else if (vb == 8) BC_HN(8, uint16_t, 2); else if (vb == 4) BC_HN(4, uint16_t, 2); else BC_HN(2, uint16_t, 2); }
+    else { if (vb == 16) BC_HN(16, uint16_t, 3); else if (vb == 8) BC_HN(8, uint16_t, 3); else if (vb == 4) BC_HN(4, uint16_t, 3); else BC_HN(2, uint16_t, 3); }
+#undef BC_HNV
+#undef BC_HN
+    return launch_status();
+}
+
+BC_EXPORT int bc_affine_act_nhwc(void *out, const void *in, const void *add, const float *scale, const float *shift, int relu,
+                                 long long pixels, int C, int dtype, void *stream)
+{
+    if (dtype < BC_F32 || dtype > BC_BF16) return BC_ERR_ELEM;
+    if (pixels < 0 || C <= 0) return BC_ERR_SHAPE;
+    if (pixels == 0) return BC_OK;
+    if (!out || !in) return BC_ERR_NULL;
+    const int E = dtype == BC_F32 ? 4 : 2;
+    if ((uint64_t)pixels * C >= (1ull << 31)) return BC_ERR_RANGE;
+    hipStream_t st = (hipStream_t)stream;
+    int q = 16 / E;
+    while (q > 1 && ((C % q) != 0 || !aligned(out, q * E) || !aligned(in, q * E) || !aligned(add, q * E))) q >>= 1;
+    const FastDiv Cq = make_fd((uint32_t)(C / q));
+    const uint32_t total = (uint32_t)((uint64_t)pixels * (C / q));
+    const int grid = grid_exact(total, 1);
+    ProfScope ps(BC_OP_AFFINE, (add ? 3.0 : 2.0) * pixels * C * E);
+#define BC_AN(T_, Q_) BC_LAUNCH(ps, (k_affine_act_nhwc<T_, Q_>), dim3(grid), dim3(WG), 0, st, (T_ *)out, (const T_ *)in, (const T_ *)add, scale, shift, relu, Cq, total)
+#define BC_ANQ(T_, QMAX_) do { if (q == QMAX_) BC_AN(T_, QMAX_); else if (q == QMAX_ / 2) BC_AN(T_, QMAX_ / 2);     \
+                               else if (QMAX_ >= 8 && q == 2) BC_AN(T_, 2); else BC_AN(T_, 1); } while (0)
+    if (dtype == BC_F32) BC_ANQ(float, 4);
+    else if (dtype == BC_F16) BC_ANQ(__half, 8);
+    else BC_ANQ(hip_bfloat16, 8);
+#undef BC_ANQ
+#undef BC_AN
+    return launch_status();
+}
+
+BC_EXPORT int bc_interp_bilinear_nhwc(void *out, const void *in, long long planes, int C, int h, int w, int H, int W,
+                                      int align_corners, float rh, float rw, int dtype, void *stream)
+{
+    if (dtype < BC_F32 || dtype > BC_BF16) return BC_ERR_ELEM;
+    if (planes < 0 || C <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return BC_ERR_SHAPE;
+    if (planes == 0) return BC_OK;
+    if (!out || !in) return BC_ERR_NULL;
+    const int E = dtype == BC_F32 ? 4 : 2;
+    if ((uint64_t)planes * H * W * C >= (1ull << 31) || (uint64_t)planes * h * w * C >= (1ull << 31)) return BC_ERR_RANGE;
+    hipStream_t st = (hipStream_t)stream;
+    int q = 16 / E;
+    while (q > 1 && ((C % q) != 0 || !aligned(out, q * E) || !aligned(in, q * E))) q >>= 1;
+    InterpNhwcGeom g;
+    g.Cq = make_fd((uint32_t)(C / q)); g.W = make_fd(W); g.H = make_fd(H);
+    g.h = h; g.w = w; g.rh = rh; g.rw = rw; g.align = align_corners;
+    g.total = (uint32_t)((uint64_t)planes * H * W * (C / q));
+    const int grid = grid_exact(g.total, 1);
+    ProfScope ps(BC_OP_INTERP, ((double)planes * h * w + (double)planes * H * W) * C * E);
+#define BC_IN(T_, Q_) BC_LAUNCH(ps, (k_interp_bilinear_nhwc<T_, Q_>), dim3(grid), dim3(WG), 0, st, (T_ *)out, (const T_ *)in, g)
+#define BC_INQ(T_, QMAX_) do { if (q == QMAX_) BC_IN(T_, QMAX_); else if (q == QMAX_ / 2) BC_IN(T_, QMAX_ / 2);     \
+                               else if (QMAX_ >= 8 && q == 2) BC_IN(T_, 2); else BC_IN(T_, 1); } while (0)
+    if (dtype == BC_F32) BC_INQ(float, 4);
+    else if (dtype == BC_F16) BC_INQ(__half, 8);
+    else BC_INQ(hip_bfloat16, 8);
+#undef BC_INQ
+#undef BC_IN
     return launch_status();
 }
 

@@ -32,7 +32,7 @@ enum {
     BC_OK = 0,
     BC_ERR_NULL = -1,      /* required pointer is NULL */
     BC_ERR_SHAPE = -2,     /* non-positive dim, H or W not a multiple of bs, pad < 1 or pad > bs */
-    BC_ERR_ELEM = -3,      /* elem_size not in {1,2,4,8} */
+    BC_ERR_ELEM = -3,      /* unsupported elem_size / dtype (halo ops: 1,2,4,8; copy ops: 1..2^20) */
     BC_ERR_RANGE = -4,     /* element offsets would not fit the reference's 31-bit index space */
     BC_ERR_ALIGN = -5      /* pointer not aligned to elem_size */
 };
@@ -129,6 +129,21 @@ int bc_pad_ring_act(void *out, const void *features, void *ring, const int32_t *
                     int dtype, const float *scale, const float *shift, int relu, void *stream);
 int bc_affine_act(void *out, const void *in, const void *add, const float *scale, const float *shift, int relu,
                   long long B, int C, long long hw, int dtype, void *stream);
+
+/* channels-last (NHWC) forms.  A channels-last (N,C,H,W) map is an NCHW (N,1,H,W) map of C*elem_size-byte units, so
+ * bc_split / bc_combine / bc_combine_copy (and bc_transfer) serve it unchanged when called with C = 1 and
+ * elem_size = C*E (any unit size from 1 to 2^20 bytes is accepted by those copy ops).  The three ops below need the
+ * channel index and have their own channels-last kernels; packed tiles are (n_exec, bs, bs, C) in memory, padded tiles
+ * (n_exec, bs+2p, bs+2p, C), ring records (N*GH*GW, 4*pad*bs, C).  In this layout every access of the halo gather is an
+ * aligned vector (C*elem_size must be a multiple of 2 bytes; 16 for full speed).
+ * bc_pad_ring_nhwc: scale = shift = NULL and relu = 0 -> pure copy (dtype ignored). */
+int bc_pad_ring_nhwc(void *out, const void *features, void *ring, const int32_t *grid_idx,
+                     const int32_t *mapping_exec, int n_exec, int N, int C, int GH, int GW, int bs, int pad,
+                     int elem_size, int dtype, const float *scale, const float *shift, int relu, void *stream);
+int bc_affine_act_nhwc(void *out, const void *in, const void *add, const float *scale, const float *shift, int relu,
+                       long long pixels, int C, int dtype, void *stream);
+int bc_interp_bilinear_nhwc(void *out, const void *in, long long planes, int C, int h, int w, int H, int W,
+                            int align_corners, float rh, float rw, int dtype, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * C. Introspection / measurement

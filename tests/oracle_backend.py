@@ -29,17 +29,30 @@ def tiles_to_ring(tiles, p):
                       tiles[:, :, :, :p].reshape(n, C, -1), tiles[:, :, :, bs - p:].reshape(n, C, -1)], dim=2)
 
 
+def _nhwc(x):
+    return x.dim() == 4 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
+
+
+def _like(t, ref):
+    """t in ref's memory layout (channels-last tensors are checked through their NCHW image)."""
+    return t.contiguous(memory_format=torch.channels_last) if _nhwc(ref) else t.contiguous()
+
+
 class OracleBackend:
     name = "oracle-cpu"
 
     def split(self, blocks, image, mapping_exec, grid_idx):
         if mapping_exec.numel():
-            O.c_split(blocks, image.contiguous(), mapping_exec)
+            tmp = torch.empty(blocks.shape, dtype=blocks.dtype)
+            O.c_split(tmp, image.contiguous(), mapping_exec)
+            blocks.copy_(tmp)
         return blocks
 
     def combine(self, blocks, out, grid_idx, mapping_exec):
         if mapping_exec.numel():
-            O.c_combine(blocks.contiguous(), out, mapping_exec)
+            tmp = out.contiguous()
+            O.c_combine(blocks.contiguous(), tmp, mapping_exec)
+            out.copy_(tmp)
         return out
 
     def transfer(self, out, prev_computed, prev_transfer, prev_grid_idx, transfer_idx, padding):
@@ -56,13 +69,16 @@ class OracleBackend:
         return out
 
     def combine_copy(self, blocks, prev, out, grid_idx):
-        out.copy_(prev)   # clone + scatter == the reference's non-in-place combine
+        tmp = prev.contiguous().clone()   # clone + scatter == the reference's non-in-place combine
         mapping = torch.nonzero(grid_idx.reshape(-1) >= 0).squeeze(1).to(torch.int32)
         if mapping.numel():
-            O.c_combine(blocks.contiguous(), out, mapping)
+            O.c_combine(blocks.contiguous(), tmp, mapping)
+        out.copy_(tmp)
         return out
 
     def pad_ring(self, data_exec, ring, grid_idx, mapping_exec, pad, prologue=None):
+        if _nhwc(data_exec):   # ring records are opaque to the host: the checker keeps its own (NCHW-style) convention
+            return _like(self.pad_ring(data_exec.contiguous(), ring, grid_idx, mapping_exec, pad, prologue), data_exec)
         gi = grid_idx.reshape(-1)
         bs = data_exec.shape[2]
         skipped = torch.nonzero(gi < 0).squeeze(1)
@@ -96,13 +112,14 @@ class OracleBackend:
             y = y + add.float()
         if relu:
             y = torch.relu(y)
-        return y.to(data.dtype)
+        return _like(y.to(data.dtype), data)
 
     supports_interp_dtypes = (torch.float32,)
 
     def interp_bilinear(self, data, out_h, out_w, align_corners, rh, rw):
         # floating-point op: the checker is stock PyTorch on the packed batch (per tile, no halo)
-        return torch.nn.functional.interpolate(data, size=(out_h, out_w), mode="bilinear", align_corners=align_corners)
+        return _like(torch.nn.functional.interpolate(data.contiguous(), size=(out_h, out_w), mode="bilinear",
+                                                     align_corners=align_corners), data)
 
     def grid_tables_host(self, grid_u8, grid_idx, mapping, prev_grid_idx=None, transfer=None):
         gi, m = O.c_grid_mappings(grid_u8.astype(bool).reshape(1, 1, 1, -1))

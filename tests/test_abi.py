@@ -41,7 +41,7 @@ def test_abi_version_and_strings(lib):
     assert lib.bc_abi_version() == 1
     assert lib.bc_error_string(0) == b"ok"
     assert b"NULL" in lib.bc_error_string(-1)
-    assert [lib.bc_op_name(i).decode() for i in range(8)] == ["split", "combine", "transfer", "pad", "combine_copy", "pad_ring", "grid_tables", "interp"]
+    assert [lib.bc_op_name(i).decode() for i in range(9)] == ["split", "combine", "transfer", "pad", "combine_copy", "pad_ring", "grid_tables", "interp", "affine"]
     assert lib.bc_op_name(99) == b"?"
 
 
@@ -51,7 +51,8 @@ def test_argument_validation_needs_no_gpu(lib):
     assert lib.bc_split(N, N, N, 4, 1, 3, 8, 8, 4, 4, N) == -1
     assert lib.bc_split(N, N, N, 4, 1, 3, 8, 10, 4, 4, N) == -2          # W % bs != 0
     assert lib.bc_split(N, N, N, -1, 1, 3, 8, 8, 4, 4, N) == -2
-    assert lib.bc_split(N, N, N, 4, 1, 3, 8, 8, 4, 16, N) == -3
+    assert lib.bc_split(N, N, N, 4, 1, 3, 8, 8, 4, 0, N) == -3           # unit size must be >= 1 byte
+    assert lib.bc_pad(N, N, N, N, N, 2, 1, 3, 2, 2, 4, 1, 16, N) == -3    # element-typed halo ops: 1, 2, 4, 8 only
     assert lib.bc_split(N, N, N, 0, 1, 3, 8, 8, 4, 4, N) == 0            # nothing to do
     assert lib.bc_combine(N, N, N, 4, 1, 1 << 12, 1 << 10, 1 << 10, 4, 4, N) == -4   # >= 2^31 elements
     assert lib.bc_combine_copy(N, N, N, N, 1, 3, 8, 8, 4, 4, N) == -1
@@ -64,6 +65,10 @@ def test_argument_validation_needs_no_gpu(lib):
     assert lib.bc_grid_tables_host(N, 0, N, N, N, N) == -2
     assert lib.bc_interp_bilinear(N, N, 4, 2, 2, 4, 4, 0, 0.5, 0.5, 7, N) == -3
     assert lib.bc_interp_bilinear(N, N, 4, 2, 2, 4, 4, 0, 0.5, 0.5, 0, N) == -1
+    assert lib.bc_pad_ring_nhwc(N, N, N, N, N, 2, 1, 8, 2, 2, 4, 1, 4, 0, N, N, 0, N) == -1
+    assert lib.bc_pad_ring_nhwc(N, N, N, N, N, 2, 1, 8, 2, 2, 4, 1, 3, 0, N, N, 0, N) == -3
+    assert lib.bc_affine_act_nhwc(N, N, N, N, N, 0, 16, 8, 0, N) == -1
+    assert lib.bc_interp_bilinear_nhwc(N, N, 4, 8, 2, 2, 4, 4, 0, 0.5, 0.5, 0, N) == -1
     assert lib.bc_prof_read(99, None, None, None) == -2
 
 

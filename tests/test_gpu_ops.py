@@ -193,7 +193,7 @@ def test_empty_and_error_paths(be):
     lib = be.lib
     assert lib.bc_split(None, None, None, 1, 1, 3, 8, 8, 4, 4, None) == -1      # BC_ERR_NULL
     assert lib.bc_split(None, None, None, 1, 1, 3, 8, 9, 4, 4, None) == -2      # W not a multiple of bs
-    assert lib.bc_split(None, None, None, 1, 1, 3, 8, 8, 4, 3, None) == -3      # elem size
+    assert lib.bc_split(None, None, None, 1, 1, 3, 8, 8, 4, 0, None) == -3      # unit size must be >= 1 byte
     assert lib.bc_pad(None, None, None, None, None, 1, 1, 3, 2, 2, 4, 0, 4, None) == -2   # pad < 1
     assert lib.bc_pad(None, None, None, None, None, 1, 1, 3, 2, 2, 4, 5, 4, None) == -2   # pad > bs
     with pytest.raises(AssertionError):
@@ -320,3 +320,79 @@ def test_pad_ring_with_activation_prologue(be, dtype, tol):
             # border zeros are exact zeros, and the ring holds raw (untransformed) values bit for bit
             assert torch.equal(got.cpu() == 0, want == 0) or float(((got.cpu() == 0) != (want == 0)).float().mean()) < 1e-3
             assert torch.equal(ring_dev.cpu(), ring_cpu)
+
+
+def _cl(x):
+    return x.contiguous(memory_format=torch.channels_last)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(1, 8, 2, 4, 8, 1), (2, 16, 3, 3, 4, 2), (1, 64, 4, 4, 2, 1), (1, 24, 3, 5, 1, 1), (2, 6, 2, 3, 6, 3),
+                                  (1, 3, 2, 3, 16, 3), (1, 64, 4, 8, 32, 1), (1, 19, 8, 16, 32, 1), (1, 5, 2, 2, 8, 1)])
+def test_channels_last_ops_match_oracle(be, case, dtype):
+    """Channels-last packed layout: gather / scatter / scatter+copy (fat-element reuse of the NCHW kernels) and the
+    NHWC halo gather over a multi-frame ring-cache chain, bit-exact against the oracle run on the NCHW images."""
+    from oracle_backend import OracleBackend
+
+    N, C, GH, GW, bs, p = case
+    H, W = GH * bs, GW * bs
+    chk = OracleBackend()
+    g = torch.Generator().manual_seed(5 + hash(case) % 1000)
+    ring_dev = torch.zeros((N * GH * GW, C, 4 * p * bs), dtype=dtype).cuda()
+    ring_cpu = torch.zeros((N * GH * GW, C, 4 * p * bs), dtype=dtype)
+    for grid in _grids(N, GH, GW, 5, 31):
+        gi, m = O.c_grid_mappings(grid)
+        image = torch.randn((N, C, H, W), generator=g).to(dtype)
+        want = torch.empty((len(m), C, bs, bs), dtype=dtype)
+        O.c_split(want, image, m)
+        got = _cl(torch.zeros((len(m), C, bs, bs), dtype=dtype).cuda())
+        be.split(got, _cl(image.cuda()), _dev(m), _dev(gi))
+        assert torch.equal(got.cpu().contiguous(), want)
+        prev = torch.randn((N, C, H, W), generator=g).to(dtype)
+        want_out = prev.clone()
+        O.c_combine(want, want_out, m)
+        got_out = _cl(prev.cuda())
+        be.combine(got, got_out, _dev(gi), _dev(m))
+        assert torch.equal(got_out.cpu().contiguous(), want_out)
+        fused = _cl(torch.zeros((N, C, H, W), dtype=dtype).cuda())
+        be.combine_copy(got, _cl(prev.cuda()), fused, _dev(gi))
+        assert torch.equal(fused.cpu().contiguous(), want_out)
+        if (C * want.element_size()) % 2 == 0:
+            feats = torch.randn((len(m), C, bs, bs), generator=g).to(dtype)
+            wantp = chk.pad_ring(feats, ring_cpu, torch.from_numpy(gi), torch.from_numpy(m), p)
+            gotp = be.pad_ring(_cl(feats.cuda()), ring_dev, _dev(gi), _dev(m), p)
+            assert gotp.shape == wantp.shape and (C == 1 or bs == 1 or not gotp.is_contiguous())   # stays channels-last
+            assert torch.equal(gotp.cpu().contiguous(), wantp)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.float16, 2e-3), (torch.bfloat16, 2e-2)])
+def test_channels_last_float_ops(be, dtype, tol):
+    """Channels-last forms of the floating-point kernels: fused epilogue, halo gather with prologue, bilinear."""
+    import torch.nn.functional as F
+    from oracle_backend import OracleBackend
+
+    chk = OracleBackend()
+    g = torch.Generator().manual_seed(9)
+    for (B, C, h, w) in [(64, 64, 8, 8), (5, 24, 4, 4), (3, 8, 1, 1), (2, 6, 3, 5)]:
+        x = torch.randn((B, C, h, w), generator=g).to(dtype)
+        add = torch.randn((B, C, h, w), generator=g).to(dtype)
+        scale, shift = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+        for kw in (dict(scale=scale, shift=shift, relu=True), dict(shift=shift, add=add, relu=True), dict(relu=True)):
+            want = chk.affine_act(x, **kw).float()
+            dev = {k: (_cl(v.cuda()) if torch.is_tensor(v) and v.dim() == 4 else (v.cuda() if torch.is_tensor(v) else v)) for k, v in kw.items()}
+            got = be.affine_act(_cl(x.cuda()), **dev)
+            assert float((got.float().cpu() - want).abs().max()) <= tol * max(1.0, float(want.abs().max()))
+        want = F.interpolate(x.float(), size=(2 * h, 2 * w), mode="bilinear")
+        got = be.interp_bilinear(_cl(x.cuda()), 2 * h, 2 * w, False, 0.5, 0.5)
+        assert float((got.float().cpu() - want).abs().max()) <= tol * max(1.0, float(want.abs().max()))
+    if dtype != torch.bfloat16:
+        N, C, GH, GW, bs, p = 1, 16, 3, 4, 8, 1
+        scale, shift = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.5
+        ring_dev = torch.zeros((N * GH * GW, C, 4 * p * bs), dtype=dtype).cuda()
+        ring_cpu = torch.zeros((N * GH * GW, C, 4 * p * bs), dtype=dtype)
+        for grid in _grids(N, GH, GW, 5, 41):
+            gi, m = O.c_grid_mappings(grid)
+            feats = torch.randn((len(m), C, bs, bs), generator=g).to(dtype)
+            want = chk.pad_ring(feats, ring_cpu, torch.from_numpy(gi), torch.from_numpy(m), p, (scale, shift, True)).float()
+            got = be.pad_ring(_cl(feats.cuda()), ring_dev, _dev(gi), _dev(m), p, (scale.cuda(), shift.cuda(), True))
+            assert float((got.float().cpu() - want).abs().max()) <= tol * max(1.0, float(want.abs().max()))

@@ -306,3 +306,31 @@ def test_rl_policy_loop_matches_reference(golden_dir, oracle_backend):
     assert float(np.mean(np.sign(d_me) == np.sign(d_ref))) > 0.98
     assert set(pm) >= {"frame_state", "grid", "grid_log_probs", "grid_probs", "information_gain", "inputs", "num_exec", "num_total",
                        "output_repr", "outputs", "outputs_prev", "perc_exec"}
+
+
+@pytest.mark.parametrize("name", ["swiftnet_rn18_a.npz", "swiftnet_rn18_n2.npz"])
+def test_channels_last_model_matches_reference_on_cpu(golden_dir, oracle_backend, name):
+    """A channels-last SwiftNet drives the engine with channels-last packed tiles (everything after the first conv):
+    the layout plumbing (packed/dense/persistent buffers keep the producer's memory format) must not change logits."""
+    import blockcopy
+    from blockcopy.backend import is_nhwc
+    from blockcopy.core.argparser import default_settings
+    from bc_workloads import seeded
+    from bc_workloads.bn_fold import fold_batchnorm
+    from bc_workloads.swiftnet import build_swiftnet
+
+    G, cfg = load_golden(golden_dir, name)
+    for graph in (0, 1):
+        net = build_swiftnet(cfg["backbone"])
+        net.load_state_dict(seeded.name_seeded_state_dict(net.state_dict()), strict=True)
+        net.eval()
+        model = blockcopy.BlockCopyModel(net, default_settings(block_policy="all", block_size=cfg["block_size"], block_graph=graph))
+        grids = [torch.from_numpy(G[f"grid{t}"]) for t in range(cfg["n_frames"])]
+        model.policy = make_forced_policy(cfg["block_size"], grids)
+        model = fold_batchnorm(model).to(memory_format=torch.channels_last)
+        model.reset_temporal()
+        with torch.no_grad():
+            for t in range(cfg["n_frames"]):
+                y = model(seeded.synthetic_frame(cfg["frame_seed0"] + t, (cfg["N"], 3, cfg["H"], cfg["W"])))
+                assert float((y - torch.from_numpy(G[f"logits{t}"])).abs().max()) <= 1e-4, (graph, t)
+        assert is_nhwc(y), "the output map should have stayed channels-last"

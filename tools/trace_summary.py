@@ -13,7 +13,7 @@ def main():
     skip = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     rows = list(csv.DictReader(open(path)))
     ks = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows)
-    marks = [s for s, e, n in ks if "k_tiles<" in n and "true>" in n]
+    marks = [s for s, e, n in ks if "k_tiles<" in n and ", true" in n]
     per_frame = 2
     fe = marks[-per_frame * skip] if skip else ks[-1][1] + 1
     fs = marks[-per_frame * (skip + n_frames)]
