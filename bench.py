@@ -47,6 +47,9 @@ def parse_args():
     ap.add_argument("--train-interval", type=int, default=3)
     ap.add_argument("--channels-last", type=int, default=1,
                     help="1 (default): channels-last weights/activations -> NHWC packed tiles, MIOpen's preferred layout; 0: NCHW")
+    ap.add_argument("--also-half", type=int, default=1,
+                    help="1 (default, N=1 only): after the timed fp32 region also measure the same workload in fp16 "
+                         "(the reference's speed configs use --half) and report it under kernels.fp16")
     ap.add_argument("--timings", type=int, default=0, help="profiler section level (blockcopy.utils.profiler); report goes to stderr")
     ap.add_argument("--engine", default="fused", choices=["fused", "reference"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -160,6 +163,10 @@ def main():
     clips = [harness.synthetic_clip(CLIP_LEN, shape, seed=(rank * n_distinct + c) * 100, device=device, dtype=dtype) for c in range(n_distinct)]
 
     t_w0 = time.perf_counter()
+    if args.graph and args.policy != "fixed":
+        # data-dependent policies visit many executed-tile counts: warm + capture all quantised buckets up front
+        harness.run_clip(model, clips[0][:1])
+        model.prewarm(clips[0][0])
     for i in range(args.warmup):
         harness.run_clip(model, clips[i % n_distinct])
     torch.cuda.synchronize(device)
@@ -223,6 +230,21 @@ def main():
             extra["dense_gpu_fps"] = dfps
             extra["speedup_vs_dense_gpu"] = fps / dfps
             del dense
+            if args.also_half and not args.half:
+                # secondary measurement, outside the timed region: the identical workload in fp16
+                del model
+                torch.cuda.empty_cache()
+                h = torch.float16
+                hm = harness.build_model(args.backbone, block_policy=args.policy, block_size=args.block_size, block_target=args.target,
+                                         device=device, dtype=h, seed=1000 * rank, block_graph=args.graph,
+                                         block_train_interval=args.train_interval, channels_last=bool(args.channels_last))
+                hclips = [[f.to(h) for f in clips[0]]]
+                hfps, _, _ = harness.measure_fps(hm, hclips, n_clips=max(1, min(args.steps, 3)), warmup_clips=2, device=device)
+                hd = harness.build_model(args.backbone, block_policy="static", device=device, dtype=h, channels_last=bool(args.channels_last))
+                hdfps, _, _ = harness.measure_fps(hd, hclips, n_clips=max(1, min(args.steps, 3)), warmup_clips=1, device=device)
+                extra["fp16"] = {"fps": hfps, "dense_gpu_fps": hdfps, "speedup_vs_dense_gpu": hfps / hdfps,
+                                 "note": "same workload, weights and masks in float16 (not parity-gated; the headline value is fp32)"}
+                del hm, hd
 
     if rank == 0:
         achieved = (cc["total_bytes"] / (cc["total_ms"] * 1e-3) / 1e9) if cc["total_ms"] > 0 else 0.0

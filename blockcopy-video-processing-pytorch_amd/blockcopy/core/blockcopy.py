@@ -58,6 +58,8 @@ class BlockCopyModel(nn.Module):
         self.clip_length += 1
 
         self.policy_meta["inputs"] = inputs
+        # tells a trainable policy whether this frame's decision will be trained on (it then needs an autograd graph)
+        self.policy_meta["train_hint"] = self.clip_length % self.train_interval == 0
         with timings.env("blockcopy/policy_forward", 3):
             # the policy writes the execution grid into policy_meta['grid'] (+ optional CPU mirror 'grid_host')
             self.policy_meta = self.policy(self.policy_meta)
@@ -86,6 +88,40 @@ class BlockCopyModel(nn.Module):
                 train_policy = self.clip_length % self.train_interval == 0
                 self.policy_meta = self.policy.optim(self.policy_meta, train=train_policy)
         return out
+
+
+@torch.no_grad()
+def prewarm(self, inputs, counts=None, **kwargs):
+    """Warm up and capture the packed pipeline for every executed-tile count the policy can produce, so that no
+    MIOpen solver search or graph capture lands inside a clip.  ``counts`` defaults to the multiples of
+    ``num_tiles / 16`` (the policies' quantisation step, policy.py ``quantize_number_exec_grid``).  Uses ``inputs`` only
+    for its shape/dtype/device; temporal state is reset afterwards (call it between clips)."""
+    from .graphs import GraphedFrame, WARM_RUNS
+
+    assert self.use_graph, "prewarm() is for the hipGraph execution mode (settings['block_graph'] = 1)"
+    key = (tuple(inputs.shape), inputs.dtype, inputs.device)
+    gf = self._graphed.get(key)
+    if gf is None:
+        gf = self._graphed[key] = GraphedFrame(inputs, self.block_size)
+    total = gf.n_total
+    if counts is None:
+        step = max(1, total // 16)
+        counts = sorted(set(list(range(step, total + 1, step)) + [total]), reverse=True)
+    assert counts[0] == total or gf.state.rings, "the first warmed count must be the all-active frame"
+    grid_dev = torch.ones(gf.grid_shape, dtype=torch.bool, device=inputs.device)
+    for n in counts:
+        host = torch.zeros(total, dtype=torch.bool)
+        host[:n] = True
+        for _ in range(WARM_RUNS + 1):           # eager warm run(s), then capture + first replay
+            gf.prev_out = None if n == total else gf.prev_out
+            gf.upload(inputs, host.view(gf.grid_shape))
+            gf.finish(gf.run(self.base_model, n, grid_dev, **kwargs))
+    torch.cuda.synchronize(inputs.device)
+    self.reset_temporal()
+    return counts
+
+
+BlockCopyModel.prewarm = prewarm
 
 
 def _forward_graphed(self, inputs, **kwargs):

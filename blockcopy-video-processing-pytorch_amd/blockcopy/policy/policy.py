@@ -47,7 +47,8 @@ def build_policy_from_settings(settings: dict):
             raise AttributeError(f'Policy with name "{name}" not defined!')
         return PolicyTrainRL(block_target=settings["block_target"], cost_momentum=settings["block_cost_momentum"],
                              optimizer=optimizer, complexity_weight=settings["block_complexity_weight"],
-                             quantize_number_exec=quantize_number_exec, policy_net=net, information_gain=ig, **common)
+                             quantize_number_exec=quantize_number_exec, policy_net=net, information_gain=ig,
+                             graph_forward=bool(settings.get("block_graph", 0)), **common)
     raise NotImplementedError(f"Policy {name} not implemented")
 
 
@@ -211,8 +212,13 @@ class PolicyTrainRL(Policy, metaclass=abc.ABCMeta):
 
     def __init__(self, block_size: int, block_target: float, optimizer: torch.optim.Optimizer, complexity_weight: float,
                  policy_net: PolicyNet, information_gain: InformationGain, cost_momentum: float = 0.9,
-                 at_least_one: bool = False, quantize_number_exec: float = 0, verbose: bool = False):
+                 at_least_one: bool = False, quantize_number_exec: float = 0, verbose: bool = False,
+                 graph_forward: bool = False):
         super().__init__(block_size, verbose, quantize_number_exec)
+        # MI355X-first: frames that will not be trained on (train_interval - 1 of every train_interval) need no autograd
+        # graph; their policy-net trunk runs as a captured hipGraph over a static input (same logits, ~40 fewer launches)
+        self.graph_forward = graph_forward
+        self._fwd_graphs = {}
         assert 0 <= block_target <= 1
         self.block_target = block_target
         self.information_gain = information_gain
@@ -229,10 +235,14 @@ class PolicyTrainRL(Policy, metaclass=abc.ABCMeta):
             # no temporal history: execute everything
             self.publish(policy_meta, torch.ones(shape, dtype=torch.bool))
         else:
+            will_train = policy_meta.get("train_hint", True)
             with torch.enable_grad():
                 with timings.env("policy/net", 3):
                     assert self.net.training
-                    grid_logits = self.net(policy_meta)
+                    if self.graph_forward and not will_train and policy_meta["inputs"].is_cuda:
+                        grid_logits = self._forward_nograd_graph(policy_meta)
+                    else:
+                        grid_logits = self.net(policy_meta)
                 with timings.env("policy/sample", 3):
                     m = Bernoulli(logits=grid_logits)
                     sample = m.sample()
@@ -245,9 +255,32 @@ class PolicyTrainRL(Policy, metaclass=abc.ABCMeta):
                 grid_host = self.quantize_number_exec_grid(grid_host)
                 self.publish(policy_meta, grid_host)
                 grid_f = policy_meta["grid"].to(grid_logits.dtype)
-                policy_meta["grid_log_probs"] = m.log_prob(grid_f)
+                policy_meta["grid_log_probs"] = m.log_prob(grid_f) if grid_logits.requires_grad or not self.graph_forward else None
                 policy_meta["grid_probs"] = m.probs
         return self.stats.add_policy_meta(policy_meta)
+
+    @torch.no_grad()
+    def _forward_nograd_graph(self, policy_meta: dict) -> torch.Tensor:
+        """Policy logits for a frame that will not be trained on: feature build (a few small ops) eagerly, the
+        resnet8 trunk + head as a captured graph over a static input.  BatchNorm stays in training mode (batch
+        statistics, running-stat updates), exactly as in the autograd path."""
+        x = self.net.build_features(policy_meta)
+        key = (tuple(x.shape), x.dtype, x.device)
+        st = self._fwd_graphs.get(key)
+        if st is None:
+            st = self._fwd_graphs[key] = {"x": torch.empty_like(x), "graph": None, "logits": None, "warm": 0}
+        if st["graph"] is None and st["warm"] < 1:
+            st["warm"] += 1
+            return self.net.layers(self.net.backbone(x))      # first encounter: eager (solver search, lazy module loads)
+        st["x"].copy_(x)
+        if st["graph"] is None:
+            torch.cuda.synchronize(x.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                st["logits"] = self.net.layers(self.net.backbone(st["x"]))
+            st["graph"] = g
+        st["graph"].replay()
+        return st["logits"]
 
     def _get_information_gain(self, policy_meta: dict) -> torch.Tensor:
         with timings.env("policy/information_gain", 3):
