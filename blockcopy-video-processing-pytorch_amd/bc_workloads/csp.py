@@ -1,0 +1,326 @@
+"""CSP pedestrian detector (ResNet-50 backbone with dilated stage 4, transposed-conv neck, centre/scale/offset head) as
+the second block-copy workload (BASELINE config C5).
+
+Own restatement of the architecture the reference evaluates (Pedestron/mmdet/models/{backbones/resnet.py,
+necks/csp_neck.py, anchor_heads/csp_head.py, detectors/csp_blockcopy.py} with
+configs/elephant/cityperson/csp_r50_clip_blockcopy_030.py): same parameter names (backbone.*, neck.p3/p4/p5(+_l2),
+bbox_head.{cls,reg,offset}_convs.0.{conv,gn}, bbox_head.csp_{cls,reg,offset}, *_scales), same op order, same per-frame
+state machine.  mmcv/mmdet are not installable here, so unlike SwiftNet this model cannot be checked against the
+reference's own outputs; tests pin it with the reference-independent properties (all-active == dense, static-clip
+invariance) and its NMS against the oracle restatement of nms_kernel.cu.
+
+What it exercises in the engine beyond SwiftNet: dilation-2 convs (halo width 2), transposed convs (run per tile
+WITHOUT halo, as in the reference), L2Norm over the channel axis, GroupNorm over all executed tiles (batched trick),
+three out-of-place combines of a 256-channel stride-4 map per frame (the largest scatter+copy of the repo), one halo
+gather of the 768-channel head input shared by the three head branches, and device-side NMS.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+import blockcopy
+from blockcopy.backend import get_backend
+from blockcopy.utils.profiler import timings
+
+
+# ----------------------------------------------------------------------------------------------- backbone
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=dilation, dilation=dilation, bias=False)   # 'pytorch' style
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        y = self.relu(self.bn1(self.conv1(x)))
+        y = self.relu(self.bn2(self.conv2(y)))
+        y = self.bn3(self.conv3(y))
+        y += x if self.downsample is None else self.downsample(x)
+        return self.relu(y)
+
+
+class CSPResNet50(nn.Module):
+    """ResNet-50, stage strides (1,2,2,1), dilations (1,1,1,2); returns the outputs of stages 2-4 (strides 8,16,16)."""
+
+    def __init__(self, strides=(1, 2, 2, 1), dilations=(1, 1, 1, 2), out_indices=(1, 2, 3)):
+        super().__init__()
+        self.out_indices = out_indices
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
+        for i, (planes, n) in enumerate(zip((64, 128, 256, 512), (3, 4, 6, 3))):
+            setattr(self, f"layer{i + 1}", self._stage(planes, n, strides[i], dilations[i]))
+
+    def _stage(self, planes, n, stride, dilation):
+        down = None
+        if stride != 1 or self.inplanes != planes * 4:
+            down = nn.Sequential(nn.Conv2d(self.inplanes, planes * 4, 1, stride=stride, bias=False), nn.BatchNorm2d(planes * 4))
+        blocks = [Bottleneck(self.inplanes, planes, stride, dilation, down)]
+        self.inplanes = planes * 4
+        blocks += [Bottleneck(self.inplanes, planes, 1, dilation) for _ in range(1, n)]
+        return nn.Sequential(*blocks)
+
+    def forward(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        outs = []
+        for i in range(4):
+            x = getattr(self, f"layer{i + 1}")(x)
+            if i in self.out_indices:
+                outs.append(x)
+        return tuple(outs)
+
+
+# ----------------------------------------------------------------------------------------------- neck
+class L2Norm(nn.Module):
+    def __init__(self, n_channels, scale):
+        super().__init__()
+        self.eps = 1e-10
+        self.weight = nn.Parameter(torch.full((n_channels,), float(scale)))
+
+    def forward(self, x):
+        norm = x.pow(2).sum(dim=1, keepdim=True).sqrt() + self.eps
+        return self.weight.view(1, -1, 1, 1) * torch.div(x, norm)
+
+
+class CSPNeck(nn.Module):
+    """Brings the three stage outputs to stride 4 with transposed convs, L2-normalises and concatenates them (768 ch)."""
+
+    def __init__(self):
+        super().__init__()
+        self.p3 = nn.ConvTranspose2d(512, 256, kernel_size=4, stride=2, padding=1)
+        self.p4 = nn.ConvTranspose2d(1024, 256, kernel_size=4, stride=4, padding=0)
+        self.p5 = nn.ConvTranspose2d(2048, 256, kernel_size=4, stride=4, padding=0)
+        self.p3_l2, self.p4_l2, self.p5_l2 = L2Norm(256, 10), L2Norm(256, 10), L2Norm(256, 10)
+
+    def forward(self, inputs):
+        p3 = self.p3_l2(self.p3(inputs[0]))
+        p4 = self.p4_l2(self.p4(inputs[1]))
+        p5 = self.p5_l2(self.p5(inputs[2]))
+        return (torch.cat([p3, p4, p5], dim=1),)
+
+
+# ----------------------------------------------------------------------------------------------- head
+class ConvGNReLU(nn.Module):
+    """mmdet ConvModule(conv 3x3 no bias -> GroupNorm(32) -> ReLU); children named conv / gn / activate."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, 3, padding=1, bias=False)
+        self.gn = nn.GroupNorm(32, cout)
+        self.activate = nn.ReLU(inplace=True)
+
+    def forward(self, x):
+        return self.activate(self.gn(self.conv(x)))
+
+
+class Scale(nn.Module):
+    def __init__(self, scale=1.0):
+        super().__init__()
+        self.scale = nn.Parameter(torch.tensor(scale, dtype=torch.float))
+
+    def forward(self, x):
+        return x * self.scale
+
+
+class CSPHead(nn.Module):
+    def __init__(self, in_channels=768, feat_channels=256, stride=4, wh_ratio=0.41):
+        super().__init__()
+        self.stride, self.wh_ratio = stride, wh_ratio
+        self.cls_convs = nn.ModuleList([ConvGNReLU(in_channels, feat_channels)])
+        self.reg_convs = nn.ModuleList([ConvGNReLU(in_channels, feat_channels)])
+        self.offset_convs = nn.ModuleList([ConvGNReLU(in_channels, feat_channels)])
+        self.csp_cls = nn.Conv2d(feat_channels, 1, 3, padding=1)
+        self.csp_reg = nn.Conv2d(feat_channels, 1, 3, padding=1)
+        self.csp_offset = nn.Conv2d(feat_channels, 2, 3, padding=1)
+        self.reg_scales = nn.ModuleList([Scale(1.0)])
+        self.offset_scales = nn.ModuleList([Scale(1.0)])
+
+    def forward(self, feats):
+        x = feats[0]
+        outs = []
+        for convs in (self.cls_convs, self.reg_convs, self.offset_convs):
+            f = x
+            for layer in convs:
+                f = blockcopy.to_tensor(layer(f))     # packed -> dense map right after the first conv (reference csp_head.py:135-151)
+            outs.append(f)
+        cls_score = self.csp_cls(outs[0])
+        bbox_pred = self.reg_scales[0](self.csp_reg(outs[1])).float()
+        offset_pred = self.offset_scales[0](self.csp_offset(outs[2]).float())
+        return cls_score, bbox_pred, offset_pred
+
+    @torch.no_grad()
+    def get_bboxes(self, cls_score, bbox_pred, offset_pred, img_shape, nms_pre=1000, score_thr=0.1, iou_thr=0.5, max_per_img=100):
+        """Decode image 0 (reference get_bboxes_single csp_head.py:229-284 + csp_height2bbox + multiclass_nms).
+        Returns (det_bboxes (k,5), det_labels (k,))."""
+        h, w = cls_score.shape[-2:]
+        dev, s = cls_score.device, self.stride
+        scores = cls_score[0].permute(1, 2, 0).reshape(-1).float().sigmoid()
+        heights = bbox_pred[0].permute(1, 2, 0).reshape(-1).exp()
+        offs = offset_pred[0].permute(1, 2, 0).reshape(-1, 2)
+        ys, xs = torch.meshgrid(torch.arange(0, h * s, s, device=dev, dtype=torch.float32),
+                                torch.arange(0, w * s, s, device=dev, dtype=torch.float32), indexing="ij")
+        px, py = xs.reshape(-1) + s // 2, ys.reshape(-1) + s // 2
+        if 0 < nms_pre < scores.numel():
+            scores, top = scores.topk(nms_pre)
+            heights, offs, px, py = heights[top], offs[top], px[top], py[top]
+        x, y = px + offs[:, 1] * s, py + offs[:, 0] * s
+        hh = heights * s
+        boxes = torch.stack([(x - self.wh_ratio * hh / 2).clamp(0, img_shape[1] - 1), (y - hh * 0.5).clamp(0, img_shape[0] - 1),
+                             (x + self.wh_ratio * hh / 2).clamp(0, img_shape[1] - 1), (y + hh * 0.5).clamp(0, img_shape[0] - 1)], -1)
+        sel = scores > score_thr
+        dets = torch.cat([boxes[sel], scores[sel, None]], dim=1).contiguous()
+        if dets.shape[0] == 0:
+            return dets, torch.zeros(0, dtype=torch.long, device=dev)
+        dets, _ = get_backend().nms(dets, iou_thr)
+        if dets.shape[0] > max_per_img:
+            dets = dets[dets[:, 4].sort(descending=True)[1][:max_per_img]]
+        return dets, torch.zeros(dets.shape[0], dtype=torch.long, device=dev)
+
+
+# ----------------------------------------------------------------------------------------------- detectors
+class CSP(nn.Module):
+    """Dense single-stage detector: backbone -> neck -> head -> decode."""
+
+    def __init__(self):
+        super().__init__()
+        self.backbone, self.neck, self.bbox_head = CSPResNet50(), CSPNeck(), CSPHead()
+
+    def extract_feat(self, img):
+        return self.neck(self.backbone(img))
+
+    def head_maps(self, img):
+        return self.bbox_head(self.extract_feat(img))
+
+    @torch.no_grad()
+    def simple_test(self, img, img_meta=None, rescale=False):
+        return self.bbox_head.get_bboxes(*self.head_maps(img), img_shape=img.shape[-2:])
+
+
+def bbox2result(det_bboxes, det_labels, num_classes=2):
+    """Per-class list of numpy (k,5) arrays (mmdet.core.bbox2result; the reference policy's output format)."""
+    b, lab = det_bboxes.detach().cpu().numpy(), det_labels.detach().cpu().numpy()
+    return [b[lab == i, :] for i in range(num_classes - 1)]
+
+
+class CSPBlockCopy(CSP):
+    """CSP with block-copy execution: the same per-frame state machine as the reference's CSPBlockCopy.simple_test
+    (detectors/csp_blockcopy.py:46-95).  ``results='numpy'`` reproduces its output type (list per class of numpy box
+    arrays, what `rl_objectdetection` consumes); ``results='device'`` keeps (det_bboxes, det_labels) on the GPU."""
+
+    def __init__(self, blockcopy_settings: dict, results: str = "numpy"):
+        super().__init__()
+        self.is_blockcopy_manager = True
+        self.policy = blockcopy.build_policy_from_settings(blockcopy_settings)
+        self.train_interval = blockcopy_settings["block_train_interval"]
+        self.block_size = blockcopy_settings["block_size"]
+        self.use_graph = bool(blockcopy_settings.get("block_graph", 0))
+        self.results = results
+        self.block_temporal_features = None
+        self._graphed = {}
+        self.reset_temporal()
+
+    def reset_temporal(self):
+        self.clip_length = 0
+        if self.block_temporal_features:
+            self.block_temporal_features.clear()
+        self.block_temporal_features = None
+        self.policy_meta = {"inputs": None, "outputs": None, "outputs_prev": None}
+        for gf in self._graphed.values():
+            gf.reset()
+
+    def _maps_from_blocks(self, blocks):
+        return self.bbox_head(self.extract_feat(blocks))
+
+    @torch.no_grad()
+    def simple_test(self, img, img_meta=None, rescale=False):
+        self.clip_length += 1
+        self.policy_meta["inputs"] = img
+        self.policy_meta["train_hint"] = self.clip_length % self.train_interval == 0
+        with timings.env("blockcopy/policy_forward", 3):
+            self.policy_meta = self.policy(self.policy_meta)
+        with timings.env("blockcopy/model", 3):
+            if self.policy_meta["num_exec"] == 0:
+                self.policy_meta = self.policy_meta.copy()
+                out = self.policy_meta["outputs"]
+            else:
+                if self.use_graph:
+                    maps = self._graphed_maps(img)
+                else:
+                    x = blockcopy.to_tensorwrapper(img)
+                    self.block_temporal_features = x.process_temporal_features(self.block_temporal_features)
+                    x = x.to_blocks(self.policy_meta["grid"], self.policy_meta.get("grid_host", None))
+                    self.policy_meta["frame_state"] = x.combine_().to_tensor()
+                    maps = self._maps_from_blocks(x)
+                self.head_out = maps
+                dets, labels = self.bbox_head.get_bboxes(*maps, img_shape=img.shape[-2:])
+                out = [bbox2result(dets, labels)] if self.results == "numpy" else (dets, labels)
+            self.policy_meta["outputs_prev"] = self.policy_meta["outputs"]
+            self.policy_meta["outputs"] = out
+        with timings.env("blockcopy/policy_optim", 3):
+            train_policy = self.clip_length % self.train_interval == 0
+            self.policy_meta = self.policy.optim(self.policy_meta, train=train_policy)
+        return out[0] if self.results == "numpy" else out
+
+    def _graphed_maps(self, img):
+        from blockcopy.core.graphs import GraphedFrame
+
+        key = (tuple(img.shape), img.dtype, img.device)
+        gf = self._graphed.get(key)
+        if gf is None:
+            gf = self._graphed[key] = GraphedFrame(img, self.block_size)
+        grid = self.policy_meta["grid"]
+        grid_host = self.policy_meta.get("grid_host", None)
+        if grid_host is None:
+            grid_host = grid.to("cpu")
+        n_exec = gf.upload(img, grid_host)
+        maps = gf.run(self._maps_from_blocks, n_exec, grid)
+        gf.prev_out = True    # marks "inside a clip" (the dense head maps live in the persistent state, not here)
+        self.policy_meta["frame_state"] = gf.frame_state
+        return maps
+
+
+def build_csp(block_policy="fixed", block_size=128, block_target=0.3, device="cuda", dtype=torch.float32, fold_bn=True,
+              channels_last=False, results="device", seed=0, **settings_overrides):
+    """CSP detector with name-seeded weights; ``block_policy='static'`` returns the dense detector."""
+    from blockcopy.core.argparser import default_settings
+
+    from . import seeded
+    from .bn_fold import fold_batchnorm
+
+    if block_policy == "static":
+        model = CSP()
+    else:
+        settings = default_settings(block_policy=block_policy, block_size=block_size, block_target=block_target, block_seed=seed,
+                                    block_num_classes=1, **settings_overrides)
+        model = CSPBlockCopy(settings, results=results)
+    core = {k: v for k, v in model.state_dict().items() if not k.startswith("policy.")}
+    model.load_state_dict(seeded.name_seeded_state_dict(core), strict=False)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, Scale):
+                m.scale.fill_(1.0)
+    model.eval()
+    if block_policy != "static" and model.policy.net is not None:
+        model.policy.net.train()
+    model = model.to(device)
+    if fold_bn:
+        model = fold_batchnorm(model)
+    if channels_last:
+        model = model.to(memory_format=torch.channels_last)
+    if dtype != torch.float32:
+        model = model.to(dtype)
+        if block_policy != "static" and model.policy.net is not None:
+            model.policy.net = model.policy.net.float()
+    return model

@@ -20,7 +20,7 @@ _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("BLOCKCOPY_HIP_LIB", os.path.join(_PKG_ROOT, "lib", "libblockcopy_hip.so"))
 
 OP_SPLIT, OP_COMBINE, OP_TRANSFER, OP_PAD, OP_COMBINE_COPY, OP_PAD_RING, OP_GRID_TABLES, OP_INTERP, OP_AFFINE = range(9)
-OP_NAMES = ("split", "combine", "transfer", "pad", "combine_copy", "pad_ring", "grid_tables", "interp", "affine")
+OP_NAMES = ("split", "combine", "transfer", "pad", "combine_copy", "pad_ring", "grid_tables", "interp", "affine", "nms")
 _DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 ABI_VERSION = 1
 
@@ -77,6 +77,7 @@ def load_library(path: str = None) -> ctypes.CDLL:
         "bc_affine_act_nhwc": [p, p, p, p, p, i, ctypes.c_longlong, i, i, p],
         "bc_interp_bilinear_nhwc": [p, p, ctypes.c_longlong, i, i, i, i, i, i, ctypes.c_float, ctypes.c_float, i, p],
         "bc_affine_act": [p, p, p, p, p, i, ctypes.c_longlong, i, ctypes.c_longlong, i, p],
+        "bc_nms_sorted": [p, i, ctypes.c_float, p, p, p, p],
         "bc_abi_version": [],
         "bc_prof_enable": [u],
         "bc_prof_reset": [],
@@ -312,6 +313,28 @@ class HipBackend:
         if rc < 0:
             self._check(rc, "grid_tables_host")
         return rc
+
+    def nms(self, dets, iou_thr):
+        """Greedy NMS on the device (reference: mmdet.ops.nms.nms_wrapper.nms -> nms_cuda).  dets: (n,5) float32
+        [x1,y1,x2,y2,score].  Returns (kept dets, original indices of the kept boxes ascending) -- the reference's
+        return contract; the index count needs one D->H read (shapes), everything else stays on the GPU."""
+        assert _ok(dets, torch.float32) and dets.dim() == 2 and dets.shape[1] == 5
+        n = dets.shape[0]
+        if n == 0:
+            return dets, torch.zeros(0, dtype=torch.long, device=dets.device)
+        assert n <= 4096, "bc_nms_sorted handles up to 4096 boxes (the CSP head keeps nms_pre = 1000)"
+        order = dets[:, 4].sort(0, descending=True)[1]
+        srt = dets.index_select(0, order).contiguous()
+        cb = (n + 63) // 64
+        ws = torch.empty(n * cb, dtype=torch.int64, device=dets.device)
+        keep = torch.empty(n, dtype=torch.int32, device=dets.device)
+        count = torch.empty(1, dtype=torch.int32, device=dets.device)
+        with torch.cuda.device_of(dets):
+            self._check(self.lib.bc_nms_sorted(srt.data_ptr(), n, float(iou_thr), ws.data_ptr(), keep.data_ptr(), count.data_ptr(),
+                                               self._stream()), "nms_sorted")
+        k = int(count.item())
+        inds = order[keep[:k].long()].sort(0)[0]
+        return dets[inds, :], inds
 
     # -- C. measurement -----------------------------------------------------------------------------------
     def prof_enable(self, ops=()):

@@ -82,11 +82,15 @@ class GraphedFrame:
         blocks = x._split(self.block_size)
         frame_state = blocks.combine_()._plain()
         out = base_model(blocks, **kwargs)
-        assert isinstance(out, TensorWrapper) and out.is_blocks, "the base model must return a packed TensorWrapper"
-        return out._plain(), frame_state
+        if isinstance(out, TensorWrapper) and out.is_blocks:
+            return out._plain(), frame_state          # packed output tiles: combined eagerly by finish()
+        # models that combine inside (e.g. the CSP head): dense maps living in the persistent state / graph pool
+        from .tensorwrapper import to_tensor
+        return to_tensor(out), frame_state
 
-    def run(self, base_model, n_exec: int, grid: torch.Tensor, **kwargs) -> torch.Tensor:
-        """Packed output tiles of this frame (eager while warming up, graph replay afterwards)."""
+    def run(self, base_model, n_exec: int, grid: torch.Tensor, **kwargs):
+        """Outputs of ``base_model(packed tiles)`` for this frame -- packed output tiles, or whatever dense structure
+        the model returns -- eager while warming up, graph replay afterwards (``base_model`` may be any callable)."""
         if self.prev_out is None:
             assert n_exec == self.n_total, "No previous features known, first run should execute all blocks!"
         b = self.buckets.setdefault(n_exec, _Bucket())

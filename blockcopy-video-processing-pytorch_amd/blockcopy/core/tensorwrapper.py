@@ -168,6 +168,7 @@ class BlockFeatures:
 
         self.rings = []              # fused engine: persistent ring caches (shared list object across frames)
         self._ring_pos = 0
+        self._pad_memo = None        # (source, padding, prologue key, padded): consecutive padded ops on the SAME tensor share one gather
         self.persistent = None       # PersistentState when running as a graph-capturable body (core/graphs.py)
 
     # ------------------------------------------------------------------ grid -> index tables
@@ -680,9 +681,18 @@ class TensorWrapper(torch.Tensor):
             data = data.contiguous()    # the reference decomposition is NCHW only
         grid_idx, mapping_exec = feats._grid_idx, feats._mapping_exec
         if feats.engine == "fused":
-            ring = feats.next_ring(data, padding)
-            with timings.env("tensorwrapper/pad", 10):
-                args[0] = pad_ring(data, ring, grid_idx, mapping_exec, padding, prologue)
+            # consecutive padded ops on the same tensor (e.g. the three CSP head branches on the 768-channel map)
+            # share ONE halo gather and ring cache; the memo holds the source, so its address cannot be recycled
+            pro_key = None if prologue is None else (id(prologue[0]), id(prologue[1]), bool(prologue[2]))
+            m = feats._pad_memo
+            if (m is not None and m[0].data_ptr() == data.data_ptr() and m[0].shape == data.shape and m[0].stride() == data.stride()
+                    and m[0]._version == data._version and m[1] == padding and m[2] == pro_key):
+                args[0] = m[3]
+            else:
+                ring = feats.next_ring(data, padding)
+                with timings.env("tensorwrapper/pad", 10):
+                    args[0] = pad_ring(data, ring, grid_idx, mapping_exec, padding, prologue)
+                feats._pad_memo = (data, padding, pro_key, args[0])
         else:
             data_transfer = self._transfer_from_prev()
             if data_transfer is None:

@@ -1025,6 +1025,63 @@ __global__ __launch_bounds__(WG) void k_interp_bilinear_nhwc(T *__restrict__ out
     reinterpret_cast<V *>(out)[i] = *reinterpret_cast<const V *>(res);
 }
 
+// ------------------------------------------------------------------------------------------ NMS (detector post-processing)
+// Replaces nms_kernel + the host-side sweep of Pedestron/mmdet/ops/nms/src/nms_kernel.cu:23-130.  Same blocking as the
+// reference for the mask (64 boxes x 64 boxes per workgroup, one 64-bit word per box and column block -- a CDNA wavefront
+// is exactly one such block), but the greedy suppression sweep also runs on the device: ONE wavefront keeps the running
+// `removed` bitmap with one 64-bit word per lane (up to 64*64 = 4096 boxes) and walks the boxes in score order, so the
+// (n x n/64) mask never crosses PCIe and nothing synchronises.
+__device__ __forceinline__ float nms_iou(const float *a, const float *b)
+{
+    const float left = fmaxf(a[0], b[0]), right = fminf(a[2], b[2]);
+    const float top = fmaxf(a[1], b[1]), bottom = fminf(a[3], b[3]);
+    const float width = fmaxf(right - left + 1.f, 0.f), height = fmaxf(bottom - top + 1.f, 0.f);
+    const float interS = width * height;
+    const float Sa = (a[2] - a[0] + 1) * (a[3] - a[1] + 1);
+    const float Sb = (b[2] - b[0] + 1) * (b[3] - b[1] + 1);
+    return interS / (Sa + Sb - interS);
+}
+
+__global__ __launch_bounds__(64) void k_nms_mask(int n, float thresh, const float *__restrict__ boxes,
+                                                 unsigned long long *__restrict__ mask, int col_blocks)
+{
+    const int row_start = blockIdx.y, col_start = blockIdx.x;
+    const int row_size = min(n - row_start * 64, 64), col_size = min(n - col_start * 64, 64);
+    __shared__ float bb[64 * 5];
+    if ((int)threadIdx.x < col_size) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) bb[threadIdx.x * 5 + k] = boxes[(64 * col_start + threadIdx.x) * 5 + k];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < row_size) {
+        const int cur = 64 * row_start + threadIdx.x;
+        const float *cb = boxes + cur * 5;
+        unsigned long long t = 0;
+        const int start = row_start == col_start ? (int)threadIdx.x + 1 : 0;
+        for (int i = start; i < col_size; ++i)
+            if (nms_iou(cb, bb + i * 5) > thresh) t |= 1ULL << i;
+        mask[(size_t)cur * col_blocks + col_start] = t;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_nms_sweep(int n, int col_blocks, const unsigned long long *__restrict__ mask,
+                                                  int32_t *__restrict__ keep, int32_t *__restrict__ count)
+{
+    const int lane = threadIdx.x;
+    unsigned long long remv = 0;        // lane w owns word w of the removed bitmap
+    int num = 0;
+    for (int i = 0; i < n; ++i) {
+        const int nblock = i >> 6, inblock = i & 63;
+        const unsigned long long w = __shfl(remv, nblock, 64);
+        if (!((w >> inblock) & 1ULL)) {            // wave-uniform: every lane sees the same word
+            if (lane == 0) keep[num] = i;
+            ++num;
+            if (lane < col_blocks && lane >= nblock) remv |= mask[(size_t)i * col_blocks + lane];
+        }
+    }
+    if (lane == 0) *count = num;
+}
+
 // ------------------------------------------------------------------------------------------ host helpers
 int pick_vb(size_t row_bytes, std::initializer_list<const void *> ptrs)
 {
@@ -1309,7 +1366,7 @@ BC_EXPORT const char *bc_error_string(int code)
 
 BC_EXPORT const char *bc_op_name(int op)
 {
-    static const char *names[BC_OP_COUNT] = {"split", "combine", "transfer", "pad", "combine_copy", "pad_ring", "grid_tables", "interp", "affine"};
+    static const char *names[BC_OP_COUNT] = {"split", "combine", "transfer", "pad", "combine_copy", "pad_ring", "grid_tables", "interp", "affine", "nms"};
     return (op >= 0 && op < BC_OP_COUNT) ? names[op] : "?";
 }
 
@@ -1482,6 +1539,19 @@ BC_EXPORT int bc_affine_act(void *out, const void *in, const void *add, const fl
     else BC_AFQ(hip_bfloat16, 8);
 #undef BC_AFQ
 #undef BC_AF
+    return launch_status();
+}
+
+BC_EXPORT int bc_nms_sorted(const float *boxes, int n, float iou_thr, unsigned long long *mask_ws, int32_t *keep,
+                            int32_t *count, void *stream)
+{
+    if (n < 0 || n > 4096) return BC_ERR_SHAPE;
+    if (!count || (n > 0 && (!boxes || !mask_ws || !keep))) return BC_ERR_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    const int cb = (n + 63) / 64;
+    ProfScope ps(BC_OP_NMS, 20.0 * n);
+    if (n > 0) hipLaunchKernelGGL(k_nms_mask, dim3(cb, cb), dim3(64), 0, st, n, iou_thr, boxes, mask_ws, cb);
+    BC_LAUNCH(ps, k_nms_sweep, dim3(1), dim3(64), 0, st, n, cb, mask_ws, keep, count);
     return launch_status();
 }
 

@@ -145,12 +145,20 @@ int bc_affine_act_nhwc(void *out, const void *in, const void *add, const float *
 int bc_interp_bilinear_nhwc(void *out, const void *in, long long planes, int C, int h, int w, int H, int W,
                             int align_corners, float rh, float rw, int dtype, void *stream);
 
+/* detector post-processing (config C5).  replaces nms_kernel + the host sweep of
+ * Pedestron/mmdet/ops/nms/src/nms_kernel.cu:23-130: boxes (n,5) float32 [x1,y1,x2,y2,score] ALREADY sorted by score
+ * descending, n <= 4096; IoU with the +1 pixel convention, suppression when IoU > iou_thr.  mask_ws: device scratch of
+ * n*ceil(n/64) 64-bit words.  Writes keep[0..count) = kept positions in the sorted order (ascending) and *count, all
+ * on the device (the reference copies the mask to the host and sweeps there). */
+int bc_nms_sorted(const float *boxes, int n, float iou_thr, unsigned long long *mask_ws, int32_t *keep,
+                  int32_t *count, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * C. Introspection / measurement
  * ------------------------------------------------------------------------------------------- */
 
 enum { BC_OP_SPLIT = 0, BC_OP_COMBINE = 1, BC_OP_TRANSFER = 2, BC_OP_PAD = 3,
-       BC_OP_COMBINE_COPY = 4, BC_OP_PAD_RING = 5, BC_OP_GRID_TABLES = 6, BC_OP_INTERP = 7, BC_OP_AFFINE = 8, BC_OP_COUNT = 9 };
+       BC_OP_COMBINE_COPY = 4, BC_OP_PAD_RING = 5, BC_OP_GRID_TABLES = 6, BC_OP_INTERP = 7, BC_OP_AFFINE = 8, BC_OP_NMS = 9, BC_OP_COUNT = 10 };
 
 int bc_abi_version(void);
 const char *bc_error_string(int code);

@@ -187,3 +187,33 @@ BCO_API int bco_transfer_idx(const int32_t *prev_grid_idx, const uint8_t *grid, 
         if (!grid[g]) transfer_idx[n_tr++] = prev_grid_idx[g];
     return n_tr;
 }
+
+/* nms_kernel + host sweep -- Pedestron/mmdet/ops/nms/src/nms_kernel.cu:12-130 (the GPU path of mmdet.ops.nms).
+ * boxes: (n,5) float [x1,y1,x2,y2,score], ALREADY sorted by score descending (the reference sorts with
+ * scores.sort(0, descending=True) at :73-75 before launching).  IoU uses the +1 pixel convention (:12-21); box j is
+ * suppressed by an earlier kept box i when IoU > thresh (strict, :61).  Writes the kept positions (indices into the
+ * sorted order, ascending) and returns their count.  The 64-wide bitmask blocking of the kernel does not change the
+ * result and is not reproduced. */
+static float bco_iou(const float *a, const float *b)
+{
+    float left = a[0] > b[0] ? a[0] : b[0], right = a[2] < b[2] ? a[2] : b[2];
+    float top = a[1] > b[1] ? a[1] : b[1], bottom = a[3] < b[3] ? a[3] : b[3];
+    float width = right - left + 1.f > 0.f ? right - left + 1.f : 0.f;
+    float height = bottom - top + 1.f > 0.f ? bottom - top + 1.f : 0.f;
+    float interS = width * height;
+    float Sa = (a[2] - a[0] + 1) * (a[3] - a[1] + 1);
+    float Sb = (b[2] - b[0] + 1) * (b[3] - b[1] + 1);
+    return interS / (Sa + Sb - interS);
+}
+
+BCO_API int bco_nms_sorted(const float *boxes, int n, float thresh, int32_t *keep)
+{
+    int num = 0;
+    for (int i = 0; i < n; ++i) {
+        int removed = 0;
+        for (int k = 0; k < num && !removed; ++k)
+            if (bco_iou(boxes + 5 * (long)keep[k], boxes + 5 * (long)i) > thresh) removed = 1;
+        if (!removed) keep[num++] = i;
+    }
+    return num;
+}

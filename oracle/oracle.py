@@ -49,6 +49,8 @@ def lib() -> ctypes.CDLL:
         _lib.bco_grid_mappings.restype = i
         _lib.bco_transfer_idx.argtypes = [p, p, i, p]
         _lib.bco_transfer_idx.restype = i
+        _lib.bco_nms_sorted.argtypes = [p, i, ctypes.c_float, p]
+        _lib.bco_nms_sorted.restype = i
         for f in (_lib.bco_split, _lib.bco_combine, _lib.bco_transfer, _lib.bco_repad):
             f.restype = None
     return _lib
@@ -131,6 +133,20 @@ def c_transfer_idx(prev_grid_idx, grid):
     out = np.empty(g.size, np.int32)
     n = lib().bco_transfer_idx(_ptr(p), _ptr(g), g.size, _ptr(out))
     return out[:n].copy()
+
+
+def c_nms(dets, iou_thr):
+    """reference: nms_cuda, Pedestron/mmdet/ops/nms/src/nms_kernel.cu:70-130 -- original indices of the kept boxes, ascending.
+    dets: (n,5) float32 [x1,y1,x2,y2,score]."""
+    d = np.ascontiguousarray(_np(dets), dtype=np.float32)
+    n = d.shape[0]
+    if n == 0:
+        return np.zeros(0, np.int64)
+    order = np.argsort(-d[:, 4], kind="stable")
+    srt = np.ascontiguousarray(d[order])
+    keep = np.empty(n, np.int32)
+    k = lib().bco_nms_sorted(_ptr(srt), n, float(iou_thr), _ptr(keep))
+    return np.sort(order[keep[:k]]).astype(np.int64)
 
 
 # --------------------------------------------------------------------------- numpy restatements

@@ -121,6 +121,10 @@ class OracleBackend:
         return _like(torch.nn.functional.interpolate(data.contiguous(), size=(out_h, out_w), mode="bilinear",
                                                      align_corners=align_corners), data)
 
+    def nms(self, dets, iou_thr):
+        inds = torch.from_numpy(O.c_nms(dets.detach().float().numpy(), iou_thr))
+        return dets[inds, :], inds
+
     def grid_tables_host(self, grid_u8, grid_idx, mapping, prev_grid_idx=None, transfer=None):
         gi, m = O.c_grid_mappings(grid_u8.astype(bool).reshape(1, 1, 1, -1))
         grid_idx[:] = gi.reshape(-1)

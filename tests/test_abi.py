@@ -41,7 +41,7 @@ def test_abi_version_and_strings(lib):
     assert lib.bc_abi_version() == 1
     assert lib.bc_error_string(0) == b"ok"
     assert b"NULL" in lib.bc_error_string(-1)
-    assert [lib.bc_op_name(i).decode() for i in range(9)] == ["split", "combine", "transfer", "pad", "combine_copy", "pad_ring", "grid_tables", "interp", "affine"]
+    assert [lib.bc_op_name(i).decode() for i in range(10)] == ["split", "combine", "transfer", "pad", "combine_copy", "pad_ring", "grid_tables", "interp", "affine", "nms"]
     assert lib.bc_op_name(99) == b"?"
 
 
@@ -69,6 +69,7 @@ def test_argument_validation_needs_no_gpu(lib):
     assert lib.bc_pad_ring_nhwc(N, N, N, N, N, 2, 1, 8, 2, 2, 4, 1, 3, 0, N, N, 0, N) == -3
     assert lib.bc_affine_act_nhwc(N, N, N, N, N, 0, 16, 8, 0, N) == -1
     assert lib.bc_interp_bilinear_nhwc(N, N, 4, 8, 2, 2, 4, 4, 0, 0.5, 0.5, 0, N) == -1
+    assert lib.bc_nms_sorted(N, 5000, 0.5, N, N, N, N) == -2 and lib.bc_nms_sorted(N, 10, 0.5, N, N, N, N) == -1
     assert lib.bc_prof_read(99, None, None, None) == -2
 
 

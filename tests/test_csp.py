@@ -1,0 +1,107 @@
+"""CSP detector workload (BASELINE config C5) on CPU with the oracle-backed checker: mmcv/mmdet cannot be installed
+here, so the model is pinned by reference-independent properties instead of reference outputs."""
+import numpy as np
+import pytest
+import torch
+
+
+def _tiny_inputs(seed=0):
+    from bc_workloads import seeded
+    return seeded.synthetic_frame(seed, (1, 3, 128, 256))
+
+
+def test_parameter_names_follow_mmdet(oracle_backend):
+    from bc_workloads.csp import CSP
+
+    keys = list(CSP().state_dict())
+    for k in ("backbone.conv1.weight", "backbone.layer1.0.downsample.0.weight", "backbone.layer4.2.bn3.running_var",
+              "neck.p3.weight", "neck.p3.bias", "neck.p5_l2.weight", "bbox_head.cls_convs.0.conv.weight",
+              "bbox_head.reg_convs.0.gn.bias", "bbox_head.offset_convs.0.gn.weight", "bbox_head.csp_cls.bias",
+              "bbox_head.csp_offset.weight", "bbox_head.reg_scales.0.scale", "bbox_head.offset_scales.0.scale"):
+        assert k in keys, k
+    m = CSP()
+    assert m.backbone.layer4[0].conv2.dilation == (2, 2) and m.backbone.layer4[0].conv2.padding == (2, 2)
+    assert m.backbone.layer4[0].conv2.stride == (1, 1) and m.backbone.layer3[0].conv2.stride == (2, 2)
+
+
+@pytest.mark.parametrize("graph", [0, 1])
+def test_all_active_equals_dense_and_static_clip_is_invariant(oracle_backend, graph):
+    """P1: with every tile executed the packed BACKBONE (incl. the dilation-2 stage, halo width 2) equals the dense one
+    (the neck's transposed convs run per tile without halo -- reference quirk -- so equality stops there).
+    P2: feeding the same frame with arbitrary masks leaves the neck's 768-channel map unchanged; the head maps are only
+    invariant when every tile is executed, because GroupNorm statistics run over the executed tiles (reference quirk,
+    core/tensorwrapper.py:600-633)."""
+    import blockcopy
+    from bc_workloads.csp import build_csp
+
+    x = _tiny_inputs()
+    dense = build_csp(block_policy="static", device="cpu")
+    blk = build_csp(block_policy="fixed", block_size=32, block_target=0.5, device="cpu", block_graph=graph)
+    with torch.no_grad():
+        want = dense.backbone(x)
+        xw = blockcopy.to_tensorwrapper(x)
+        xw.process_temporal_features(None)
+        grid = torch.ones(1, 1, 4, 8, dtype=torch.bool)
+        got = blk.backbone(xw.to_blocks(grid, grid))
+        for w, g in zip(want, got):
+            full = g.combine().to_tensor()
+            assert float((full - w).abs().max()) <= 1e-4 * max(1.0, float(w.abs().max()))
+
+        neck_maps = []
+        hook = blk.neck.register_forward_hook(lambda mod, inp, out: neck_maps.append(out[0].combine().to_tensor().clone()))
+        blk.reset_temporal()
+        for t in range(4):
+            blk.simple_test(x)
+        hook.remove()
+        assert len(neck_maps) == 4 and neck_maps[0].shape == (1, 768, 32, 64)
+        for t in range(1, 4):
+            assert float((neck_maps[t] - neck_maps[0]).abs().max()) <= 1e-4 * max(1.0, float(neck_maps[0].abs().max())), t
+        assert blk.policy.stats.exec == 32 + 3 * 16
+
+        allb = build_csp(block_policy="all", block_size=32, device="cpu", block_graph=graph)
+        allb.reset_temporal()
+        allb.simple_test(x)
+        first = [m.clone() for m in allb.head_out]
+        allb.simple_test(x)
+        for a, b_ in zip(first, allb.head_out):
+            assert a.shape[-2:] == (32, 64) and float((a - b_).abs().max()) <= 1e-5 * max(1.0, float(a.abs().max()))
+
+
+def test_detections_and_reference_output_format(oracle_backend):
+    from bc_workloads.csp import build_csp
+
+    blk = build_csp(block_policy="fixed", block_size=32, block_target=0.5, device="cpu", results="numpy")
+    x = _tiny_inputs(1)
+    blk.reset_temporal()
+    out = blk.simple_test(x)
+    assert isinstance(out, list) and len(out) == 1 and isinstance(out[0], np.ndarray) and out[0].shape[1] == 5
+    assert out[0].shape[0] <= 100 and (out[0][:, 4] > 0.1).all()
+    assert (out[0][:, 2] >= out[0][:, 0]).all() and (out[0][:, 0] >= 0).all() and (out[0][:, 2] <= 255).all()
+    # num_exec == 0 returns the cached result object
+    blk.policy.block_target = 0.0
+    prev = blk.policy_meta["outputs"]
+    blk.simple_test(x)
+    assert blk.policy_meta["num_exec"] == 0 and blk.policy_meta["outputs"] is prev
+
+
+def test_three_head_branches_share_one_halo_gather(oracle_backend):
+    """The 768-channel head input is padded once for the three 3x3 branches."""
+    import blockcopy.backend as bk
+    from bc_workloads.csp import build_csp
+
+    be = bk.get_backend()
+    calls = []
+    orig = be.pad_ring
+
+    def counting(data, *a, **k):
+        calls.append(tuple(data.shape))
+        return orig(data, *a, **k)
+
+    be.pad_ring = counting
+    try:
+        blk = build_csp(block_policy="all", block_size=32, device="cpu")
+        blk.reset_temporal()
+        blk.simple_test(_tiny_inputs(2))
+    finally:
+        be.pad_ring = orig
+    assert sum(1 for s in calls if s[1] == 768) == 1, calls
