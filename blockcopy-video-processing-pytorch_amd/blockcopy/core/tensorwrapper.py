@@ -455,12 +455,13 @@ class TensorWrapper(torch.Tensor):
 
             ps = self._features.persistent
             if ps is not None:
-                # graph-capturable body: scatter into the call site's persistent map (fixed address); an
-                # out-of-place combine then snapshots it (values identical to clone + scatter).
+                # graph-capturable body: scatter into the call site's persistent map (fixed address) and hand that map
+                # out, for in-place and out-of-place combines alike: a snapshot would live in the graph's private pool,
+                # which is recycled at the next replay, so it could not outlive the frame any more than the map does
+                # (each call site owns its map; nothing else writes it until the next frame).  Only the executed
+                # tiles move: 2*n_exec*C*bs^2*E bytes instead of the 2*N*C*H*W*E of a full copy.
                 buf = ps.next_map(out_shape, blocks.dtype, blocks.device, is_nhwc(blocks))
                 out = CombineFunction.apply(blocks, buf, grid_idx, mapping_exec)
-                if not inplace:
-                    out = out.clone()
                 return self._wrap_like(out, self, False)
 
             if self._features_prev:
