@@ -48,7 +48,8 @@ def _as_int_boxes(arr: np.ndarray, div: int = 1) -> np.ndarray:
 def box_iou(a, b) -> float:
     ax1, ay1, ax2, ay2 = a
     bx1, by1, bx2, by2 = b
-    assert ax1 < ax2 and ay1 < ay2 and bx1 < bx2 and by1 < by2, (a, b)
+    if not (ax1 < ax2 and ay1 < ay2 and bx1 < bx2 and by1 < by2):
+        return 0.0   # a box that collapses at half resolution overlaps nothing (the reference asserts here, :137-140)
     xl, yt, xr, yb = max(ax1, bx1), max(ay1, by1), min(ax2, bx2), min(ay2, by2)
     if xr < xl or yb < yt:
         return 0.0

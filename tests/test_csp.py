@@ -105,3 +105,28 @@ def test_three_head_branches_share_one_halo_gather(oracle_backend):
     finally:
         be.pad_ring = orig
     assert sum(1 for s in calls if s[1] == 768) == 1, calls
+
+
+def test_rl_objectdetection_policy_drives_the_detector(oracle_backend):
+    """The reference's detector config uses the `rl_objectdetection` policy (csp_r50_clip_blockcopy_030.py:5-17): its
+    output representation and information gain are built from the per-class numpy box lists the detector returns."""
+    import random
+
+    from bc_workloads.csp import build_csp
+
+    torch.manual_seed(0)
+    random.seed(0)
+    blk = build_csp(block_policy="rl_objectdetection", block_size=32, block_target=0.3, device="cpu", results="numpy",
+                    block_train_interval=2)
+    assert blk.policy.net.training
+    w0 = blk.policy.net.backbone.conv1.weight.detach().clone()
+    blk.reset_temporal()
+    execs = []
+    for t in range(4):
+        out = blk.simple_test(_tiny_inputs(t))
+        assert isinstance(out, list) and out[0].shape[1] == 5
+        execs.append(blk.policy_meta["num_exec"])
+        assert blk.policy_meta["output_repr"].shape == (1, 1, 128, 256)
+    assert execs[0] == 32 and all(e % 2 == 0 for e in execs)
+    assert "information_gain" in blk.policy_meta and blk.policy_meta["information_gain"].shape == (1, 1, 128, 256)
+    assert not torch.equal(w0, blk.policy.net.backbone.conv1.weight)      # the policy trained online
