@@ -38,6 +38,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=2, help="untimed clips per rank")
     ap.add_argument("--half", action="store_true", help="fp16 compute (reference speed configs use --half); default fp32")
     ap.add_argument("--backbone", default="resnet18")
+    ap.add_argument("--batch", type=int, default=1, help="clips processed side by side (the reference's speed configs use 2); C2 is defined at 1")
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--block-size", type=int, default=128)
@@ -67,7 +68,7 @@ def cpu_dense_baseline(args, n_frames):
 
     cores = torch.get_num_threads()
     model = harness.build_model(args.backbone, block_policy="static", device="cpu")
-    x = seeded.synthetic_frame(0, (1, 3, args.height, args.width))
+    x = seeded.synthetic_frame(0, (1, 3, args.height, args.width))   # the CPU baseline is always one frame at a time
     with torch.no_grad():
         model(x)   # warm-up (oneDNN primitive creation)
         t0 = time.perf_counter()
@@ -85,6 +86,8 @@ def cpu_dense_baseline(args, n_frames):
 
 def config_name(args):
     """Which BASELINE.json config the arguments correspond to."""
+    if args.batch != 1:
+        return f"custom(batch {args.batch})"
     base = (args.backbone, args.height, args.width, args.block_size)
     if base == ("resnet18", 1024, 2048, 128):
         return "C2" if args.policy == "fixed" and args.target == 0.5 else ("C3" if args.policy == "rl_semseg" else "C2-variant")
@@ -151,7 +154,7 @@ def main():
     tw.set_engine(args.engine)
     be = bk.get_backend()
     dtype = torch.float16 if args.half else torch.float32
-    shape = (1, 3, args.height, args.width)
+    shape = (args.batch, 3, args.height, args.width)
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
 
     model = harness.build_model(args.backbone, block_policy=args.policy, block_size=args.block_size, block_target=args.target,
@@ -191,7 +194,7 @@ def main():
     timings.set_level(0)
 
     # whole-job throughput: all ranks' frames / slowest rank's time (no collective on the data path)
-    fps, elapsed, frames_total = replicas.job_throughput(args.steps * CLIP_LEN, elapsed, world, device)
+    fps, elapsed, frames_total = replicas.job_throughput(args.steps * CLIP_LEN * args.batch, elapsed, world, device)
     exec_frac = model.policy.stats.get_exec_percentage()
 
     extra = {}
@@ -245,6 +248,20 @@ def main():
                 extra["fp16"] = {"fps": hfps, "dense_gpu_fps": hdfps, "speedup_vs_dense_gpu": hfps / hdfps,
                                  "note": "same workload, weights and masks in float16 (not parity-gated; the headline value is fp32)"}
                 del hm, hd
+                if args.batch == 1:
+                    # secondary measurement: two clips side by side (the reference's speed configs use --batch-size 2)
+                    torch.cuda.empty_cache()
+                    bshape = (2, 3, args.height, args.width)
+                    bclips = [harness.synthetic_clip(CLIP_LEN, bshape, seed=7, device=device, dtype=dtype)]
+                    bm = harness.build_model(args.backbone, block_policy=args.policy, block_size=args.block_size, block_target=args.target,
+                                             device=device, dtype=dtype, seed=1000 * rank, block_graph=args.graph,
+                                             block_train_interval=args.train_interval, channels_last=bool(args.channels_last))
+                    bfps, _, _ = harness.measure_fps(bm, bclips, n_clips=max(1, min(args.steps, 3)), warmup_clips=2, device=device)
+                    bd = harness.build_model(args.backbone, block_policy="static", device=device, dtype=dtype, channels_last=bool(args.channels_last))
+                    bdfps, _, _ = harness.measure_fps(bd, bclips, n_clips=max(1, min(args.steps, 3)), warmup_clips=1, device=device)
+                    extra["batch2"] = {"fps": bfps, "dense_gpu_fps": bdfps, "speedup_vs_dense_gpu": bfps / bdfps,
+                                       "note": "same workload with 2 clips per step (batch 2), fp32; the headline value is batch 1"}
+                    del bm, bd
 
     if rank == 0:
         achieved = (cc["total_bytes"] / (cc["total_ms"] * 1e-3) / 1e9) if cc["total_ms"] > 0 else 0.0
