@@ -116,17 +116,27 @@ def main():
         E = torch.empty(0, dtype=dt).element_size()
         for name, GH, GW, n_exec, C, bs, p in h_cases:
             tag = f"pad_ring {name} ({n_exec},{C},{bs},{bs}) p{p} {str(dt)[6:]}"
-            if args.filter not in tag:
+            if not any(args.filter in t for t in (tag, tag.replace("pad_ring", "pad_ring_nhwc"), tag.replace("pad_ring", "pad(noring)"))):
                 continue
             gi, m = grid_tables(1, GH, GW, n_exec)
             feats = torch.randn((n_exec, C, bs, bs), device="cuda").to(dt)
             ring = torch.randn((GH * GW, C, 4 * p * bs), device="cuda").to(dt)
-            us = timeit(lambda: be.pad_ring(feats, ring, gi, m, p), args.iters)
-            report(tag, us, 2.0 * n_exec * C * (bs + 2 * p) ** 2 * E)
+            if args.filter in tag:
+                us = timeit(lambda: be.pad_ring(feats, ring, gi, m, p), args.iters)
+                report(tag, us, 2.0 * n_exec * C * (bs + 2 * p) ** 2 * E)
+            tagn = tag.replace("pad_ring", "pad_ring_nhwc")
+            if args.filter in tagn and (C * E) % 16 == 0:
+                fcl = feats.contiguous(memory_format=torch.channels_last)
+                us = timeit(lambda: be.pad_ring(fcl, ring, gi, m, p), args.iters)
+                report(tagn, us, 2.0 * n_exec * C * (bs + 2 * p) ** 2 * E)
+                sc = torch.rand(C, device="cuda") + 0.5
+                us = timeit(lambda: be.pad_ring(fcl, ring, gi, m, p, (sc, sc, True)), args.iters)
+                report(tagn + "+act", us, 2.0 * n_exec * C * (bs + 2 * p) ** 2 * E)
             tag2 = tag.replace("pad_ring", "pad(noring)")
             tr = torch.randn((GH * GW - n_exec, C, bs, bs), device="cuda").to(dt)
-            us = timeit(lambda: be.pad(feats, tr, gi, m, p), args.iters)
-            report(tag2, us, 2.0 * n_exec * C * (bs + 2 * p) ** 2 * E)
+            if args.filter in tag2:
+                us = timeit(lambda: be.pad(feats, tr, gi, m, p), args.iters)
+                report(tag2, us, 2.0 * n_exec * C * (bs + 2 * p) ** 2 * E)
             del feats, ring, tr
 
     # ---------------- per-tile bilinear x2
