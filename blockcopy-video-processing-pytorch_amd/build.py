@@ -40,5 +40,24 @@ def build_hip_library(force: bool = False, verbose: bool = False) -> str:
     return OUT
 
 
+ABI_DEMO_SRC = os.path.join(os.path.dirname(HERE), "tests", "abi_c", "abi_roundtrip.cpp")
+ABI_DEMO = os.path.join(os.path.dirname(HERE), "tests", "abi_c", "abi_roundtrip")
+
+
+def build_abi_consumer(force: bool = False) -> str:
+    """tests/abi_c/abi_roundtrip: a C++/HIP program that uses the library through include/blockcopy_hip.h alone (no
+    PyTorch) -- what a non-Python host of the reference's block ops would link."""
+    lib = build_hip_library()
+    if not force and os.path.exists(ABI_DEMO) and os.path.getmtime(ABI_DEMO) >= max(
+            os.path.getmtime(f) for f in [ABI_DEMO_SRC, lib] + HDR):
+        return ABI_DEMO
+    cmd = [hipcc(), f"--offload-arch={ARCH}", "-O2", "-std=c++17", "-I", os.path.dirname(HDR[0]), ABI_DEMO_SRC,
+           "-L", os.path.dirname(lib), "-lblockcopy_hip", "-Wl,-rpath," + os.path.dirname(lib),
+           "-Wl,-rpath,$ORIGIN/../../blockcopy-video-processing-pytorch_amd/lib", "-o", ABI_DEMO + ".tmp"]
+    subprocess.check_call(cmd)
+    os.replace(ABI_DEMO + ".tmp", ABI_DEMO)
+    return ABI_DEMO
+
+
 if __name__ == "__main__":
     print(build_hip_library(force="--force" in sys.argv, verbose="-v" in sys.argv))

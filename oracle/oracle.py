@@ -60,7 +60,12 @@ def _np(x) -> np.ndarray:
     """numpy view of a numpy array or a CPU torch tensor (shares memory)."""
     if isinstance(x, np.ndarray):
         return x
-    return x.detach().numpy()
+    x = x.detach()
+    if str(x.dtype) == "torch.bfloat16":   # numpy has no bf16; the block ops are pure copies => raw 16-bit words
+        import torch
+
+        x = x.view(torch.int16)
+    return x.numpy()
 
 
 def _ptr(a: np.ndarray) -> ctypes.c_void_p:

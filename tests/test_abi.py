@@ -78,3 +78,14 @@ def test_profiling_counters_idle(lib):
     assert lib.bc_prof_reset() == 0 and lib.bc_prof_enable(0) == 0
     assert lib.bc_prof_read(4, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(by)) == 0
     assert (n.value, ms.value, by.value) == (0, 0.0, 0.0)
+
+
+def test_plain_c_consumer_links():
+    """tests/abi_c/abi_roundtrip.cpp uses nothing but include/blockcopy_hip.h + the HIP runtime and links against the
+    library (run on the GPU by tests/test_gpu_ops.py::test_plain_c_consumer_runs)."""
+    import build as bc_build
+
+    exe = bc_build.build_abi_consumer()
+    assert os.access(exe, os.X_OK)
+    src = open(bc_build.ABI_DEMO_SRC).read()
+    assert "torch" not in src.replace("PyTorch", "") and "Python.h" not in src

@@ -413,3 +413,37 @@ def test_nms_matches_oracle(be):
             kept, inds = be.nms(torch.from_numpy(dets).cuda(), thr)
             assert np.array_equal(inds.cpu().numpy(), want), (n, thr)
             assert kept.shape == (len(inds), 5) and torch.equal(kept.cpu(), torch.from_numpy(dets)[inds.cpu()])
+
+
+def test_plain_c_consumer_runs():
+    """The PyTorch-free C++ consumer of the ABI (tests/abi_c) passes its own checks on the device."""
+    import subprocess
+
+    import build as bc_build
+
+    exe = bc_build.build_abi_consumer()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "abi_roundtrip ok" in r.stdout
+
+
+def test_random_geometries_auto(be):
+    """60 random geometries x 4 frames (dtype, layout, grid all random), default kernel selection."""
+    import random_geometry
+
+    cases = random_geometry.sweep(seed=2024, count=60)
+    assert len(cases) == 60 and {c[2] for c in cases} == {"nchw", "nhwc"}
+
+
+@pytest.mark.parametrize("variant", ["rows", "lds", "simple"])
+def test_random_geometries_forced_halo_kernel(variant):
+    """Same sweep with each NCHW halo kernel forced (BC_HALO_KERNEL is read once per process => child process)."""
+    import os
+    import subprocess
+    import sys
+
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "random_geometry.py")
+    env = dict(os.environ, BC_HALO_KERNEL=variant)
+    r = subprocess.run([sys.executable, script, "77", "40"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert f"BC_HALO_KERNEL={variant}" in r.stdout
