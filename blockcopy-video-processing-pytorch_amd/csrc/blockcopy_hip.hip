@@ -65,6 +65,26 @@ template <> struct VecOf<4> { typedef uint32_t type; };
 template <> struct VecOf<2> { typedef uint16_t type; };
 template <> struct VecOf<1> { typedef uint8_t type; };
 
+// streaming (nontemporal) access on the native vector type of the same width
+template <typename V> struct NativeOf { typedef V type; };
+template <> struct NativeOf<uint4> { typedef uint32_t type __attribute__((ext_vector_type(4))); };
+template <> struct NativeOf<uint2> { typedef uint32_t type __attribute__((ext_vector_type(2))); };
+template <typename V> __device__ __forceinline__ V nt_load(const V *p)
+{
+    typedef typename NativeOf<V>::type T;
+    const T t = __builtin_nontemporal_load(reinterpret_cast<const T *>(p));
+    V v;
+    __builtin_memcpy(&v, &t, sizeof(V));
+    return v;
+}
+template <typename V> __device__ __forceinline__ void nt_store(const V &v, V *p)
+{
+    typedef typename NativeOf<V>::type T;
+    T t;
+    __builtin_memcpy(&t, &v, sizeof(V));
+    __builtin_nontemporal_store(t, reinterpret_cast<T *>(p));
+}
+
 constexpr int WG = 256;          // 4 wavefronts
 constexpr int MAX_WG = 256 * 8;  // 8 resident workgroups per CU on 256 CUs
 constexpr int UNROLL = 4;
@@ -131,7 +151,12 @@ struct DenseGeom {
     uint32_t total;               // N*C*H*vprW
 };
 
-template <int VB, int U>
+// One output vector per lane, every lane live (exact grid, clamped tail), streaming (nontemporal) loads and stores:
+// both inputs are read exactly once and the output is not re-read by this pipeline, so none of it should displace
+// L2 / Infinity Cache lines.  Measured on MI355X with caches evicted before every launch (tools/kbench_cold.py,
+// profiles/r01/kbench_cold_*.txt): 268 MB 73 -> 43 us, 80 MB 24 -> 15 us, 20 MB 7.7 -> 6.0 us against the 4-per-lane
+// cached variant; with warm caches it is level or faster up to 2 GB.  (Deeper per-lane unrolling only helps the warm case.)
+template <int VB>
 __global__ __launch_bounds__(WG) void k_combine_copy(const typename VecOf<VB>::type *__restrict__ blocks,
                                                      long long prev_delta,   // (prev - blocks) in vectors
                                                      typename VecOf<VB>::type *__restrict__ out,
@@ -139,36 +164,17 @@ __global__ __launch_bounds__(WG) void k_combine_copy(const typename VecOf<VB>::t
 {
     // Both sources are addressed from ONE base (blocks + signed offset): with two base pointers selected per lane
     // the compiler loses the no-alias information against `out` and serialises load -> store -> load.
-    typedef typename VecOf<VB>::type V;
-    const uint32_t stride = gridDim.x * WG;
-    const uint32_t v0 = blockIdx.x * WG + threadIdx.x;
-    const uint32_t last = g.total - 1;
-    uint32_t vc[U], tile[U], inner[U];
-    int32_t idx[U];
-    V val[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const uint32_t v = v0 + u * stride;
-        vc[u] = v < last ? v : last;
-        uint32_t r, xw, r2, y, n, c, gw, xv, gh, h;
-        fd_divmod(vc[u], g.vprW, r, xw);
-        fd_divmod(r, g.H, r2, y);
-        fd_divmod(r2, g.C, n, c);
-        fd_divmod(xw, g.vpr, gw, xv);
-        fd_divmod(y, g.bs, gh, h);
-        tile[u] = (n * g.GH + gh) * g.GW + gw;
-        inner[u] = (c * g.bs.d + h) * g.vpr.d + xv;   // vector offset inside a packed tile
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) idx[u] = grid_idx[tile[u]];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const long long off = idx[u] >= 0 ? (long long)((uint32_t)idx[u] * g.C.d * g.bs.d * g.vpr.d + inner[u])
-                                          : prev_delta + (long long)vc[u];
-        val[u] = blocks[off];
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) out[vc[u]] = val[u];   // clamped duplicates rewrite the same value (see k_tiles)
+    const uint32_t v = min(blockIdx.x * WG + threadIdx.x, g.total - 1);   // tail lanes redo the last vector (same value)
+    uint32_t r, xw, r2, y, n, c, gw, xv, gh, h;
+    fd_divmod(v, g.vprW, r, xw);
+    fd_divmod(r, g.H, r2, y);
+    fd_divmod(r2, g.C, n, c);
+    fd_divmod(xw, g.vpr, gw, xv);
+    fd_divmod(y, g.bs, gh, h);
+    const int32_t idx = grid_idx[(n * g.GH + gh) * g.GW + gw];
+    const uint32_t inner = (c * g.bs.d + h) * g.vpr.d + xv;   // vector offset inside a packed tile
+    const long long off = idx >= 0 ? (long long)((uint32_t)idx * g.C.d * g.bs.d * g.vpr.d + inner) : prev_delta + (long long)v;
+    nt_store(nt_load(blocks + off), out + v);
 }
 
 // ------------------------------------------------------------------------------------------ border-ring transfer
@@ -879,7 +885,7 @@ __global__ __launch_bounds__(WG) void k_halo_nhwc(typename VecOf<VB>::type *__re
     typedef typename VecOf<VB>::type V;
     constexpr int VE = VB / (int)sizeof(T);
     const uint32_t b = blockIdx.y;
-    const uint32_t bs = g.bs, p = g.pad, BSP = g.BSP.d, K = g.K.d;
+    const uint32_t bs = g.bs, p = g.pad, K = g.K.d;
     const uint32_t tile_vecs = bs * bs * K;          // vectors per packed tile
     const uint32_t RSV = 4 * p * bs * K;             // vectors per compact ring record (fat pixels x K)
 
@@ -935,7 +941,7 @@ __global__ __launch_bounds__(WG) void k_halo_nhwc(typename VecOf<VB>::type *__re
         zero[u] = sy == 0 ? z0 : (sy == 1 ? z1 : z2);
         const bool from_ring = sy == 0 ? r0 : (sy == 1 ? r1 : r2);
         const uint32_t off = (from_ring ? ring_elem(sy, sx, hs, ws, bs, p) : hs * bs + ws) * K + k;
-        vec[u] = features[zero[u] ? 0 : base + off];
+        vec[u] = features[zero[u] ? 0 : base + off];   // inputs are fresh from the producing kernel: streaming loads measured slower here
         fo[u] = f; kk[u] = k; hs_[u] = hs; ws_[u] = ws;
         own[u] = sy == 1 && sx == 1;
     }
@@ -1144,8 +1150,10 @@ struct ProfScope {
         std::lock_guard<std::mutex> lk(g_prof.mu);
         if (!g_prof.pool.empty()) { rec = g_prof.pool.back(); g_prof.pool.pop_back(); }
         else {
-            if (hipEventCreate(&rec.a) != hipSuccess) return;
-            if (hipEventCreate(&rec.b) != hipSuccess) { (void)hipEventDestroy(rec.a); return; }
+            // timing-only events: no system-scope fence (its cache write-back would be charged to the timed kernel;
+            // measured +0.8-1.1 us on a 6 us launch).  Readers synchronise the stream before bc_prof_read.
+            if (hipEventCreateWithFlags(&rec.a, hipEventDisableSystemFence) != hipSuccess) return;
+            if (hipEventCreateWithFlags(&rec.b, hipEventDisableSystemFence) != hipSuccess) { (void)hipEventDestroy(rec.a); return; }
         }
         g_prof.bytes[op] += bytes;
         on = true;
@@ -1413,19 +1421,13 @@ BC_EXPORT int bc_combine_copy(const void *blocks, const void *prev, void *out, c
     g.vprW = make_fd(vprW); g.H = make_fd(H); g.C = make_fd(C); g.vpr = make_fd(vpr); g.bs = make_fd(bs);
     g.GH = H / bs; g.GW = W / bs;
     g.total = (uint32_t)((uint64_t)N * C * H * vprW);
-    const bool small = g.total < SMALL_LAUNCH_VECTORS;
-    const int grid = grid_exact(g.total, small ? 1 : UNROLL);
+    const int grid = grid_exact(g.total, 1);
     ProfScope ps(BC_OP_COMBINE_COPY, 2.0 * N * C * H * W * E);
 #define BC_CC(VB_)                                                                                             \
     case VB_:                                                                                                  \
-        if (small)                                                                                             \
-            BC_LAUNCH(ps, (k_combine_copy<VB_, 1>), dim3(grid), dim3(WG), 0, st, (const VecOf<VB_>::type *)bl, \
-                      (long long)(((const char *)pv - (const char *)bl) / VB_), (VecOf<VB_>::type *)out,       \
-                      grid_idx, g);                                                                            \
-        else                                                                                                   \
-        BC_LAUNCH(ps, (k_combine_copy<VB_, UNROLL>), dim3(grid), dim3(WG), 0, st, (const VecOf<VB_>::type *)bl,   \
-                           (long long)(((const char *)pv - (const char *)bl) / VB_), (VecOf<VB_>::type *)out,  \
-                           grid_idx, g);                                                                       \
+        BC_LAUNCH(ps, (k_combine_copy<VB_>), dim3(grid), dim3(WG), 0, st, (const VecOf<VB_>::type *)bl,        \
+                  (long long)(((const char *)pv - (const char *)bl) / VB_), (VecOf<VB_>::type *)out,           \
+                  grid_idx, g);                                                                                \
         break;
     switch (vb) { BC_CC(16) BC_CC(8) BC_CC(4) BC_CC(2) BC_CC(1) }
 #undef BC_CC
