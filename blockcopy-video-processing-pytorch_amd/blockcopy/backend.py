@@ -20,7 +20,7 @@ _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("BLOCKCOPY_HIP_LIB", os.path.join(_PKG_ROOT, "lib", "libblockcopy_hip.so"))
 
 OP_SPLIT, OP_COMBINE, OP_TRANSFER, OP_PAD, OP_COMBINE_COPY, OP_PAD_RING, OP_GRID_TABLES, OP_INTERP, OP_AFFINE = range(9)
-OP_NAMES = ("split", "combine", "transfer", "pad", "combine_copy", "pad_ring", "grid_tables", "interp", "affine", "nms")
+OP_NAMES = ("split", "combine", "transfer", "pad", "combine_copy", "pad_ring", "grid_tables", "interp", "affine", "nms", "conv3x3")
 _DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 ABI_VERSION = 1
 
@@ -75,6 +75,7 @@ def load_library(path: str = None) -> ctypes.CDLL:
         "bc_pad_ring_act": [p, p, p, p, p] + [i] * 8 + [p, p, i, p],
         "bc_pad_ring_nhwc": [p, p, p, p, p] + [i] * 9 + [p, p, i, p],
         "bc_affine_act_nhwc": [p, p, p, p, p, i, ctypes.c_longlong, i, i, p],
+        "bc_conv3x3_ring_nhwc": [p, p, p, p, p, p] + [i] * 8 + [p, p, i, p, p, p, i, p],
         "bc_interp_bilinear_nhwc": [p, p, ctypes.c_longlong, i, i, i, i, i, i, ctypes.c_float, ctypes.c_float, i, p],
         "bc_affine_act": [p, p, p, p, p, i, ctypes.c_longlong, i, ctypes.c_longlong, i, p],
         "bc_nms_sorted": [p, i, ctypes.c_float, p, p, p, p],
@@ -241,6 +242,52 @@ class HipBackend:
                                                          scale.data_ptr() if scale is not None else None,
                                                          shift.data_ptr() if shift is not None else None, int(bool(relu)),
                                                          self._stream()), "pad_ring_act")
+        return out
+
+    @staticmethod
+    def conv3x3_supported(data_exec, weight, stride=1, padding=1, dilation=1, groups=1):
+        """Shapes the fused MFMA conv covers (everything else goes halo gather + library conv)."""
+        def _one(v):
+            return v if isinstance(v, int) else (v[0] if len(set(v)) == 1 else None)
+        bs = data_exec.shape[2]
+        return (data_exec.dtype == torch.float32 and weight.dtype == torch.float32 and is_nhwc(data_exec)
+                and tuple(weight.shape[2:]) == (3, 3) and _one(stride) == 1 and _one(padding) == 1 and _one(dilation) == 1
+                and groups == 1 and weight.shape[1] % 32 == 0 and weight.shape[0] % 64 == 0
+                and data_exec.shape[2] == data_exec.shape[3] and (bs == 4 or (bs % 8 == 0 and bs <= 248)))
+
+    @staticmethod
+    def pack_conv3x3_weights(weight):
+        """(Cout, Cin, 3, 3) -> the MFMA operand stream of bc_conv3x3_ring_nhwc (include/blockcopy_hip.h):
+        wpk[nb][chunk][tap][cg][lane][j] = W[32*nb + lane%32][32*chunk + 8*cg + 4*(lane//32) + j][tap]."""
+        Cout, Cin, kh, kw = weight.shape
+        assert (kh, kw) == (3, 3) and Cin % 32 == 0 and Cout % 32 == 0
+        w = weight.detach().as_subclass(torch.Tensor).permute(2, 3, 1, 0).reshape(9, Cin // 32, 4, 2, 4, Cout // 32, 32)   # tap, chunk, cg, h, j, nb, n
+        return w.permute(5, 1, 0, 2, 3, 6, 4).contiguous().view(-1)                               # nb, chunk, tap, cg, h, n, j
+
+    def conv3x3_ring(self, data_exec, ring, wpk, cout, grid_idx, mapping_exec, prologue=None, epilogue=None):
+        """Fused halo gather + 3x3/s1/p1 conv (+ optional epilogue) of a channels-last packed batch on the fp32 matrix
+        cores.  prologue = (scale, shift, relu) per input channel, epilogue = (scale, shift, add, relu) per output channel."""
+        assert _ok(data_exec, torch.float32) and is_nhwc(data_exec) and _ok(ring, torch.float32) and _ok(wpk, torch.float32)
+        assert _ok(mapping_exec, torch.int32) and _ok(grid_idx, torch.int32)
+        N, _, GH, GW = grid_idx.shape
+        B, C, bs, _ = data_exec.shape
+        n_exec = mapping_exec.numel()
+        assert n_exec == B and wpk.numel() == 9 * C * cout
+        assert tuple(ring.shape) == (N * GH * GW, C, 4 * bs), (ring.shape, (N * GH * GW, C, 4 * bs))
+        out = empty_like_layout((B, cout, bs, bs), data_exec)
+        isc, ish, irelu = prologue if prologue is not None else (None, None, False)
+        osc, osh, oadd, orelu = epilogue if epilogue is not None else (None, None, None, False)
+        for v, n in ((isc, C), (ish, C), (osc, cout), (osh, cout)):
+            assert v is None or (_ok(v, torch.float32) and v.numel() == n)
+        assert oadd is None or (_ok(oadd, torch.float32) and oadd.shape == out.shape and is_nhwc(oadd))
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        if n_exec > 0:
+            with torch.cuda.device_of(data_exec):
+                self._check(self.lib.bc_conv3x3_ring_nhwc(out.data_ptr(), data_exec.data_ptr(), ring.data_ptr(), wpk.data_ptr(),
+                                                          grid_idx.data_ptr(), mapping_exec.data_ptr(), n_exec, N, C, cout, GH, GW,
+                                                          bs, _DTYPE_CODE[data_exec.dtype], ptr(isc), ptr(ish), int(bool(irelu)),
+                                                          ptr(osc), ptr(osh), ptr(oadd), int(bool(orelu)), self._stream()),
+                            "conv3x3_ring_nhwc")
         return out
 
     def affine_act(self, data, scale=None, shift=None, add=None, relu=False):

@@ -84,6 +84,32 @@ def channel_vector(t: torch.Tensor) -> torch.Tensor:
     return v
 
 
+def packed_conv3x3_weight(weight: torch.Tensor, pack) -> torch.Tensor:
+    """MFMA operand stream of a (Cout, Cin, 3, 3) weight for the fused halo+conv kernel, derived once per parameter."""
+    k = ("wpk",) + _key(weight)
+    v = _lookup(k, (weight,))
+    if v is None:
+        with torch.no_grad():
+            v = _store(k, (weight,), pack(weight))
+    return v
+
+
+CONV_MODE = os.environ.get("BLOCKCOPY_CONV", "auto")   # auto | native | library
+
+
+def use_native_conv3x3(n_exec: int, bs: int, cin: int, cout: int) -> bool:
+    """Where the hand-written fused halo+conv beats halo gather + library conv INSIDE a frame on MI355X
+    (profiles/r01/20_*: the library's asm implicit-GEMM reaches ~107 TFLOP/s fp32 in-frame on 64-channel 32x32 tiles and
+    keeps those; the fused kernel wins on the mid-size layers, where the separate halo gather and the library's
+    split-K zero-fill weigh most)."""
+    if CONV_MODE == "library":
+        return False
+    if CONV_MODE == "native":
+        return True
+    items64 = n_exec * bs * bs // 64 * (cout // 64)
+    return (bs >= 16 and items64 < 768) or (bs == 8 and cin * cout <= 128 * 128)
+
+
 def batchnorm_affine(running_mean, running_var, weight, bias, eps):
     """Eval-mode batch norm as y = x*scale + shift."""
     ts = (running_mean, running_var, weight, bias)

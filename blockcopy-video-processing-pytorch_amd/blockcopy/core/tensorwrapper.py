@@ -681,6 +681,20 @@ class TensorWrapper(torch.Tensor):
         if feats.engine != "fused" and is_nhwc(data):
             data = data.contiguous()    # the reference decomposition is NCHW only
         grid_idx, mapping_exec = feats._grid_idx, feats._mapping_exec
+        if feats.engine == "fused" and fuse and op == "conv2d" and padding == 1:
+            # 3x3 / stride 1 convs on large tiles: ONE hand-written MFMA kernel gathers the halo and convolves
+            # (no padded tensor, no library conv); everything else falls through to halo gather + library conv
+            be = get_backend()
+            weight = args[1] if len(args) > 1 else kwargs["weight"]
+            cv = {k: kwargs.get(k, args[i] if len(args) > i else d) for k, i, d in (("stride", 3, 1), ("dilation", 5, 1), ("groups", 6, 1))}
+            if (isinstance(weight, torch.Tensor) and hasattr(be, "conv3x3_ring")
+                    and be.conv3x3_supported(data, weight, cv["stride"], 1, cv["dilation"], cv["groups"])
+                    and fusion.use_native_conv3x3(data.shape[0], data.shape[2], weight.shape[1], weight.shape[0])):
+                wpk = fusion.packed_conv3x3_weight(weight, be.pack_conv3x3_weights)   # cached per parameter object
+                ring = feats.next_ring(data, padding)
+                feats._pad_memo = None
+                with timings.env("tensorwrapper/conv3x3_fused", 10):
+                    return be.conv3x3_ring(data, ring, wpk, weight.shape[0], grid_idx, mapping_exec, prologue, None), pend_out
         if feats.engine == "fused":
             # consecutive padded ops on the same tensor (e.g. the three CSP head branches on the 768-channel map)
             # share ONE halo gather and ring cache; the memo holds the source, so its address cannot be recycled

@@ -8,7 +8,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = [os.path.join(HERE, "csrc", "blockcopy_hip.hip")]
-HDR = [os.path.join(os.path.dirname(HERE), "include", "blockcopy_hip.h")]
+HDR = [os.path.join(os.path.dirname(HERE), "include", "blockcopy_hip.h"), os.path.join(HERE, "csrc", "conv3x3_mfma.inc")]
 OUT = os.path.join(HERE, "lib", "libblockcopy_hip.so")
 ARCH = "gfx950"
 

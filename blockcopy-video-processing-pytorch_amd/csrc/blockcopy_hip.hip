@@ -1354,6 +1354,8 @@ int check_halo(const void *out, const void *features, const int32_t *grid_idx, c
     return BC_OK;
 }
 
+#include "conv3x3_mfma.inc"
+
 }  // namespace
 
 // ================================================================================================ C ABI
@@ -1374,7 +1376,7 @@ BC_EXPORT const char *bc_error_string(int code)
 
 BC_EXPORT const char *bc_op_name(int op)
 {
-    static const char *names[BC_OP_COUNT] = {"split", "combine", "transfer", "pad", "combine_copy", "pad_ring", "grid_tables", "interp", "affine", "nms"};
+    static const char *names[BC_OP_COUNT] = {"split", "combine", "transfer", "pad", "combine_copy", "pad_ring", "grid_tables", "interp", "affine", "nms", "conv3x3"};
     return (op >= 0 && op < BC_OP_COUNT) ? names[op] : "?";
 }
 
@@ -1624,6 +1626,53 @@ BC_EXPORT int bc_pad_ring_nhwc(void *out, const void *features, void *ring, cons
     else { if (vb == 16) BC_HN(16, uint16_t, 3); else if (vb == 8) BC_HN(8, uint16_t, 3); else if (vb == 4) BC_HN(4, uint16_t, 3); else BC_HN(2, uint16_t, 3); }
 #undef BC_HNV
 #undef BC_HN
+    return launch_status();
+}
+
+BC_EXPORT int bc_conv3x3_ring_nhwc(void *out, const void *features, void *ring, const void *weights_packed,
+                                   const int32_t *grid_idx, const int32_t *mapping_exec, int n_exec, int N, int Cin, int Cout,
+                                   int GH, int GW, int bs, int dtype, const float *in_scale, const float *in_shift, int in_relu,
+                                   const float *out_scale, const float *out_shift, const void *out_add, int out_relu, void *stream)
+{
+    if (dtype != BC_F32) return BC_ERR_ELEM;
+    if (n_exec < 0 || N <= 0 || Cin <= 0 || Cout <= 0 || GH <= 0 || GW <= 0 || bs <= 0) return BC_ERR_SHAPE;
+    if (Cin % CV_CH != 0 || Cout % 64 != 0) return BC_ERR_SHAPE;
+    if (!(bs == 4 || bs % 8 == 0) || bs > 248) return BC_ERR_SHAPE;
+    if (n_exec == 0) return BC_OK;
+    if (!out || !features || !ring || !weights_packed || !grid_idx || !mapping_exec) return BC_ERR_NULL;
+    if ((uint64_t)n_exec * bs * bs * (uint64_t)(Cin > Cout ? Cin : Cout) >= (1ull << 31) ||
+        (uint64_t)N * GH * GW * 4 * bs * Cin >= (1ull << 31)) return BC_ERR_RANGE;
+    if (!aligned(out, 16) || !aligned(features, 16) || !aligned(ring, 16) || !aligned(weights_packed, 16) || !aligned(out_add, 4))
+        return BC_ERR_ALIGN;
+    // workgroup = 32*WM pixels x 64 output channels.  64-pixel items halve the weight traffic and the halo overhead; 32-pixel
+    // items balance better over the 256 CUs when there are few of them (measured, profiles/r01/kbench_conv_*.txt).
+    // BC_CONV_WM=1|2 overrides for A/B runs.
+    static const int wm_env = [] { const char *e = getenv("BC_CONV_WM"); return e ? atoi(e) : 0; }();
+    const uint64_t items64 = (uint64_t)n_exec * bs * bs / 64 * (Cout / 64);
+    const int WM_ = wm_env == 1 || wm_env == 2 ? wm_env : ((bs >= 16 && items64 < 768) ? 1 : 2);
+    ConvGeom g;
+    g.Cin = Cin; g.Cout = Cout; g.bs = bs; g.GH = GH; g.GW = GW; g.n_exec = n_exec;
+    g.pw = bs < 8 ? 4 : 8;
+    const uint32_t ph = g.pw == 8 ? 4 * WM_ : 4;
+    g.patches_x = bs / g.pw;
+    g.patches_per_tile = g.patches_x * (bs / ph);
+    g.tiles_per_wg = 32 * WM_ / (g.pw * ph);
+    g.PW2 = g.pw + 2; g.PP = g.PW2 * (ph + 2);
+    g.n_vec = g.tiles_per_wg * g.PP * CV_VPP;
+    g.cin_chunks = Cin / CV_CH; g.CG = Cin / 8; g.NB = Cout / 32;
+    const unsigned gx = g.pw == 8 ? (unsigned)n_exec * g.patches_per_tile : ((unsigned)n_exec + g.tiles_per_wg - 1) / g.tiles_per_wg;
+    const dim3 grid(gx, (unsigned)Cout / 64);
+    const size_t lds_bytes = 2 * (size_t)g.tiles_per_wg * g.PP * CV_CHP * sizeof(float);   // two images (double buffer)
+    Prologue pr{in_scale, in_shift, in_relu};
+    Epilogue ep{out_scale, out_shift, (const float *)out_add, out_relu};
+    ProfScope ps(BC_OP_CONV3X3, 2.0 * n_exec * bs * bs * 9.0 * Cin * Cout);   // FLOPs, not bytes: the op is MFMA-bound
+#define BC_CV(PW_, WMT_)                                                                                                \
+    BC_LAUNCH(ps, (k_conv3x3_f32<PW_, WMT_>), grid, dim3(128 * WMT_), lds_bytes, (hipStream_t)stream, (float *)out,     \
+              (const float *)features, (long long)((const float *)ring - (const float *)features), (float *)ring,     \
+              (const float4 *)weights_packed, grid_idx, mapping_exec, g, pr, ep)
+    if (g.pw == 8) { if (WM_ == 2) BC_CV(8, 2); else BC_CV(8, 1); }
+    else { if (WM_ == 2) BC_CV(4, 2); else BC_CV(4, 1); }
+#undef BC_CV
     return launch_status();
 }
 

@@ -145,6 +145,24 @@ int bc_affine_act_nhwc(void *out, const void *in, const void *add, const float *
 int bc_interp_bilinear_nhwc(void *out, const void *in, long long planes, int C, int h, int w, int H, int W,
                             int align_corners, float rh, float rw, int dtype, void *stream);
 
+/* fused halo gather + 3x3 / stride 1 / pad 1 convolution of a packed channels-last tile batch on the matrix cores:
+ * out = epilogue(conv3x3(prologue(halo-padded tiles))) in ONE launch, without materialising the padded tensor.
+ * Replaces, for one padded conv layer of the reference (core/tensorwrapper.py:478-527: BlockPad.apply, then the stock
+ * F.conv2d with padding 0 on the padded batch), the sequence bc_pad_ring_nhwc + library conv [+ bc_affine_act_nhwc].
+ *   features (n_exec, bs, bs, Cin), out (n_exec, bs, bs, Cout), ring (N*GH*GW, 4*bs, Cin) as for bc_pad_ring_nhwc
+ *   with pad = 1 (read for non-executed neighbours, refreshed with the RAW border of every executed tile);
+ *   prologue: x -> relu?(x*in_scale[cin] + in_shift[cin]) on real values, zeros beyond the image border stay zero;
+ *   epilogue: y -> relu?(y*out_scale[cout] + out_shift[cout] + out_add[pixel, cout]); any of them may be NULL/0.
+ *   weights_packed: float32[9 * Cin * Cout] in the MFMA operand order
+ *       wpk[nb][chunk][tap][cg][lane][j] = W[cout = 32*nb + lane%32][cin = 32*chunk + 8*cg + 4*(lane/32) + j][ky = tap/3][kx = tap%3]
+ *   (nb < Cout/32, chunk < Cin/32, tap 0..8, cg < 4, lane < 64, j < 4) -- a pure permutation of the (Cout, Cin, 3, 3) weight.
+ * Arithmetic: exact fp32 (v_mfma_f32_32x32x2_f32 = k-ordered fma chain), summation order cin-chunk / tap / channel.
+ * Constraints: dtype = BC_F32, Cin % 32 == 0, Cout % 64 == 0, bs = 4 or a multiple of 8 (<= 248), 16-byte aligned. */
+int bc_conv3x3_ring_nhwc(void *out, const void *features, void *ring, const void *weights_packed,
+                         const int32_t *grid_idx, const int32_t *mapping_exec, int n_exec, int N, int Cin, int Cout,
+                         int GH, int GW, int bs, int dtype, const float *in_scale, const float *in_shift, int in_relu,
+                         const float *out_scale, const float *out_shift, const void *out_add, int out_relu, void *stream);
+
 /* detector post-processing (config C5).  replaces nms_kernel + the host sweep of
  * Pedestron/mmdet/ops/nms/src/nms_kernel.cu:23-130: boxes (n,5) float32 [x1,y1,x2,y2,score] ALREADY sorted by score
  * descending, n <= 4096; IoU with the +1 pixel convention, suppression when IoU > iou_thr.  mask_ws: device scratch of
@@ -158,7 +176,7 @@ int bc_nms_sorted(const float *boxes, int n, float iou_thr, unsigned long long *
  * ------------------------------------------------------------------------------------------- */
 
 enum { BC_OP_SPLIT = 0, BC_OP_COMBINE = 1, BC_OP_TRANSFER = 2, BC_OP_PAD = 3,
-       BC_OP_COMBINE_COPY = 4, BC_OP_PAD_RING = 5, BC_OP_GRID_TABLES = 6, BC_OP_INTERP = 7, BC_OP_AFFINE = 8, BC_OP_NMS = 9, BC_OP_COUNT = 10 };
+       BC_OP_COMBINE_COPY = 4, BC_OP_PAD_RING = 5, BC_OP_GRID_TABLES = 6, BC_OP_INTERP = 7, BC_OP_AFFINE = 8, BC_OP_NMS = 9, BC_OP_CONV3X3 = 10, BC_OP_COUNT = 11 };
 
 int bc_abi_version(void);
 const char *bc_error_string(int code);

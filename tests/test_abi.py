@@ -41,7 +41,7 @@ def test_abi_version_and_strings(lib):
     assert lib.bc_abi_version() == 1
     assert lib.bc_error_string(0) == b"ok"
     assert b"NULL" in lib.bc_error_string(-1)
-    assert [lib.bc_op_name(i).decode() for i in range(10)] == ["split", "combine", "transfer", "pad", "combine_copy", "pad_ring", "grid_tables", "interp", "affine", "nms"]
+    assert [lib.bc_op_name(i).decode() for i in range(11)] == ["split", "combine", "transfer", "pad", "combine_copy", "pad_ring", "grid_tables", "interp", "affine", "nms", "conv3x3"]
     assert lib.bc_op_name(99) == b"?"
 
 

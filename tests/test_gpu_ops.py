@@ -447,3 +447,41 @@ def test_random_geometries_forced_halo_kernel(variant):
     r = subprocess.run([sys.executable, script, "77", "40"], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert f"BC_HALO_KERNEL={variant}" in r.stdout
+
+
+@pytest.mark.parametrize("case", [(1, 32, 64, 2, 3, 8), (1, 64, 64, 3, 4, 16), (2, 32, 128, 2, 2, 4), (1, 64, 64, 3, 5, 4),
+                                  (1, 32, 64, 1, 1, 32), (1, 96, 192, 2, 3, 8)])
+def test_fused_conv3x3_matches_halo_plus_conv(be, case):
+    """bc_conv3x3_ring_nhwc == bc_pad_ring_nhwc (bit-exact against the oracle elsewhere) followed by an fp32 conv, over a
+    multi-frame chain with changing grids, prologue and epilogue (tolerance: fp32 summation order only), and it leaves
+    the ring cache in exactly the same state."""
+    import torch.nn.functional as F
+
+    N, Cin, Cout, GH, GW, bs = case
+    gen = torch.Generator().manual_seed(sum(case))
+    T = N * GH * GW
+    w = (torch.randn((Cout, Cin, 3, 3), generator=gen) * (2.0 / (9 * Cin)) ** 0.5).cuda()
+    wpk = be.pack_conv3x3_weights(w)
+    isc, ish = (torch.rand(Cin, generator=gen) + 0.5).cuda(), (torch.randn(Cin, generator=gen) * 0.1).cuda()
+    osc, osh = (torch.rand(Cout, generator=gen) + 0.5).cuda(), (torch.randn(Cout, generator=gen) * 0.1).cuda()
+    ring_a = torch.zeros((T, Cin, 4 * bs)).cuda()
+    ring_b = torch.zeros((T, Cin, 4 * bs)).cuda()
+    for t, grid in enumerate(_grids(N, GH, GW, 6, 3)):
+        gi, m = O.c_grid_mappings(grid)
+        gi_d, m_d = _dev(gi), _dev(m)
+        feats = _cl(torch.randn((len(m), Cin, bs, bs), generator=gen).cuda())
+        add = _cl(torch.randn((len(m), Cout, bs, bs), generator=gen).cuda())
+        pro = None if t % 3 == 0 else (isc, ish, t % 3 == 2)
+        epi = None if t % 2 == 0 else (osc, osh, add if t % 4 == 1 else None, True)
+        padded = be.pad_ring(feats, ring_a, gi_d, m_d, 1, pro)
+        want = F.conv2d(padded.double(), w.double()).float()
+        if epi is not None:
+            want = want * osc.view(1, -1, 1, 1) + osh.view(1, -1, 1, 1)
+            if epi[2] is not None:
+                want = want + add
+            want = torch.relu(want)
+        got = be.conv3x3_ring(feats, ring_b, wpk, Cout, gi_d, m_d, pro, epi)
+        assert got.shape == want.shape and (bs == 1 or not got.is_contiguous())
+        err = (got - want).abs().max().item()
+        assert err <= 2e-5 * max(1.0, want.abs().max().item()), (case, t, err)
+        assert torch.equal(ring_a, ring_b), (case, t)
