@@ -485,3 +485,41 @@ def test_fused_conv3x3_matches_halo_plus_conv(be, case):
         err = (got - want).abs().max().item()
         assert err <= 2e-5 * max(1.0, want.abs().max().item()), (case, t, err)
         assert torch.equal(ring_a, ring_b), (case, t)
+
+
+def test_fused_conv3x3_random_geometries(be):
+    """20 random (Cin, Cout, tile size, grid, batch) cases x 3 frames with random masks, prologue and epilogue: the fused
+    kernel against halo gather + an fp64 conv of the padded batch; ring caches must stay bit-identical."""
+    import torch.nn.functional as F
+
+    rng = np.random.default_rng(99)
+    gen = torch.Generator().manual_seed(99)
+    for case in range(20):
+        Cin, Cout = int(rng.choice([32, 64, 96, 160])), int(rng.choice([64, 128, 192]))
+        bs = int(rng.choice([4, 8, 16, 24, 40]))
+        N, GH, GW = int(rng.choice([1, 2])), int(rng.integers(1, 5)), int(rng.integers(1, 5))
+        T = N * GH * GW
+        w = (torch.randn((Cout, Cin, 3, 3), generator=gen) * (2.0 / (9 * Cin)) ** 0.5).cuda()
+        wpk = be.pack_conv3x3_weights(w)
+        ring_a, ring_b = torch.zeros((T, Cin, 4 * bs)).cuda(), torch.zeros((T, Cin, 4 * bs)).cuda()
+        for t in range(3):
+            g = np.ones(T, bool) if t == 0 else rng.random(T) < rng.choice([0.2, 0.5, 0.9])
+            if not g.any():
+                g[int(rng.integers(T))] = True
+            gi, m = O.c_grid_mappings(g.reshape(N, 1, GH, GW))
+            gi_d, m_d = _dev(gi), _dev(m)
+            feats = _cl(torch.randn((len(m), Cin, bs, bs), generator=gen).cuda())
+            pro = None if rng.random() < 0.3 else ((torch.rand(Cin, generator=gen) + 0.5).cuda(), (torch.randn(Cin, generator=gen) * 0.1).cuda(), bool(rng.integers(2)))
+            add = _cl(torch.randn((len(m), Cout, bs, bs), generator=gen).cuda()) if rng.random() < 0.5 else None
+            epi = None if rng.random() < 0.3 else ((torch.rand(Cout, generator=gen) + 0.5).cuda(), (torch.randn(Cout, generator=gen) * 0.1).cuda(), add, bool(rng.integers(2)))
+            want = F.conv2d(be.pad_ring(feats, ring_a, gi_d, m_d, 1, pro).double(), w.double())
+            if epi is not None:
+                want = want * epi[0].view(1, -1, 1, 1) + epi[1].view(1, -1, 1, 1)
+                if epi[2] is not None:
+                    want = want + epi[2]
+                if epi[3]:
+                    want = torch.relu(want)
+            got = be.conv3x3_ring(feats, ring_b, wpk, Cout, gi_d, m_d, pro, epi)
+            err = (got.double() - want).abs().max().item()
+            assert err <= 2e-5 * max(1.0, want.abs().max().item()), (case, (Cin, Cout, bs, N, GH, GW), t, err)
+            assert torch.equal(ring_a, ring_b), (case, t)

@@ -334,3 +334,21 @@ def test_channels_last_model_matches_reference_on_cpu(golden_dir, oracle_backend
                 y = model(seeded.synthetic_frame(cfg["frame_seed0"] + t, (cfg["N"], 3, cfg["H"], cfg["W"])))
                 assert float((y - torch.from_numpy(G[f"logits{t}"])).abs().max()) <= 1e-4, (graph, t)
         assert is_nhwc(y), "the output map should have stayed channels-last"
+
+
+def test_conv3x3_weight_packing_matches_the_header_formula():
+    """pack_conv3x3_weights is the pure permutation include/blockcopy_hip.h documents for bc_conv3x3_ring_nhwc:
+    wpk[nb][chunk][tap][cg][lane][j] = W[32*nb + lane%32][32*chunk + 8*cg + 4*(lane//32) + j][tap//3][tap%3]."""
+    import torch
+
+    from blockcopy.backend import HipBackend
+
+    Cout, Cin = 64, 96
+    w = torch.arange(Cout * Cin * 9, dtype=torch.float32).reshape(Cout, Cin, 3, 3)
+    wpk = HipBackend.pack_conv3x3_weights(w).reshape(Cout // 32, Cin // 32, 9, 4, 64, 4)
+    assert wpk.numel() == w.numel() and sorted(wpk.reshape(-1).tolist()) == sorted(w.reshape(-1).tolist())
+    rng = np.random.default_rng(0)
+    for _ in range(500):
+        nb, chunk, tap, cg, lane, j = (int(rng.integers(n)) for n in (Cout // 32, Cin // 32, 9, 4, 64, 4))
+        want = w[32 * nb + lane % 32, 32 * chunk + 8 * cg + 4 * (lane // 32) + j, tap // 3, tap % 3]
+        assert wpk[nb, chunk, tap, cg, lane, j] == want
