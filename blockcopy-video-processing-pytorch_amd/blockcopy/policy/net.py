@@ -1,8 +1,18 @@
-"""Policy network: one execution logit per tile from (down-scaled frame, frame state, previous output, previous grid).
+"""Policy network of the online-RL policies: one execution logit per tile.
 
-Architecture and input recipe follow the reference (policy/net.py:17-125): nearest-downscale by 0.25*128/block_size,
-channel concat, resnet8(width x2), then three stride-2 3x3 convs 128 -> 128 -> 1."""
+What it sees (reference recipe, policy/net.py:17-125, kept so that trained policies transfer): the frame and everything
+the engine knows about the previous step, all brought to ONE low resolution by nearest-neighbour resampling and stacked
+along channels --
+
+    frame (3) | frame state = last executed pixels (3) | previous task output as class scores (num_classes) | previous grid (1)
+
+with the resolution chosen so that one tile covers 32 x 32 policy pixels (scale = 32 / block_size).  A resnet8 trunk
+(width x2, stride 4) and three stride-2 3x3 convs (128, 128, 1 channels) then reduce every tile to one logit.
+Parameter names (``backbone.*``, ``layers.<i>.<j>.*``) match the reference's, so its checkpoints load.
+"""
 from __future__ import annotations
+
+from typing import Dict, List
 
 import torch
 import torch.nn as nn
@@ -11,61 +21,59 @@ import torch.nn.functional as F
 from blockcopy.policy.resnet import resnet8
 from blockcopy.utils.profiler import timings
 
+POLICY_PIXELS_PER_TILE = 32
+HEAD_WIDTH = 128
 
-def build_policy_net_from_settings(settings: dict):
-    return PolicyNet(block_size=settings["block_size"], task_num_classes=settings["block_num_classes"])
+
+def _head_stage(cin: int, cout: int, last: bool) -> nn.Sequential:
+    """3x3 stride-2 conv; every stage but the last is followed by BN (slow running stats) and ReLU and has no bias."""
+    mods: List[nn.Module] = [nn.Conv2d(cin, cout, kernel_size=3, stride=2, padding=1, bias=last)]
+    if not last:
+        mods += [nn.BatchNorm2d(cout, momentum=0.02), nn.ReLU(inplace=False)]
+    return nn.Sequential(*mods)
 
 
 class PolicyNet(nn.Module):
-    def __init__(self, block_size, task_num_classes) -> None:
+    def __init__(self, block_size: int, task_num_classes: int) -> None:
         super().__init__()
         self.block_size = block_size
-        self.scale_factor = 0.25 * 128 / self.block_size
-        self.use_frame_state = True
-        self.use_prev_output = True
-        self.use_prev_grid = True
         self.task_num_classes = task_num_classes
-        in_channels = 3 + (3 if self.use_frame_state else 0) + (task_num_classes if self.use_prev_output else 0) \
-            + (1 if self.use_prev_grid else 0)
-        self.backbone = resnet8(pretrained=False, in_channels=in_channels, width_factor=2)
-        planes = 128
-        self.layers = nn.Sequential(
-            self._make_layer(self.backbone.OUT_CHANNELS, planes, stride=2, relu=True),
-            self._make_layer(planes, planes, stride=2, relu=True),
-            self._make_layer(planes, 1, stride=2, relu=False))
+        self.scale_factor = POLICY_PIXELS_PER_TILE / block_size
+        self.backbone = resnet8(pretrained=False, in_channels=3 + 3 + task_num_classes + 1, width_factor=2)
+        self.layers = nn.Sequential(_head_stage(self.backbone.OUT_CHANNELS, HEAD_WIDTH, last=False),
+                                    _head_stage(HEAD_WIDTH, HEAD_WIDTH, last=False),
+                                    _head_stage(HEAD_WIDTH, 1, last=True))
 
-    @staticmethod
-    def _make_layer(cin, cout, kernel_size=3, stride=1, relu=True):
-        mods = [nn.Conv2d(cin, cout, kernel_size=kernel_size, padding=(kernel_size - 1) // 2, stride=stride, bias=not relu)]
-        if relu:
-            mods += [nn.BatchNorm2d(cout, momentum=0.02), nn.ReLU(inplace=False)]
-        return nn.Sequential(*mods)
-
-    def build_features(self, policy_meta: dict) -> torch.Tensor:
+    def build_features(self, policy_meta: Dict) -> torch.Tensor:
+        """(N, 7 + num_classes, h, w) policy input; nothing here carries gradient."""
         frame = policy_meta["inputs"]
-        assert frame.dim() == 4 and frame.size(1) == 3
-        feats = [F.interpolate(frame, scale_factor=self.scale_factor, mode="nearest").float()]
-        size = feats[0].shape[2:]
-        if self.use_frame_state:
-            feats.append(F.interpolate(policy_meta["frame_state"], size=size, mode="nearest").float())
-        if self.use_prev_output:
-            assert policy_meta.get("output_repr", None) is not None
-            rep = policy_meta["output_repr"]
-            assert rep.dim() == 4
-            feats.append(F.interpolate(rep, size=size, mode="nearest").type(feats[0].dtype) - 0.5)
-        if self.use_prev_grid:
-            assert policy_meta.get("grid", None) is not None
-            g = policy_meta["grid"].type(feats[0].dtype)
-            assert g.dim() == 4
-            feats.append(F.interpolate(g, size=size, mode="nearest") - 0.5)
-        return torch.cat(feats, dim=1).detach()
+        if frame.dim() != 4 or frame.size(1) != 3:
+            raise ValueError(f"policy expects (N,3,H,W) frames, got {tuple(frame.shape)}")
+        low = F.interpolate(frame, scale_factor=self.scale_factor, mode="nearest").float()
+        hw = low.shape[2:]
 
-    def forward(self, policy_meta: dict):
-        N, C, H, W = policy_meta["inputs"].shape
+        def at_policy_resolution(t: torch.Tensor, centre: bool) -> torch.Tensor:
+            assert t is not None and t.dim() == 4
+            t = F.interpolate(t.to(low.dtype) if t.dtype == torch.bool else t, size=hw, mode="nearest").to(low.dtype)
+            return t - 0.5 if centre else t    # scores and masks live in [0, 1]: centre them
+
+        parts = [low,
+                 at_policy_resolution(policy_meta["frame_state"], centre=False),
+                 at_policy_resolution(policy_meta.get("output_repr"), centre=True),
+                 at_policy_resolution(policy_meta.get("grid"), centre=True)]
+        return torch.cat(parts, dim=1).detach()
+
+    def forward(self, policy_meta: Dict) -> torch.Tensor:
+        n, _, height, width = policy_meta["inputs"].shape
         with timings.env("policy/net/build_features", 5):
             x = self.build_features(policy_meta)
         with timings.env("policy/net/layers", 5):
             logits = self.layers(self.backbone(x))
-        expect = (N, 1, H // self.block_size, W // self.block_size)
-        assert logits.shape == expect, f"logits shape: {logits.shape}, frame shape: {(N, C, H, W)}, block size: {self.block_size}"
+        want = (n, 1, height // self.block_size, width // self.block_size)
+        if tuple(logits.shape) != want:
+            raise AssertionError(f"policy logits {tuple(logits.shape)} do not tile a {height}x{width} frame with block {self.block_size}")
         return logits
+
+
+def build_policy_net_from_settings(settings: dict) -> PolicyNet:
+    return PolicyNet(block_size=settings["block_size"], task_num_classes=settings["block_num_classes"])
