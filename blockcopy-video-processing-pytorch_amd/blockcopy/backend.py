@@ -75,6 +75,7 @@ def load_library(path: str = None) -> ctypes.CDLL:
         "bc_pad_ring_act": [p, p, p, p, p] + [i] * 8 + [p, p, i, p],
         "bc_pad_ring_nhwc": [p, p, p, p, p] + [i] * 9 + [p, p, i, p],
         "bc_affine_act_nhwc": [p, p, p, p, p, i, ctypes.c_longlong, i, i, p],
+        "bc_maxpool3x3s2_ring_nhwc": [p, p, p, p, p] + [i] * 7 + [p, p, i, p],
         "bc_conv3x3_ring_nhwc": [p, p, p, p, p, p] + [i] * 8 + [p, p, i, p, p, p, i, p],
         "bc_interp_bilinear_nhwc": [p, p, ctypes.c_longlong, i, i, i, i, i, i, ctypes.c_float, ctypes.c_float, i, p],
         "bc_affine_act": [p, p, p, p, p, i, ctypes.c_longlong, i, ctypes.c_longlong, i, p],
@@ -242,6 +243,32 @@ class HipBackend:
                                                          scale.data_ptr() if scale is not None else None,
                                                          shift.data_ptr() if shift is not None else None, int(bool(relu)),
                                                          self._stream()), "pad_ring_act")
+        return out
+
+    @staticmethod
+    def maxpool3x3s2_supported(data_exec):
+        bs = data_exec.shape[2]
+        return (is_nhwc(data_exec) and data_exec.dtype in _DTYPE_CODE and bs == data_exec.shape[3] and bs >= 2 and bs % 2 == 0
+                and (data_exec.shape[1] * data_exec.element_size()) % 16 == 0)
+
+    def maxpool3x3s2_ring(self, data_exec, ring, grid_idx, mapping_exec, prologue=None):
+        """Fused halo gather + max_pool2d(3, stride 2, padding 1) on a channels-last packed batch (ring as for pad_ring, pad 1)."""
+        assert _ok(data_exec, *_DTYPE_CODE) and is_nhwc(data_exec) and _ok(ring, data_exec.dtype)
+        assert _ok(mapping_exec, torch.int32) and _ok(grid_idx, torch.int32)
+        N, _, GH, GW = grid_idx.shape
+        B, C, bs, _ = data_exec.shape
+        assert mapping_exec.numel() == B and tuple(ring.shape) == (N * GH * GW, C, 4 * bs)
+        out = empty_like_layout((B, C, bs // 2, bs // 2), data_exec)
+        scale, shift, relu = prologue if prologue is not None else (None, None, False)
+        for v in (scale, shift):
+            assert v is None or (_ok(v, torch.float32) and v.numel() == C)
+        if B > 0:
+            with torch.cuda.device_of(data_exec):
+                self._check(self.lib.bc_maxpool3x3s2_ring_nhwc(out.data_ptr(), data_exec.data_ptr(), ring.data_ptr(), grid_idx.data_ptr(),
+                                                               mapping_exec.data_ptr(), B, N, C, GH, GW, bs, _DTYPE_CODE[data_exec.dtype],
+                                                               scale.data_ptr() if scale is not None else None,
+                                                               shift.data_ptr() if shift is not None else None, int(bool(relu)),
+                                                               self._stream()), "maxpool3x3s2_ring_nhwc")
         return out
 
     @staticmethod

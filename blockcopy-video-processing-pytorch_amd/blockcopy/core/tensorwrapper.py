@@ -402,8 +402,15 @@ class TensorWrapper(torch.Tensor):
             block_size = self.shape[2] // grid.shape[2]
         return self._split(block_size)
 
+    @property
+    def fuses_dense_ops(self) -> bool:
+        """True when elementwise ops on this (dense or packed) tensor are recorded and fused instead of launched."""
+        return bool(fusion.ENABLED and self.is_init and self._features is not None and self._features.engine == "fused")
+
     def to_blocks_like(self, other: "TensorWrapper") -> "TensorWrapper":
         """Pack with the same grid as ``other``."""
+        if self._pending is not None:
+            self._materialize()
         self._init_metadata(other)
         self._is_blocks = False
         with _NoDispatch():
@@ -519,7 +526,7 @@ class TensorWrapper(torch.Tensor):
             assert self is not None and self.is_init, "TensorWrapper used before process_temporal_features/to_blocks"
 
             pend = None
-            if self._is_blocks and fusion.ENABLED and self._features.engine == "fused" and op in _FUSABLE:
+            if op in _FUSABLE and fusion.ENABLED and self._features is not None and self._features.engine == "fused":
                 ret, pend, done = self._func_fused(op, func, args, kwargs)
                 if done:
                     if isinstance(ret, TensorWrapper):
@@ -695,6 +702,18 @@ class TensorWrapper(torch.Tensor):
                 feats._pad_memo = None
                 with timings.env("tensorwrapper/conv3x3_fused", 10):
                     return be.conv3x3_ring(data, ring, wpk, weight.shape[0], grid_idx, mapping_exec, prologue, None), pend_out
+        if feats.engine == "fused" and fuse and op == "max_pool2d" and padding == 1:
+            # the ResNet stem pool (3x3, stride 2): halo gather + max in one kernel, no padded tensor
+            be = get_backend()
+            mp = {k: kwargs.get(k, args[i] if len(args) > i else d) for k, i, d in
+                  (("kernel_size", 1, None), ("stride", 2, None), ("dilation", 4, 1), ("ceil_mode", 5, False), ("return_indices", 6, False))}
+            one = lambda v: v if isinstance(v, int) else (v[0] if isinstance(v, (tuple, list)) and len(set(v)) == 1 else None)
+            if (hasattr(be, "maxpool3x3s2_ring") and one(mp["kernel_size"]) == 3 and one(mp["stride"]) == 2 and one(mp["dilation"]) == 1
+                    and not mp["ceil_mode"] and not mp["return_indices"] and be.maxpool3x3s2_supported(data)):
+                ring = feats.next_ring(data, padding)
+                feats._pad_memo = None
+                with timings.env("tensorwrapper/maxpool_fused", 10):
+                    return be.maxpool3x3s2_ring(data, ring, grid_idx, mapping_exec, prologue), pend_out
         if feats.engine == "fused":
             # consecutive padded ops on the same tensor (e.g. the three CSP head branches on the 768-channel map)
             # share ONE halo gather and ring cache; the memo holds the source, so its address cannot be recycled

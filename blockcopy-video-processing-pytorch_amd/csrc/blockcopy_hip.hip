@@ -742,14 +742,17 @@ template <typename T> struct Cvt;
 template <> struct Cvt<float> {
     static __device__ __forceinline__ float ld(const float *p) { return *p; }
     static __device__ __forceinline__ float st(float v) { return v; }
+    static __device__ __forceinline__ float ld_round(float v) { return v; }
 };
 template <> struct Cvt<__half> {
     static __device__ __forceinline__ float ld(const __half *p) { return __half2float(*p); }
     static __device__ __forceinline__ __half st(float v) { return __float2half(v); }
+    static __device__ __forceinline__ float ld_round(float v) { return __half2float(__float2half(v)); }
 };
 template <> struct Cvt<hip_bfloat16> {
     static __device__ __forceinline__ float ld(const hip_bfloat16 *p) { return (float)(*p); }
     static __device__ __forceinline__ hip_bfloat16 st(float v) { return hip_bfloat16(v); }
+    static __device__ __forceinline__ float ld_round(float v) { return (float)hip_bfloat16(v); }
 };
 
 struct InterpGeom {
@@ -966,6 +969,109 @@ __global__ __launch_bounds__(WG) void k_halo_nhwc(typename VecOf<VB>::type *__re
         if (zero[u]) v = V{};
         out_t[fo[u]] = v;
     }
+}
+
+// ------------------------------------------------------------------------------------------ fused halo + 3x3/s2 max-pool (NHWC)
+// The one padded op of the path that is not a conv (ResNet stem): max_pool2d(k=3, s=2, p=1) on the packed batch.  The
+// reference materialises the halo-padded tiles and pools them with padding 0 (core/tensorwrapper.py:478-527); here one
+// kernel reads tile + halo (top / left / top-left only: with an even tile the windows never reach past the bottom or
+// right edge), applies the pending activation, takes the max and refreshes the ring record -- the padded tensor
+// (4.4x the output) is never written or re-read.  Image-border halo = zeros that take part in the max, as in the
+// reference.  One lane = one 16-byte vector of one output pixel; 3x3 neighbour table wave-uniform as in k_halo_nhwc.
+struct PoolGeom {
+    FastDiv K, OB, GW, GH;    // vectors per fat pixel, output tile edge bs/2, grid dims
+    uint32_t bs, n_total, per_tile;   // per_tile = OB*OB*K output vectors per executed tile
+};
+
+template <typename T, int VE, int DT>
+__global__ __launch_bounds__(WG) void k_maxpool3x3s2_nhwc(typename VecOf<sizeof(T) * VE>::type *__restrict__ out,
+                                                          const typename VecOf<sizeof(T) * VE>::type *__restrict__ features,
+                                                          long long other_delta, typename VecOf<sizeof(T) * VE>::type *__restrict__ ring_w,
+                                                          const int32_t *__restrict__ grid_idx, const int32_t *__restrict__ mapping_exec,
+                                                          PoolGeom g, Prologue pr)
+{
+    typedef typename VecOf<sizeof(T) * VE>::type V;
+    const uint32_t b = blockIdx.y, bs = g.bs, K = g.K.d;
+    const uint32_t tile_vecs = bs * bs * K, RSV = 4 * bs * K;
+    const uint32_t ig = (uint32_t)mapping_exec[b];
+    uint32_t t0, gw, n0, gh;
+    fd_divmod(ig, g.GW, t0, gw);
+    fd_divmod(t0, g.GH, n0, gh);
+    // sources of the own tile (k = 3), the tile above (1), to the left (2) and above-left (0)
+    long long nbb[4];
+    bool nbz[4], nbr[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int dy = (k >> 1) - 1, dx = (k & 1) - 1;
+        const int nh = (int)gh + dy, nw = (int)gw + dx;
+        nbz[k] = nh < 0 || nw < 0;
+        nbr[k] = false;
+        nbb[k] = 0;
+        if (k == 3) nbb[k] = (long long)b * tile_vecs;
+        else if (!nbz[k]) {
+            const uint32_t g_in = (uint32_t)((int)ig + dx + (int)g.GW.d * dy);
+            const int32_t idx = grid_idx[g_in];
+            if (idx >= 0) nbb[k] = (long long)idx * tile_vecs;
+            else { nbb[k] = other_delta + (long long)g_in * RSV; nbr[k] = true; }
+        }
+    }
+    const uint32_t f = blockIdx.x * WG + threadIdx.x;
+    if (f >= g.per_tile) return;
+    uint32_t pix, kq, oy, ox;
+    fd_divmod(f, g.K, pix, kq);
+    fd_divmod(pix, g.OB, oy, ox);
+    float sc[VE], sh[VE];
+    load_coeffs<VE>(pr.scale, kq * VE, 1.0f, sc);
+    load_coeffs<VE>(pr.shift, kq * VE, 0.0f, sh);
+    V *__restrict__ rec = ring_w + (long long)ig * RSV;
+
+    V raw[9];
+    bool zero[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int y = 2 * (int)oy + t / 3 - 1, x = 2 * (int)ox + t % 3 - 1;   // >= -1, <= bs - 1
+        const uint32_t sy = y < 0 ? 0u : 1u, sx = x < 0 ? 0u : 1u;
+        const uint32_t k = sy * 2 + sx;
+        const uint32_t hs = y < 0 ? bs - 1 : (uint32_t)y, ws = x < 0 ? bs - 1 : (uint32_t)x;
+        const long long base = k == 0 ? nbb[0] : (k == 1 ? nbb[1] : (k == 2 ? nbb[2] : nbb[3]));
+        const bool from_ring = k == 0 ? nbr[0] : (k == 1 ? nbr[1] : (k == 2 ? nbr[2] : false));
+        zero[t] = k == 0 ? nbz[0] : (k == 1 ? nbz[1] : (k == 2 ? nbz[2] : false));
+        const uint32_t pos = from_ring ? ring_elem(sy, sx, hs, ws, bs, 1u) : hs * bs + ws;
+        raw[t] = features[zero[t] ? 0 : base + (long long)pos * K + kq];
+    }
+    // ring refresh: this lane owns the 2x2 input block (2oy..2oy+1, 2ox..2ox+1) = taps 4, 5, 7, 8
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        if (t != 4 && t != 5 && t != 7 && t != 8) continue;
+        const uint32_t hs = 2 * oy + t / 3 - 1, ws = 2 * ox + t % 3 - 1;
+        if (hs == 0) rec[(ws)*K + kq] = raw[t];
+        if (hs == bs - 1) rec[(bs + ws) * K + kq] = raw[t];
+        if (ws == 0) rec[(2 * bs + hs) * K + kq] = raw[t];
+        if (ws == bs - 1) rec[(3 * bs + hs) * K + kq] = raw[t];
+    }
+    float best[VE];
+#pragma unroll
+    for (int j = 0; j < VE; ++j) best[j] = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const T *e = reinterpret_cast<const T *>(&raw[t]);
+#pragma unroll
+        for (int j = 0; j < VE; ++j) {
+            float x = Cvt<T>::ld(e + j);
+            if (DT != 0) {
+                x = Cvt<T>::ld(e + j) * sc[j] + sh[j];
+                if (pr.relu) x = fmaxf(x, 0.0f);
+                x = Cvt<T>::ld_round(x);     // the reference pools the ROUNDED activations
+            }
+            if (zero[t]) x = 0.0f;
+            best[j] = fmaxf(best[j], x);
+        }
+    }
+    V res;
+    T *r = reinterpret_cast<T *>(&res);
+#pragma unroll
+    for (int j = 0; j < VE; ++j) r[j] = Cvt<T>::st(best[j]);
+    out[(size_t)b * g.per_tile + f] = res;
 }
 
 // channels-last fused epilogue: channel index runs fastest
@@ -1673,6 +1779,38 @@ BC_EXPORT int bc_conv3x3_ring_nhwc(void *out, const void *features, void *ring, 
     if (g.pw == 8) { if (WM_ == 2) BC_CV(8, 2); else BC_CV(8, 1); }
     else { if (WM_ == 2) BC_CV(4, 2); else BC_CV(4, 1); }
 #undef BC_CV
+    return launch_status();
+}
+
+BC_EXPORT int bc_maxpool3x3s2_ring_nhwc(void *out, const void *features, void *ring, const int32_t *grid_idx,
+                                        const int32_t *mapping_exec, int n_exec, int N, int C, int GH, int GW, int bs, int dtype,
+                                        const float *scale, const float *shift, int relu, void *stream)
+{
+    if (dtype < BC_F32 || dtype > BC_BF16) return BC_ERR_ELEM;
+    const int E = dtype == BC_F32 ? 4 : 2;
+    if (n_exec < 0 || N <= 0 || C <= 0 || GH <= 0 || GW <= 0 || bs < 2 || (bs & 1)) return BC_ERR_SHAPE;
+    if (((size_t)C * E) % 16 != 0) return BC_ERR_SHAPE;
+    if (n_exec == 0) return BC_OK;
+    if (!out || !features || !ring || !grid_idx || !mapping_exec) return BC_ERR_NULL;
+    if ((uint64_t)n_exec * C * bs * bs >= (1ull << 31) || (uint64_t)N * GH * GW * C * 4 * bs >= (1ull << 31)) return BC_ERR_RANGE;
+    if (!aligned(out, 16) || !aligned(features, 16) || !aligned(ring, 16)) return BC_ERR_ALIGN;
+    PoolGeom g;
+    const uint32_t K = (uint32_t)((size_t)C * E / 16), OB = bs / 2;
+    g.K = make_fd(K); g.OB = make_fd(OB); g.GW = make_fd(GW); g.GH = make_fd(GH);
+    g.bs = bs; g.n_total = (uint32_t)N * GH * GW; g.per_tile = OB * OB * K;
+    const dim3 grid((g.per_tile + WG - 1) / WG, (unsigned)n_exec);
+    const long long delta = ((const char *)ring - (const char *)features) / 16;
+    const bool act = scale || shift || relu;
+    Prologue pr{scale, shift, relu};
+    // algorithmic bytes: tile + top/left halo in, pooled tile out (+ ring refresh)
+    ProfScope ps(BC_OP_PAD_RING, (double)n_exec * C * E * ((double)(bs + 1) * (bs + 1) + (double)OB * OB + 4.0 * bs));
+#define BC_MP(T_, VE_, DT_)                                                                                           \
+    BC_LAUNCH(ps, (k_maxpool3x3s2_nhwc<T_, VE_, DT_>), grid, dim3(WG), 0, (hipStream_t)stream, (VecOf<16>::type *)out, \
+              (const VecOf<16>::type *)features, delta, (VecOf<16>::type *)ring, grid_idx, mapping_exec, g, pr)
+    if (dtype == BC_F32) { if (act) BC_MP(float, 4, 1); else BC_MP(float, 4, 0); }
+    else if (dtype == BC_F16) { if (act) BC_MP(__half, 8, 1); else BC_MP(__half, 8, 0); }
+    else { if (act) BC_MP(hip_bfloat16, 8, 1); else BC_MP(hip_bfloat16, 8, 0); }
+#undef BC_MP
     return launch_status();
 }
 

@@ -163,6 +163,15 @@ int bc_conv3x3_ring_nhwc(void *out, const void *features, void *ring, const void
                          int GH, int GW, int bs, int dtype, const float *in_scale, const float *in_shift, int in_relu,
                          const float *out_scale, const float *out_shift, const void *out_add, int out_relu, void *stream);
 
+/* fused halo gather + max_pool2d(kernel 3, stride 2, padding 1) of a packed channels-last batch (the ResNet stem pool, the
+ * one padded op of the path that is not a conv; reference: BlockPad.apply + F.max_pool2d(padding=0),
+ * core/tensorwrapper.py:478-527).  features (n_exec, bs, bs, C) -> out (n_exec, bs/2, bs/2, C); ring and prologue exactly
+ * as for bc_pad_ring_nhwc with pad = 1 (zeros beyond the image border take part in the max, the ring keeps raw values);
+ * bit-identical to bc_pad_ring_nhwc followed by a pad-0 pool.  bs even, C*elem_size a multiple of 16 bytes. */
+int bc_maxpool3x3s2_ring_nhwc(void *out, const void *features, void *ring, const int32_t *grid_idx,
+                              const int32_t *mapping_exec, int n_exec, int N, int C, int GH, int GW, int bs, int dtype,
+                              const float *scale, const float *shift, int relu, void *stream);
+
 /* detector post-processing (config C5).  replaces nms_kernel + the host sweep of
  * Pedestron/mmdet/ops/nms/src/nms_kernel.cu:23-130: boxes (n,5) float32 [x1,y1,x2,y2,score] ALREADY sorted by score
  * descending, n <= 4096; IoU with the +1 pixel convention, suppression when IoU > iou_thr.  mask_ws: device scratch of

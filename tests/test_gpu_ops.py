@@ -523,3 +523,35 @@ def test_fused_conv3x3_random_geometries(be):
             err = (got.double() - want).abs().max().item()
             assert err <= 2e-5 * max(1.0, want.abs().max().item()), (case, (Cin, Cout, bs, N, GH, GW), t, err)
             assert torch.equal(ring_a, ring_b), (case, t)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_fused_maxpool_matches_halo_plus_pool(be, dtype):
+    """bc_maxpool3x3s2_ring_nhwc == bc_pad_ring_nhwc followed by a pad-0 3x3/s2 max pool, BIT-exact (max is exact; the
+    activation prologue is rounded per element exactly as in the halo gather), over a multi-frame chain with random
+    masks; ring caches bit-identical."""
+    import torch.nn.functional as F
+
+    rng = np.random.default_rng(5)
+    gen = torch.Generator().manual_seed(5)
+    E = torch.empty((), dtype=dtype).element_size()
+    for case in range(12):
+        C = int(rng.choice([4, 8, 16, 64])) * (4 // E if E == 4 else 1) * (1 if E == 4 else 2)
+        bs = int(rng.choice([2, 4, 6, 8, 16, 64]))
+        N, GH, GW = int(rng.choice([1, 2])), int(rng.integers(1, 5)), int(rng.integers(1, 5))
+        T = N * GH * GW
+        ring_a, ring_b = torch.zeros((T, C, 4 * bs), dtype=dtype).cuda(), torch.zeros((T, C, 4 * bs), dtype=dtype).cuda()
+        sc, sh = (torch.rand(C, generator=gen) + 0.5).cuda(), (torch.randn(C, generator=gen) * 0.3).cuda()
+        for t in range(4):
+            g = np.ones(T, bool) if t == 0 else rng.random(T) < rng.choice([0.2, 0.5, 0.9])
+            if not g.any():
+                g[int(rng.integers(T))] = True
+            gi, m = O.c_grid_mappings(g.reshape(N, 1, GH, GW))
+            gi_d, m_d = _dev(gi), _dev(m)
+            feats = _cl(torch.randn((len(m), C, bs, bs), generator=gen).to(dtype).cuda())
+            pro = None if t % 3 == 0 else (sc if t % 3 == 1 else None, sh, t % 2 == 0)
+            want = F.max_pool2d(be.pad_ring(feats, ring_a, gi_d, m_d, 1, pro).float(), 3, 2, 0).to(dtype)
+            assert be.maxpool3x3s2_supported(feats)
+            got = be.maxpool3x3s2_ring(feats, ring_b, gi_d, m_d, pro)
+            assert got.shape == want.shape and torch.equal(got.contiguous(), want.contiguous()), (case, t, C, bs)
+            assert torch.equal(ring_a, ring_b), (case, t)
