@@ -76,6 +76,7 @@ def load_library(path: str = None) -> ctypes.CDLL:
         "bc_pad_ring_nhwc": [p, p, p, p, p] + [i] * 9 + [p, p, i, p],
         "bc_affine_act_nhwc": [p, p, p, p, p, i, ctypes.c_longlong, i, i, p],
         "bc_maxpool3x3s2_ring_nhwc": [p, p, p, p, p] + [i] * 7 + [p, p, i, p],
+        "bc_pad_ring_add_nhwc": [p, p, p, p, p, p, p] + [i] * 8 + [p, p, i, p],
         "bc_conv3x3_ring_nhwc": [p, p, p, p, p, p] + [i] * 8 + [p, p, i, p, p, p, i, p],
         "bc_interp_bilinear_nhwc": [p, p, ctypes.c_longlong, i, i, i, i, i, i, ctypes.c_float, ctypes.c_float, i, p],
         "bc_affine_act": [p, p, p, p, p, i, ctypes.c_longlong, i, ctypes.c_longlong, i, p],
@@ -244,6 +245,33 @@ class HipBackend:
                                                          shift.data_ptr() if shift is not None else None, int(bool(relu)),
                                                          self._stream()), "pad_ring_act")
         return out
+
+    @staticmethod
+    def pad_ring_add_supported(data_exec, add):
+        return (is_nhwc(data_exec) and data_exec.dtype in _DTYPE_CODE and (data_exec.shape[1] * data_exec.element_size()) % 16 == 0
+                and add.shape == data_exec.shape and add.dtype == data_exec.dtype and is_nhwc(add) and add.is_contiguous(memory_format=torch.channels_last))
+
+    def pad_ring_add(self, data_exec, add, ring, grid_idx, mapping_exec, pad, prologue):
+        """Halo gather of v = relu?(data*scale + shift + add) plus the plain v as a by-product: returns (padded, v).
+        The ring cache of this op holds activated values (see include/blockcopy_hip.h)."""
+        assert _ok(data_exec, *_DTYPE_CODE) and is_nhwc(data_exec) and _ok(add, data_exec.dtype) and _ok(ring, data_exec.dtype)
+        assert _ok(mapping_exec, torch.int32) and _ok(grid_idx, torch.int32)
+        N, _, GH, GW = grid_idx.shape
+        B, C, bs, _ = data_exec.shape
+        assert mapping_exec.numel() == B and add.shape == data_exec.shape and tuple(ring.shape) == (N * GH * GW, C, 4 * pad * bs)
+        out = empty_like_layout((B, C, bs + 2 * pad, bs + 2 * pad), data_exec)
+        act = empty_like_layout((B, C, bs, bs), data_exec)
+        scale, shift, relu = prologue
+        for v in (scale, shift):
+            assert v is None or (_ok(v, torch.float32) and v.numel() == C)
+        if B > 0:
+            with torch.cuda.device_of(data_exec):
+                self._check(self.lib.bc_pad_ring_add_nhwc(out.data_ptr(), act.data_ptr(), data_exec.data_ptr(), add.data_ptr(), ring.data_ptr(),
+                                                          grid_idx.data_ptr(), mapping_exec.data_ptr(), B, N, C, GH, GW, bs, int(pad),
+                                                          _DTYPE_CODE[data_exec.dtype], scale.data_ptr() if scale is not None else None,
+                                                          shift.data_ptr() if shift is not None else None, int(bool(relu)), self._stream()),
+                            "pad_ring_add_nhwc")
+        return out, act
 
     @staticmethod
     def maxpool3x3s2_supported(data_exec):

@@ -677,14 +677,34 @@ class TensorWrapper(torch.Tensor):
 
         feats = self._features
         prologue = None
+        residual = None      # pending residual add folded into the halo gather (with the activated tiles as a by-product)
         if isinstance(x, TensorWrapper) and x._pending is not None:
             P = x._pending
             if fuse and P.add is None:
                 prologue = (P.scale, P.shift, P.relu)     # folded into the halo gather; x itself stays pending
+            elif fuse and feats.engine == "fused" and self._residual_gather_ok(op, x, P, args, kwargs, padding):
+                residual = P
             else:
                 x._materialize()
         _materialize_args(args[1:])
         data = dense_layout(x._raw() if isinstance(x, TensorWrapper) else x)
+        if residual is not None:
+            # end of a residual block: v = relu(raw*s + t + identity) is computed INSIDE the gather, which also emits the
+            # plain v that the next shortcut needs -- one launch instead of affine pass + gather
+            with timings.env("tensorwrapper/pad_residual", 10):
+                padded, act = get_backend().pad_ring_add(data, dense_layout(residual.add), feats.next_ring(data, padding),
+                                                         feats._grid_idx, feats._mapping_exec, padding,
+                                                         (residual.scale, residual.shift, residual.relu))
+            x._pending = None
+            x.data = act
+            feats._pad_memo = None
+            args[0] = padded
+            if "padding" in kwargs:
+                kwargs = dict(kwargs, padding=zeros)
+            else:
+                args[pos] = zeros
+            with timings.env("tensorwrapper/pad_func", 11):
+                return func(*args, **kwargs), pend_out
         if feats.engine != "fused" and is_nhwc(data):
             data = data.contiguous()    # the reference decomposition is NCHW only
         grid_idx, mapping_exec = feats._grid_idx, feats._mapping_exec
@@ -742,6 +762,24 @@ class TensorWrapper(torch.Tensor):
             args[pos] = zeros
         with timings.env("tensorwrapper/pad_func", 11):
             return func(*args, **kwargs), pend_out
+
+    def _residual_gather_ok(self, op, x, P, args, kwargs, padding) -> bool:
+        """Can the pending residual add of ``x`` be folded into this padded op's halo gather?"""
+        be = get_backend()
+        if not hasattr(be, "pad_ring_add") or P.add is None or not isinstance(P.add, torch.Tensor):
+            return False
+        raw = x._raw()
+        if not (is_nhwc(raw) and be.pad_ring_add_supported(dense_layout(raw), dense_layout(P.add))):
+            return False
+        if op == "conv2d" and padding == 1:
+            # layers that go to the fused MFMA conv keep the plain route (materialise, then conv without prologue)
+            weight = args[1] if len(args) > 1 else kwargs.get("weight")
+            cv = {k: kwargs.get(k, args[i] if len(args) > i else d) for k, i, d in (("stride", 3, 1), ("dilation", 5, 1), ("groups", 6, 1))}
+            if (isinstance(weight, torch.Tensor) and hasattr(be, "conv3x3_ring")
+                    and be.conv3x3_supported(dense_layout(raw), weight, cv["stride"], 1, cv["dilation"], cv["groups"])
+                    and fusion.use_native_conv3x3(raw.shape[0], raw.shape[2], weight.shape[1], weight.shape[0])):
+                return False
+        return True
 
     def _func_interpolate(self, func, args, kwargs):
         """Resampling runs per tile on the packed batch, i.e. WITHOUT halo: a tile's border pixels are interpolated

@@ -971,6 +971,137 @@ __global__ __launch_bounds__(WG) void k_halo_nhwc(typename VecOf<VB>::type *__re
     }
 }
 
+// ------------------------------------------------------------------------------------------ halo gather with residual add (NHWC)
+// End of a residual block:  v = relu?(raw*scale[c] + shift[c] + identity)  feeds (a) the next padded conv and (b) the next
+// block's shortcut.  Instead of one bc_affine_act pass (write v) followed by a halo gather of v (read it again), this
+// kernel computes v while gathering: it writes the padded batch AND the plain activated tiles (`act_out`, own interior
+// only) in one launch.  Values of executed neighbours are activated on the fly from their raw + identity tiles (same
+// packed row in both tensors); non-executed neighbours come from the ring cache, which for this op holds ACTIVATED
+// values (= what a gather of the materialised v would have stored).  Arithmetic identical to k_affine_act_nhwc.
+template <int DT, typename T> struct ActAdd;
+template <> struct ActAdd<1, uint32_t> {
+    static __device__ __forceinline__ uint32_t apply(uint32_t v, uint32_t a, float s, float t, int relu)
+    {
+        float x = __uint_as_float(v) * s + t;
+        x += __uint_as_float(a);
+        if (relu) x = fmaxf(x, 0.0f);
+        return __float_as_uint(x);
+    }
+};
+template <> struct ActAdd<2, uint16_t> {
+    static __device__ __forceinline__ uint16_t apply(uint16_t v, uint16_t a, float s, float t, int relu)
+    {
+        float x = __half2float(__ushort_as_half(v)) * s + t;
+        x += __half2float(__ushort_as_half(a));
+        if (relu) x = fmaxf(x, 0.0f);
+        return __half_as_ushort(__float2half(x));
+    }
+};
+template <> struct ActAdd<3, uint16_t> {
+    static __device__ __forceinline__ uint16_t apply(uint16_t v, uint16_t a, float s, float t, int relu)
+    {
+        float x = __uint_as_float((uint32_t)v << 16) * s + t;
+        x += __uint_as_float((uint32_t)a << 16);
+        if (relu) x = fmaxf(x, 0.0f);
+        hip_bfloat16 b(x);
+        return *reinterpret_cast<uint16_t *>(&b);
+    }
+};
+
+template <int VB, typename T, int DT>
+__global__ __launch_bounds__(WG) void k_halo_add_nhwc(typename VecOf<VB>::type *__restrict__ out,
+                                                      typename VecOf<VB>::type *__restrict__ act_out,
+                                                      const typename VecOf<VB>::type *__restrict__ features, long long add_delta,
+                                                      long long other_delta, typename VecOf<VB>::type *__restrict__ ring_w,
+                                                      const int32_t *__restrict__ grid_idx, const int32_t *__restrict__ mapping_exec,
+                                                      HaloNhwcGeom g, Prologue pr)
+{
+    typedef typename VecOf<VB>::type V;
+    constexpr int VE = VB / (int)sizeof(T);
+    const uint32_t b = blockIdx.y;
+    const uint32_t bs = g.bs, p = g.pad, K = g.K.d;
+    const uint32_t tile_vecs = bs * bs * K, RSV = 4 * p * bs * K;
+    const uint32_t ig = (uint32_t)mapping_exec[b];
+    uint32_t t0, gw, n0, gh;
+    fd_divmod(ig, g.GW, t0, gw);
+    fd_divmod(t0, g.GH, n0, gh);
+    long long nbb[9];
+    bool nbz[9], nbr[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int dy = k / 3 - 1, dx = k % 3 - 1;
+        const int nh = (int)gh + dy, nw = (int)gw + dx;
+        nbz[k] = nh < 0 || nh >= (int)g.GH.d || nw < 0 || nw >= (int)g.GW.d;
+        nbr[k] = false;
+        nbb[k] = 0;
+        if (k == 4) nbb[k] = (long long)b * tile_vecs;
+        else if (!nbz[k]) {
+            const uint32_t g_in = (uint32_t)((int)ig + dx + (int)g.GW.d * dy);
+            const int32_t idx = grid_idx[g_in];
+            if (idx >= 0) nbb[k] = (long long)idx * tile_vecs;
+            else { nbb[k] = other_delta + (long long)g_in * RSV; nbr[k] = true; }
+        }
+    }
+    V *__restrict__ out_t = out + (size_t)b * g.per_tile;
+    V *__restrict__ act_t = act_out + (size_t)b * tile_vecs;
+    V *__restrict__ rec = ring_w + (long long)ig * RSV;
+
+    V vec[UNROLL], avec[UNROLL];
+    uint32_t fo[UNROLL], kk[UNROLL], hs_[UNROLL], ws_[UNROLL];
+    bool zero[UNROLL], own[UNROLL], ring[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+        const uint32_t f = min((blockIdx.x * UNROLL + u) * WG + threadIdx.x, g.per_tile - 1);
+        uint32_t pix, k, hp, wp;
+        fd_divmod(f, g.K, pix, k);
+        fd_divmod(pix, g.BSP, hp, wp);
+        const uint32_t sy = hp < p ? 0u : (hp >= p + bs ? 2u : 1u);
+        const uint32_t sx = wp < p ? 0u : (wp >= p + bs ? 2u : 1u);
+        const uint32_t hs = hp - p + bs - sy * bs, ws = wp - p + bs - sx * bs;
+        const long long b0 = sx == 0 ? nbb[0] : (sx == 1 ? nbb[1] : nbb[2]);
+        const long long b1 = sx == 0 ? nbb[3] : (sx == 1 ? nbb[4] : nbb[5]);
+        const long long b2 = sx == 0 ? nbb[6] : (sx == 1 ? nbb[7] : nbb[8]);
+        const bool z0 = sx == 0 ? nbz[0] : (sx == 1 ? nbz[1] : nbz[2]);
+        const bool z1 = sx == 0 ? nbz[3] : (sx == 1 ? false : nbz[5]);
+        const bool z2 = sx == 0 ? nbz[6] : (sx == 1 ? nbz[7] : nbz[8]);
+        const bool r0 = sx == 0 ? nbr[0] : (sx == 1 ? nbr[1] : nbr[2]);
+        const bool r1 = sx == 0 ? nbr[3] : (sx == 1 ? false : nbr[5]);
+        const bool r2 = sx == 0 ? nbr[6] : (sx == 1 ? nbr[7] : nbr[8]);
+        const long long base = sy == 0 ? b0 : (sy == 1 ? b1 : b2);
+        zero[u] = sy == 0 ? z0 : (sy == 1 ? z1 : z2);
+        ring[u] = sy == 0 ? r0 : (sy == 1 ? r1 : r2);
+        const uint32_t off = (ring[u] ? ring_elem(sy, sx, hs, ws, bs, p) : hs * bs + ws) * K + k;
+        const long long src = zero[u] ? 0 : base + off;
+        vec[u] = features[src];
+        avec[u] = features[(zero[u] || ring[u]) ? add_delta : add_delta + src];   // identity tile: same packed row / offset
+        fo[u] = f; kk[u] = k; hs_[u] = hs; ws_[u] = ws;
+        own[u] = sy == 1 && sx == 1;
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+        V v = vec[u];
+        if (!ring[u]) {   // ring records already hold activated values
+            T *e = reinterpret_cast<T *>(&v);
+            const T *a = reinterpret_cast<const T *>(&avec[u]);
+            float sc[VE], sh[VE];
+            load_coeffs<VE>(pr.scale, kk[u] * VE, 1.0f, sc);
+            load_coeffs<VE>(pr.shift, kk[u] * VE, 0.0f, sh);
+#pragma unroll
+            for (int j = 0; j < VE; ++j) e[j] = ActAdd<DT, T>::apply(e[j], a[j], sc[j], sh[j], pr.relu);
+        }
+        if (zero[u]) v = V{};
+        if (own[u]) {
+            const uint32_t hs = hs_[u], ws = ws_[u], k = kk[u];
+            act_t[(hs * bs + ws) * K + k] = v;
+            if (hs < p) rec[(hs * bs + ws) * K + k] = v;
+            if (hs >= bs - p) rec[(p * bs + (hs - (bs - p)) * bs + ws) * K + k] = v;
+            if (ws < p) rec[(2 * p * bs + hs * p + ws) * K + k] = v;
+            if (ws >= bs - p) rec[(2 * p * bs + bs * p + hs * p + (ws - (bs - p))) * K + k] = v;
+        }
+        out_t[fo[u]] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ fused halo + 3x3/s2 max-pool (NHWC)
 // The one padded op of the path that is not a conv (ResNet stem): max_pool2d(k=3, s=2, p=1) on the packed batch.  The
 // reference materialises the halo-padded tiles and pools them with padding 0 (core/tensorwrapper.py:478-527); here one
@@ -1779,6 +1910,40 @@ BC_EXPORT int bc_conv3x3_ring_nhwc(void *out, const void *features, void *ring, 
     if (g.pw == 8) { if (WM_ == 2) BC_CV(8, 2); else BC_CV(8, 1); }
     else { if (WM_ == 2) BC_CV(4, 2); else BC_CV(4, 1); }
 #undef BC_CV
+    return launch_status();
+}
+
+BC_EXPORT int bc_pad_ring_add_nhwc(void *out, void *act_out, const void *features, const void *add, void *ring,
+                                   const int32_t *grid_idx, const int32_t *mapping_exec, int n_exec, int N, int C, int GH, int GW,
+                                   int bs, int pad, int dtype, const float *scale, const float *shift, int relu, void *stream)
+{
+    if (dtype < BC_F32 || dtype > BC_BF16) return BC_ERR_ELEM;
+    const int E = dtype == BC_F32 ? 4 : 2;
+    if (n_exec < 0 || N <= 0 || C <= 0 || GH <= 0 || GW <= 0 || bs <= 0 || pad < 1 || pad > bs) return BC_ERR_SHAPE;
+    if (((size_t)C * E) % 16 != 0) return BC_ERR_SHAPE;
+    if (n_exec == 0) return BC_OK;
+    if (!out || !act_out || !features || !add || !ring || !grid_idx || !mapping_exec) return BC_ERR_NULL;
+    const uint64_t bsp = (uint64_t)bs + 2 * pad;
+    if ((uint64_t)n_exec * C * bsp * bsp >= (1ull << 31) || (uint64_t)N * GH * GW * C * bs * bs >= (1ull << 31)) return BC_ERR_RANGE;
+    if (!aligned(out, 16) || !aligned(act_out, 16) || !aligned(features, 16) || !aligned(add, 16) || !aligned(ring, 16)) return BC_ERR_ALIGN;
+    HaloNhwcGeom g;
+    const uint32_t K = (uint32_t)((size_t)C * E / 16);
+    g.K = make_fd(K); g.BSP = make_fd((uint32_t)bsp); g.GW = make_fd(GW); g.GH = make_fd(GH);
+    g.C = C; g.bs = bs; g.pad = pad; g.n_total = (uint32_t)N * GH * GW;
+    g.per_tile = (uint32_t)(bsp * bsp * K);
+    g.epv = 16 / E;
+    const dim3 grid((g.per_tile + WG * UNROLL - 1) / (WG * UNROLL), (unsigned)n_exec);
+    const long long ring_delta = ((const char *)ring - (const char *)features) / 16;
+    const long long add_delta = ((const char *)add - (const char *)features) / 16;
+    Prologue pr{scale, shift, relu};
+    // bytes: raw + identity tiles in, padded batch + activated tiles out
+    ProfScope ps(BC_OP_PAD_RING, halo_bytes(n_exec, C, bs, pad, E) + 2.0 * n_exec * C * bs * bs * E);
+#define BC_HA(T_, DT_)                                                                                               \
+    BC_LAUNCH(ps, (k_halo_add_nhwc<16, T_, DT_>), grid, dim3(WG), 0, (hipStream_t)stream, (VecOf<16>::type *)out,      \
+              (VecOf<16>::type *)act_out, (const VecOf<16>::type *)features, add_delta, ring_delta, (VecOf<16>::type *)ring, \
+              grid_idx, mapping_exec, g, pr)
+    if (dtype == BC_F32) BC_HA(uint32_t, 1); else if (dtype == BC_F16) BC_HA(uint16_t, 2); else BC_HA(uint16_t, 3);
+#undef BC_HA
     return launch_status();
 }
 

@@ -163,6 +163,16 @@ int bc_conv3x3_ring_nhwc(void *out, const void *features, void *ring, const void
                          int GH, int GW, int bs, int dtype, const float *in_scale, const float *in_shift, int in_relu,
                          const float *out_scale, const float *out_shift, const void *out_add, int out_relu, void *stream);
 
+/* halo gather with a residual-add prologue and a by-product: v = relu?(features*scale[c] + shift[c] + add) is computed while
+ * gathering; `out` receives the padded batch of v and `act_out` (n_exec, bs, bs, C) the plain v of every executed tile
+ * (what the next block's shortcut reads), so the end of a residual block costs one launch instead of bc_affine_act_nhwc
+ * + bc_pad_ring_nhwc.  `add` has the layout of `features`.  The ring cache of this op holds ACTIVATED values (exactly
+ * what bc_pad_ring_nhwc of the materialised v would store), so both forms may serve the same layer on different frames.
+ * C*elem_size a multiple of 16 bytes. */
+int bc_pad_ring_add_nhwc(void *out, void *act_out, const void *features, const void *add, void *ring,
+                         const int32_t *grid_idx, const int32_t *mapping_exec, int n_exec, int N, int C, int GH, int GW,
+                         int bs, int pad, int dtype, const float *scale, const float *shift, int relu, void *stream);
+
 /* fused halo gather + max_pool2d(kernel 3, stride 2, padding 1) of a packed channels-last batch (the ResNet stem pool, the
  * one padded op of the path that is not a conv; reference: BlockPad.apply + F.max_pool2d(padding=0),
  * core/tensorwrapper.py:478-527).  features (n_exec, bs, bs, C) -> out (n_exec, bs/2, bs/2, C); ring and prologue exactly

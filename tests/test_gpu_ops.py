@@ -555,3 +555,37 @@ def test_fused_maxpool_matches_halo_plus_pool(be, dtype):
             got = be.maxpool3x3s2_ring(feats, ring_b, gi_d, m_d, pro)
             assert got.shape == want.shape and torch.equal(got.contiguous(), want.contiguous()), (case, t, C, bs)
             assert torch.equal(ring_a, ring_b), (case, t)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_residual_gather_matches_affine_plus_gather(be, dtype):
+    """bc_pad_ring_add_nhwc == bc_affine_act_nhwc followed by bc_pad_ring_nhwc, BIT-exact on the padded batch, on the
+    activated tiles it emits and on the ring cache, over multi-frame chains with random masks (so ring-sourced halos,
+    which hold activated values, are exercised)."""
+    rng = np.random.default_rng(11)
+    gen = torch.Generator().manual_seed(11)
+    E = torch.empty((), dtype=dtype).element_size()
+    for case in range(12):
+        C = int(rng.choice([4, 8, 24, 64])) * (1 if E == 4 else 2)
+        bs, pad = int(rng.choice([1, 2, 4, 8, 16, 32])), 1
+        N, GH, GW = int(rng.choice([1, 2])), int(rng.integers(1, 5)), int(rng.integers(1, 5))
+        T = N * GH * GW
+        ring_a, ring_b = torch.zeros((T, C, 4 * bs), dtype=dtype).cuda(), torch.zeros((T, C, 4 * bs), dtype=dtype).cuda()
+        sc, sh = (torch.rand(C, generator=gen) + 0.5).cuda(), (torch.randn(C, generator=gen) * 0.3).cuda()
+        for t in range(4):
+            g = np.ones(T, bool) if t == 0 else rng.random(T) < rng.choice([0.2, 0.5, 0.9])
+            if not g.any():
+                g[int(rng.integers(T))] = True
+            gi, m = O.c_grid_mappings(g.reshape(N, 1, GH, GW))
+            gi_d, m_d = _dev(gi), _dev(m)
+            feats = _cl(torch.randn((len(m), C, bs, bs), generator=gen).to(dtype).cuda())
+            ident = _cl(torch.randn((len(m), C, bs, bs), generator=gen).to(dtype).cuda())
+            pro = (sc if t % 2 == 0 else None, sh if t % 3 != 0 else None, t != 1)
+            want_act = be.affine_act(feats, pro[0], pro[1], ident, pro[2])
+            want = be.pad_ring(want_act, ring_a, gi_d, m_d, pad, None)
+            if not be.pad_ring_add_supported(feats, ident):
+                continue
+            got, got_act = be.pad_ring_add(feats, ident, ring_b, gi_d, m_d, pad, pro)
+            assert torch.equal(got_act.contiguous(), want_act.contiguous()), (case, t, "act")
+            assert torch.equal(got.contiguous(), want.contiguous()), (case, t, "padded")
+            assert torch.equal(ring_a, ring_b), (case, t, "ring")
