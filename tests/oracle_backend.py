@@ -114,6 +114,26 @@ class OracleBackend:
             y = torch.relu(y)
         return _like(y.to(data.dtype), data)
 
+    # ---- by-composition checkers of the fused MI355X forms (the GPU tests assert exactly these equivalences bit for bit)
+    @staticmethod
+    def pad_ring_add_supported(data_exec, add):
+        return _nhwc(data_exec) and add.shape == data_exec.shape and add.dtype == data_exec.dtype
+
+    def pad_ring_add(self, data_exec, add, ring, grid_idx, mapping_exec, pad, prologue):
+        """residual gather == fused affine pass, then a plain halo gather of its result (ring keeps the activated values)."""
+        scale, shift, relu = prologue
+        act = self.affine_act(data_exec, scale, shift, add, relu)
+        return self.pad_ring(act, ring, grid_idx, mapping_exec, pad, None), act
+
+    @staticmethod
+    def maxpool3x3s2_supported(data_exec):
+        return _nhwc(data_exec) and data_exec.shape[2] == data_exec.shape[3] and data_exec.shape[2] % 2 == 0
+
+    def maxpool3x3s2_ring(self, data_exec, ring, grid_idx, mapping_exec, prologue=None):
+        """fused halo + pool == halo gather, then the stock pad-0 pool."""
+        padded = self.pad_ring(data_exec, ring, grid_idx, mapping_exec, 1, prologue)
+        return _like(torch.nn.functional.max_pool2d(padded.contiguous(), 3, 2, 0), data_exec)
+
     supports_interp_dtypes = (torch.float32,)
 
     def interp_bilinear(self, data, out_h, out_w, align_corners, rh, rw):

@@ -319,7 +319,14 @@ def test_channels_last_model_matches_reference_on_cpu(golden_dir, oracle_backend
     from bc_workloads.bn_fold import fold_batchnorm
     from bc_workloads.swiftnet import build_swiftnet
 
+    import blockcopy.backend as bk
+
     G, cfg = load_golden(golden_dir, name)
+    # the engine's MI355X-specific routes must be taken on this model: residual gather (by-product), fused halo+pool
+    chk, hits = bk.get_backend(), {"pad_ring_add": 0, "maxpool3x3s2_ring": 0}
+    for meth in hits:
+        orig = getattr(chk, meth)
+        setattr(chk, meth, (lambda o, k: lambda *a, **kw: (hits.__setitem__(k, hits[k] + 1), o(*a, **kw))[1])(orig, meth))
     for graph in (0, 1):
         net = build_swiftnet(cfg["backbone"])
         net.load_state_dict(seeded.name_seeded_state_dict(net.state_dict()), strict=True)
@@ -334,6 +341,7 @@ def test_channels_last_model_matches_reference_on_cpu(golden_dir, oracle_backend
                 y = model(seeded.synthetic_frame(cfg["frame_seed0"] + t, (cfg["N"], 3, cfg["H"], cfg["W"])))
                 assert float((y - torch.from_numpy(G[f"logits{t}"])).abs().max()) <= 1e-4, (graph, t)
         assert is_nhwc(y), "the output map should have stayed channels-last"
+    assert hits["pad_ring_add"] >= 7 * cfg["n_frames"] and hits["maxpool3x3s2_ring"] >= cfg["n_frames"], hits
 
 
 def test_conv3x3_weight_packing_matches_the_header_formula():
