@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""List the stock PyTorch elementwise / copy / pooling ops one eager C2 frame still launches (name, input shapes, device
+time) -- the tool that found the BN + layout-copy + ReLU chains on the dense pyramid-pooling maps and the stem pool.
+usage: python tools/list_dense_ops.py"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "blockcopy-video-processing-pytorch_amd"))
