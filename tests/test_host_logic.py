@@ -360,3 +360,17 @@ def test_conv3x3_weight_packing_matches_the_header_formula():
         nb, chunk, tap, cg, lane, j = (int(rng.integers(n)) for n in (Cout // 32, Cin // 32, 9, 4, 64, 4))
         want = w[32 * nb + lane % 32, 32 * chunk + 8 * cg + 4 * (lane // 32) + j, tap // 3, tap % 3]
         assert wpk[nb, chunk, tap, cg, lane, j] == want
+
+
+def test_fusion_switch_off_gives_the_same_logits(golden_dir, oracle_backend):
+    """BLOCKCOPY_FUSE=0 (fusion.set_enabled(False)): every elementwise op launches separately, dense maps inside
+    noblocks modules are plain tensors again, no residual gather / fused pool -- the logits must not move."""
+    from blockcopy.core import fusion
+
+    G, cfg = load_golden(golden_dir, "swiftnet_rn18_a.npz")
+    prev = fusion.set_enabled(False)
+    try:
+        errs, _ = run_golden_clip(G, cfg, "cpu", "fused")
+    finally:
+        fusion.set_enabled(prev)
+    assert max(errs) <= 2e-5, errs
