@@ -79,6 +79,7 @@ def load_library(path: str = None) -> ctypes.CDLL:
         "bc_pad_ring_add_nhwc": [p, p, p, p, p, p, p] + [i] * 8 + [p, p, i, p],
         "bc_conv3x3_ring_nhwc": [p, p, p, p, p, p] + [i] * 8 + [p, p, i, p, p, p, i, p],
         "bc_interp_bilinear_nhwc": [p, p, ctypes.c_longlong, i, i, i, i, i, i, ctypes.c_float, ctypes.c_float, i, p],
+        "bc_interp_bilinear_act_nhwc": [p, p, ctypes.c_longlong, i, i, i, i, i, i, ctypes.c_float, ctypes.c_float, i, p, p, p, i, p],
         "bc_affine_act": [p, p, p, p, p, i, ctypes.c_longlong, i, ctypes.c_longlong, i, p],
         "bc_nms_sorted": [p, i, ctypes.c_float, p, p, p, p],
         "bc_abi_version": [],
@@ -371,11 +372,32 @@ class HipBackend:
 
     supports_fusion_dtypes = tuple(_DTYPE_CODE)
 
-    def interp_bilinear(self, data, out_h, out_w, align_corners, rh, rw):
-        """per-tile bilinear resampling (planes = all leading dims); arithmetic of torch's upsample_bilinear2d."""
+    @staticmethod
+    def interp_epilogue_supported(data):
+        """Deferred interpolation (epilogue fused into the resampling launch) exists for channels-last tensors."""
+        return data.dim() == 4 and is_nhwc(data) and data.dtype in _DTYPE_CODE
+
+    def interp_bilinear(self, data, out_h, out_w, align_corners, rh, rw, epilogue=None):
+        """per-tile bilinear resampling (planes = all leading dims); arithmetic of torch's upsample_bilinear2d.
+        epilogue = (scale, shift, add, relu) on the resampled value (channels-last only)."""
         assert _ok(data, *_DTYPE_CODE) and data.dim() == 4
         B, C, h, w = data.shape
         out = empty_like_layout((B, C, out_h, out_w), data)
+        if epilogue is not None:
+            assert is_nhwc(data), "interp epilogue: channels-last only"
+            scale, shift, add, relu = epilogue
+            for v in (scale, shift):
+                assert v is None or (_ok(v, torch.float32) and v.numel() == C)
+            assert add is None or (_ok(add, data.dtype) and tuple(add.shape) == tuple(out.shape) and is_nhwc(add))
+            if out.numel() > 0:
+                with torch.cuda.device_of(data):
+                    self._check(self.lib.bc_interp_bilinear_act_nhwc(out.data_ptr(), data.data_ptr(), B, C, h, w, out_h, out_w,
+                                                                     int(bool(align_corners)), float(rh), float(rw), _DTYPE_CODE[data.dtype],
+                                                                     scale.data_ptr() if scale is not None else None,
+                                                                     shift.data_ptr() if shift is not None else None,
+                                                                     add.data_ptr() if add is not None else None, int(bool(relu)),
+                                                                     self._stream()), "interp_bilinear_act_nhwc")
+            return out
         if out.numel() > 0 and is_nhwc(data):
             with torch.cuda.device_of(data):
                 self._check(self.lib.bc_interp_bilinear_nhwc(out.data_ptr(), data.data_ptr(), B, C, h, w, out_h, out_w,

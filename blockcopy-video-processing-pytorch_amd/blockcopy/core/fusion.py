@@ -27,13 +27,18 @@ def set_enabled(flag: bool) -> bool:
 
 
 class Pending:
-    __slots__ = ("scale", "shift", "add", "relu")
+    """value = relu?( base * scale[c] + shift[c] + add ),  base = the stored data, or -- deferred interpolation --
+    ``bilinear(interp[0])`` with ``interp = (source, H, W, align_corners, rh, rw)``: the resampling launch has not
+    happened yet (the stored data is an unwritten placeholder of the right shape) and will carry the rest of the record
+    as its epilogue, e.g. a decoder's ``x = upsample(x); x += skip`` becomes one kernel."""
 
-    def __init__(self, scale=None, shift=None, add=None, relu=False):
-        self.scale, self.shift, self.add, self.relu = scale, shift, add, relu
+    __slots__ = ("scale", "shift", "add", "relu", "interp")
+
+    def __init__(self, scale=None, shift=None, add=None, relu=False, interp=None):
+        self.scale, self.shift, self.add, self.relu, self.interp = scale, shift, add, relu, interp
 
     def copy(self):
-        return Pending(self.scale, self.shift, self.add, self.relu)
+        return Pending(self.scale, self.shift, self.add, self.relu, self.interp)
 
     @property
     def affine_only(self):

@@ -360,7 +360,11 @@ class TensorWrapper(torch.Tensor):
             if add is not None:
                 add = dense_layout(add)
             be = get_backend()
-            if raw.dtype in getattr(be, "supports_fusion_dtypes", ()):
+            if P.interp is not None:      # deferred interpolation: resample now, the rest of the record is its epilogue
+                src, H, W, align, rh, rw = P.interp
+                plain = P.scale is None and P.shift is None and add is None and not P.relu
+                out = be.interp_bilinear(src, H, W, align, rh, rw, None if plain else (P.scale, P.shift, add, P.relu))
+            elif raw.dtype in getattr(be, "supports_fusion_dtypes", ()):
                 out = be.affine_act(raw, P.scale, P.shift, add, P.relu)
             else:   # exotic dtype: the same arithmetic with stock ops
                 out = raw.float()
@@ -543,7 +547,7 @@ class TensorWrapper(torch.Tensor):
                 if op in OPS["PADDED"]:
                     ret, pend = self._func_replace_padding(op, func, args, kwargs)
                 elif op in OPS["INTERPOLATE"]:
-                    ret = self._func_interpolate(func, args, kwargs)
+                    ret, pend = self._func_interpolate(func, args, kwargs)
                 elif op in OPS["BATCHED"]:
                     ret = self._func_batched(func, args, kwargs)
                 elif op in OPS["CHANNELONLY"]:
@@ -609,7 +613,7 @@ class TensorWrapper(torch.Tensor):
         P = x._pending if inplace else x._pending.copy()
         if isinstance(y, TensorWrapper) and y._pending is not None:
             q = y._pending
-            if q.scale is None and q.affine_only:      # (raw_y + shift_y): fold the shift, add the raw tensor
+            if q.scale is None and q.affine_only and q.interp is None:      # (raw_y + shift_y): fold the shift, add the raw tensor
                 P.shift = fusion.add_shifts(P.shift, q.shift)
                 P.add = y._raw()
             else:
@@ -680,7 +684,7 @@ class TensorWrapper(torch.Tensor):
         residual = None      # pending residual add folded into the halo gather (with the activated tiles as a by-product)
         if isinstance(x, TensorWrapper) and x._pending is not None:
             P = x._pending
-            if fuse and P.add is None:
+            if fuse and P.add is None and P.interp is None:
                 prologue = (P.scale, P.shift, P.relu)     # folded into the halo gather; x itself stays pending
             elif fuse and feats.engine == "fused" and self._residual_gather_ok(op, x, P, args, kwargs, padding):
                 residual = P
@@ -766,7 +770,7 @@ class TensorWrapper(torch.Tensor):
     def _residual_gather_ok(self, op, x, P, args, kwargs, padding) -> bool:
         """Can the pending residual add of ``x`` be folded into this padded op's halo gather?"""
         be = get_backend()
-        if not hasattr(be, "pad_ring_add") or P.add is None or not isinstance(P.add, torch.Tensor):
+        if not hasattr(be, "pad_ring_add") or P.add is None or P.interp is not None or not isinstance(P.add, torch.Tensor):
             return False
         raw = x._raw()
         if not (is_nhwc(raw) and be.pad_ring_add_supported(dense_layout(raw), dense_layout(P.add))):
@@ -794,7 +798,7 @@ class TensorWrapper(torch.Tensor):
         be = get_backend()
         if (mode != "bilinear" or data.dim() != 4 or kwargs.get("antialias", False)
                 or data.dtype not in getattr(be, "supports_interp_dtypes", ())):
-            return func(*args, **kwargs)
+            return func(*args, **kwargs), None
         size = kwargs.get("size", args[1] if len(args) > 1 else None)
         scale = kwargs.get("scale_factor", args[2] if len(args) > 2 else None)
         align = bool(kwargs.get("align_corners", False))
@@ -814,7 +818,14 @@ class TensorWrapper(torch.Tensor):
                 return np.float32(in_size - 1) / np.float32(out_size - 1) if out_size > 1 else np.float32(0)
             return np.float32(1.0 / s) if (s is not None and s > 0) else np.float32(in_size) / np.float32(out_size)
 
-        return be.interp_bilinear(dense_layout(data), H, W, align, resolved(h, H, sh), resolved(w, W, sw))
+        src, rh, rw = dense_layout(data), resolved(h, H, sh), resolved(w, W, sw)
+        if (fusion.ENABLED and self._features.engine == "fused" and hasattr(be, "interp_epilogue_supported")
+                and be.interp_epilogue_supported(src) and src.dtype in getattr(be, "supports_fusion_dtypes", ())):
+            # deferred: the launch happens when the value is needed, with whatever elementwise work was recorded by then
+            # as its epilogue (decoder: "upsample, += skip" -> one kernel).  The placeholder is never read or written.
+            placeholder = empty_like_layout((src.shape[0], src.shape[1], H, W), src)
+            return placeholder, fusion.Pending(interp=(src, H, W, align, rh, rw))
+        return be.interp_bilinear(src, H, W, align, rh, rw), None
 
     def _func_batched(self, func, args, kwargs):
         """Ops with per-sample statistics (group_norm): fold the tile axis into the spatial axis so statistics

@@ -1242,8 +1242,23 @@ struct InterpNhwcGeom {
     int align;
 };
 
+// one fixed evaluation order for the 4-tap blend, so that the plain and the epilogue form of the kernel agree bit for bit
+__device__ __forceinline__ float bilerp(float a, float b, float c, float d, float lx0, float lx1, float ly0, float ly1)
+{
+    const float top = fmaf(lx1, b, lx0 * a), bot = fmaf(lx1, d, lx0 * c);
+    return fmaf(ly1, bot, ly0 * top);
+}
+
+// optional epilogue relu?(y*scale[c] + shift[c] + add) on the interpolated (and, as in the two-kernel route, rounded) value:
+// the decoder's "upsample, then += skip" costs one launch instead of two
+struct InterpEpi {
+    const float *scale, *shift;
+    const void *add;     // (planes, H, W, C), may be null
+    int relu, on;
+};
+
 template <typename T, int Q>
-__global__ __launch_bounds__(WG) void k_interp_bilinear_nhwc(T *__restrict__ out, const T *__restrict__ in, InterpNhwcGeom g)
+__global__ __launch_bounds__(WG) void k_interp_bilinear_nhwc(T *__restrict__ out, const T *__restrict__ in, InterpNhwcGeom g, InterpEpi ep)
 {
     typedef typename VecOf<sizeof(T) * Q>::type V;
     const uint32_t i = blockIdx.x * WG + threadIdx.x;
@@ -1262,9 +1277,26 @@ __global__ __launch_bounds__(WG) void k_interp_bilinear_nhwc(T *__restrict__ out
     const T *a = reinterpret_cast<const T *>(&v00), *bq = reinterpret_cast<const T *>(&v01);
     const T *c = reinterpret_cast<const T *>(&v10), *d = reinterpret_cast<const T *>(&v11);
     T res[Q];
+    if (!ep.on) {
 #pragma unroll
-    for (int k = 0; k < Q; ++k)
-        res[k] = Cvt<T>::st(ly0 * (lx0 * Cvt<T>::ld(a + k) + lx1 * Cvt<T>::ld(bq + k)) + ly1 * (lx0 * Cvt<T>::ld(c + k) + lx1 * Cvt<T>::ld(d + k)));
+        for (int k = 0; k < Q; ++k)
+            res[k] = Cvt<T>::st(bilerp(Cvt<T>::ld(a + k), Cvt<T>::ld(bq + k), Cvt<T>::ld(c + k), Cvt<T>::ld(d + k), lx0, lx1, ly0, ly1));
+    } else {
+        float sc[Q], sh[Q];
+        load_coeffs<Q>(ep.scale, q * Q, 1.0f, sc);
+        load_coeffs<Q>(ep.shift, q * Q, 0.0f, sh);
+        V av = V{};
+        if (ep.add) av = reinterpret_cast<const V *>(ep.add)[i];
+        const T *e = reinterpret_cast<const T *>(&av);
+#pragma unroll
+        for (int k = 0; k < Q; ++k) {
+            const float y = Cvt<T>::ld_round(bilerp(Cvt<T>::ld(a + k), Cvt<T>::ld(bq + k), Cvt<T>::ld(c + k), Cvt<T>::ld(d + k), lx0, lx1, ly0, ly1));
+            float x = y * sc[k] + sh[k];
+            if (ep.add) x += Cvt<T>::ld(e + k);
+            if (ep.relu) x = fmaxf(x, 0.0f);
+            res[k] = Cvt<T>::st(x);
+        }
+    }
     reinterpret_cast<V *>(out)[i] = *reinterpret_cast<const V *>(res);
 }
 
@@ -2006,8 +2038,9 @@ BC_EXPORT int bc_affine_act_nhwc(void *out, const void *in, const void *add, con
     return launch_status();
 }
 
-BC_EXPORT int bc_interp_bilinear_nhwc(void *out, const void *in, long long planes, int C, int h, int w, int H, int W,
-                                      int align_corners, float rh, float rw, int dtype, void *stream)
+BC_EXPORT int bc_interp_bilinear_act_nhwc(void *out, const void *in, long long planes, int C, int h, int w, int H, int W,
+                                          int align_corners, float rh, float rw, int dtype, const float *scale, const float *shift,
+                                          const void *add, int relu, void *stream)
 {
     if (dtype < BC_F32 || dtype > BC_BF16) return BC_ERR_ELEM;
     if (planes < 0 || C <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return BC_ERR_SHAPE;
@@ -2017,14 +2050,15 @@ BC_EXPORT int bc_interp_bilinear_nhwc(void *out, const void *in, long long plane
     if ((uint64_t)planes * H * W * C >= (1ull << 31) || (uint64_t)planes * h * w * C >= (1ull << 31)) return BC_ERR_RANGE;
     hipStream_t st = (hipStream_t)stream;
     int q = 16 / E;
-    while (q > 1 && ((C % q) != 0 || !aligned(out, q * E) || !aligned(in, q * E))) q >>= 1;
+    while (q > 1 && ((C % q) != 0 || !aligned(out, q * E) || !aligned(in, q * E) || !aligned(add, q * E))) q >>= 1;
+    InterpEpi ep{scale, shift, add, relu, (scale || shift || add || relu) ? 1 : 0};
     InterpNhwcGeom g;
     g.Cq = make_fd((uint32_t)(C / q)); g.W = make_fd(W); g.H = make_fd(H);
     g.h = h; g.w = w; g.rh = rh; g.rw = rw; g.align = align_corners;
     g.total = (uint32_t)((uint64_t)planes * H * W * (C / q));
     const int grid = grid_exact(g.total, 1);
-    ProfScope ps(BC_OP_INTERP, ((double)planes * h * w + (double)planes * H * W) * C * E);
-#define BC_IN(T_, Q_) BC_LAUNCH(ps, (k_interp_bilinear_nhwc<T_, Q_>), dim3(grid), dim3(WG), 0, st, (T_ *)out, (const T_ *)in, g)
+    ProfScope ps(BC_OP_INTERP, ((double)planes * h * w + (double)planes * H * W * (add ? 2 : 1)) * C * E);
+#define BC_IN(T_, Q_) BC_LAUNCH(ps, (k_interp_bilinear_nhwc<T_, Q_>), dim3(grid), dim3(WG), 0, st, (T_ *)out, (const T_ *)in, g, ep)
 #define BC_INQ(T_, QMAX_) do { if (q == QMAX_) BC_IN(T_, QMAX_); else if (q == QMAX_ / 2) BC_IN(T_, QMAX_ / 2);     \
                                else if (QMAX_ >= 8 && q == 2) BC_IN(T_, 2); else BC_IN(T_, 1); } while (0)
     if (dtype == BC_F32) BC_INQ(float, 4);
@@ -2033,6 +2067,12 @@ BC_EXPORT int bc_interp_bilinear_nhwc(void *out, const void *in, long long plane
 #undef BC_INQ
 #undef BC_IN
     return launch_status();
+}
+
+BC_EXPORT int bc_interp_bilinear_nhwc(void *out, const void *in, long long planes, int C, int h, int w, int H, int W,
+                                      int align_corners, float rh, float rw, int dtype, void *stream)
+{
+    return bc_interp_bilinear_act_nhwc(out, in, planes, C, h, w, H, W, align_corners, rh, rw, dtype, nullptr, nullptr, nullptr, 0, stream);
 }
 
 BC_EXPORT int bc_grid_tables(const uint8_t *grid, int n_total, int32_t *grid_idx, int32_t *mapping_exec,

@@ -144,6 +144,11 @@ int bc_affine_act_nhwc(void *out, const void *in, const void *add, const float *
                        long long pixels, int C, int dtype, void *stream);
 int bc_interp_bilinear_nhwc(void *out, const void *in, long long planes, int C, int h, int w, int H, int W,
                             int align_corners, float rh, float rw, int dtype, void *stream);
+/* the same with an epilogue on the interpolated value y (rounded to the tensor dtype first, as a separate launch would see
+ * it): out = relu?(y*scale[c] + shift[c] + add), add (planes, H, W, C) or NULL -- "upsample, then += skip" in one launch. */
+int bc_interp_bilinear_act_nhwc(void *out, const void *in, long long planes, int C, int h, int w, int H, int W,
+                                int align_corners, float rh, float rw, int dtype, const float *scale, const float *shift,
+                                const void *add, int relu, void *stream);
 
 /* fused halo gather + 3x3 / stride 1 / pad 1 convolution of a packed channels-last tile batch on the matrix cores:
  * out = epilogue(conv3x3(prologue(halo-padded tiles))) in ONE launch, without materialising the padded tensor.

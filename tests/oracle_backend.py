@@ -136,10 +136,18 @@ class OracleBackend:
 
     supports_interp_dtypes = (torch.float32,)
 
-    def interp_bilinear(self, data, out_h, out_w, align_corners, rh, rw):
+    @staticmethod
+    def interp_epilogue_supported(data):
+        return _nhwc(data)
+
+    def interp_bilinear(self, data, out_h, out_w, align_corners, rh, rw, epilogue=None):
         # floating-point op: the checker is stock PyTorch on the packed batch (per tile, no halo)
-        return _like(torch.nn.functional.interpolate(data.contiguous(), size=(out_h, out_w), mode="bilinear",
-                                                     align_corners=align_corners), data)
+        y = _like(torch.nn.functional.interpolate(data.contiguous(), size=(out_h, out_w), mode="bilinear",
+                                                  align_corners=align_corners), data)
+        if epilogue is not None:   # deferred interpolation == resample, then the fused affine pass
+            scale, shift, add, relu = epilogue
+            y = self.affine_act(y, scale, shift, add, relu)
+        return y
 
     def nms(self, dets, iou_thr):
         inds = torch.from_numpy(O.c_nms(dets.detach().float().numpy(), iou_thr))

@@ -589,3 +589,22 @@ def test_residual_gather_matches_affine_plus_gather(be, dtype):
             assert torch.equal(got_act.contiguous(), want_act.contiguous()), (case, t, "act")
             assert torch.equal(got.contiguous(), want.contiguous()), (case, t, "padded")
             assert torch.equal(ring_a, ring_b), (case, t, "ring")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_interp_epilogue_matches_two_kernel_route(be, dtype):
+    """bc_interp_bilinear_act_nhwc == bc_interp_bilinear_nhwc followed by bc_affine_act_nhwc, bit for bit (the
+    interpolated value is rounded to the tensor dtype before the epilogue, as the separate launch would see it)."""
+    gen = torch.Generator().manual_seed(3)
+    for (B, C, h, w, H, W, align) in [(5, 16, 4, 4, 8, 8, False), (3, 128, 8, 8, 16, 16, False), (2, 24, 5, 7, 10, 14, True),
+                                      (7, 8, 16, 16, 32, 32, False), (1, 40, 3, 3, 7, 5, False)]:
+        x = _cl(torch.randn((B, C, h, w), generator=gen).to(dtype).cuda())
+        add = _cl(torch.randn((B, C, H, W), generator=gen).to(dtype).cuda())
+        sc, sh = (torch.rand(C, generator=gen) + 0.5).cuda(), (torch.randn(C, generator=gen) * 0.2).cuda()
+        rh = np.float32(h - 1) / np.float32(H - 1) if align else np.float32(h) / np.float32(H)
+        rw = np.float32(w - 1) / np.float32(W - 1) if align else np.float32(w) / np.float32(W)
+        plain = be.interp_bilinear(x, H, W, align, rh, rw)
+        for epi in [(None, None, add, False), (sc, sh, add, True), (None, sh, None, True), (sc, None, None, False)]:
+            want = be.affine_act(plain, epi[0], epi[1], epi[2], epi[3])
+            got = be.interp_bilinear(x, H, W, align, rh, rw, epi)
+            assert torch.equal(got.contiguous(), want.contiguous()), (dtype, (B, C, h, w, H, W), [e is not None for e in epi[:3]], epi[3])
