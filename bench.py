@@ -3,7 +3,10 @@
 50 % execution mask (BASELINE.json config C2), plus the HBM roofline of the fused scatter+copy kernel and the host-CPU
 dense baseline.
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 run directly: bench.py starts its own N worker processes (one per GPU) before anything touches the GPU; under
+``torch.distributed.run`` (WORLD_SIZE already set) it is a worker.
 
 A *step* is one 20-frame clip (reset_temporal(); frame 0 executes all 128 tiles, frames 1..19 execute a seeded 64 of
 128) with every frame already resident in HBM.  fps = frames / wall, device-synchronised on both sides, exactly as the
@@ -24,14 +27,14 @@ for _p in (os.path.join(ROOT, "blockcopy-video-processing-pytorch_amd"),):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-import torch  # noqa: E402
+torch = None   # imported by the worker only: the launcher parent never touches torch or the GPU
 
 METRIC = "frames/sec SwiftNet-RN18 1024×2048 @ 50% active blocks, 1→8 GPU; scatter GB/s"
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 CLIP_LEN = 20
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5, help="timed clips per rank")
@@ -58,7 +61,11 @@ def parse_args():
     ap.add_argument("--miopen-find", type=int, default=1, help="torch.backends.cudnn.benchmark during warm-up")
     ap.add_argument("--cpu-frames", type=int, default=8)
     ap.add_argument("--graph", type=int, default=1, help="hipGraph replay of the packed pipeline (0 = eager launches)")
-    return ap.parse_args()
+    ap.add_argument("--stub-cpu", action="store_true",
+                    help="(tests only) replace the GPU workload by a tiny CPU stand-in so that the launcher, the per-rank "
+                         "environment and the clock bracket can be exercised on a machine without a GPU")
+    ap.add_argument("--launch-timeout", type=float, default=3000.0, help="seconds before the launcher gives up on its replicas")
+    return ap.parse_args(argv)
 
 
 def cpu_dense_baseline(args, n_frames):
@@ -133,19 +140,139 @@ def pmc_traffic():
     return t.get("k_combine_copy_bytes_per_launch"), t.get("source")
 
 
-def main():
+def _free_port():
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_replicas(args, argv):
+    """``python bench.py --gpus N`` (N > 1) run directly: start one worker process per GPU and relay rank 0's JSON line.
+
+    The launcher never imports torch and never touches the GPU (a process that has initialised HIP must not exec or
+    fork workers); the workers are plain children (``subprocess``), each with the torchrun environment
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT) and its GPU = LOCAL_RANK.  Exit code is
+    non-zero if any worker fails; the others are then terminated (only processes started here are signalled).
+    The reference has no multi-GPU launcher (semantic_segmentation/test_swiftnet.py:57 pins one device)."""
+    import signal
+    import subprocess
+
+    world = args.gpus
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BC_BENCH_WORKER="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or world) // world)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, start_new_session=True))
+    import threading
+
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)   # drain rank 0's pipe
+    reader.start()
+    deadline = time.time() + args.launch_timeout
+    rc = 0
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                raise RuntimeError("replica(s) failed: " + ", ".join(f"rank {r} exit code {c}" for r, c in bad))
+            if all(c == 0 for c in codes):
+                break
+            if time.time() > deadline:
+                raise RuntimeError(f"replicas still running after {args.launch_timeout:.0f} s")
+            time.sleep(0.1)
+    except (RuntimeError, KeyboardInterrupt) as e:
+        print(f"bench.py launcher: {e}; stopping the other replicas", file=sys.stderr)
+        rc = 1
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGTERM)   # the worker's own session: nothing else lives in that group
+                except ProcessLookupError:
+                    pass
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+    reader.join(10)
+    out0 = b"".join(c for c in chunks if c)
+    sys.stdout.write(out0.decode(errors="replace"))
+    sys.stdout.flush()
+    if rc == 0 and not any(line.lstrip().startswith("{") for line in out0.decode(errors="replace").splitlines()):
+        print("bench.py launcher: rank 0 printed no JSON line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
+def stub_cpu_worker(args, rank, world):
+    """Test stand-in for the GPU workload (``--stub-cpu``): same launcher, environment, clock bracket and JSON schema,
+    with a small dense conv on the CPU as a 'frame'."""
     from bc_workloads import replicas
 
-    args = parse_args()
+    torch.set_num_threads(1)
+    if os.environ.get("BC_STUB_FAIL_RANK") == str(rank):
+        sys.exit(3)   # tests: a replica that dies must take the whole job down with a non-zero exit code
+    if world > 1:
+        replicas.init_clock_group()
+    conv = torch.nn.Conv2d(3, 8, 3, padding=1)
+    x = torch.randn(1, 3, 32, 64)
+    with torch.no_grad():
+        for _ in range(args.warmup * CLIP_LEN):
+            conv(x)
+        replicas.barrier(world)
+        t0 = time.perf_counter()
+        for _ in range(args.steps * CLIP_LEN):
+            conv(x)
+        replicas.barrier(world)
+        elapsed = time.perf_counter() - t0
+    fps, elapsed, frames = replicas.job_throughput(args.steps * CLIP_LEN, elapsed, world)
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "STUB (cpu conv, launcher test only)", "frames_total": frames,
+                                     "local_rank": int(os.environ.get("LOCAL_RANK", "-1")),
+                                     "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}"}}), flush=True)
+    if world > 1:
+        replicas.barrier(world)
+        torch.distributed.destroy_process_group()
+
+
+def main(argv=None):
+    global torch
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and env_world == 1:
+        # run directly (the driver's `python bench.py --gpus N`): become the launcher BEFORE anything touches torch / HIP
+        sys.exit(launch_replicas(args, argv))
+    if env_world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the environment says WORLD_SIZE={env_world}")
+
+    import torch as _torch
+    torch = _torch
+    from bc_workloads import replicas
+
     rank, world, local = replicas.dist_env()
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
+    if args.stub_cpu:
+        return stub_cpu_worker(args, rank, world)
     assert torch.cuda.is_available(), "bench.py needs the GPU"
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     if world > 1:
-        torch.distributed.init_process_group("nccl", device_id=device)
+        # replicas only: torch.distributed brackets the clock (barrier + MAX/SUM of two scalars) and nothing else, so the
+        # control group is host-side (gloo) -- no collective is invented on the data path (SURVEY.md section 8(e))
+        replicas.init_clock_group()
 
     import blockcopy.backend as bk
     from blockcopy.core import tensorwrapper as tw
@@ -287,7 +414,7 @@ def main():
         print(json.dumps(out), flush=True)
 
     if world > 1:
-        torch.distributed.barrier()
+        replicas.barrier(world, device)
         torch.distributed.destroy_process_group()
 
 

@@ -32,13 +32,28 @@ class Pending:
     happened yet (the stored data is an unwritten placeholder of the right shape) and will carry the rest of the record
     as its epilogue, e.g. a decoder's ``x = upsample(x); x += skip`` becomes one kernel."""
 
-    __slots__ = ("scale", "shift", "add", "relu", "interp")
+    __slots__ = ("scale", "shift", "add", "relu", "interp", "add_version")
 
-    def __init__(self, scale=None, shift=None, add=None, relu=False, interp=None):
+    def __init__(self, scale=None, shift=None, add=None, relu=False, interp=None, add_version=None):
         self.scale, self.shift, self.add, self.relu, self.interp = scale, shift, add, relu, interp
+        self.add_version = add._version if (add is not None and add_version is None) else add_version
 
     def copy(self):
-        return Pending(self.scale, self.shift, self.add, self.relu, self.interp)
+        return Pending(self.scale, self.shift, self.add, self.relu, self.interp, self.add_version)
+
+    def set_add(self, t):
+        """Record the residual operand by alias, together with its version counter: the sum is formed when the record
+        is consumed, so a real in-place write to the operand in between would silently change it."""
+        self.add = t
+        self.add_version = t._version
+
+    def checked_add(self):
+        """The residual operand, or a loud error if it was modified in place after the add was recorded."""
+        if self.add is not None and self.add._version != self.add_version:
+            raise RuntimeError("blockcopy lazy fusion: a tensor recorded as a residual operand (x + y) was modified in place "
+                               "before the sum was consumed; materialise the sum first (e.g. call .clone() on it) or set "
+                               "BLOCKCOPY_FUSE=0")
+        return self.add
 
     @property
     def affine_only(self):

@@ -356,7 +356,7 @@ class TensorWrapper(torch.Tensor):
         self._pending = None
         with _NoDispatch():
             raw = dense_layout(self.as_subclass(torch.Tensor))
-            add = P.add
+            add = P.checked_add()
             if add is not None:
                 add = dense_layout(add)
             be = get_backend()
@@ -522,6 +522,11 @@ class TensorWrapper(torch.Tensor):
                 if not isinstance(ret, torch.Tensor):
                     return ret   # shape / dtype / device / ... : nothing to wrap
                 self = _find_wrapper(args)
+                if args and isinstance(args[0], TensorWrapper) and args[0]._pending is not None:
+                    # tensor-valued attribute (.data, .T, .mT, .real, ...) of a lazily fused tensor: it must show the VALUE,
+                    # not the stored pre-activation data / the unwritten placeholder of a deferred resampling
+                    args[0]._materialize()
+                    ret = func(*args, **kwargs)
                 return cls._wrap_result(ret, self)
 
             self = _find_wrapper(args)
@@ -600,9 +605,11 @@ class TensorWrapper(torch.Tensor):
             scale, shift = fusion.batchnorm_affine(rm, rv, w, b, eps)
             if x._pending is not None and not x._pending.affine_only:
                 x._materialize()
+            interp = None
             if x._pending is not None:
                 scale, shift = fusion.compose_affine(x._pending.scale, x._pending.shift, scale, shift)
-            return x._sibling(fusion.Pending(scale=scale, shift=shift)), None, True
+                interp = x._pending.interp    # deferred resampling stays the base of the record (its source, not the placeholder)
+            return x._sibling(fusion.Pending(scale=scale, shift=shift, interp=interp)), None, True
         # residual add:  x (+)= y
         y = args[1] if len(args) > 1 else kwargs.get("other", None)
         alpha = kwargs.get("alpha", args[2] if len(args) > 2 else 1)
@@ -615,11 +622,11 @@ class TensorWrapper(torch.Tensor):
             q = y._pending
             if q.scale is None and q.affine_only and q.interp is None:      # (raw_y + shift_y): fold the shift, add the raw tensor
                 P.shift = fusion.add_shifts(P.shift, q.shift)
-                P.add = y._raw()
+                P.set_add(y._raw())
             else:
-                P.add = y._plain()
+                P.set_add(y._plain())
         else:
-            P.add = y._raw() if isinstance(y, TensorWrapper) else y
+            P.set_add(y._raw() if isinstance(y, TensorWrapper) else y)
         return (x if inplace else x._sibling(P)), None, True
 
     @classmethod
@@ -696,7 +703,7 @@ class TensorWrapper(torch.Tensor):
             # end of a residual block: v = relu(raw*s + t + identity) is computed INSIDE the gather, which also emits the
             # plain v that the next shortcut needs -- one launch instead of affine pass + gather
             with timings.env("tensorwrapper/pad_residual", 10):
-                padded, act = get_backend().pad_ring_add(data, dense_layout(residual.add), feats.next_ring(data, padding),
+                padded, act = get_backend().pad_ring_add(data, dense_layout(residual.checked_add()), feats.next_ring(data, padding),
                                                          feats._grid_idx, feats._mapping_exec, padding,
                                                          (residual.scale, residual.shift, residual.relu))
             x._pending = None
@@ -741,10 +748,13 @@ class TensorWrapper(torch.Tensor):
         if feats.engine == "fused":
             # consecutive padded ops on the same tensor (e.g. the three CSP head branches on the 768-channel map)
             # share ONE halo gather and ring cache; the memo holds the source, so its address cannot be recycled
-            pro_key = None if prologue is None else (id(prologue[0]), id(prologue[1]), bool(prologue[2]))
+            # (the memo keeps the prologue tensors themselves and compares identities: an id() alone could be recycled)
+            pro_key = None if prologue is None else (prologue[0], prologue[1], bool(prologue[2]))
             m = feats._pad_memo
+            same_pro = m is not None and ((m[2] is None and pro_key is None) or (
+                m[2] is not None and pro_key is not None and m[2][0] is pro_key[0] and m[2][1] is pro_key[1] and m[2][2] == pro_key[2]))
             if (m is not None and m[0].data_ptr() == data.data_ptr() and m[0].shape == data.shape and m[0].stride() == data.stride()
-                    and m[0]._version == data._version and m[1] == padding and m[2] == pro_key):
+                    and m[0]._version == data._version and m[1] == padding and same_pro):
                 args[0] = m[3]
             else:
                 ring = feats.next_ring(data, padding)
