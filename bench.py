@@ -64,6 +64,8 @@ def parse_args(argv=None):
     ap.add_argument("--stub-cpu", action="store_true",
                     help="(tests only) replace the GPU workload by a tiny CPU stand-in so that the launcher, the per-rank "
                          "environment and the clock bracket can be exercised on a machine without a GPU")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="(tests only) let several replicas share a GPU when fewer than --gpus devices are visible")
     ap.add_argument("--launch-timeout", type=float, default=3000.0, help="seconds before the launcher gives up on its replicas")
     return ap.parse_args(argv)
 
@@ -267,6 +269,11 @@ def main(argv=None):
     if args.stub_cpu:
         return stub_cpu_worker(args, rank, world)
     assert torch.cuda.is_available(), "bench.py needs the GPU"
+    n_dev = torch.cuda.device_count()
+    if local >= n_dev:
+        if not args.oversubscribe:
+            sys.exit(f"bench.py: rank {rank} wants GPU {local} but only {n_dev} device(s) are visible (--oversubscribe shares GPUs; tests only)")
+        local %= n_dev
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     if world > 1:

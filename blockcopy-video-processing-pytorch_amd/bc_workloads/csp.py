@@ -22,7 +22,6 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 import blockcopy
-from blockcopy.backend import get_backend
 from blockcopy.utils.profiler import timings
 
 
@@ -183,6 +182,8 @@ class CSPHead(nn.Module):
         dets = torch.cat([boxes[sel], scores[sel, None]], dim=1).contiguous()
         if dets.shape[0] == 0:
             return dets, torch.zeros(0, dtype=torch.long, device=dev)
+        from blockcopy.backend import get_backend   # (lazy: the model classes above import cleanly without the HIP binding)
+
         dets, _ = get_backend().nms(dets, iou_thr)
         if dets.shape[0] > max_per_img:
             dets = dets[dets[:, 4].sort(descending=True)[1][:max_per_img]]
@@ -193,9 +194,10 @@ class CSPHead(nn.Module):
 class CSP(nn.Module):
     """Dense single-stage detector: backbone -> neck -> head -> decode."""
 
-    def __init__(self):
+    def __init__(self, arch=None):
         super().__init__()
-        self.backbone, self.neck, self.bbox_head = CSPResNet50(), CSPNeck(), CSPHead()
+        # arch = (backbone, neck, head): any detector of this shape (tests drive a miniature one through the same manager)
+        self.backbone, self.neck, self.bbox_head = arch if arch is not None else (CSPResNet50(), CSPNeck(), CSPHead())
 
     def extract_feat(self, img):
         return self.neck(self.backbone(img))
@@ -219,8 +221,8 @@ class CSPBlockCopy(CSP):
     (detectors/csp_blockcopy.py:46-95).  ``results='numpy'`` reproduces its output type (list per class of numpy box
     arrays, what `rl_objectdetection` consumes); ``results='device'`` keeps (det_bboxes, det_labels) on the GPU."""
 
-    def __init__(self, blockcopy_settings: dict, results: str = "numpy"):
-        super().__init__()
+    def __init__(self, blockcopy_settings: dict, results: str = "numpy", arch=None):
+        super().__init__(arch)
         self.is_blockcopy_manager = True
         self.policy = blockcopy.build_policy_from_settings(blockcopy_settings)
         self.train_interval = blockcopy_settings["block_train_interval"]
@@ -244,7 +246,13 @@ class CSPBlockCopy(CSP):
         return self.bbox_head(self.extract_feat(blocks))
 
     @torch.no_grad()
-    def simple_test(self, img, img_meta=None, rescale=False):
+    def forward_maps(self, img):
+        """The per-frame state machine up to the dense head maps (cls, reg, offset) -- what the reference's head returns
+        before ``get_bboxes`` (detectors/csp_blockcopy.py:46-77); the maps become ``policy_meta['outputs']``."""
+        return self.simple_test(img, decode=False)
+
+    @torch.no_grad()
+    def simple_test(self, img, img_meta=None, rescale=False, decode=True):
         self.clip_length += 1
         self.policy_meta["inputs"] = img
         self.policy_meta["train_hint"] = self.clip_length % self.train_interval == 0
@@ -264,14 +272,17 @@ class CSPBlockCopy(CSP):
                     self.policy_meta["frame_state"] = x.combine_().to_tensor()
                     maps = self._maps_from_blocks(x)
                 self.head_out = maps
-                dets, labels = self.bbox_head.get_bboxes(*maps, img_shape=img.shape[-2:])
-                out = [bbox2result(dets, labels)] if self.results == "numpy" else (dets, labels)
+                if decode:
+                    dets, labels = self.bbox_head.get_bboxes(*maps, img_shape=img.shape[-2:])
+                    out = [bbox2result(dets, labels)] if self.results == "numpy" else (dets, labels)
+                else:
+                    out = maps
             self.policy_meta["outputs_prev"] = self.policy_meta["outputs"]
             self.policy_meta["outputs"] = out
         with timings.env("blockcopy/policy_optim", 3):
             train_policy = self.clip_length % self.train_interval == 0
             self.policy_meta = self.policy.optim(self.policy_meta, train=train_policy)
-        return out[0] if self.results == "numpy" else out
+        return out[0] if (decode and self.results == "numpy") else out
 
     def _graphed_maps(self, img):
         from blockcopy.core.graphs import GraphedFrame

@@ -288,9 +288,70 @@ def gen_rl(ref):
     print("rl_semseg_run.npz exec per frame:", [int(out[f"grid{t}"].sum()) for t in range(4)], "running_cost", float(out["running_cost3"]))
 
 
+# ----------------------------------------------------------------------------- F. detector op classes (Pedestron CSP path)
+def _detector_fixture(ref, name, modules, cfg, grids, extra=None):
+    """Drive (backbone, neck, head) through the REFERENCE TensorWrapper with forced grids; store head maps + frame_state."""
+    import warnings
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import tinycsp
+
+    for m in modules:
+        m.eval()
+    frames = [seeded.synthetic_frame(cfg["frame_seed0"] + t, (cfg["N"], 3, cfg["H"], cfg["W"])) for t in range(cfg["n_frames"])]
+    ref_loader.CALL_LOG = []
+    with warnings.catch_warnings(), quiet():
+        warnings.simplefilter("ignore")
+        res = tinycsp.run_detector_clip(modules, frames, grids)
+    log, ref_loader.CALL_LOG = ref_loader.CALL_LOG, None
+    names = [n for n, _ in log]
+    out = {"cfg": np.frombuffer(json.dumps(dict(cfg, **(extra or {}))).encode(), dtype=np.uint8),
+           "kernel_calls": np.frombuffer(json.dumps({n: names.count(n) for n in sorted(set(names))}).encode(), dtype=np.uint8)}
+    for t, (maps, fs) in enumerate(res):
+        out[f"grid{t}"] = grids[t].numpy()
+        for k, m in zip(("cls", "reg", "offset"), maps):
+            out[f"{k}{t}"] = m.numpy().copy()
+        if t < 2:
+            out[f"frame_state{t}"] = fs.numpy().copy()
+    np.savez_compressed(os.path.join(GOLD, name), **out)
+    print(name, {n: names.count(n) for n in sorted(set(names))}, "cls range", float(res[0][0][0].min()), float(res[0][0][0].max()))
+
+
+def gen_tinycsp(ref):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import tinycsp
+
+    modules = tinycsp.seed_weights(tinycsp.tinycsp_arch())
+    _detector_fixture(ref, "tinycsp.npz", modules, tinycsp.CFG, tinycsp.tinycsp_grids())
+
+
+def gen_csp_r50(ref):
+    """The repo's own restatement of the CSP-ResNet50 detector (bc_workloads/csp.py: backbone / neck / head modules,
+    pure torch) driven through the REFERENCE TensorWrapper at 128x256, block 32: pins the C5 op sequence (dilated stage,
+    transposed-conv neck, GroupNorm head, three to_tensor branches) against the reference's routing."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import tinycsp
+    from bc_workloads import csp   # imports `blockcopy` = the reference here (only its public names are used by the modules)
+
+    assert csp.blockcopy.__file__.startswith(ref_loader.REF_ROOT)
+    det = csp.CSP()
+    core = {k: v for k, v in det.state_dict().items()}
+    det.load_state_dict(seeded.name_seeded_state_dict(core), strict=True)
+    cfg = dict(N=1, H=128, W=256, block_size=32, n_frames=4, frame_seed0=52000, grid_seed=83)
+    _detector_fixture(ref, "csp_r50.npz", (det.backbone, det.neck, det.bbox_head), cfg, tinycsp.tinycsp_grids(cfg),
+                      extra=dict(weights="name-seeded over CSP().state_dict() keys, BN not folded (Pedestron does not fold)"))
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     ref = ref_loader.load_reference()
+    only = set(sys.argv[1:])
+    if only:   # regenerate selected fixtures only:  python oracle/gen_golden.py tinycsp csp_r50
+        for name in only:
+            globals()[f"gen_{name}"](ref)
+        return
+    gen_tinycsp(ref)
+    gen_csp_r50(ref)
     gen_keys(ref)
     gen_rl(ref)
     gen_index_tables(ref)

@@ -67,3 +67,40 @@ def run_golden_clip(G, cfg, device, engine, graph=0, repeats=1):
                 if f"frame_state{t}" in G.files:
                     fs_errs.append(float((model.policy_meta["frame_state"].cpu() - torch.from_numpy(G[f"frame_state{t}"])).abs().max()))
     return errs, fs_errs
+
+
+def run_golden_detector_clip(G, cfg, modules, device, engine, graph=0, channels_last=False, fold_bn=False, repeats=1):
+    """Replays a golden detector clip (tests/golden/tinycsp.npz, csp_r50.npz: head maps the REFERENCE TensorWrapper
+    produced for the same modules) through this repo's CSPBlockCopy manager; returns per-frame max abs errors of the
+    three head maps relative to max(1, |golden|max), and of frame_state (absolute)."""
+    from blockcopy.core import tensorwrapper as tw
+    from blockcopy.core.argparser import default_settings
+    from bc_workloads import seeded
+    from bc_workloads.bn_fold import fold_batchnorm
+    from bc_workloads.csp import CSPBlockCopy
+
+    tw.set_engine(engine)
+    grids = [torch.from_numpy(G[f"grid{t}"]) for t in range(cfg["n_frames"])]
+    det = CSPBlockCopy(default_settings(block_policy="all", block_size=cfg["block_size"], block_graph=graph), results="device", arch=modules)
+    det.policy = make_forced_policy(cfg["block_size"], grids * repeats)
+    det.eval()
+    det = det.to(device)
+    if fold_bn:
+        det = fold_batchnorm(det)
+    if channels_last:
+        det = det.to(memory_format=torch.channels_last)
+    errs, fs_errs = [], []
+    for rep in range(repeats):
+        det.reset_temporal()
+        for t in range(cfg["n_frames"]):
+            x = seeded.synthetic_frame(cfg["frame_seed0"] + t, (cfg["N"], 3, cfg["H"], cfg["W"])).to(device)
+            maps = det.forward_maps(x)
+            e = 0.0
+            for k, m in zip(("cls", "reg", "offset"), maps):
+                want = torch.from_numpy(G[f"{k}{t}"])
+                assert tuple(m.shape) == tuple(want.shape), (k, t, m.shape, want.shape)
+                e = max(e, float((m.float().cpu() - want).abs().max()) / max(1.0, float(want.abs().max())))
+            errs.append(e)
+            if f"frame_state{t}" in G.files:
+                fs_errs.append(float((det.policy_meta["frame_state"].cpu() - torch.from_numpy(G[f"frame_state{t}"])).abs().max()))
+    return errs, fs_errs

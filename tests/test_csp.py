@@ -130,3 +130,48 @@ def test_rl_objectdetection_policy_drives_the_detector(oracle_backend):
     assert execs[0] == 32 and all(e % 2 == 0 for e in execs)
     assert "information_gain" in blk.policy_meta and blk.policy_meta["information_gain"].shape == (1, 1, 128, 256)
     assert not torch.equal(w0, blk.policy.net.backbone.conv1.weight)      # the policy trained online
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Reference-generated fixtures for the detector op classes: group_norm batched trick, per-tile
+# conv_transpose2d, dilation-2 halo, blockcopy.to_tensor inside the head.  tests/golden/{tinycsp,csp_r50}.npz were
+# produced by the REFERENCE TensorWrapper (oracle/gen_golden.py gen_tinycsp / gen_csp_r50) for the same torch modules.
+@pytest.mark.parametrize("graph", [0, 1])
+@pytest.mark.parametrize("engine", ["fused", "reference"])
+def test_tinycsp_matches_reference(golden_dir, oracle_backend, engine, graph):
+    import tinycsp
+    from blockcopy.core import tensorwrapper as tw
+    from common import load_golden, run_golden_detector_clip
+
+    if engine == "reference" and graph:
+        pytest.skip("graph replay exists for the fused engine only")
+    G, cfg = load_golden(golden_dir, "tinycsp.npz")
+    try:
+        errs, fs = run_golden_detector_clip(G, cfg, tinycsp.seed_weights(tinycsp.tinycsp_arch()), "cpu", engine, graph)
+    finally:
+        tw.set_engine("fused")
+    assert max(errs) <= 2e-5, errs
+    assert fs and all(e == 0.0 for e in fs)
+
+
+@pytest.mark.parametrize("engine,cl", [("fused", False), ("fused", True), ("reference", False)])
+def test_csp_r50_matches_reference(golden_dir, oracle_backend, engine, cl):
+    """This repo's CSP-ResNet50 restatement (bc_workloads/csp.py) through this repo's engine vs the SAME modules through
+    the reference's TensorWrapper (128x256, block 32, masks all / half / one / all-but-one)."""
+    import json
+    from bc_workloads import seeded
+    from bc_workloads.csp import CSP
+    from blockcopy.core import tensorwrapper as tw
+    from common import load_golden, run_golden_detector_clip
+
+    G, cfg = load_golden(golden_dir, "csp_r50.npz")
+    det = CSP()
+    det.load_state_dict(seeded.name_seeded_state_dict(dict(det.state_dict())), strict=True)
+    try:
+        errs, fs = run_golden_detector_clip(G, cfg, (det.backbone, det.neck, det.bbox_head), "cpu", engine, 0, channels_last=cl)
+    finally:
+        tw.set_engine("fused")
+    assert max(errs) <= 5e-5, errs
+    assert fs and all(e == 0.0 for e in fs)
+    calls = json.loads(bytes(G["kernel_calls"]).decode())
+    assert calls["pad"] == 21 * cfg["n_frames"]     # 16 bottleneck 3x3 + stem conv + stem pool + 3 head convs, per frame

@@ -374,3 +374,42 @@ def test_fusion_switch_off_gives_the_same_logits(golden_dir, oracle_backend):
     finally:
         fusion.set_enabled(prev)
     assert max(errs) <= 2e-5, errs
+
+
+def test_c1_cpu_plumbing_4x512x1024_block128_all_active(oracle_backend):
+    """BASELINE config C1 at its stated shape: SwiftNet-RN18 on 4 synthetic 512x1024 frames, block 128 (4x8 tiles),
+    policy forced 100 %-active, no GPU (the block ops are served by the checker backend).  Both engines agree, every
+    tile is executed on every frame, the packed encoder equals the dense one (P1) and frame_state is the input."""
+    import blockcopy
+    from blockcopy.core import tensorwrapper as tw
+    from bc_workloads import harness, seeded
+
+    frames = [seeded.synthetic_frame(t, (1, 3, 512, 1024)) for t in range(4)]   # torch.randn, seeds 0..3
+    outs = {}
+    try:
+        for engine in ("fused", "reference"):
+            tw.set_engine(engine)
+            model = harness.build_model("resnet18", block_policy="all", block_size=128, device="cpu")
+            model.reset_temporal()
+            with torch.no_grad():
+                ys = []
+                for f in frames if engine == "fused" else frames[:2]:
+                    ys.append(model(f).clone())
+                    assert model.policy_meta["num_exec"] == 32 and model.policy_meta["num_total"] == 32
+                    assert torch.equal(model.policy_meta["frame_state"], f)
+            outs[engine] = ys
+            assert ys[0].shape == (1, 19, 128, 256) and all(torch.isfinite(y).all() for y in ys)
+    finally:
+        tw.set_engine("fused")
+    for a, b in zip(outs["fused"], outs["reference"]):
+        assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
+    dense = harness.build_model("resnet18", block_policy="static", device="cpu")
+    model = harness.build_model("resnet18", block_policy="all", block_size=128, device="cpu")
+    with torch.no_grad():
+        want = dense.forward_down(frames[0])
+        xw = blockcopy.to_tensorwrapper(frames[0])
+        xw.process_temporal_features(None)
+        grid = torch.ones(1, 1, 4, 8, dtype=torch.bool)
+        got = model.base_model.forward_down(xw.to_blocks(grid, grid))
+        for w, g in zip(want, got):
+            assert float((g.combine().to_tensor() - w).abs().max()) <= 1e-4 * max(1.0, float(w.abs().max()))
