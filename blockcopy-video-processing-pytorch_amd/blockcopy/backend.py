@@ -82,6 +82,9 @@ def load_library(path: str = None) -> ctypes.CDLL:
         "bc_interp_bilinear_act_nhwc": [p, p, ctypes.c_longlong, i, i, i, i, i, i, ctypes.c_float, ctypes.c_float, i, p, p, p, i, p],
         "bc_affine_act": [p, p, p, p, p, i, ctypes.c_longlong, i, ctypes.c_longlong, i, p],
         "bc_nms_sorted": [p, i, ctypes.c_float, p, p, p, p],
+        "bc_tune_set": [ctypes.c_char_p, i],
+        "bc_tune_get": [ctypes.c_char_p, ctypes.POINTER(i)],
+        "bc_tune_set_ptr": [ctypes.c_char_p, p],
         "bc_abi_version": [],
         "bc_prof_enable": [u],
         "bc_prof_reset": [],
@@ -461,6 +464,18 @@ class HipBackend:
         return dets[inds, :], inds
 
     # -- C. measurement -----------------------------------------------------------------------------------
+    def tune(self, key: str, value: int):
+        """A/B knob of the library (include/blockcopy_hip.h bc_tune_set): conv_impl, conv2_cfg, conv2_min_lds."""
+        self._check(self.lib.bc_tune_set(key.encode(), int(value)), "tune_set")
+
+    def tune_ptr(self, key: str, tensor):
+        self._check(self.lib.bc_tune_set_ptr(key.encode(), tensor.data_ptr() if tensor is not None else None), "tune_set_ptr")
+
+    def tune_get(self, key: str) -> int:
+        v = ctypes.c_int(0)
+        self._check(self.lib.bc_tune_get(key.encode(), ctypes.byref(v)), "tune_get")
+        return v.value
+
     def prof_enable(self, ops=()):
         mask = 0
         for op in ops:

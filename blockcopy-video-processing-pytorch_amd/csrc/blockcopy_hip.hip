@@ -1624,6 +1624,7 @@ int check_halo(const void *out, const void *features, const int32_t *grid_idx, c
 }
 
 #include "conv3x3_mfma.inc"
+#include "conv3x3_v2.inc"
 
 }  // namespace
 
@@ -1898,6 +1899,148 @@ BC_EXPORT int bc_pad_ring_nhwc(void *out, const void *features, void *ring, cons
     return launch_status();
 }
 
+// ---- tuning knobs (bc_tune_set; defaults may also come from the environment, read once)
+struct TuneState {
+    int conv_impl = [] { const char *e = getenv("BC_CONV_IMPL"); return e ? atoi(e) : 2; }();              // 1 = first-generation conv kernel
+    int conv2_cfg = [] { const char *e = getenv("BC_CONV2_CFG"); return e ? atoi(e) : -1; }();             // >= 0: force a decomposition
+    unsigned long long *conv_stamps = nullptr;   // device buffer for in-kernel s_memtime stamps (bc_tune_set_ptr), measurement only
+    int conv_last_cfg = -2;   // decomposition of the most recent bc_conv3x3_ring_nhwc launch (-1: first-generation kernel)
+    int conv2_min_lds = [] { const char *e = getenv("BC_CONV2_MINLDS"); return e ? atoi(e) : 84 * 1024; }();   // bytes; > 80 KB = one workgroup per CU
+} g_tune;
+
+// ---- host side of conv3x3_v2.inc: choose the decomposition whose workgroup count best fills whole rounds of one
+// 8-wave workgroup per CU with equal MFMA counts per wave, then launch it.
+struct Conv2Cfg { int RM, RN, WMW, WNW, WKW; };
+
+static int device_cu_count()
+{
+    static const int n = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        return cus;
+    }();
+    return n;
+}
+
+template <int RM, int RN, int WMW, int WNW, int WKW, int PW>
+static void launch_conv3x3_v2_cfg(ProfScope &ps, dim3 grid, size_t lds_bytes, hipStream_t st, void *out, const void *features, void *ring,
+                                  const void *wpk, const int32_t *grid_idx, const int32_t *mapping_exec, const ConvGeom2 &g,
+                                  const Prologue &pr, const Epilogue &ep)
+{
+    static bool attr_set = false;   // > 64 KB of dynamic LDS needs the opt-in once per kernel
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_v2<RM, RN, WMW, WNW, WKW, PW>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+        attr_set = true;
+    }
+    BC_LAUNCH(ps, (k_conv3x3_v2<RM, RN, WMW, WNW, WKW, PW>), grid, dim3(512), lds_bytes, st, (float *)out, (const float *)features,
+              (long long)((const float *)ring - (const float *)features), (float *)ring, (const float4 *)wpk, grid_idx, mapping_exec,
+              g, pr, ep, g_tune.conv_stamps);
+}
+
+static int launch_conv3x3_v2(ProfScope &ps, void *out, const void *features, void *ring, const void *wpk, const int32_t *grid_idx,
+                             const int32_t *mapping_exec, int n_exec, int Cin, int Cout, int GH, int GW, int bs,
+                             const Prologue &pr, const Epilogue &ep, hipStream_t st)
+{
+    static const Conv2Cfg cfgs[] = {{2, 2, 4, 2, 1}, {2, 1, 4, 2, 1}, {1, 2, 4, 2, 1}, {1, 1, 4, 2, 1},     // 0-3: many pixels
+                                    {1, 1, 2, 4, 1}, {1, 1, 2, 2, 2}, {1, 1, 1, 4, 2}, {1, 1, 1, 2, 4},     // 4-7: 1x1 wave tiles
+                                    {2, 2, 2, 2, 2}, {2, 2, 1, 2, 4}, {2, 1, 2, 2, 2}, {2, 1, 1, 4, 2},     // 8-11: 2-block tiles + K groups
+                                    {2, 1, 1, 2, 4}, {2, 1, 1, 1, 8}, {1, 2, 1, 1, 8}, {1, 1, 1, 1, 8}};    // 12-15
+    const int force = g_tune.conv2_cfg, min_lds = g_tune.conv2_min_lds;
+    const int pw = bs == 4 ? 4 : 8;
+    if (pw == 8 && bs % 8 != 0) return BC_ERR_SHAPE;
+    const int cus = device_cu_count();
+    int best = -1;
+    double best_t = 0;
+    for (int c = 0; c < (int)(sizeof(cfgs) / sizeof(cfgs[0])); ++c) {
+        const Conv2Cfg &k = cfgs[c];
+        if (force >= 0 && c != force) continue;
+        if (pw == 4 && k.RM != 1 && k.WMW != 1) continue;      // 4x4 tiles: 4 tile slots per wave row only in single-row workgroups (LDS)
+        if (pw == 8 && bs % (4 * k.RM) != 0) continue;
+        if (Cout % (32 * k.RN * k.WNW) != 0) continue;
+        if (k.WKW == 8 && Cin % 64 != 0) continue;
+        const long long rows = pw == 8 ? (long long)n_exec * (bs / 8) * (bs / (4 * k.RM)) : ((long long)n_exec + 2 * k.RM - 1) / (2 * k.RM);
+        const long long wgs = ((rows + k.WMW - 1) / k.WMW) * (Cout / (32 * k.RN * k.WNW));
+        const long long rounds = (wgs + cus - 1) / cus;
+        const double mf = (double)k.RM * k.RN * 9.0 * (Cin / 8) * 4.0 / k.WKW;        // MFMAs per wave
+        // per-MFMA slowdown from operand delivery (tools/probes/mfma_probe2: 1x1 tiles ~0.72, 2x1 ~0.79, 2x2 ~0.82 of peak)
+        const double eff = k.RM * k.RN >= 4 ? 0.82 : (k.RM * k.RN == 2 ? (k.RM == 2 ? 0.79 : 0.74) : 0.70);
+        const double t = rounds * (mf / eff + 70.0 + 12.0 * (k.WKW - 1) * k.RM * k.RN);
+        if (best < 0 || t < best_t) { best = c; best_t = t; }
+    }
+    if (best < 0) return BC_ERR_SHAPE;
+    g_tune.conv_last_cfg = best;
+    const Conv2Cfg &k = cfgs[best];
+    ConvGeom2 g;
+    g.Cin = Cin; g.Cout = Cout; g.bs = bs; g.GH = GH; g.GW = GW; g.n_exec = n_exec;
+    g.patches_x = pw == 8 ? bs / 8 : 1;
+    g.patches_per_tile = pw == 8 ? (bs / 8) * (bs / (4 * k.RM)) : 1;
+    g.n_rows = pw == 8 ? (uint32_t)n_exec * g.patches_per_tile : ((uint32_t)n_exec + 2 * k.RM - 1) / (2 * k.RM);
+    g.cin_chunks = Cin / CV_CH;
+    const uint32_t slot_px = pw == 8 ? 10u * (4 * k.RM + 2) : 36u, tpr = pw == 8 ? 1u : 2u * k.RM;
+    const uint32_t chp = CV_CH * (k.WKW > 4 ? k.WKW / 4 : 1) + 4;
+    const size_t img = (size_t)k.WMW * tpr * slot_px * chp * sizeof(float);
+    const size_t red = (size_t)k.WMW * k.WNW * (k.WKW - 1) * k.RM * k.RN * 16 * 64 * sizeof(float);
+    size_t lds_bytes = 2 * img > red ? 2 * img : red;
+    if (lds_bytes < (size_t)min_lds) lds_bytes = min_lds;      // one workgroup per CU: two waves on every SIMD, no more
+    const dim3 grid((g.n_rows + k.WMW - 1) / k.WMW, (unsigned)Cout / (32 * k.RN * k.WNW));
+#define BC_CV2(RM_, RN_, WMW_, WNW_, WKW_)                                                                                   \
+    do {                                                                                                                 \
+        if (pw == 8) launch_conv3x3_v2_cfg<RM_, RN_, WMW_, WNW_, WKW_, 8>(ps, grid, lds_bytes, st, out, features, ring, wpk, grid_idx, mapping_exec, g, pr, ep); \
+        else launch_conv3x3_v2_cfg<(WMW_ == 1 ? RM_ : 1), RN_, WMW_, WNW_, WKW_, 4>(ps, grid, lds_bytes, st, out, features, ring, wpk, grid_idx, mapping_exec, g, pr, ep); \
+    } while (0)
+    switch (best) {
+    case 0: BC_CV2(2, 2, 4, 2, 1); break;
+    case 1: BC_CV2(2, 1, 4, 2, 1); break;
+    case 2: BC_CV2(1, 2, 4, 2, 1); break;
+    case 3: BC_CV2(1, 1, 4, 2, 1); break;
+    case 4: BC_CV2(1, 1, 2, 4, 1); break;
+    case 5: BC_CV2(1, 1, 2, 2, 2); break;
+    case 6: BC_CV2(1, 1, 1, 4, 2); break;
+    case 7: BC_CV2(1, 1, 1, 2, 4); break;
+    case 8: BC_CV2(2, 2, 2, 2, 2); break;
+    case 9: BC_CV2(2, 2, 1, 2, 4); break;
+    case 10: BC_CV2(2, 1, 2, 2, 2); break;
+    case 11: BC_CV2(2, 1, 1, 4, 2); break;
+    case 12: BC_CV2(2, 1, 1, 2, 4); break;
+    case 13: BC_CV2(2, 1, 1, 1, 8); break;
+    case 14: BC_CV2(1, 2, 1, 1, 8); break;
+    default: BC_CV2(1, 1, 1, 1, 8); break;
+    }
+#undef BC_CV2
+    return launch_status();
+}
+
+BC_EXPORT int bc_tune_set(const char *key, int value)
+{
+    if (!key) return BC_ERR_NULL;
+    if (!strcmp(key, "conv_impl")) g_tune.conv_impl = value;
+    else if (!strcmp(key, "conv2_cfg")) g_tune.conv2_cfg = value;
+    else if (!strcmp(key, "conv2_min_lds")) g_tune.conv2_min_lds = value;
+    else return BC_ERR_SHAPE;
+    return BC_OK;
+}
+
+BC_EXPORT int bc_tune_set_ptr(const char *key, void *ptr)
+{
+    if (!key) return BC_ERR_NULL;
+    if (!strcmp(key, "conv_stamps")) g_tune.conv_stamps = (unsigned long long *)ptr;
+    else return BC_ERR_SHAPE;
+    return BC_OK;
+}
+
+BC_EXPORT int bc_tune_get(const char *key, int *value)
+{
+    if (!key || !value) return BC_ERR_NULL;
+    if (!strcmp(key, "conv_impl")) *value = g_tune.conv_impl;
+    else if (!strcmp(key, "conv2_cfg")) *value = g_tune.conv2_cfg;
+    else if (!strcmp(key, "conv2_min_lds")) *value = g_tune.conv2_min_lds;
+    else if (!strcmp(key, "conv_last_cfg")) *value = g_tune.conv_last_cfg;
+    else return BC_ERR_SHAPE;
+    return BC_OK;
+}
+
 BC_EXPORT int bc_conv3x3_ring_nhwc(void *out, const void *features, void *ring, const void *weights_packed,
                                    const int32_t *grid_idx, const int32_t *mapping_exec, int n_exec, int N, int Cin, int Cout,
                                    int GH, int GW, int bs, int dtype, const float *in_scale, const float *in_shift, int in_relu,
@@ -1913,6 +2056,16 @@ BC_EXPORT int bc_conv3x3_ring_nhwc(void *out, const void *features, void *ring, 
         (uint64_t)N * GH * GW * 4 * bs * Cin >= (1ull << 31)) return BC_ERR_RANGE;
     if (!aligned(out, 16) || !aligned(features, 16) || !aligned(ring, 16) || !aligned(weights_packed, 16) || !aligned(out_add, 4))
         return BC_ERR_ALIGN;
+    Prologue pr{in_scale, in_shift, in_relu};
+    Epilogue ep{out_scale, out_shift, (const float *)out_add, out_relu};
+    ProfScope ps(BC_OP_CONV3X3, 2.0 * n_exec * bs * bs * 9.0 * Cin * Cout);   // FLOPs, not bytes: the op is MFMA-bound
+    // BC_CONV_IMPL=1 selects the first-generation kernel (A/B runs); default: the CU-balanced kernel (conv3x3_v2.inc)
+    if (g_tune.conv_impl != 1) {
+        const int rc = launch_conv3x3_v2(ps, out, features, ring, weights_packed, grid_idx, mapping_exec, n_exec, Cin, Cout, GH, GW, bs,
+                                         pr, ep, (hipStream_t)stream);
+        if (rc != BC_ERR_SHAPE) return rc;   // shapes the balanced kernel does not cover fall through
+    }
+    g_tune.conv_last_cfg = -1;
     // workgroup = 32*WM pixels x 64 output channels.  64-pixel items halve the weight traffic and the halo overhead; 32-pixel
     // items balance better over the 256 CUs when there are few of them (measured, profiles/r01/kbench_conv_*.txt).
     // BC_CONV_WM=1|2 overrides for A/B runs.
@@ -1932,9 +2085,6 @@ BC_EXPORT int bc_conv3x3_ring_nhwc(void *out, const void *features, void *ring, 
     const unsigned gx = g.pw == 8 ? (unsigned)n_exec * g.patches_per_tile : ((unsigned)n_exec + g.tiles_per_wg - 1) / g.tiles_per_wg;
     const dim3 grid(gx, (unsigned)Cout / 64);
     const size_t lds_bytes = 2 * (size_t)g.tiles_per_wg * g.PP * CV_CHP * sizeof(float);   // two images (double buffer)
-    Prologue pr{in_scale, in_shift, in_relu};
-    Epilogue ep{out_scale, out_shift, (const float *)out_add, out_relu};
-    ProfScope ps(BC_OP_CONV3X3, 2.0 * n_exec * bs * bs * 9.0 * Cin * Cout);   // FLOPs, not bytes: the op is MFMA-bound
 #define BC_CV(PW_, WMT_)                                                                                                \
     BC_LAUNCH(ps, (k_conv3x3_f32<PW_, WMT_>), grid, dim3(128 * WMT_), lds_bytes, (hipStream_t)stream, (float *)out,     \
               (const float *)features, (long long)((const float *)ring - (const float *)features), (float *)ring,     \

@@ -195,6 +195,18 @@ int bc_maxpool3x3s2_ring_nhwc(void *out, const void *features, void *ring, const
 int bc_nms_sorted(const float *boxes, int n, float iou_thr, unsigned long long *mask_ws, int32_t *keep,
                   int32_t *count, void *stream);
 
+/* tuning / A-B knob (measurement infrastructure; defaults are the shipped behaviour): key in
+ *   "conv_impl"      1 = first-generation fused conv kernel, 2 = CU-balanced kernel (default)
+ *   "conv2_cfg"      -1 = choose the decomposition per launch (default), 0..15 = force one (BC_ERR_SHAPE at launch if it does not fit)
+ *   "conv2_min_lds"  dynamic LDS floor in bytes (default 84 KiB: one 8-wave workgroup per CU)
+ * Not part of the reference's boundary. */
+int bc_tune_set(const char *key, int value);
+/* "conv_stamps": device buffer (8 x uint64 per workgroup) that receives in-kernel s_memtime stamps of the balanced conv kernel
+ * (prologue / first stage / main loop / reduction / store); NULL (default) disables them.  Measurement only. */
+int bc_tune_set_ptr(const char *key, void *ptr);
+/* read a knob back; "conv_last_cfg" = decomposition index the most recent bc_conv3x3_ring_nhwc launch used (-1 = first-generation kernel) */
+int bc_tune_get(const char *key, int *value);
+
 /* ---------------------------------------------------------------------------------------------
  * C. Introspection / measurement
  * ------------------------------------------------------------------------------------------- */

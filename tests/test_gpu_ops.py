@@ -487,6 +487,75 @@ def test_fused_conv3x3_matches_halo_plus_conv(be, case):
         assert torch.equal(ring_a, ring_b), (case, t)
 
 
+@pytest.mark.parametrize("cfg", list(range(16)))
+def test_fused_conv3x3_every_decomposition(be, cfg):
+    """The CU-balanced conv kernel (csrc/conv3x3_v2.inc) picks one of 16 decompositions per launch (register blocking
+    RM x RN, wave grid, in-workgroup split-K); here each one is FORCED in turn on shapes it covers -- incl. ragged wave
+    rows, 4x4 tiles, prologue, epilogue with residual, ring cache from a previous frame -- against halo gather + fp64 conv
+    (2e-5 relative: fp32 summation order), with the ring cache left bit-identical."""
+    import torch.nn.functional as F
+
+    rng = np.random.default_rng(500 + cfg)
+    gen = torch.Generator().manual_seed(500 + cfg)
+    be.tune("conv2_cfg", cfg)
+    try:
+        for case, (Cin, Cout, bs, N, GH, GW) in enumerate([(64, 128, 8, 1, 3, 5), (32, 128, 16, 2, 2, 3), (96, 256, 4, 1, 4, 7),
+                                                            (64, 128, 32, 1, 2, 2), (128, 128, 4, 1, 5, 5), (160, 128, 24, 1, 2, 3)]):
+            if (cfg in (0, 1, 8, 10) and bs == 4) or (cfg >= 13 and Cin % 64):
+                continue      # multi-row RM = 2 decompositions need 8-row patches; 8 K groups stage 64 channels at a time
+            T = N * GH * GW
+            w = (torch.randn((Cout, Cin, 3, 3), generator=gen) * (2.0 / (9 * Cin)) ** 0.5).cuda()
+            wpk = be.pack_conv3x3_weights(w)
+            ring_a, ring_b = torch.zeros((T, Cin, 4 * bs)).cuda(), torch.zeros((T, Cin, 4 * bs)).cuda()
+            for t in range(3):
+                g = np.ones(T, bool) if t == 0 else rng.random(T) < (0.3, 0.5, 0.8)[t]
+                if not g.any():
+                    g[int(rng.integers(T))] = True
+                gi, m = O.c_grid_mappings(g.reshape(N, 1, GH, GW))
+                gi_d, m_d = _dev(gi), _dev(m)
+                feats = _cl(torch.randn((len(m), Cin, bs, bs), generator=gen).cuda())
+                pro = None if t == 0 else ((torch.rand(Cin, generator=gen) + 0.5).cuda(), (torch.randn(Cin, generator=gen) * 0.1).cuda(), t == 2)
+                add = _cl(torch.randn((len(m), Cout, bs, bs), generator=gen).cuda()) if t == 1 else None
+                epi = None if t == 0 else ((torch.rand(Cout, generator=gen) + 0.5).cuda(), (torch.randn(Cout, generator=gen) * 0.1).cuda(), add, t == 1)
+                want = F.conv2d(be.pad_ring(feats, ring_a, gi_d, m_d, 1, pro).double(), w.double())
+                if epi is not None:
+                    want = want * epi[0].view(1, -1, 1, 1) + epi[1].view(1, -1, 1, 1)
+                    if epi[2] is not None:
+                        want = want + epi[2]
+                    if epi[3]:
+                        want = torch.relu(want)
+                got = be.conv3x3_ring(feats, ring_b, wpk, Cout, gi_d, m_d, pro, epi)
+                assert be.tune_get("conv_last_cfg") == cfg, "the forced decomposition did not run"
+                err = (got.double() - want).abs().max().item()
+                assert err <= 2e-5 * max(1.0, want.abs().max().item()), (cfg, case, t, err)
+                assert torch.equal(ring_a, ring_b), (cfg, case, t)
+    finally:
+        be.tune("conv2_cfg", -1)
+
+
+def test_fused_conv3x3_generations_agree(be):
+    """First-generation kernel (conv_impl = 1) and the CU-balanced one on the same launch: same ring state, outputs equal
+    to summation order."""
+    gen = torch.Generator().manual_seed(7)
+    Cin, Cout, bs, N, GH, GW = 64, 64, 16, 1, 3, 4
+    w = (torch.randn((Cout, Cin, 3, 3), generator=gen) * 0.05).cuda()
+    wpk = be.pack_conv3x3_weights(w)
+    g = np.ones(N * GH * GW, bool)
+    g[[1, 6]] = False
+    gi, m = O.c_grid_mappings(g.reshape(N, 1, GH, GW))
+    feats = _cl(torch.randn((len(m), Cin, bs, bs), generator=gen).cuda())
+    ring0 = torch.randn((N * GH * GW, Cin, 4 * bs), generator=gen).cuda()
+    outs, rings = [], []
+    for impl in (1, 2):
+        be.tune("conv_impl", impl)
+        ring = ring0.clone()
+        outs.append(be.conv3x3_ring(feats, ring, wpk, Cout, _dev(gi), _dev(m), None, None))
+        rings.append(ring)
+    be.tune("conv_impl", 2)
+    assert torch.equal(rings[0], rings[1])
+    assert (outs[0] - outs[1]).abs().max().item() <= 2e-5 * max(1.0, outs[0].abs().max().item())
+
+
 def test_fused_conv3x3_random_geometries(be):
     """20 random (Cin, Cout, tile size, grid, batch) cases x 3 frames with random masks, prologue and epilogue: the fused
     kernel against halo gather + an fp64 conv of the padded batch; ring caches must stay bit-identical."""

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Where does a launch of the balanced fused conv (csrc/conv3x3_v2.inc) spend its cycles?  In-kernel s_memtime stamps of
+wave 0 of every workgroup: [start, tables done, first stage done, main loop done, reduction done, stores done].
+usage: python tools/conv_stamps.py [--n 64] [--cfg -1]"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "blockcopy-video-processing-pytorch_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import torch  # noqa: E402
+
+import blockcopy.backend as bk  # noqa: E402
+from kbench import grid_tables  # noqa: E402
+
+CASES = [("layer1", 64, 64, 32), ("layer2", 128, 128, 16), ("layer3", 256, 256, 8), ("layer4", 512, 512, 4), ("up1/4", 128, 128, 32)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=64)
+    ap.add_argument("--cfg", type=int, default=-1)
+    a = ap.parse_args()
+    be = bk.get_backend()
+    be.tune("conv2_cfg", a.cfg)
+    for name, Cin, Cout, bs in CASES:
+        gi, m = grid_tables(1, 8, 16, a.n)
+        feats = torch.randn((a.n, Cin, bs, bs), device="cuda").contiguous(memory_format=torch.channels_last)
+        ring = torch.randn((128, Cin, 4 * bs), device="cuda")
+        w = (torch.randn((Cout, Cin, 3, 3), device="cuda") * 0.05).contiguous(memory_format=torch.channels_last)
+        wpk = be.pack_conv3x3_weights(w)
+        stamps = torch.zeros(8 * 4096, dtype=torch.int64, device="cuda")
+        for _ in range(3):
+            be.conv3x3_ring(feats, ring, wpk, Cout, gi, m, None, None)
+        torch.cuda.synchronize()
+        be.tune_ptr("conv_stamps", stamps)
+        be.conv3x3_ring(feats, ring, wpk, Cout, gi, m, None, None)
+        torch.cuda.synchronize()
+        be.tune_ptr("conv_stamps", None)
+        cfg = be.tune_get("conv_last_cfg")
+        s = stamps.view(-1, 8).cpu()
+        s = s[s[:, 0] != 0]
+        t0 = s[:, 0].min()
+        rel = (s[:, :6] - t0).double()
+        seg = rel[:, 1:] - rel[:, :-1]
+        names = ["tables", "first stage", "main loop", "reduction", "stores"]
+        print(f"{name} n={a.n} cfg {cfg}: {s.shape[0]} workgroups; start skew max {rel[:, 0].max():.0f} cyc; end: mean {rel[:, 5].mean():.0f} max {rel[:, 5].max():.0f} cyc"
+              f" (s_memtime ticks = 100 MHz? see below)")
+        print("   " + " | ".join(f"{n} {seg[:, i].mean():.0f} (max {seg[:, i].max():.0f})" for i, n in enumerate(names)))
+
+
+if __name__ == "__main__":
+    main()

@@ -31,6 +31,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--filter", default="")
+    ap.add_argument("--cfgs", default="", help="comma list of forced conv2 decompositions to time besides auto (e.g. 0,1,2,3,4,5,6,7)")
+    ap.add_argument("--no-lib", action="store_true")
+    ap.add_argument("--n", type=int, default=0, help="override the executed-tile count of every case")
     a = ap.parse_args()
     torch.backends.cudnn.benchmark = True
     be = bk.get_backend()
@@ -38,6 +41,8 @@ def main():
         if a.filter not in name:
             continue
         N = 2 if "batch2" in name else 1
+        if a.n:
+            n_exec = a.n
         gi, m = grid_tables(N, GH, GW // N if False else GW, n_exec) if N == 1 else grid_tables(2, GH, GW, n_exec)
         feats = torch.randn((n_exec, Cin, bs, bs), device="cuda").contiguous(memory_format=torch.channels_last)
         ring = torch.randn((N * GH * GW, Cin, 4 * bs), device="cuda")
@@ -50,13 +55,28 @@ def main():
         def lib_path():
             return F.conv2d(be.pad_ring(feats, ring, gi, m, 1, pro), w)
 
-        lib_path()   # MIOpen find
-        us_halo = timeit(lambda: be.pad_ring(feats, ring, gi, m, 1, pro), a.iters)
-        us_lib = timeit(lib_path, a.iters)
-        us_fused = timeit(lambda: be.conv3x3_ring(feats, ring, wpk, Cout, gi, m, pro, None), a.iters)
+        fused = lambda: be.conv3x3_ring(feats, ring, wpk, Cout, gi, m, pro, None)
+        if a.no_lib:
+            us_halo = us_lib = float("nan")
+        else:
+            lib_path()   # MIOpen find
+            us_halo = timeit(lambda: be.pad_ring(feats, ring, gi, m, 1, pro), a.iters)
+            us_lib = timeit(lib_path, a.iters)
+        be.tune("conv_impl", 1)
+        us_v1 = timeit(fused, a.iters)
+        be.tune("conv_impl", 2)
+        us_v2 = timeit(fused, a.iters)
+        extra = ""
+        for c in [int(x) for x in a.cfgs.split(",") if x != ""]:
+            be.tune("conv2_cfg", c)
+            try:
+                extra += f" c{c}={timeit(fused, a.iters):.1f}"
+            finally:
+                be.tune("conv2_cfg", -1)
+        tf = lambda us: flops / us / 1e6
         print(f"{name:18s} ({n_exec},{Cin}->{Cout},{bs}x{bs}) {flops / 1e9:6.2f} GFLOP | halo {us_halo:6.1f} + conv {us_lib - us_halo:6.1f} = {us_lib:6.1f} us"
-              f" ({flops / us_lib / 1e6:5.1f} TF) | fused {us_fused:6.1f} us ({flops / us_fused / 1e6:5.1f} TF = {flops / us_fused / 1e6 / 157.3:4.0%} of fp32 MFMA peak)"
-              f" | x{us_lib / us_fused:4.2f}", flush=True)
+              f" ({tf(us_lib):5.1f} TF) | v1 {us_v1:6.1f} us ({tf(us_v1) / 157.3:4.0%}) | v2 {us_v2:6.1f} us ({tf(us_v2):5.1f} TF = {tf(us_v2) / 157.3:4.0%} of fp32 MFMA peak)"
+              f" | v2 vs lib x{us_lib / us_v2:4.2f}, vs v1 x{us_v1 / us_v2:4.2f}{extra}", flush=True)
 
 
 if __name__ == "__main__":
