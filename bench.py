@@ -360,6 +360,11 @@ def main(argv=None):
         torch.cuda.synchronize(device)
         extra["host_enqueue_ms_per_frame"] = 1e3 * host_s / CLIP_LEN
         extra["roofline_large"] = scatter_copy_large(be, device)
+        from blockcopy.core import fusion
+        # measured route per padded 3x3 layer shape (fusion.conv3x3_plan): library = halo gather + MIOpen, cN = fused kernel
+        extra["conv3x3_plans"] = [{"n_exec": k[0], "tile": k[1], "cin": k[2], "cout": k[3], "choice": best,
+                                   "us": round(times[best], 1), "library_us": round(times.get("library", float("nan")), 1)}
+                                  for k, times, best in fusion.CONV_TUNE_LOG]
         if not args.no_dense and world == 1:
             dense = harness.build_model(args.backbone, block_policy="static", device=device, dtype=dtype,
                                         channels_last=bool(args.channels_last))

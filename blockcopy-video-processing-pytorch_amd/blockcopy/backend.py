@@ -110,6 +110,8 @@ class HipBackend:
 
     def __init__(self, path: str = None):
         self.lib = load_library(path)
+        self._conv_cfg = None          # value last handed to the library
+        self._conv_cfg_pinned = -1     # value pinned through tune("conv2_cfg", ...) for calls that do not choose themselves
 
     # -- helpers
     def _check(self, rc: int, op: str):
@@ -323,7 +325,48 @@ class HipBackend:
         w = weight.detach().as_subclass(torch.Tensor).permute(2, 3, 1, 0).reshape(9, Cin // 32, 4, 2, 4, Cout // 32, 32)   # tap, chunk, cg, h, j, nb, n
         return w.permute(5, 1, 0, 2, 3, 6, 4).contiguous().view(-1)                               # nb, chunk, tap, cg, h, n, j
 
-    def conv3x3_ring(self, data_exec, ring, wpk, cout, grid_idx, mapping_exec, prologue=None, epilogue=None):
+    CONV2_CFGS = ((2, 2, 4, 2, 1), (2, 1, 4, 2, 1), (1, 2, 4, 2, 1), (1, 1, 4, 2, 1), (1, 1, 2, 4, 1), (1, 1, 2, 2, 2), (1, 1, 1, 4, 2),
+                  (1, 1, 1, 2, 4), (2, 2, 2, 2, 2), (2, 2, 1, 2, 4), (2, 1, 2, 2, 2), (2, 1, 1, 4, 2), (2, 1, 1, 2, 4), (2, 1, 1, 1, 8),
+                  (1, 2, 1, 1, 8), (1, 1, 1, 1, 8))    # (RM, RN, WMW, WNW, WKW) of csrc/blockcopy_hip.hip launch_conv3x3_v2
+
+    def conv3x3_candidates(self, n_exec, cin, cout, bs):
+        """Decomposition indices of the balanced conv kernel that cover this layer shape (same rules as the launcher)."""
+        out = []
+        for c, (rm, rn, wmw, wnw, wkw) in enumerate(self.CONV2_CFGS):
+            if bs == 4:
+                if rm != 1 and wmw != 1:
+                    continue
+            elif bs % 8 or bs % (4 * rm):
+                continue
+            if cout % (32 * rn * wnw) or (wkw == 8 and cin % 64):
+                continue
+            out.append(c)
+        return out
+
+    @staticmethod
+    def time_routes(routes, reps=3, launches=4):
+        """{name: median microseconds per call} of each callable, measured with events on the current stream."""
+        out = {}
+        torch.cuda.synchronize()
+        for name, fn in routes.items():
+            try:
+                fn()
+                fn()
+            except Exception:
+                continue
+            ts = []
+            for _ in range(reps):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(launches):
+                    fn()
+                b.record()
+                b.synchronize()
+                ts.append(a.elapsed_time(b) * 1e3 / launches)
+            out[name] = sorted(ts)[len(ts) // 2]
+        return out
+
+    def conv3x3_ring(self, data_exec, ring, wpk, cout, grid_idx, mapping_exec, prologue=None, epilogue=None, cfg=None):
         """Fused halo gather + 3x3/s1/p1 conv (+ optional epilogue) of a channels-last packed batch on the fp32 matrix
         cores.  prologue = (scale, shift, relu) per input channel, epilogue = (scale, shift, add, relu) per output channel."""
         assert _ok(data_exec, torch.float32) and is_nhwc(data_exec) and _ok(ring, torch.float32) and _ok(wpk, torch.float32)
@@ -342,6 +385,10 @@ class HipBackend:
         ptr = lambda t: t.data_ptr() if t is not None else None
         if n_exec > 0:
             with torch.cuda.device_of(data_exec):
+                want = int(cfg) if cfg is not None else self._conv_cfg_pinned      # explicit > pinned by tune() > library's choice
+                if want != self._conv_cfg:
+                    self._check(self.lib.bc_tune_set(b"conv2_cfg", want), "tune_set")
+                    self._conv_cfg = want
                 self._check(self.lib.bc_conv3x3_ring_nhwc(out.data_ptr(), data_exec.data_ptr(), ring.data_ptr(), wpk.data_ptr(),
                                                           grid_idx.data_ptr(), mapping_exec.data_ptr(), n_exec, N, C, cout, GH, GW,
                                                           bs, _DTYPE_CODE[data_exec.dtype], ptr(isc), ptr(ish), int(bool(irelu)),
@@ -466,6 +513,8 @@ class HipBackend:
     # -- C. measurement -----------------------------------------------------------------------------------
     def tune(self, key: str, value: int):
         """A/B knob of the library (include/blockcopy_hip.h bc_tune_set): conv_impl, conv2_cfg, conv2_min_lds."""
+        if key == "conv2_cfg":
+            self._conv_cfg_pinned = self._conv_cfg = int(value)
         self._check(self.lib.bc_tune_set(key.encode(), int(value)), "tune_set")
 
     def tune_ptr(self, key: str, tensor):

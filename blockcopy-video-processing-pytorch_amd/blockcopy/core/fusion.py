@@ -115,19 +115,44 @@ def packed_conv3x3_weight(weight: torch.Tensor, pack) -> torch.Tensor:
 
 
 CONV_MODE = os.environ.get("BLOCKCOPY_CONV", "auto")   # auto | native | library
+CONV_TUNE = os.environ.get("BLOCKCOPY_CONV_TUNE", "1") != "0"   # auto mode: measure each new layer shape once (eager runs only)
+_conv_plans = {}      # (n_exec, bs, cin, cout, n_total, dtype) -> None (library conv) | decomposition index (-1 = library's own choice)
+CONV_TUNE_LOG = []    # (key, {candidate: microseconds}, choice) of every measurement, for the bench report
 
 
-def use_native_conv3x3(n_exec: int, bs: int, cin: int, cout: int) -> bool:
-    """Where the hand-written fused halo+conv beats halo gather + library conv INSIDE a frame on MI355X
-    (profiles/r01/20_*: the library's asm implicit-GEMM reaches ~107 TFLOP/s fp32 in-frame on 64-channel 32x32 tiles and
-    keeps those; the fused kernel wins on the mid-size layers, where the separate halo gather and the library's
-    split-K zero-fill weigh most)."""
+def clear_conv_plans():
+    _conv_plans.clear()
+    del CONV_TUNE_LOG[:]
+
+
+def default_native_conv3x3(n_exec: int, bs: int, cin: int, cout: int) -> bool:
+    """Untuned choice between the hand-written fused halo+conv and halo gather + library conv (profiles/r02/kbench_conv_*:
+    the CU-balanced kernel wins on every SwiftNet / CSP layer shape except 4x4 tiles with few executed tiles)."""
+    return not (bs <= 4 and n_exec * bs * bs < 1024)
+
+
+def conv3x3_plan(n_exec: int, bs: int, cin: int, cout: int, n_total: int, dtype, tuner=None):
+    """How to run one padded 3x3 / stride 1 conv layer: ``None`` = halo gather + library conv, ``int`` = the fused
+    halo+conv kernel with that decomposition (-1: the library's cost model).  In ``auto`` mode a new layer shape is
+    MEASURED once (``tuner()`` times the library route and every decomposition on the live tensors) -- the same idea as the
+    conv library's own solver search -- but never during graph capture; until measured, a fixed rule decides."""
     if CONV_MODE == "library":
-        return False
+        return None
     if CONV_MODE == "native":
-        return True
-    items64 = n_exec * bs * bs // 64 * (cout // 64)
-    return (bs >= 16 and items64 < 768) or (bs == 8 and cin * cout <= 128 * 128)
+        return -1
+    key = (n_exec, bs, cin, cout, n_total, dtype)
+    if key in _conv_plans:
+        return _conv_plans[key]
+    capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+    if tuner is not None and CONV_TUNE and not capturing:
+        times = tuner()
+        if times:
+            best = min(times, key=times.get)
+            plan = None if best == "library" else int(best)
+            _conv_plans[key] = plan
+            CONV_TUNE_LOG.append((key, times, best))
+            return plan
+    return -1 if default_native_conv3x3(n_exec, bs, cin, cout) else None
 
 
 def batchnorm_affine(running_mean, running_var, weight, bias, eps):

@@ -720,19 +720,17 @@ class TensorWrapper(torch.Tensor):
             data = data.contiguous()    # the reference decomposition is NCHW only
         grid_idx, mapping_exec = feats._grid_idx, feats._mapping_exec
         if feats.engine == "fused" and fuse and op == "conv2d" and padding == 1:
-            # 3x3 / stride 1 convs on large tiles: ONE hand-written MFMA kernel gathers the halo and convolves
-            # (no padded tensor, no library conv); everything else falls through to halo gather + library conv
+            # 3x3 / stride 1 convs: ONE hand-written MFMA kernel gathers the halo and convolves (no padded tensor, no
+            # library conv) wherever it is the faster route for this layer shape; else halo gather + library conv
             be = get_backend()
-            weight = args[1] if len(args) > 1 else kwargs["weight"]
-            cv = {k: kwargs.get(k, args[i] if len(args) > i else d) for k, i, d in (("stride", 3, 1), ("dilation", 5, 1), ("groups", 6, 1))}
-            if (isinstance(weight, torch.Tensor) and hasattr(be, "conv3x3_ring")
-                    and be.conv3x3_supported(data, weight, cv["stride"], 1, cv["dilation"], cv["groups"])
-                    and fusion.use_native_conv3x3(data.shape[0], data.shape[2], weight.shape[1], weight.shape[0])):
+            plan = self._conv3x3_plan(be, data, args, kwargs, grid_idx, mapping_exec, func)
+            if plan is not None:
+                weight = args[1] if len(args) > 1 else kwargs["weight"]
                 wpk = fusion.packed_conv3x3_weight(weight, be.pack_conv3x3_weights)   # cached per parameter object
                 ring = feats.next_ring(data, padding)
                 feats._pad_memo = None
                 with timings.env("tensorwrapper/conv3x3_fused", 10):
-                    return be.conv3x3_ring(data, ring, wpk, weight.shape[0], grid_idx, mapping_exec, prologue, None), pend_out
+                    return be.conv3x3_ring(data, ring, wpk, weight.shape[0], grid_idx, mapping_exec, prologue, None, cfg=plan), pend_out
         if feats.engine == "fused" and fuse and op == "max_pool2d" and padding == 1:
             # the ResNet stem pool (3x3, stride 2): halo gather + max in one kernel, no padded tensor
             be = get_backend()
@@ -777,6 +775,29 @@ class TensorWrapper(torch.Tensor):
         with timings.env("tensorwrapper/pad_func", 11):
             return func(*args, **kwargs), pend_out
 
+    def _conv3x3_plan(self, be, data, args, kwargs, grid_idx, mapping_exec, func):
+        """None = halo gather + library conv; int = fused halo+conv kernel with that decomposition (fusion.conv3x3_plan)."""
+        weight = args[1] if len(args) > 1 else kwargs.get("weight")
+        cv = {k: kwargs.get(k, args[i] if len(args) > i else d) for k, i, d in (("stride", 3, 1), ("dilation", 5, 1), ("groups", 6, 1))}
+        if not (isinstance(weight, torch.Tensor) and hasattr(be, "conv3x3_ring")
+                and be.conv3x3_supported(data, weight, cv["stride"], 1, cv["dilation"], cv["groups"])):
+            return None
+        n_exec, cin, bs = data.shape[0], data.shape[1], data.shape[2]
+        cout, n_total = weight.shape[0], grid_idx.numel()
+
+        def tuner():
+            if not hasattr(be, "conv3x3_candidates") or not data.is_cuda:
+                return None
+            w_plain = weight.as_subclass(torch.Tensor) if isinstance(weight, TensorWrapper) else weight
+            wpk = fusion.packed_conv3x3_weight(weight, be.pack_conv3x3_weights)
+            scratch = torch.zeros((n_total, cin, 4 * bs), dtype=data.dtype, device=data.device)   # a ring nobody else reads
+            routes = {"library": lambda: torch.nn.functional.conv2d(be.pad_ring(data, scratch, grid_idx, mapping_exec, 1, None), w_plain.detach())}
+            for c in be.conv3x3_candidates(n_exec, cin, cout, bs):
+                routes[str(c)] = (lambda c_: lambda: be.conv3x3_ring(data, scratch, wpk, cout, grid_idx, mapping_exec, None, None, cfg=c_))(c)
+            return be.time_routes(routes)
+
+        return fusion.conv3x3_plan(n_exec, bs, cin, cout, n_total, data.dtype, tuner)
+
     def _residual_gather_ok(self, op, x, P, args, kwargs, padding) -> bool:
         """Can the pending residual add of ``x`` be folded into this padded op's halo gather?"""
         be = get_backend()
@@ -787,11 +808,8 @@ class TensorWrapper(torch.Tensor):
             return False
         if op == "conv2d" and padding == 1:
             # layers that go to the fused MFMA conv keep the plain route (materialise, then conv without prologue)
-            weight = args[1] if len(args) > 1 else kwargs.get("weight")
-            cv = {k: kwargs.get(k, args[i] if len(args) > i else d) for k, i, d in (("stride", 3, 1), ("dilation", 5, 1), ("groups", 6, 1))}
-            if (isinstance(weight, torch.Tensor) and hasattr(be, "conv3x3_ring")
-                    and be.conv3x3_supported(dense_layout(raw), weight, cv["stride"], 1, cv["dilation"], cv["groups"])
-                    and fusion.use_native_conv3x3(raw.shape[0], raw.shape[2], weight.shape[1], weight.shape[0])):
+            feats = self._features
+            if self._conv3x3_plan(be, dense_layout(raw), args, kwargs, feats._grid_idx, feats._mapping_exec, None) is not None:
                 return False
         return True
 
