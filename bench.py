@@ -61,6 +61,7 @@ def parse_args(argv=None):
     ap.add_argument("--miopen-find", type=int, default=1, help="torch.backends.cudnn.benchmark during warm-up")
     ap.add_argument("--cpu-frames", type=int, default=8)
     ap.add_argument("--graph", type=int, default=1, help="hipGraph replay of the packed pipeline (0 = eager launches)")
+    ap.add_argument("--upload-variant", type=int, default=1, help="1 (default, N=1): also report the PCIe-inclusive fps of the reference's full loop")
     ap.add_argument("--stub-cpu", action="store_true",
                     help="(tests only) replace the GPU workload by a tiny CPU stand-in so that the launcher, the per-rank "
                          "environment and the clock bracket can be exercised on a machine without a GPU")
@@ -360,6 +361,18 @@ def main(argv=None):
         torch.cuda.synchronize(device)
         extra["host_enqueue_ms_per_frame"] = 1e3 * host_s / CLIP_LEN
         extra["roofline_large"] = scatter_copy_large(be, device)
+        if world == 1 and args.upload_variant:
+            # the reference driver's complete loop: per-frame upload from pinned host memory + last-frame upsample / argmax / .cpu()
+            # (test_swiftnet.py:181-197); the headline `value` keeps inputs resident in HBM, these two figures do not
+            hclips = [[f.cpu() for f in clips[0]]]
+            up = {}
+            for name, pf in (("reference_loop_sync_upload", False), ("double_buffered_upload", True)):
+                ufps, _, _ = harness.measure_fps_with_upload(model, hclips, n_clips=max(1, min(args.steps, 3)), warmup_clips=1, device=device,
+                                                             dtype=dtype, prefetch=pf)
+                up[name] = ufps
+            up["note"] = ("frames start in pinned host memory and are uploaded inside the timed region; last frame of each clip: bilinear "
+                          "upsample to input size + argmax + .cpu() (reference test_swiftnet.py:190-197). PCIe-inclusive: never `value`")
+            extra["upload_inclusive"] = up
         from blockcopy.core import fusion
         # measured route per padded 3x3 layer shape (fusion.conv3x3_plan): library = halo gather + MIOpen, cN = fused kernel
         extra["conv3x3_plans"] = [{"n_exec": k[0], "tile": k[1], "cin": k[2], "cout": k[3], "choice": best,

@@ -81,3 +81,66 @@ def measure_fps(model, clips: Sequence[Sequence[torch.Tensor]], n_clips: int, wa
     sync(device)
     dt = time.perf_counter() - t0
     return n_frames / dt, dt, n_frames
+
+
+@torch.no_grad()
+def measure_fps_with_upload(model, host_clips, n_clips: int, warmup_clips: int = 1, device="cuda", dtype=torch.float32, prefetch: bool = True):
+    """frames/s of the reference driver's FULL per-clip loop (semantic_segmentation/test_swiftnet.py:181-197): every frame
+    starts in (pinned) host memory and is uploaded inside the timed region, and the last frame of each clip is upsampled to
+    the input resolution, arg-maxed and copied back to the host (``preds = out.max(dim=1)[1].cpu()``).
+
+    ``prefetch=False`` is the reference's own form: ``inputs.to(device, non_blocking=True)`` on the compute stream, i.e. the
+    25 MB upload of frame t sits between the models of frames t-1 and t.  ``prefetch=True`` is the MI355X-first form: frame
+    t+1 travels on a copy stream into the other half of a double buffer while frame t is computed (PCIe and compute overlap)."""
+    dev = torch.device(device)
+    host_clips = [[f.pin_memory() if not f.is_pinned() else f for f in clip] for clip in host_clips]
+    compute = torch.cuda.current_stream(dev)
+    copy = torch.cuda.Stream(dev) if prefetch else None
+    shape = host_clips[0][0].shape
+    bufs = [torch.empty(shape, dtype=dtype, device=dev) for _ in range(2)]
+    staged = [torch.cuda.Event() for _ in range(2)]      # upload into bufs[i] finished
+    consumed = [torch.cuda.Event() for _ in range(2)]    # model finished reading bufs[i]
+
+    def upload(frame, i):
+        with torch.cuda.stream(copy):
+            copy.wait_event(consumed[i])
+            bufs[i].copy_(frame, non_blocking=True)       # fp32 -> dtype conversion happens on the device side of the copy
+            staged[i].record(copy)
+
+    def run(clip):
+        if hasattr(model, "reset_temporal"):
+            model.reset_temporal()
+        preds = None
+        if prefetch:
+            upload(clip[0], 0)
+        for t, frame in enumerate(clip):
+            if prefetch:
+                if t + 1 < len(clip):
+                    upload(clip[t + 1], (t + 1) % 2)
+                compute.wait_event(staged[t % 2])
+                inputs = bufs[t % 2]
+            else:
+                inputs = frame.to(dev, non_blocking=True, dtype=dtype)
+            out = model(inputs)
+            if prefetch:
+                consumed[t % 2].record(compute)
+            if t == len(clip) - 1:
+                out = torch.nn.functional.interpolate(out, size=inputs.shape[2:], mode="bilinear")
+                preds = out.detach().max(dim=1)[1].cpu()
+        return preds
+
+    for i in range(2):
+        consumed[i].record(compute)
+    for i in range(warmup_clips):
+        run(host_clips[i % len(host_clips)])
+    sync(dev)
+    t0 = time.perf_counter()
+    n_frames = 0
+    for i in range(n_clips):
+        clip = host_clips[i % len(host_clips)]
+        preds = run(clip)
+        n_frames += len(clip) * clip[0].shape[0]
+    sync(dev)
+    dt = time.perf_counter() - t0
+    assert preds is not None and tuple(preds.shape) == (shape[0], shape[2], shape[3])
+    return n_frames / dt, dt, n_frames

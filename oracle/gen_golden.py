@@ -342,6 +342,101 @@ def gen_csp_r50(ref):
                       extra=dict(weights="name-seeded over CSP().state_dict() keys, BN not folded (Pedestron does not fold)"))
 
 
+# ----------------------------------------------------------------------------- G. I/O format, quality metrics, GMACs counter
+def gen_io_metrics(ref):
+    """Fixtures for the components either side of the hot path, from the reference's own
+    CityscapesVid / StreamSegMetrics / flopscounter run in this container (cv2 is only imported, never called, by these
+    modules: a bare stub module satisfies the import; torchvision-based transforms are not used)."""
+    import importlib.util
+    import tempfile
+    import types
+    import warnings
+
+    if "cv2" not in sys.modules:
+        sys.modules["cv2"] = types.ModuleType("cv2")
+    from lib.datasets.cityscapes_vid import CityscapesVid
+    from lib.utils.metrics import StreamSegMetrics
+    from bc_workloads import cityscapes as cs
+
+    out = {}
+    # (1) clip layout + label encoding: a synthetic tree written by bc_workloads.cityscapes.write_synthetic_tree (data only)
+    cfg = dict(split="val", cities=["aachen", "bonn"], clips_per_city=2, clip_length=4, size=[24, 48], seed=5)
+    with tempfile.TemporaryDirectory() as root:
+        cs.write_synthetic_tree(root, cfg["split"], cfg["cities"], cfg["clips_per_city"], cfg["clip_length"], tuple(cfg["size"]), cfg["seed"])
+        plain = lambda img, lbl: (np.array(img, dtype=np.uint8), lbl)     # noqa: E731  (PIL -> array, label untouched)
+        with quiet():
+            ds = CityscapesVid(root, split=cfg["split"], transform=plain, clip_length=cfg["clip_length"], has_labels=True)
+        order = sorted(range(len(ds)), key=lambda i: ds.relative_dirs[i])    # os.listdir order is filesystem-dependent
+        rels = []
+        for k, i in enumerate(order):
+            vid, target, meta = ds[i]
+            out[f"clip{k}_frames"] = np.stack(vid)
+            out[f"clip{k}_target"] = np.asarray(target)
+            rels.append(meta["relpath"])
+        out["io_cfg"] = np.frombuffer(json.dumps(dict(cfg, relpaths=rels, mean=list(CityscapesVid.mean), std=list(CityscapesVid.std),
+                                                      fine_classes=list(CityscapesVid.fine_classes))).encode(), dtype=np.uint8)
+        out["encode_all_ids"] = CityscapesVid.encode_target(np.arange(-1, 34))
+        out["decode_all_train_ids"] = CityscapesVid.decode_target(np.array(list(range(19)) + [255]))
+        out["encode_test_all"] = CityscapesVid.encode_target_test(np.arange(19))
+
+    # (2) StreamSegMetrics: three updates of seeded labels / predictions (255 = ignore present)
+    rng = np.random.default_rng(77)
+    m = StreamSegMetrics(19, classes=CityscapesVid.fine_classes)
+    res = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for u in range(3):
+            lt = rng.integers(0, 19, (2, 16, 32))
+            lt[rng.random(lt.shape) < 0.1] = 255
+            if u == 0:
+                lt[lt == 16] = 255           # a class absent from the first update: NaN handling
+            lp = np.where(rng.random(lt.shape) < 0.6, np.where(lt == 255, 0, lt), rng.integers(0, 19, lt.shape))
+            m.update(lt, lp)
+            out[f"m_lt{u}"], out[f"m_lp{u}"] = lt, lp
+            r = m.get_results()
+            res.append({k: (float(v) if k != "Class IoU" else {kk: float(vv) for kk, vv in v.items()}) for k, v in r.items()})
+    out["m_confusion"] = m.confusion_matrix
+    out["m_ious"], out["m_ious_sum"] = np.array(m.ious), np.array(m.ious_sum)
+    out["m_accs"], out["m_accs_sum"] = np.array(m.accs), np.array(m.accs_sum)
+    out["m_results"] = np.frombuffer(json.dumps(res).encode(), dtype=np.uint8)
+
+    # (3) GMACs: the reference's counter on the reference SwiftNet-RN18, dense and under block execution (packed batch = executed tiles)
+    spec = importlib.util.spec_from_file_location("ref_flopscounter", os.path.join(ref_loader.REF_ROOT, "Pedestron", "tools", "flopscounter.py"))
+    fc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fc)
+    N, H, W, bs = 1, 128, 256, 32
+    grids = scenario_grids(N, H // bs, W // bs, 21)[:4]
+    frames = [seeded.synthetic_frame(6000 + t, (N, 3, H, W)) for t in range(4)]
+    g = {}
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with quiet():
+            bb = ref.resnet.resnet18(pretrained=False)
+            dense = ref.swiftnet.SwiftNet(backbone=bb, num_classes=19, num_features=128, use_spp=True).eval()
+        fc.add_flops_counting_methods(dense)
+        dense.start_flops_count()
+        dense(frames[0])
+        dense(frames[1])
+        g["dense_avg"], g["dense_frames"] = [float(x) for x in dense.compute_average_flops_cost()]
+        dense.stop_flops_count()
+        blk, _ = build_ref_swiftnet(ref, "resnet18", bs, grids)     # BN folded, forced grids
+        fc.add_flops_counting_methods(blk)
+        blk.start_flops_count()
+        blk.reset_temporal()
+        per_frame = []
+        for t in range(4):
+            blk(frames[t])
+            tot, _, n = blk.compute_total_flops_cost()
+            per_frame.append(float(tot))
+        g["block_avg"], g["block_frames"] = [float(x) for x in blk.compute_average_flops_cost()]
+        g["block_total_after_frame"] = per_frame
+        blk.stop_flops_count()
+    g.update(N=N, H=H, W=W, block_size=bs, grid_seed=21, frame_seed0=6000, exec=[int(x.sum()) for x in grids])
+    out["gmacs"] = np.frombuffer(json.dumps(g).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(GOLD, "io_metrics.npz"), **out)
+    print("io_metrics.npz", rels, "mIoU", res[-1]["Mean IoU"], "GMACs dense", g["dense_avg"] / 1e9, "block avg", g["block_avg"] / 1e9, g["exec"])
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     ref = ref_loader.load_reference()

@@ -104,3 +104,16 @@ def run_golden_detector_clip(G, cfg, modules, device, engine, graph=0, channels_
             if f"frame_state{t}" in G.files:
                 fs_errs.append(float((det.policy_meta["frame_state"].cpu() - torch.from_numpy(G[f"frame_state{t}"])).abs().max()))
     return errs, fs_errs
+
+
+def scenario_grids(N, GH, GW, seed):
+    """The mask sequence of the golden clips (oracle/gen_golden.py scenario_grids): all, half, one, all-but-one, none, quarter."""
+    from bc_workloads import seeded
+
+    total = N * GH * GW
+    return [torch.ones(N, 1, GH, GW, dtype=torch.bool),
+            seeded.fixed_fraction_grid(seed + 1, N, GH, GW, total // 2),
+            seeded.fixed_fraction_grid(seed + 2, N, GH, GW, 1),
+            seeded.fixed_fraction_grid(seed + 3, N, GH, GW, total - 1),
+            torch.zeros(N, 1, GH, GW, dtype=torch.bool),
+            seeded.fixed_fraction_grid(seed + 5, N, GH, GW, total // 4)]
