@@ -175,3 +175,37 @@ def test_csp_r50_matches_reference(golden_dir, oracle_backend, engine, cl):
     assert fs and all(e == 0.0 for e in fs)
     calls = json.loads(bytes(G["kernel_calls"]).decode())
     assert calls["pad"] == 21 * cfg["n_frames"]     # 16 bottleneck 3x3 + stem conv + stem pool + 3 head convs, per frame
+
+
+def test_vectorised_detection_rewards_equal_the_loop_restatement():
+    """build_instance_mask / build_instance_mask_iou_gain without per-box loops == the box-by-box
+    restatement of reference policy/information_gain.py:55-108, bit for bit, on random and adversarial detections
+    (ties, collapsed boxes at half resolution, no matches, empty frames, several classes)."""
+    import policy_oracle as L
+    from blockcopy.policy import information_gain as V
+
+    rng = np.random.default_rng(3)
+
+    def dets(n, H=96, W=160):
+        x1, y1 = rng.integers(0, W - 8, n), rng.integers(0, H - 8, n)
+        w, h = rng.integers(1, 40, n), rng.integers(1, 60, n)
+        b = np.stack([x1, y1, np.minimum(x1 + w, W - 1), np.minimum(y1 + h, H - 1), rng.random(n) * 0.9 + 0.1], 1).astype(np.float32)
+        return b
+
+    cases = [(dets(30), dets(25)), (dets(1), dets(0)), (dets(0), dets(7)), (dets(0), dets(0)), (dets(120), dets(150))]
+    a = dets(12)
+    shifted = a.copy(); shifted[:, [0, 2]] += 2                      # heavy overlaps
+    cases += [(a, a.copy()), (a, shifted), (np.repeat(a[:3], 3, 0), a[:3])]   # exact matches (gain 0), duplicates / ties
+    tiny = a.copy(); tiny[:, 2] = tiny[:, 0] + 1; tiny[:, 3] = tiny[:, 1] + 1   # collapse to empty at SUBSAMPLE 2
+    cases.append((tiny, a))
+    size = (1, 1, 96, 160)
+    for cur, prev in cases:
+        want = L.build_instance_mask_iou_gain([[cur]], [[prev]], size)
+        got = V.build_instance_mask_iou_gain([[cur]], [[prev]], size)
+        assert got.shape == want.shape == size and torch.equal(got, want)
+        assert torch.equal(V.build_instance_mask([[cur]], size), L.build_instance_mask([[cur]], size))
+    # two classes: both paint channel 0 of the gain map (reference quirk); the score mask keeps its per-channel rule
+    size2 = (1, 2, 96, 160)
+    c2, p2 = [[dets(9), dets(11)]], [[dets(10), dets(4)]]
+    assert torch.equal(V.build_instance_mask_iou_gain(c2, p2, size2), L.build_instance_mask_iou_gain(c2, p2, size2))
+    assert torch.equal(V.build_instance_mask(c2, size2), L.build_instance_mask(c2, size2))
