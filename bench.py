@@ -137,10 +137,14 @@ def pmc_traffic():
     (tools/pmc_traffic.py writes profiles/traffic_latest.json); None when no such measurement is committed."""
     path = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if not os.path.exists(path):
-        return None, None
+        return None, None, {}
     with open(path) as f:
         t = json.load(f)
-    return t.get("k_combine_copy_bytes_per_launch"), t.get("source")
+    per_kernel = {label: {"kernel": v.get("kernel"), "hbm_MB": round(v["hbm_bytes_per_launch"] / 1e6, 2),
+                          "algorithmic_MB": round(v["algorithmic_bytes_per_launch"] / 1e6, 2),
+                          "traffic_over_algorithmic": round(v["traffic_over_algorithmic"], 3)}
+                  for label, v in t.get("kernels", {}).items() if "traffic_over_algorithmic" in v}
+    return t.get("k_combine_copy_bytes_per_launch"), t.get("source"), per_kernel
 
 
 def _free_port():
@@ -417,7 +421,10 @@ def main(argv=None):
 
     if rank == 0:
         achieved = (cc["total_bytes"] / (cc["total_ms"] * 1e-3) / 1e9) if cc["total_ms"] > 0 else 0.0
-        traffic, traffic_src = pmc_traffic()
+        traffic, traffic_src, traffic_kernels = pmc_traffic()
+        if traffic_kernels:
+            # committed PMC measurement (profiles/traffic_latest.json: rocprofv3 --pmc passes of tools/pmc_driver.py at these shapes)
+            extra["pmc_traffic"] = traffic_kernels
         out = {
             "metric": METRIC, "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

@@ -82,6 +82,7 @@ def load_library(path: str = None) -> ctypes.CDLL:
         "bc_interp_bilinear_act_nhwc": [p, p, ctypes.c_longlong, i, i, i, i, i, i, ctypes.c_float, ctypes.c_float, i, p, p, p, i, p],
         "bc_affine_act": [p, p, p, p, p, i, ctypes.c_longlong, i, ctypes.c_longlong, i, p],
         "bc_nms_sorted": [p, i, ctypes.c_float, p, p, p, p],
+        "bc_policy_step": [p, i, ctypes.c_ulonglong, ctypes.c_ulonglong, i, i, p, p, p, p, p, p],
         "bc_tune_set": [ctypes.c_char_p, i],
         "bc_tune_get": [ctypes.c_char_p, ctypes.POINTER(i)],
         "bc_tune_set_ptr": [ctypes.c_char_p, p],
@@ -477,6 +478,20 @@ class HipBackend:
                                                 transfer.data_ptr() if transfer is not None else None,
                                                 counts.data_ptr(), self._stream()), "grid_tables")
         return grid_idx, mapping, transfer, counts
+
+    def policy_step(self, logits, seed: int, counter: int, multiple: int, at_least_one: bool, grid_u8, tables, counts, mailbox=None):
+        """Device policy decision (include/blockcopy_hip.h bc_policy_step): Bernoulli(logits) + round-up-to-multiple + index
+        tables in one launch.  ``grid_u8`` uint8[n_total], ``tables`` int32[2*n_total] = [grid_idx | mapping_exec], ``counts``
+        int32[4] are caller-owned device buffers; ``mailbox`` an optional pinned-host int32[4] that receives the counts."""
+        assert _ok(logits, torch.float32) and logits.is_contiguous() and _ok(grid_u8, torch.uint8) and _ok(tables, torch.int32) and _ok(counts, torch.int32)
+        n_total = logits.numel()
+        assert grid_u8.numel() == n_total and tables.numel() == 2 * n_total and counts.numel() >= 4
+        assert mailbox is None or (mailbox.is_pinned() and mailbox.dtype == torch.int32 and mailbox.numel() >= 4)
+        with torch.cuda.device_of(logits):
+            self._check(self.lib.bc_policy_step(logits.data_ptr(), n_total, int(seed) & (2 ** 64 - 1), int(counter) & (2 ** 64 - 1),
+                                                int(multiple), int(bool(at_least_one)), grid_u8.data_ptr(), tables.data_ptr(),
+                                                tables.data_ptr() + 4 * n_total, counts.data_ptr(),
+                                                mailbox.data_ptr() if mailbox is not None else None, self._stream()), "policy_step")
 
     def grid_tables_host(self, grid_u8: np.ndarray, grid_idx: np.ndarray, mapping: np.ndarray,
                          prev_grid_idx: np.ndarray = None, transfer: np.ndarray = None) -> int:

@@ -73,6 +73,7 @@ class BlockCopyModel(nn.Module):
             elif self.use_graph and blockcopy.core.tensorwrapper.ENGINE == "fused":
                 out = self._forward_graphed(inputs, **kwargs)
             else:
+                self.policy_meta.pop("grid_tables", None)   # (eager engines build their tables from the host mirror)
                 self.block_temporal_features = x.process_temporal_features(self.block_temporal_features)
                 blocks = x.to_blocks(self.policy_meta["grid"], self.policy_meta.get("grid_host", None))
                 # frame state = most recently executed pixels of every tile
@@ -132,10 +133,14 @@ def _forward_graphed(self, inputs, **kwargs):
     if gf is None:
         gf = self._graphed[key] = GraphedFrame(inputs, self.block_size)
     grid = self.policy_meta["grid"]
-    grid_host = self.policy_meta.get("grid_host", None)
-    if grid_host is None:
-        grid_host = grid.to("cpu")   # device-only grid: the one D->H sync of the frame
-    n_exec = gf.upload(inputs, grid_host)
+    dev_tables = self.policy_meta.pop("grid_tables", None)
+    if dev_tables is not None:
+        n_exec = gf.upload_tables(inputs, *dev_tables)      # tables built by the device policy step: no host table work
+    else:
+        grid_host = self.policy_meta.get("grid_host", None)
+        if grid_host is None:
+            grid_host = grid.to("cpu")   # device-only grid: the one D->H sync of the frame
+        n_exec = gf.upload(inputs, grid_host)
     out_blocks = gf.run(self.base_model, n_exec, grid, **kwargs)
     self.policy_meta["frame_state"] = gf.frame_state
     return gf.finish(out_blocks)

@@ -66,6 +66,14 @@ class GraphedFrame:
             self.static_in.copy_(inputs, non_blocking=True)
         return n_exec
 
+    def upload_tables(self, inputs: torch.Tensor, tables: torch.Tensor, n_exec: int) -> int:
+        """Per-frame work when the policy already built the index tables on the device (bc_policy_step): two D->D copies."""
+        assert tables.numel() == 2 * self.n_total and tables.dtype == torch.int32
+        self.tables.copy_(tables, non_blocking=True)
+        if inputs.data_ptr() != self.static_in.data_ptr():
+            self.static_in.copy_(inputs, non_blocking=True)
+        return int(n_exec)
+
     # ------------------------------------------------------------------ the capturable body
     def body(self, base_model, n_exec: int, grid: torch.Tensor, **kwargs):
         feats = BlockFeatures(self.device, engine="fused")

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import abc
 import logging
+import os
 import random
 from abc import abstractmethod
 
@@ -20,6 +21,12 @@ from torch.distributions import Bernoulli
 from blockcopy.policy.information_gain import InformationGain, InformationGainObjectDetection, InformationGainSemSeg
 from blockcopy.policy.net import PolicyNet, build_policy_net_from_settings
 from blockcopy.utils.profiler import timings
+
+
+def _backend():
+    from blockcopy.backend import get_backend
+
+    return get_backend()
 
 
 def build_policy_from_settings(settings: dict):
@@ -68,8 +75,9 @@ class PolicyStats:
     def add_policy_meta(self, policy_meta: dict) -> dict:
         grid = policy_meta["grid"]
         host = policy_meta.get("grid_host", None)
-        # host mirror available -> count there; otherwise this is the one D->H sync of the frame
-        num_exec = int(host.sum()) if host is not None else int(grid.sum())
+        known = policy_meta.pop("num_exec_known", None)
+        # count known from the device policy step / host mirror available -> no sync; otherwise the one D->H sync of the frame
+        num_exec = int(known) if known is not None else (int(host.sum()) if host is not None else int(grid.sum()))
         num_total = int(grid.numel())
         policy_meta["num_exec"] = num_exec
         policy_meta["num_total"] = num_total
@@ -219,6 +227,12 @@ class PolicyTrainRL(Policy, metaclass=abc.ABCMeta):
         # graph; their policy-net trunk runs as a captured hipGraph over a static input (same logits, ~40 fewer launches)
         self.graph_forward = graph_forward
         self._fwd_graphs = {}
+        # MI355X-first: sampling + count quantisation + index tables in ONE device kernel (bc_policy_step) on GPU frames;
+        # the host only waits for the executed-tile count (it selects the captured graph).  False = the reference's host route.
+        self.device_step = os.environ.get("BLOCKCOPY_DEVICE_POLICY", "1") != "0"
+        self.rng_seed = None          # counter-based RNG of the device step: drawn from torch's generator at first use
+        self.rng_counter = 0
+        self._step_bufs = {}
         assert 0 <= block_target <= 1
         self.block_target = block_target
         self.information_gain = information_gain
@@ -243,6 +257,10 @@ class PolicyTrainRL(Policy, metaclass=abc.ABCMeta):
                         grid_logits = self._forward_nograd_graph(policy_meta)
                     else:
                         grid_logits = self.net(policy_meta)
+                if self.device_step and grid_logits.is_cuda and hasattr(_backend(), "policy_step"):
+                    with timings.env("policy/sample", 3):
+                        self._device_step(policy_meta, grid_logits, shape)
+                    return self.stats.add_policy_meta(policy_meta)
                 with timings.env("policy/sample", 3):
                     m = Bernoulli(logits=grid_logits)
                     sample = m.sample()
@@ -258,6 +276,40 @@ class PolicyTrainRL(Policy, metaclass=abc.ABCMeta):
                 policy_meta["grid_log_probs"] = m.log_prob(grid_f) if grid_logits.requires_grad or not self.graph_forward else None
                 policy_meta["grid_probs"] = m.probs
         return self.stats.add_policy_meta(policy_meta)
+
+    def _device_step(self, policy_meta: dict, grid_logits: torch.Tensor, shape):
+        """Decision on the device: one launch samples, rounds the executed count up to the quantisation step and builds the
+        index tables; an async copy mirrors the grid into pinned memory; ONE event wait then gives the host the executed-tile
+        count (mailbox) and the mirror.  Distribution-identical to the host route (reference policy.py:283-288 + :124-144);
+        bit-identical to the CPU restatement oracle/bc_oracle.c bco_policy_step for the same (seed, counter)."""
+        be = _backend()
+        dev = grid_logits.device
+        n_total = grid_logits.numel()
+        if self.rng_seed is None:
+            self.rng_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        st = self._step_bufs.get((dev, n_total))
+        if st is None:
+            st = self._step_bufs[(dev, n_total)] = {
+                "grid": torch.zeros(n_total, dtype=torch.uint8, device=dev), "tables": torch.zeros(2 * n_total, dtype=torch.int32, device=dev),
+                "counts": torch.zeros(4, dtype=torch.int32, device=dev), "mailbox": torch.zeros(4, dtype=torch.int32).pin_memory(),
+                "host": torch.zeros(n_total, dtype=torch.uint8).pin_memory(), "event": torch.cuda.Event()}
+        multiple = max(1, int(n_total * self.quantize_number_exec)) if self.quantize_number_exec > 0 else 1
+        logits = grid_logits.detach().float().contiguous()
+        be.policy_step(logits, self.rng_seed, self.rng_counter, multiple, self.at_least_one, st["grid"], st["tables"], st["counts"], st["mailbox"])
+        self.rng_counter += 1
+        st["host"].copy_(st["grid"], non_blocking=True)
+        st["event"].record()
+        st["event"].synchronize()          # the frame's single wait: n_exec selects the captured graph
+        n_exec, _, nan, _ = st["mailbox"].tolist()
+        assert nan == 0, "Policy net returned NaN's, maybe optimization problem?"
+        grid = st["grid"].view(torch.bool).view(shape).clone()
+        policy_meta["grid"] = grid
+        policy_meta["grid_host"] = st["host"].view(torch.bool).view(shape).clone()
+        policy_meta["grid_tables"] = (st["tables"], n_exec)      # consumed by the engine instead of rebuilding them on the host
+        policy_meta["num_exec_known"] = n_exec
+        m = Bernoulli(logits=grid_logits)
+        policy_meta["grid_log_probs"] = m.log_prob(grid.to(grid_logits.dtype)) if grid_logits.requires_grad or not self.graph_forward else None
+        policy_meta["grid_probs"] = m.probs
 
     @torch.no_grad()
     def _forward_nograd_graph(self, policy_meta: dict) -> torch.Tensor:

@@ -737,6 +737,131 @@ __global__ __launch_bounds__(1024) void k_grid_tables(const uint8_t *__restrict_
     if (threadIdx.x == 0) { counts[0] = carry; counts[1] = n_total - carry; }
 }
 
+// ------------------------------------------------------------------------------------------ device policy step
+// Decision of the online-RL policy for one frame, entirely on the device: Bernoulli sampling of
+// the tile logits, rounding the executed count UP to a multiple (switching on randomly chosen skipped tiles) and the index
+// tables -- the reference does this with a D->H copy, Python `random.sample` and a CPU TorchScript function
+// (policy/policy.py:124-144,283-288; core/tensorwrapper.py:108-128).  Randomness is COUNTER-BASED so that the CPU
+// restatement (oracle/bc_oracle.c bc_oracle_policy_step) reproduces every decision bit for bit:
+//     z(stream) = splitmix64( seed ^ counter * 0xD1342543DE82EF95 + (2 * tile + stream + 1) * 0x9E3779B97F4A7C15 )
+//     stream 0: u = (z >> 40) * 2^-24, tile sampled iff u < sigmoid(logit)      (torch: Bernoulli(logits).sample() = rand < p)
+//     stream 1: key = z >> 24; of the skipped tiles the `need` smallest (key, tile) are switched on
+// and sigmoid() is evaluated with one fixed sequence of IEEE operations (bc_sigmoid_repro) instead of the library expf.
+__host__ __device__ __forceinline__ unsigned long long bc_policy_rand(unsigned long long seed, unsigned long long counter,
+                                                                       unsigned int tile, unsigned int stream)
+{
+    unsigned long long z = (seed ^ (counter * 0xD1342543DE82EF95ull)) + (2ull * tile + stream + 1ull) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ float bc_sigmoid_repro(float x)
+{
+    float t = -x * 1.44269504f;                    // single rounding
+    t = fminf(fmaxf(t, -126.0f), 126.0f);
+    const float nf = rintf(t);
+    const float f = t - nf;                        // exact, |f| <= 0.5
+    float p = 1.54035304e-4f;                      // 2^f = sum (f ln 2)^k / k!, Horner with fused multiply-adds
+    p = fmaf(p, f, 1.33335581e-3f);
+    p = fmaf(p, f, 9.61812911e-3f);
+    p = fmaf(p, f, 5.55041087e-2f);
+    p = fmaf(p, f, 2.40226507e-1f);
+    p = fmaf(p, f, 6.93147181e-1f);
+    p = fmaf(p, f, 1.0f);
+    const float e = __uint_as_float(__float_as_uint(p) + ((uint32_t)(int32_t)nf << 23));   // p * 2^nf
+    return __fdiv_rn(1.0f, 1.0f + e);
+}
+
+constexpr int POLICY_MAX_TILES = 8192;
+
+__global__ __launch_bounds__(1024) void k_policy_step(const float *__restrict__ logits, int n_total, unsigned long long seed,
+                                                      unsigned long long counter, int multiple, int at_least_one,
+                                                      uint8_t *__restrict__ grid, int32_t *__restrict__ grid_idx,
+                                                      int32_t *__restrict__ mapping_exec, int32_t *__restrict__ counts,
+                                                      volatile int32_t *__restrict__ mailbox)
+{
+    __shared__ unsigned long long key[POLICY_MAX_TILES];    // (key40 << 16 | tile) of skipped tiles, ~0 for sampled ones
+    __shared__ int32_t wave_cnt[16];
+    __shared__ int32_t s_n, s_nan, carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { s_n = 0; s_nan = 0; carry = 0; }
+    __syncthreads();
+    // ---- 1. Bernoulli sample
+    int my_n = 0, my_nan = 0;
+    for (int i = tid; i < n_total; i += 1024) {
+        const float x = logits[i];
+        const bool nan = x != x;
+        const float u = (float)(bc_policy_rand(seed, counter, (unsigned)i, 0u) >> 40) * 5.9604644775390625e-8f;
+        const bool on = !nan && u < bc_sigmoid_repro(x);
+        my_n += on;
+        my_nan |= nan;
+        key[i] = on ? ~0ull : (((bc_policy_rand(seed, counter, (unsigned)i, 1u) >> 24) << 16) | (unsigned long long)i);
+    }
+    if (my_n) atomicAdd(&s_n, my_n);
+    if (my_nan) atomicOr(&s_nan, 1);
+    __syncthreads();
+    int n = s_n;
+    if (at_least_one && n == 0) {
+        if (tid == 0) key[0] = ~0ull;
+        n = 1;
+    }
+    __syncthreads();
+    // ---- 2. round the executed count up to a multiple: the `need` skipped tiles with the smallest keys are switched on
+    int rounded = 0;
+    if (n > 0) {
+        rounded = multiple * (1 + (n - 1) / multiple);
+        if (rounded > n_total) rounded = n_total;
+    }
+    const int need = rounded - n;
+    if (need > 0) {
+        bool add[POLICY_MAX_TILES / 1024];
+#pragma unroll
+        for (int r = 0; r < POLICY_MAX_TILES / 1024; ++r) {
+            const int i = tid + r * 1024;
+            add[r] = false;
+            if (i < n_total && key[i] != ~0ull) {
+                const unsigned long long mine = key[i];
+                int rank = 0;
+                for (int j = 0; j < n_total; ++j) rank += key[j] < mine;     // sampled tiles hold ~0: never smaller
+                add[r] = rank < need;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < POLICY_MAX_TILES / 1024; ++r)
+            if (add[r]) key[tid + r * 1024] = ~0ull;
+        __syncthreads();
+    }
+    // ---- 3. index tables (as k_grid_tables) + the bool grid
+    for (int base = 0; base < n_total; base += 1024) {
+        const int gidx = base + tid;
+        const bool on = gidx < n_total && key[gidx] == ~0ull;
+        const unsigned long long m = __ballot(on);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[wave] = __popcll(m);
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wave_cnt[w];
+        int chunk = 0;
+        for (int w = 0; w < 16; ++w) chunk += wave_cnt[w];
+        const int c0 = carry;
+        if (gidx < n_total) {
+            const int e = c0 + woff + before;
+            grid[gidx] = on ? 1 : 0;
+            if (on) { grid_idx[gidx] = e; mapping_exec[e] = gidx; }
+            else grid_idx[gidx] = -n_total + (gidx - e);
+        }
+        __syncthreads();
+        if (tid == 0) carry = c0 + chunk;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        counts[0] = carry; counts[1] = n; counts[2] = s_nan; counts[3] = (int32_t)counter;
+        if (mailbox) { mailbox[0] = carry; mailbox[1] = n; mailbox[2] = s_nan; mailbox[3] = (int32_t)counter; }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ per-tile bilinear resampling
 template <typename T> struct Cvt;
 template <> struct Cvt<float> {
@@ -2234,6 +2359,18 @@ BC_EXPORT int bc_grid_tables(const uint8_t *grid, int n_total, int32_t *grid_idx
     ProfScope ps(BC_OP_GRID_TABLES, 9.0 * n_total);
     BC_LAUNCH(ps, k_grid_tables, dim3(1), dim3(1024), 0, (hipStream_t)stream, grid, n_total, grid_idx,
                        mapping_exec, prev_grid_idx, transfer_idx, counts);
+    return launch_status();
+}
+
+BC_EXPORT int bc_policy_step(const float *logits, int n_total, unsigned long long seed, unsigned long long counter, int multiple,
+                              int at_least_one, uint8_t *grid, int32_t *grid_idx, int32_t *mapping_exec, int32_t *counts,
+                              int32_t *host_mailbox, void *stream)
+{
+    if (n_total <= 0 || n_total > POLICY_MAX_TILES || multiple <= 0) return BC_ERR_SHAPE;
+    if (!logits || !grid || !grid_idx || !mapping_exec || !counts) return BC_ERR_NULL;
+    ProfScope ps(BC_OP_GRID_TABLES, 13.0 * n_total);
+    BC_LAUNCH(ps, k_policy_step, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, n_total, seed, counter, multiple, at_least_one,
+              grid, grid_idx, mapping_exec, counts, (volatile int32_t *)host_mailbox);
     return launch_status();
 }
 

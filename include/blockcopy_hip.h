@@ -195,6 +195,20 @@ int bc_maxpool3x3s2_ring_nhwc(void *out, const void *features, void *ring, const
 int bc_nms_sorted(const float *boxes, int n, float iou_thr, unsigned long long *mask_ws, int32_t *keep,
                   int32_t *count, void *stream);
 
+/* device policy step: the per-frame decision of the online-RL policies without leaving the GPU.
+ * Replaces, in one launch: Bernoulli(logits).sample() + `.cpu()` (policy/policy.py:283-288), quantize_number_exec_grid
+ * (:124-144: Python random.sample on the host) and get_grid_mappings (core/tensorwrapper.py:108-128, CPU TorchScript).
+ *   logits float32[n_total] (raster order of the (N,1,GH,GW) grid); seed/counter: counter-based RNG (same arguments -> same
+ *   decision; the engine passes its frame counter); multiple = max(1, int(n_total * quantize_number_exec));
+ *   outputs: grid uint8[n_total] (1 = execute), grid_idx / mapping_exec as bc_grid_tables, counts int32[4] =
+ *   {n_exec, n_sampled (before rounding up), any-NaN-logit flag, low 32 bits of counter}; host_mailbox (optional): the same four
+ *   ints stored to device-visible pinned HOST memory so that the engine learns n_exec (it selects the captured graph)
+ *   without a device->host copy.  n_total <= 8192.  Exact arithmetic definition: csrc/blockcopy_hip.hip k_policy_step,
+ *   restated on the CPU by oracle/bc_oracle.c bc_oracle_policy_step (bit-identical decisions). */
+int bc_policy_step(const float *logits, int n_total, unsigned long long seed, unsigned long long counter, int multiple,
+                   int at_least_one, uint8_t *grid, int32_t *grid_idx, int32_t *mapping_exec, int32_t *counts,
+                   int32_t *host_mailbox, void *stream);
+
 /* tuning / A-B knob (measurement infrastructure; defaults are the shipped behaviour): key in
  *   "conv_impl"      1 = first-generation fused conv kernel, 2 = CU-balanced kernel (default)
  *   "conv2_cfg"      -1 = choose the decomposition per launch (default), 0..15 = force one (BC_ERR_SHAPE at launch if it does not fit)

@@ -21,7 +21,9 @@
  * reference-independent properties P1 (all-active == dense zero-padded conv)
  * and P2 (static clip invariance); see DESIGN.md "Oracle".
  */
+#include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #define BCO_API __attribute__((visibility("default")))
@@ -216,4 +218,78 @@ BCO_API int bco_nms_sorted(const float *boxes, int n, float thresh, int32_t *kee
         if (!removed) keep[num++] = i;
     }
     return num;
+}
+
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Policy step: Bernoulli sampling of tile logits + rounding the executed count up to a multiple + the bool grid
+ * (index tables: bco_grid_mappings above).  The PRODUCT defines this operation (include/blockcopy_hip.h bc_policy_step,
+ * csrc/blockcopy_hip.hip k_policy_step): the reference samples with torch's global RNG and Python's `random.sample`
+ * (blockcopy/blockcopy/policy/policy.py:124-144, 283-288), which no other implementation can reproduce, so the pinned
+ * contract is the product's counter-based RNG restated here operation by operation.  Compile without FP contraction. */
+static uint64_t bco_policy_rand(uint64_t seed, uint64_t counter, uint32_t tile, uint32_t stream)
+{
+    uint64_t z = (seed ^ (counter * 0xD1342543DE82EF95ull)) + (2ull * tile + stream + 1ull) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+static float bco_sigmoid_repro(float x)
+{
+    float t = -x * 1.44269504f;
+    t = fminf(fmaxf(t, -126.0f), 126.0f);
+    const float nf = rintf(t);
+    const float f = t - nf;
+    float p = 1.54035304e-4f;
+    p = fmaf(p, f, 1.33335581e-3f);
+    p = fmaf(p, f, 9.61812911e-3f);
+    p = fmaf(p, f, 5.55041087e-2f);
+    p = fmaf(p, f, 2.40226507e-1f);
+    p = fmaf(p, f, 6.93147181e-1f);
+    p = fmaf(p, f, 1.0f);
+    uint32_t bits;
+    memcpy(&bits, &p, 4);
+    bits += (uint32_t)(int32_t)nf << 23;
+    float e;
+    memcpy(&e, &bits, 4);
+    const float d = 1.0f + e;
+    return 1.0f / d;
+}
+
+/* grid[i] = 1 for executed tiles; returns n_exec; counts = {n_exec, n_sampled, nan flag}; probs (optional) = the sigmoid values */
+BCO_API int bco_policy_step(const float *logits, int n_total, uint64_t seed, uint64_t counter, int multiple, int at_least_one,
+                               uint8_t *grid, int32_t *counts, float *probs)
+{
+    int n = 0, nan_flag = 0;
+    uint64_t *key = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)n_total);
+    for (int i = 0; i < n_total; ++i) {
+        const float x = logits[i];
+        const int is_nan = x != x;
+        const float u = (float)(bco_policy_rand(seed, counter, (uint32_t)i, 0u) >> 40) * 5.9604644775390625e-8f;
+        const float pr = bco_sigmoid_repro(x);
+        if (probs) probs[i] = pr;
+        const int on = !is_nan && u < pr;
+        n += on;
+        nan_flag |= is_nan;
+        key[i] = on ? ~0ull : (((bco_policy_rand(seed, counter, (uint32_t)i, 1u) >> 24) << 16) | (uint64_t)i);
+    }
+    const int n_sampled = n;
+    if (at_least_one && n == 0) { key[0] = ~0ull; n = 1; }
+    int rounded = 0;
+    if (n > 0) {
+        rounded = multiple * (1 + (n - 1) / multiple);
+        if (rounded > n_total) rounded = n_total;
+    }
+    for (int need = rounded - n; need > 0; --need) {      /* switch on the skipped tile with the smallest key, `need` times */
+        int best = -1;
+        for (int i = 0; i < n_total; ++i)
+            if (key[i] != ~0ull && (best < 0 || key[i] < key[best])) best = i;
+        key[best] = ~0ull;
+        ++n;
+    }
+    for (int i = 0; i < n_total; ++i) grid[i] = key[i] == ~0ull;
+    free(key);
+    if (counts) { counts[0] = n; counts[1] = at_least_one && n_sampled == 0 ? 1 : n_sampled; counts[2] = nan_flag; }
+    return n;
 }

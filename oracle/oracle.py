@@ -140,6 +140,24 @@ def c_transfer_idx(prev_grid_idx, grid):
     return out[:n].copy()
 
 
+def c_policy_step(logits, seed, counter, multiple, at_least_one=False):
+    """CPU restatement of the product's device policy step (include/blockcopy_hip.h bc_policy_step): returns
+    (grid bool like logits, counts int32[3] = {n_exec, n_sampled, nan flag}, probs float32)."""
+    import ctypes
+
+    x = np.ascontiguousarray(_np(logits), dtype=np.float32)
+    grid = np.empty(x.size, np.uint8)
+    counts = np.zeros(3, np.int32)
+    probs = np.empty(x.size, np.float32)
+    fn = lib().bco_policy_step
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                   ctypes.c_void_p, ctypes.c_void_p]
+    fn.restype = ctypes.c_int
+    fn(_ptr(x), x.size, int(seed) & (2 ** 64 - 1), int(counter) & (2 ** 64 - 1), int(multiple), int(bool(at_least_one)), _ptr(grid),
+       _ptr(counts), _ptr(probs))
+    return grid.astype(bool).reshape(x.shape), counts, probs.reshape(x.shape)
+
+
 def c_nms(dets, iou_thr):
     """reference: nms_cuda, Pedestron/mmdet/ops/nms/src/nms_kernel.cu:70-130 -- original indices of the kept boxes, ascending.
     dets: (n,5) float32 [x1,y1,x2,y2,score]."""

@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
-"""Launches each hand-written kernel a few times at the shapes bench.py runs them at (C2) plus the large scatter+copy
-shape, with nothing else on the GPU -- the command to put behind `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
-(one counter per pass; a PMC pass over the whole bench.py takes >15 min because every MIOpen kernel is serialised)."""
+"""Launches every hand-written kernel of the DEFAULT bench path (channels-last fp32, C2 shapes, 64 of 128 tiles executed)
+plus the large scatter+copy shape a few times each, with nothing else on the GPU -- the command to put behind
+`rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (one counter per pass; a PMC pass over the whole bench.py takes >15 min
+because every library kernel is serialised).  Writes the manifest of what was launched, in launch order, with the
+ALGORITHMIC bytes of each launch (SURVEY.md section 8(d) formulas) to gpurun_out/pmc_manifest.json; tools/pmc_traffic.py
+joins it with the counter CSVs."""
+import json
 import os
 import sys
 
@@ -10,37 +14,78 @@ sys.path.insert(0, os.path.join(ROOT, "blockcopy-video-processing-pytorch_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
 
 import blockcopy.backend as bk  # noqa: E402
 from kbench import grid_tables  # noqa: E402
 
+REPS = 5
+
+
+def cl(t):
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+def halo_bytes(n, C, bs, p, E=4):
+    """repad formula: read (bs+2p)^2 - z, write (bs+2p)^2 per tile and channel; z (image-border zeros) ignored here (upper bound),
+    plus the ring refresh n*C*4*p*bs."""
+    return n * C * (2 * (bs + 2 * p) ** 2 + 4 * p * bs) * E
+
 
 def main():
     be = bk.get_backend()
-    reps = 5
-    # fused scatter+copy: C2 logits and C5 head
-    for (N, C, H, W, bs, n_exec) in [(1, 19, 256, 512, 32, 64), (1, 256, 256, 512, 32, 64)]:
-        gi, m = grid_tables(N, H // bs, W // bs, n_exec)
-        blocks = torch.randn((n_exec, C, bs, bs), device="cuda")
-        prev = torch.randn((N, C, H, W), device="cuda")
-        out = torch.empty_like(prev)
-        for _ in range(reps):
-            be.combine_copy(blocks, prev, out, gi)
+    manifest = []
+
+    def run(label, algorithmic_bytes, fn):
+        for _ in range(REPS):
+            fn()
         torch.cuda.synchronize()
-    # gather / in-place scatter of the network input
-    gi, m = grid_tables(1, 8, 16, 64)
+        manifest.append({"label": label, "algorithmic_bytes": float(algorithmic_bytes), "launches": REPS})
+
+    n = 64
+    gi, m = grid_tables(1, 8, 16, n)
+    # fused scatter+copy: C2 logits and the C5 head map
+    for (C, H, W, bs, name) in [(19, 256, 512, 32, "combine_copy C2 logits (1,19,256,512)"), (256, 256, 512, 32, "combine_copy C5 head (1,256,256,512)")]:
+        blocks = cl(torch.randn((n, C, bs, bs), device="cuda"))
+        prev = cl(torch.randn((1, C, H, W), device="cuda"))
+        out = torch.empty_like(prev)
+        run(name, 2.0 * C * H * W * 4, lambda: be.combine_copy(blocks, prev, out, gi))
+    # gather / in-place scatter of the network input (NCHW frame)
     img = torch.randn((1, 3, 1024, 2048), device="cuda")
-    blocks = torch.empty((64, 3, 128, 128), device="cuda")
-    for _ in range(reps):
-        be.split(blocks, img, m, gi)
-        be.combine(blocks, img, gi, m)
-    # halo gathers (layer1 and max-pool input shapes)
-    for (C, bs, p) in [(64, 32, 1), (64, 64, 1)]:
-        feats = torch.randn((64, C, bs, bs), device="cuda")
-        ring = torch.randn((128, C, 4 * p * bs), device="cuda")
-        for _ in range(reps):
-            be.pad_ring(feats, ring, gi, m, p)
-    torch.cuda.synchronize()
+    blocks = torch.empty((n, 3, 128, 128), device="cuda")
+    run("split network input (64,3,128,128)", 2.0 * n * 3 * 128 * 128 * 4, lambda: be.split(blocks, img, m, gi))
+    run("combine_ frame_state (64,3,128,128)", 2.0 * n * 3 * 128 * 128 * 4, lambda: be.combine(blocks, img, gi, m))
+    # channels-last halo gathers still on the default path: stride-2 conv inputs, stem pool
+    for (C, bs, name) in [(64, 32, "pad_ring_nhwc layer2.0.conv1 input (64,64,32,32)"), (128, 16, "pad_ring_nhwc layer3.0.conv1 input (64,128,16,16)"),
+                          (256, 8, "pad_ring_nhwc layer4.0.conv1 input (64,256,8,8)")]:
+        feats = cl(torch.randn((n, C, bs, bs), device="cuda"))
+        ring = torch.randn((128, C, 4 * bs), device="cuda")
+        sc = torch.rand(C, device="cuda") + 0.5
+        run(name, halo_bytes(n, C, bs, 1), lambda: be.pad_ring(feats, ring, gi, m, 1, (sc, sc, True)))
+        add = cl(torch.randn((n, C, bs, bs), device="cuda"))
+        run(name.replace("pad_ring_nhwc", "pad_ring_add_nhwc"), halo_bytes(n, C, bs, 1) + 2.0 * n * C * bs * bs * 4,
+            lambda: be.pad_ring_add(feats, add, ring, gi, m, 1, (sc, sc, True)))
+    feats = cl(torch.randn((n, 64, 64, 64), device="cuda"))
+    ring = torch.randn((128, 64, 4 * 64), device="cuda")
+    run("maxpool3x3s2_ring_nhwc stem (64,64,64,64)", n * 64 * 4 * ((64 + 1) ** 2 + 64 * 64 / 4 + 4 * 64),
+        lambda: be.maxpool3x3s2_ring(feats, ring, gi, m, None))
+    # fused halo+conv (CU-balanced kernel): bytes = input tiles + halo ring reads (~4*bs per tile and channel) + output + weights
+    for (Cin, Cout, bs, name) in [(64, 64, 32, "conv3x3 layer1"), (128, 128, 16, "conv3x3 layer2"), (256, 256, 8, "conv3x3 layer3"),
+                                  (512, 512, 4, "conv3x3 layer4"), (128, 128, 32, "conv3x3 up 1/4")]:
+        feats = cl(torch.randn((n, Cin, bs, bs), device="cuda"))
+        ring = torch.randn((128, Cin, 4 * bs), device="cuda")
+        wpk = be.pack_conv3x3_weights(torch.randn((Cout, Cin, 3, 3), device="cuda") * 0.05)
+        alg = 4.0 * (n * Cin * ((bs + 2) ** 2 + 4 * bs) + n * Cout * bs * bs + 9 * Cin * Cout)
+        run(f"{name} ({n},{Cin}->{Cout},{bs}x{bs})", alg, lambda: be.conv3x3_ring(feats, ring, wpk, Cout, gi, m, None, None))
+    # fused epilogue pass and per-tile bilinear resampling
+    x = cl(torch.randn((n, 128, 16, 16), device="cuda"))
+    sc = torch.rand(128, device="cuda")
+    run("affine_act_nhwc (64,128,16,16) + residual", 3.0 * x.numel() * 4, lambda: be.affine_act(x, sc, sc, x, True))
+    run("interp_bilinear_nhwc (64,128,16,16)->32x32 + skip add", (x.numel() + 2 * 4 * x.numel()) * 4.0,
+        lambda: be.interp_bilinear(x, 32, 32, False, 0.5, 0.5, (None, None, cl(torch.zeros((n, 128, 32, 32), device="cuda")), False)))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "pmc_manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=1)
 
 
 if __name__ == "__main__":

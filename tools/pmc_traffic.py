@@ -1,50 +1,50 @@
 #!/usr/bin/env python3
-"""Per-launch HBM traffic of the block-copy kernels from two rocprofv3 --pmc runs (FETCH_SIZE and WRITE_SIZE cannot
-share a pass: MI355X_MICROARCH.md 'rocprofv3 PMC slots').
+"""Per-launch HBM traffic of the hand-written kernels from two rocprofv3 --pmc runs of tools/pmc_driver.py (FETCH_SIZE and
+WRITE_SIZE cannot share a pass: MI355X_MICROARCH.md 'rocprofv3 PMC slots').
 
-usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> [out.json]
+usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <pmc_manifest.json> [out.json]
 Corrections for gfx950 as the guide prescribes: counter unit = KiB; FETCH_SIZE reports exactly half of the bytes of a
-wide coalesced read stream, so it is doubled; WRITE_SIZE is exact for 16-byte-per-lane stores."""
-import collections
+wide coalesced read stream, so it is doubled; WRITE_SIZE is exact for 16-byte-per-lane stores.  The i-th run of consecutive
+launches of one (kernel, grid) pair in dispatch order belongs to the i-th manifest entry (the driver launches each case
+REPS times back to back)."""
 import csv
 import json
 import re
 import sys
 
 
-def per_kernel(path, counter):
-    acc = collections.defaultdict(lambda: [0.0, 0])
-    for r in csv.DictReader(open(path)):
-        if r.get("Counter_Name") != counter:
-            continue
-        a = acc[(r["Kernel_Name"], int(r["Grid_Size"]))]
-        a[0] += float(r["Counter_Value"])
-        a[1] += 1
-    return acc
+def runs(path, counter):
+    rows = [r for r in csv.DictReader(open(path)) if r.get("Counter_Name") == counter and "(anonymous namespace)::k_" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    out = []
+    for r in rows:
+        key = (r["Kernel_Name"], int(r["Grid_Size"]))
+        if out and out[-1][0] == key:
+            out[-1][1].append(float(r["Counter_Value"]))
+        else:
+            out.append([key, [float(r["Counter_Value"])]])
+    return out
 
 
 def main():
-    fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
-    write = per_kernel(sys.argv[2], "WRITE_SIZE")
+    fetch, write = runs(sys.argv[1], "FETCH_SIZE"), runs(sys.argv[2], "WRITE_SIZE")
+    manifest = json.load(open(sys.argv[3]))
+    assert len(fetch) == len(write) == len(manifest), (len(fetch), len(write), len(manifest))
     out = {}
-    for key in sorted(set(fetch) | set(write)):
-        name, grid = key
-        m = re.search(r"\(anonymous namespace\)::(k_\w+(?:<[^(]*>)?)\(", name)
-        if not m:
-            continue
-        short = m.group(1) + f" grid={grid}"
-        f, fn = fetch.get(key, [0, 0])
-        w, wn = write.get(key, [0, 0])
-        n = max(fn, wn, 1)
-        rd, wr = 2.0 * f * 1024 / max(fn, 1), w * 1024 / max(wn, 1)
-        out[short] = dict(launches=n, read_bytes_per_launch=rd, write_bytes_per_launch=wr, hbm_bytes_per_launch=rd + wr)
-        print(f"{short:40s} launches {n:6d}  read {rd / 1e6:9.2f} MB  write {wr / 1e6:9.2f} MB  total {(rd + wr) / 1e6:9.2f} MB per launch")
-    if len(sys.argv) > 3:
-        # bench.py's roofline kernel: the C2 logits map (1,19,256,512) f32 = 622592 16-byte vectors, one per lane
-        cc = next((v for k, v in out.items() if k.startswith("k_combine_copy") and k.endswith("grid=622592")), None)
-        with open(sys.argv[3], "w") as fjson:
+    for (key, fv), (key2, wv), man in zip(fetch, write, manifest):
+        assert key == key2, (key, key2)
+        m = re.search(r"\(anonymous namespace\)::(k_\w+(?:<[^(]*>)?)\(", key[0])
+        rd, wr = 2.0 * 1024 * sum(fv) / len(fv), 1024 * sum(wv) / len(wv)
+        alg = man["algorithmic_bytes"]
+        out[man["label"]] = dict(kernel=m.group(1) if m else key[0][:60], grid=key[1], launches=len(fv), read_bytes_per_launch=rd,
+                                 write_bytes_per_launch=wr, hbm_bytes_per_launch=rd + wr, algorithmic_bytes_per_launch=alg,
+                                 traffic_over_algorithmic=(rd + wr) / alg)
+        print(f"{man['label']:62s} {out[man['label']]['kernel'][:44]:44s} read {rd / 1e6:8.2f} MB write {wr / 1e6:8.2f} MB | algorithmic {alg / 1e6:8.2f} MB | x{(rd + wr) / alg:5.2f}")
+    if len(sys.argv) > 4:
+        cc = out.get("combine_copy C2 logits (1,19,256,512)")
+        with open(sys.argv[4], "w") as fjson:
             json.dump({"k_combine_copy_bytes_per_launch": cc["hbm_bytes_per_launch"] if cc else None,
-                       "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of tools/pmc_driver.py (same kernel, same shape as bench.py's); FETCH_SIZE x2 (gfx950), KiB units",
+                       "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of tools/pmc_driver.py (same kernels and shapes as bench.py's default path); FETCH_SIZE x2 (gfx950), KiB units",
                        "kernels": out}, fjson, indent=1)
 
 
