@@ -83,6 +83,7 @@ def load_library(path: str = None) -> ctypes.CDLL:
         "bc_affine_act": [p, p, p, p, p, i, ctypes.c_longlong, i, ctypes.c_longlong, i, p],
         "bc_nms_sorted": [p, i, ctypes.c_float, p, p, p, p],
         "bc_policy_step": [p, i, ctypes.c_ulonglong, ctypes.c_ulonglong, i, i, p, p, p, p, p, p],
+        "bc_policy_features": [p, i, i, i, p, p, p, p, p],
         "bc_tune_set": [ctypes.c_char_p, i],
         "bc_tune_get": [ctypes.c_char_p, ctypes.POINTER(i)],
         "bc_tune_set_ptr": [ctypes.c_char_p, p],
@@ -312,25 +313,29 @@ class HipBackend:
         def _one(v):
             return v if isinstance(v, int) else (v[0] if len(set(v)) == 1 else None)
         bs = data_exec.shape[2]
-        return (data_exec.dtype == torch.float32 and weight.dtype == torch.float32 and is_nhwc(data_exec)
+        cin_unit = 32 if data_exec.dtype == torch.float32 else 64     # 16-bit: two 32-channel units are staged per K iteration
+        return (data_exec.dtype in _DTYPE_CODE and weight.dtype == data_exec.dtype and is_nhwc(data_exec)
                 and tuple(weight.shape[2:]) == (3, 3) and _one(stride) == 1 and _one(padding) == 1 and _one(dilation) == 1
-                and groups == 1 and weight.shape[1] % 32 == 0 and weight.shape[0] % 64 == 0
+                and groups == 1 and weight.shape[1] % cin_unit == 0 and weight.shape[0] % 64 == 0
                 and data_exec.shape[2] == data_exec.shape[3] and (bs == 4 or (bs % 8 == 0 and bs <= 248)))
 
     @staticmethod
     def pack_conv3x3_weights(weight):
-        """(Cout, Cin, 3, 3) -> the MFMA operand stream of bc_conv3x3_ring_nhwc (include/blockcopy_hip.h):
-        wpk[nb][chunk][tap][cg][lane][j] = W[32*nb + lane%32][32*chunk + 8*cg + 4*(lane//32) + j][tap]."""
+        """(Cout, Cin, 3, 3) -> the MFMA operand stream of bc_conv3x3_ring_nhwc (include/blockcopy_hip.h), in the weight's dtype:
+        wpk[nb][unit][tap][step][lane][j] = W[32*nb + lane%32][32*unit + 2*EPV*step + EPV*(lane//32) + j][tap] with EPV = elements
+        per 16-byte vector (4 for fp32: 4 steps per 32-channel unit; 8 for fp16 / bf16: 2 steps)."""
         Cout, Cin, kh, kw = weight.shape
         assert (kh, kw) == (3, 3) and Cin % 32 == 0 and Cout % 32 == 0
-        w = weight.detach().as_subclass(torch.Tensor).permute(2, 3, 1, 0).reshape(9, Cin // 32, 4, 2, 4, Cout // 32, 32)   # tap, chunk, cg, h, j, nb, n
-        return w.permute(5, 1, 0, 2, 3, 6, 4).contiguous().view(-1)                               # nb, chunk, tap, cg, h, n, j
+        epv = 16 // weight.element_size()
+        steps = 32 // (2 * epv)
+        w = weight.detach().as_subclass(torch.Tensor).permute(2, 3, 1, 0).reshape(9, Cin // 32, steps, 2, epv, Cout // 32, 32)   # tap, unit, step, h, j, nb, n
+        return w.permute(5, 1, 0, 2, 3, 6, 4).contiguous().view(-1)                                    # nb, unit, tap, step, h, n, j
 
     CONV2_CFGS = ((2, 2, 4, 2, 1), (2, 1, 4, 2, 1), (1, 2, 4, 2, 1), (1, 1, 4, 2, 1), (1, 1, 2, 4, 1), (1, 1, 2, 2, 2), (1, 1, 1, 4, 2),
                   (1, 1, 1, 2, 4), (2, 2, 2, 2, 2), (2, 2, 1, 2, 4), (2, 1, 2, 2, 2), (2, 1, 1, 4, 2), (2, 1, 1, 2, 4), (2, 1, 1, 1, 8),
                   (1, 2, 1, 1, 8), (1, 1, 1, 1, 8))    # (RM, RN, WMW, WNW, WKW) of csrc/blockcopy_hip.hip launch_conv3x3_v2
 
-    def conv3x3_candidates(self, n_exec, cin, cout, bs):
+    def conv3x3_candidates(self, n_exec, cin, cout, bs, elem_size=4):
         """Decomposition indices of the balanced conv kernel that cover this layer shape (same rules as the launcher)."""
         out = []
         for c, (rm, rn, wmw, wnw, wkw) in enumerate(self.CONV2_CFGS):
@@ -339,7 +344,8 @@ class HipBackend:
                     continue
             elif bs % 8 or bs % (4 * rm):
                 continue
-            if cout % (32 * rn * wnw) or (wkw == 8 and cin % 64):
+            sc = (2 if wkw == 8 else 1) * (1 if elem_size == 4 else 2)
+            if cout % (32 * rn * wnw) or cin % (32 * sc):
                 continue
             out.append(c)
         return out
@@ -370,7 +376,8 @@ class HipBackend:
     def conv3x3_ring(self, data_exec, ring, wpk, cout, grid_idx, mapping_exec, prologue=None, epilogue=None, cfg=None):
         """Fused halo gather + 3x3/s1/p1 conv (+ optional epilogue) of a channels-last packed batch on the fp32 matrix
         cores.  prologue = (scale, shift, relu) per input channel, epilogue = (scale, shift, add, relu) per output channel."""
-        assert _ok(data_exec, torch.float32) and is_nhwc(data_exec) and _ok(ring, torch.float32) and _ok(wpk, torch.float32)
+        dt = data_exec.dtype
+        assert _ok(data_exec, *_DTYPE_CODE) and is_nhwc(data_exec) and _ok(ring, dt) and _ok(wpk, dt)
         assert _ok(mapping_exec, torch.int32) and _ok(grid_idx, torch.int32)
         N, _, GH, GW = grid_idx.shape
         B, C, bs, _ = data_exec.shape
@@ -382,7 +389,7 @@ class HipBackend:
         osc, osh, oadd, orelu = epilogue if epilogue is not None else (None, None, None, False)
         for v, n in ((isc, C), (ish, C), (osc, cout), (osh, cout)):
             assert v is None or (_ok(v, torch.float32) and v.numel() == n)
-        assert oadd is None or (_ok(oadd, torch.float32) and oadd.shape == out.shape and is_nhwc(oadd))
+        assert oadd is None or (_ok(oadd, dt) and oadd.shape == out.shape and is_nhwc(oadd))
         ptr = lambda t: t.data_ptr() if t is not None else None
         if n_exec > 0:
             with torch.cuda.device_of(data_exec):
@@ -492,6 +499,30 @@ class HipBackend:
                                                 int(multiple), int(bool(at_least_one)), grid_u8.data_ptr(), tables.data_ptr(),
                                                 tables.data_ptr() + 4 * n_total, counts.data_ptr(),
                                                 mailbox.data_ptr() if mailbox is not None else None, self._stream()), "policy_step")
+
+    def policy_features(self, sources, h: int, w: int):
+        """One-gather input of the policy net: ``sources`` = 4 x (tensor (N,C,H,W) any strides, scale_h, scale_w, offset) ->
+        float32 (N, sum C, h, w) = concat of nearest-resampled sources (+ offset), ATen 'nearest' index arithmetic."""
+        assert len(sources) == 4
+        N = sources[0][0].shape[0]
+        ptrs = (ctypes.c_void_p * 4)()
+        strides = (ctypes.c_longlong * 16)()
+        dims = (ctypes.c_int * 16)()
+        scales = (ctypes.c_float * 12)()
+        ctot = 0
+        for k, (t, sh, sw, off) in enumerate(sources):
+            assert t.is_cuda and t.dim() == 4 and t.shape[0] == N
+            code = 3 if t.dtype in (torch.bool, torch.uint8) else _DTYPE_CODE[t.dtype]
+            ptrs[k] = t.data_ptr()
+            strides[4 * k:4 * k + 4] = list(t.stride())
+            dims[4 * k:4 * k + 4] = [t.shape[1], t.shape[2], t.shape[3], code]
+            scales[3 * k:3 * k + 3] = [float(sh), float(sw), float(off)]
+            ctot += t.shape[1]
+        out = torch.empty((N, ctot, h, w), dtype=torch.float32, device=sources[0][0].device)
+        with torch.cuda.device_of(out):
+            self._check(self.lib.bc_policy_features(out.data_ptr(), N, h, w, ptrs, strides, dims, scales, self._stream()), "policy_features")
+        self._keepalive = (ptrs, strides, dims, scales)   # (arguments are read at enqueue time; kept for tidiness)
+        return out
 
     def grid_tables_host(self, grid_u8: np.ndarray, grid_idx: np.ndarray, mapping: np.ndarray,
                          prev_grid_idx: np.ndarray = None, transfer: np.ndarray = None) -> int:

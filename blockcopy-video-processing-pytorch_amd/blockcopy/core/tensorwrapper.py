@@ -792,7 +792,7 @@ class TensorWrapper(torch.Tensor):
             wpk = fusion.packed_conv3x3_weight(weight, be.pack_conv3x3_weights)
             scratch = torch.zeros((n_total, cin, 4 * bs), dtype=data.dtype, device=data.device)   # a ring nobody else reads
             routes = {"library": lambda: torch.nn.functional.conv2d(be.pad_ring(data, scratch, grid_idx, mapping_exec, 1, None), w_plain.detach())}
-            for c in be.conv3x3_candidates(n_exec, cin, cout, bs):
+            for c in be.conv3x3_candidates(n_exec, cin, cout, bs, data.element_size()):
                 routes[str(c)] = (lambda c_: lambda: be.conv3x3_ring(data, scratch, wpk, cout, grid_idx, mapping_exec, None, None, cfg=c_))(c)
             return be.time_routes(routes)
 

@@ -21,6 +21,9 @@ import torch.nn.functional as F
 from blockcopy.policy.resnet import resnet8
 from blockcopy.utils.profiler import timings
 
+import os
+
+FUSED_FEATURES = os.environ.get("BLOCKCOPY_FUSED_FEATURES", "1") != "0"
 POLICY_PIXELS_PER_TILE = 32
 HEAD_WIDTH = 128
 
@@ -49,6 +52,10 @@ class PolicyNet(nn.Module):
         frame = policy_meta["inputs"]
         if frame.dim() != 4 or frame.size(1) != 3:
             raise ValueError(f"policy expects (N,3,H,W) frames, got {tuple(frame.shape)}")
+        if frame.is_cuda and FUSED_FEATURES:
+            fused = self._build_features_fused(policy_meta)
+            if fused is not None:
+                return fused
         low = F.interpolate(frame, scale_factor=self.scale_factor, mode="nearest").float()
         hw = low.shape[2:]
 
@@ -62,6 +69,29 @@ class PolicyNet(nn.Module):
                  at_policy_resolution(policy_meta.get("output_repr"), centre=True),
                  at_policy_resolution(policy_meta.get("grid"), centre=True)]
         return torch.cat(parts, dim=1).detach()
+
+    def _build_features_fused(self, policy_meta: Dict):
+        """The same tensor from ONE gather kernel (bc_policy_features) instead of 4 resamplings + casts + 2 subtractions +
+        concat; index arithmetic identical to F.interpolate(mode='nearest') (float32 scale: 1/scale_factor where a factor is
+        given, in/out where a size is given), so the result is bit-identical."""
+        import numpy as np
+
+        from blockcopy.backend import get_backend
+
+        be = get_backend()
+        if not hasattr(be, "policy_features"):
+            return None
+        frame, state, rep, grid = (policy_meta["inputs"], policy_meta["frame_state"], policy_meta.get("output_repr"), policy_meta.get("grid"))
+        ok = lambda t: t is not None and t.is_cuda and t.dim() == 4 and t.dtype in (torch.float32, torch.float16, torch.bfloat16, torch.bool, torch.uint8)
+        if not all(ok(t) for t in (frame, state, rep, grid)):
+            return None
+        H, W = frame.shape[2:]
+        h, w = int(np.floor(H * self.scale_factor)), int(np.floor(W * self.scale_factor))
+        by_factor = float(np.float32(1.0 / self.scale_factor))
+        by_size = lambda t: (float(np.float32(t.shape[2]) / np.float32(h)), float(np.float32(t.shape[3]) / np.float32(w)))
+        srcs = [(frame, by_factor, by_factor, 0.0), (state,) + by_size(state) + (0.0,), (rep,) + by_size(rep) + (-0.5,), (grid,) + by_size(grid) + (-0.5,)]
+        with torch.no_grad():
+            return be.policy_features(srcs, h, w)
 
     def forward(self, policy_meta: Dict) -> torch.Tensor:
         n, _, height, width = policy_meta["inputs"].shape

@@ -862,6 +862,49 @@ __global__ __launch_bounds__(1024) void k_policy_step(const float *__restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------ policy-net input features
+// The policy net's input (reference policy/net.py:82-113): frame, frame state, previous output scores and previous grid, each
+// brought to ONE low resolution by nearest-neighbour resampling and stacked along channels (scores and grid centred by -0.5).
+// The reference (and the first version here) runs four F.interpolate launches, casts, two subtractions and a concat; this is
+// one gather.  Source index exactly as ATen's legacy 'nearest': min((int)floorf(dst * scale), in - 1) with a float32 scale.
+struct FeatSrc {
+    const void *ptr;
+    long long sn, sc, sh, sw;   // element strides
+    int C, H, W, dtype;         // dtype: BC_F32 / BC_F16 / BC_BF16, 3 = uint8 / bool
+    float scale_h, scale_w, offset;
+};
+
+struct FeatGeom {
+    FeatSrc src[4];
+    int N, h, w, Ctot;
+};
+
+__device__ __forceinline__ float feat_load(const FeatSrc &s, long long off)
+{
+    switch (s.dtype) {
+    case 0: return reinterpret_cast<const float *>(s.ptr)[off];
+    case 1: return __half2float(reinterpret_cast<const __half *>(s.ptr)[off]);
+    case 2: return __uint_as_float((uint32_t)reinterpret_cast<const uint16_t *>(s.ptr)[off] << 16);
+    default: return reinterpret_cast<const uint8_t *>(s.ptr)[off] ? 1.0f : 0.0f;
+    }
+}
+
+__global__ __launch_bounds__(WG) void k_policy_features(float *__restrict__ out, FeatGeom g)
+{
+    const uint32_t total = (uint32_t)g.N * g.Ctot * g.h * g.w;
+    for (uint32_t i = blockIdx.x * WG + threadIdx.x; i < total; i += gridDim.x * WG) {
+        const uint32_t x = i % g.w, y = (i / g.w) % g.h, c = (i / (g.w * g.h)) % g.Ctot, n = i / (g.w * g.h * g.Ctot);
+        uint32_t cc = c;
+        int k = 0;
+        while (k < 3 && cc >= (uint32_t)g.src[k].C) { cc -= g.src[k].C; ++k; }
+        const FeatSrc &s = g.src[k];
+        int sy = (int)floorf((float)y * s.scale_h), sx = (int)floorf((float)x * s.scale_w);
+        sy = sy < s.H - 1 ? sy : s.H - 1;
+        sx = sx < s.W - 1 ? sx : s.W - 1;
+        out[i] = feat_load(s, n * s.sn + cc * s.sc + sy * s.sh + sx * s.sw) + s.offset;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ per-tile bilinear resampling
 template <typename T> struct Cvt;
 template <> struct Cvt<float> {
@@ -2048,47 +2091,51 @@ static int device_cu_count()
     return n;
 }
 
-template <int RM, int RN, int WMW, int WNW, int WKW, int PW>
+template <int DT, int RM, int RN, int WMW, int WNW, int WKW, int SC, int PW>
 static void launch_conv3x3_v2_cfg(ProfScope &ps, dim3 grid, size_t lds_bytes, hipStream_t st, void *out, const void *features, void *ring,
                                   const void *wpk, const int32_t *grid_idx, const int32_t *mapping_exec, const ConvGeom2 &g,
-                                  const Prologue &pr, const Epilogue &ep)
+                                  const Prologue &pr, const EpilogueT &ep)
 {
     static bool attr_set = false;   // > 64 KB of dynamic LDS needs the opt-in once per kernel
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_v2<RM, RN, WMW, WNW, WKW, PW>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_v2<DT, RM, RN, WMW, WNW, WKW, SC, PW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
         attr_set = true;
     }
-    BC_LAUNCH(ps, (k_conv3x3_v2<RM, RN, WMW, WNW, WKW, PW>), grid, dim3(512), lds_bytes, st, (float *)out, (const float *)features,
-              (long long)((const float *)ring - (const float *)features), (float *)ring, (const float4 *)wpk, grid_idx, mapping_exec,
-              g, pr, ep, g_tune.conv_stamps);
+    BC_LAUNCH(ps, (k_conv3x3_v2<DT, RM, RN, WMW, WNW, WKW, SC, PW>), grid, dim3(512), lds_bytes, st, (typename CvType<DT>::T *)out,
+              (const uint4 *)features, (long long)(((const char *)ring - (const char *)features) / 16), (uint4 *)ring, (const uint4 *)wpk,
+              grid_idx, mapping_exec, g, pr, ep, g_tune.conv_stamps);
 }
 
+static const Conv2Cfg CONV2_CFGS[] = {{2, 2, 4, 2, 1}, {2, 1, 4, 2, 1}, {1, 2, 4, 2, 1}, {1, 1, 4, 2, 1},     // 0-3: many pixels
+                                      {1, 1, 2, 4, 1}, {1, 1, 2, 2, 2}, {1, 1, 1, 4, 2}, {1, 1, 1, 2, 4},     // 4-7: 1x1 wave tiles
+                                      {2, 2, 2, 2, 2}, {2, 2, 1, 2, 4}, {2, 1, 2, 2, 2}, {2, 1, 1, 4, 2},     // 8-11: 2-block tiles + K groups
+                                      {2, 1, 1, 2, 4}, {2, 1, 1, 1, 8}, {1, 2, 1, 1, 8}, {1, 1, 1, 1, 8}};    // 12-15
+
+template <int DT>
 static int launch_conv3x3_v2(ProfScope &ps, void *out, const void *features, void *ring, const void *wpk, const int32_t *grid_idx,
                              const int32_t *mapping_exec, int n_exec, int Cin, int Cout, int GH, int GW, int bs,
-                             const Prologue &pr, const Epilogue &ep, hipStream_t st)
+                             const Prologue &pr, const EpilogueT &ep, hipStream_t st)
 {
-    static const Conv2Cfg cfgs[] = {{2, 2, 4, 2, 1}, {2, 1, 4, 2, 1}, {1, 2, 4, 2, 1}, {1, 1, 4, 2, 1},     // 0-3: many pixels
-                                    {1, 1, 2, 4, 1}, {1, 1, 2, 2, 2}, {1, 1, 1, 4, 2}, {1, 1, 1, 2, 4},     // 4-7: 1x1 wave tiles
-                                    {2, 2, 2, 2, 2}, {2, 2, 1, 2, 4}, {2, 1, 2, 2, 2}, {2, 1, 1, 4, 2},     // 8-11: 2-block tiles + K groups
-                                    {2, 1, 1, 2, 4}, {2, 1, 1, 1, 8}, {1, 2, 1, 1, 8}, {1, 1, 1, 1, 8}};    // 12-15
+    constexpr int E = CvType<DT>::E, UV = CvType<DT>::UV;
+    constexpr int SC_LO = DT == BC_F32 ? 1 : 2, SC_HI = 2 * SC_LO;      // 32-channel units staged per iteration (SC_HI with 8 K groups)
     const int force = g_tune.conv2_cfg, min_lds = g_tune.conv2_min_lds;
     const int pw = bs == 4 ? 4 : 8;
     if (pw == 8 && bs % 8 != 0) return BC_ERR_SHAPE;
     const int cus = device_cu_count();
     int best = -1;
     double best_t = 0;
-    for (int c = 0; c < (int)(sizeof(cfgs) / sizeof(cfgs[0])); ++c) {
-        const Conv2Cfg &k = cfgs[c];
+    for (int c = 0; c < (int)(sizeof(CONV2_CFGS) / sizeof(CONV2_CFGS[0])); ++c) {
+        const Conv2Cfg &k = CONV2_CFGS[c];
         if (force >= 0 && c != force) continue;
         if (pw == 4 && k.RM != 1 && k.WMW != 1) continue;      // 4x4 tiles: 4 tile slots per wave row only in single-row workgroups (LDS)
         if (pw == 8 && bs % (4 * k.RM) != 0) continue;
         if (Cout % (32 * k.RN * k.WNW) != 0) continue;
-        if (k.WKW == 8 && Cin % 64 != 0) continue;
+        if (Cin % (32 * (k.WKW == 8 ? SC_HI : SC_LO)) != 0) continue;
         const long long rows = pw == 8 ? (long long)n_exec * (bs / 8) * (bs / (4 * k.RM)) : ((long long)n_exec + 2 * k.RM - 1) / (2 * k.RM);
         const long long wgs = ((rows + k.WMW - 1) / k.WMW) * (Cout / (32 * k.RN * k.WNW));
         const long long rounds = (wgs + cus - 1) / cus;
-        const double mf = (double)k.RM * k.RN * 9.0 * (Cin / 8) * 4.0 / k.WKW;        // MFMAs per wave
+        const double mf = (double)k.RM * k.RN * 9.0 * (Cin / 8) * 4.0 / k.WKW;        // fp32 MFMAs per wave (16-bit: the same ranking)
         // per-MFMA slowdown from operand delivery (tools/probes/mfma_probe2: 1x1 tiles ~0.72, 2x1 ~0.79, 2x2 ~0.82 of peak)
         const double eff = k.RM * k.RN >= 4 ? 0.82 : (k.RM * k.RN == 2 ? (k.RM == 2 ? 0.79 : 0.74) : 0.70);
         const double t = rounds * (mf / eff + 70.0 + 12.0 * (k.WKW - 1) * k.RM * k.RN);
@@ -2096,7 +2143,7 @@ static int launch_conv3x3_v2(ProfScope &ps, void *out, const void *features, voi
     }
     if (best < 0) return BC_ERR_SHAPE;
     g_tune.conv_last_cfg = best;
-    const Conv2Cfg &k = cfgs[best];
+    const Conv2Cfg &k = CONV2_CFGS[best];
     ConvGeom2 g;
     g.Cin = Cin; g.Cout = Cout; g.bs = bs; g.GH = GH; g.GW = GW; g.n_exec = n_exec;
     g.patches_x = pw == 8 ? bs / 8 : 1;
@@ -2104,16 +2151,18 @@ static int launch_conv3x3_v2(ProfScope &ps, void *out, const void *features, voi
     g.n_rows = pw == 8 ? (uint32_t)n_exec * g.patches_per_tile : ((uint32_t)n_exec + 2 * k.RM - 1) / (2 * k.RM);
     g.cin_chunks = Cin / CV_CH;
     const uint32_t slot_px = pw == 8 ? 10u * (4 * k.RM + 2) : 36u, tpr = pw == 8 ? 1u : 2u * k.RM;
-    const uint32_t chp = CV_CH * (k.WKW > 4 ? k.WKW / 4 : 1) + 4;
-    const size_t img = (size_t)k.WMW * tpr * slot_px * chp * sizeof(float);
+    const uint32_t chp = UV * (k.WKW == 8 ? SC_HI : SC_LO) + 1;        // pixel stride in 16-byte vectors
+    const size_t img = (size_t)k.WMW * tpr * slot_px * chp * 16;
     const size_t red = (size_t)k.WMW * k.WNW * (k.WKW - 1) * k.RM * k.RN * 16 * 64 * sizeof(float);
     size_t lds_bytes = 2 * img > red ? 2 * img : red;
     if (lds_bytes < (size_t)min_lds) lds_bytes = min_lds;      // one workgroup per CU: two waves on every SIMD, no more
+    (void)E;
     const dim3 grid((g.n_rows + k.WMW - 1) / k.WMW, (unsigned)Cout / (32 * k.RN * k.WNW));
 #define BC_CV2(RM_, RN_, WMW_, WNW_, WKW_)                                                                                   \
     do {                                                                                                                 \
-        if (pw == 8) launch_conv3x3_v2_cfg<RM_, RN_, WMW_, WNW_, WKW_, 8>(ps, grid, lds_bytes, st, out, features, ring, wpk, grid_idx, mapping_exec, g, pr, ep); \
-        else launch_conv3x3_v2_cfg<(WMW_ == 1 ? RM_ : 1), RN_, WMW_, WNW_, WKW_, 4>(ps, grid, lds_bytes, st, out, features, ring, wpk, grid_idx, mapping_exec, g, pr, ep); \
+        constexpr int SC_ = WKW_ == 8 ? SC_HI : SC_LO;                                                                   \
+        if (pw == 8) launch_conv3x3_v2_cfg<DT, RM_, RN_, WMW_, WNW_, WKW_, SC_, 8>(ps, grid, lds_bytes, st, out, features, ring, wpk, grid_idx, mapping_exec, g, pr, ep); \
+        else launch_conv3x3_v2_cfg<DT, (WMW_ == 1 ? RM_ : 1), RN_, WMW_, WNW_, WKW_, SC_, 4>(ps, grid, lds_bytes, st, out, features, ring, wpk, grid_idx, mapping_exec, g, pr, ep); \
     } while (0)
     switch (best) {
     case 0: BC_CV2(2, 2, 4, 2, 1); break;
@@ -2171,7 +2220,7 @@ BC_EXPORT int bc_conv3x3_ring_nhwc(void *out, const void *features, void *ring, 
                                    int GH, int GW, int bs, int dtype, const float *in_scale, const float *in_shift, int in_relu,
                                    const float *out_scale, const float *out_shift, const void *out_add, int out_relu, void *stream)
 {
-    if (dtype != BC_F32) return BC_ERR_ELEM;
+    if (dtype < BC_F32 || dtype > BC_BF16) return BC_ERR_ELEM;
     if (n_exec < 0 || N <= 0 || Cin <= 0 || Cout <= 0 || GH <= 0 || GW <= 0 || bs <= 0) return BC_ERR_SHAPE;
     if (Cin % CV_CH != 0 || Cout % 64 != 0) return BC_ERR_SHAPE;
     if (!(bs == 4 || bs % 8 == 0) || bs > 248) return BC_ERR_SHAPE;
@@ -2179,18 +2228,24 @@ BC_EXPORT int bc_conv3x3_ring_nhwc(void *out, const void *features, void *ring, 
     if (!out || !features || !ring || !weights_packed || !grid_idx || !mapping_exec) return BC_ERR_NULL;
     if ((uint64_t)n_exec * bs * bs * (uint64_t)(Cin > Cout ? Cin : Cout) >= (1ull << 31) ||
         (uint64_t)N * GH * GW * 4 * bs * Cin >= (1ull << 31)) return BC_ERR_RANGE;
-    if (!aligned(out, 16) || !aligned(features, 16) || !aligned(ring, 16) || !aligned(weights_packed, 16) || !aligned(out_add, 4))
+    if (!aligned(out, 16) || !aligned(features, 16) || !aligned(ring, 16) || !aligned(weights_packed, 16) || !aligned(out_add, 2))
         return BC_ERR_ALIGN;
     Prologue pr{in_scale, in_shift, in_relu};
-    Epilogue ep{out_scale, out_shift, (const float *)out_add, out_relu};
     ProfScope ps(BC_OP_CONV3X3, 2.0 * n_exec * bs * bs * 9.0 * Cin * Cout);   // FLOPs, not bytes: the op is MFMA-bound
-    // BC_CONV_IMPL=1 selects the first-generation kernel (A/B runs); default: the CU-balanced kernel (conv3x3_v2.inc)
-    if (g_tune.conv_impl != 1) {
-        const int rc = launch_conv3x3_v2(ps, out, features, ring, weights_packed, grid_idx, mapping_exec, n_exec, Cin, Cout, GH, GW, bs,
-                                         pr, ep, (hipStream_t)stream);
-        if (rc != BC_ERR_SHAPE) return rc;   // shapes the balanced kernel does not cover fall through
+    // conv_impl = 1 selects the first-generation kernel (fp32 only; A/B runs); default: the CU-balanced kernel (conv3x3_v2.inc)
+    if (g_tune.conv_impl != 1 || dtype != BC_F32) {
+        EpilogueT ept{out_scale, out_shift, out_add, out_relu};
+        int rc;
+        if (dtype == BC_F32)
+            rc = launch_conv3x3_v2<BC_F32>(ps, out, features, ring, weights_packed, grid_idx, mapping_exec, n_exec, Cin, Cout, GH, GW, bs, pr, ept, (hipStream_t)stream);
+        else if (dtype == BC_F16)
+            rc = launch_conv3x3_v2<BC_F16>(ps, out, features, ring, weights_packed, grid_idx, mapping_exec, n_exec, Cin, Cout, GH, GW, bs, pr, ept, (hipStream_t)stream);
+        else
+            rc = launch_conv3x3_v2<BC_BF16>(ps, out, features, ring, weights_packed, grid_idx, mapping_exec, n_exec, Cin, Cout, GH, GW, bs, pr, ept, (hipStream_t)stream);
+        if (rc != BC_ERR_SHAPE || dtype != BC_F32) return rc;   // fp32 shapes the balanced kernel does not cover fall through
     }
     g_tune.conv_last_cfg = -1;
+    Epilogue ep{out_scale, out_shift, (const float *)out_add, out_relu};
     // workgroup = 32*WM pixels x 64 output channels.  64-pixel items halve the weight traffic and the halo overhead; 32-pixel
     // items balance better over the 256 CUs when there are few of them (measured, profiles/r01/kbench_conv_*.txt).
     // BC_CONV_WM=1|2 overrides for A/B runs.
@@ -2371,6 +2426,31 @@ BC_EXPORT int bc_policy_step(const float *logits, int n_total, unsigned long lon
     ProfScope ps(BC_OP_GRID_TABLES, 13.0 * n_total);
     BC_LAUNCH(ps, k_policy_step, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, n_total, seed, counter, multiple, at_least_one,
               grid, grid_idx, mapping_exec, counts, (volatile int32_t *)host_mailbox);
+    return launch_status();
+}
+
+BC_EXPORT int bc_policy_features(float *out, int N, int h, int w, const void *const *ptrs, const long long *strides, const int *dims,
+                                  const float *scales, void *stream)
+{
+    if (!out || !ptrs || !strides || !dims || !scales) return BC_ERR_NULL;
+    if (N <= 0 || h <= 0 || w <= 0) return BC_ERR_SHAPE;
+    FeatGeom g;
+    g.N = N; g.h = h; g.w = w; g.Ctot = 0;
+    for (int k = 0; k < 4; ++k) {
+        FeatSrc &s = g.src[k];
+        s.ptr = ptrs[k];
+        if (!s.ptr) return BC_ERR_NULL;
+        s.sn = strides[4 * k]; s.sc = strides[4 * k + 1]; s.sh = strides[4 * k + 2]; s.sw = strides[4 * k + 3];
+        s.C = dims[4 * k]; s.H = dims[4 * k + 1]; s.W = dims[4 * k + 2]; s.dtype = dims[4 * k + 3];
+        if (s.C <= 0 || s.H <= 0 || s.W <= 0 || s.dtype < 0 || s.dtype > 3) return BC_ERR_SHAPE;
+        s.scale_h = scales[3 * k]; s.scale_w = scales[3 * k + 1]; s.offset = scales[3 * k + 2];
+        g.Ctot += s.C;
+    }
+    const uint64_t total = (uint64_t)N * g.Ctot * h * w;
+    if (total >= (1ull << 31)) return BC_ERR_RANGE;
+    ProfScope ps(BC_OP_AFFINE, 2.0 * total * 4);
+    const unsigned grid = (unsigned)((total + WG - 1) / WG < (uint64_t)MAX_WG * 4 ? (total + WG - 1) / WG : (uint64_t)MAX_WG * 4);
+    BC_LAUNCH(ps, k_policy_features, dim3(grid), dim3(WG), 0, (hipStream_t)stream, out, g);
     return launch_status();
 }
 

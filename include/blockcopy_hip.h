@@ -158,11 +158,15 @@ int bc_interp_bilinear_act_nhwc(void *out, const void *in, long long planes, int
  *   with pad = 1 (read for non-executed neighbours, refreshed with the RAW border of every executed tile);
  *   prologue: x -> relu?(x*in_scale[cin] + in_shift[cin]) on real values, zeros beyond the image border stay zero;
  *   epilogue: y -> relu?(y*out_scale[cout] + out_shift[cout] + out_add[pixel, cout]); any of them may be NULL/0.
- *   weights_packed: float32[9 * Cin * Cout] in the MFMA operand order
- *       wpk[nb][chunk][tap][cg][lane][j] = W[cout = 32*nb + lane%32][cin = 32*chunk + 8*cg + 4*(lane/32) + j][ky = tap/3][kx = tap%3]
- *   (nb < Cout/32, chunk < Cin/32, tap 0..8, cg < 4, lane < 64, j < 4) -- a pure permutation of the (Cout, Cin, 3, 3) weight.
- * Arithmetic: exact fp32 (v_mfma_f32_32x32x2_f32 = k-ordered fma chain), summation order cin-chunk / tap / channel.
- * Constraints: dtype = BC_F32, Cin % 32 == 0, Cout % 64 == 0, bs = 4 or a multiple of 8 (<= 248), 16-byte aligned. */
+ *   weights_packed: 9 * Cin * Cout elements of the tensor dtype in the MFMA operand order
+ *       wpk[nb][unit][tap][step][lane][j] = W[cout = 32*nb + lane%32][cin = 32*unit + 2*EPV*step + EPV*(lane/32) + j][ky = tap/3][kx = tap%3]
+ *   with EPV = 16 / elem_size (nb < Cout/32, unit < Cin/32, tap 0..8, step < 16/EPV, lane < 64, j < EPV) -- a pure permutation of
+ *   the (Cout, Cin, 3, 3) weight.
+ * Arithmetic: BC_F32: exact fp32 (v_mfma_f32_32x32x2_f32 = k-ordered fma chain); BC_F16 / BC_BF16: v_mfma_f32_32x32x16_f16 / _bf16
+ * with fp32 accumulation, epilogue in fp32, ONE rounding to the tensor dtype at the store; the prologue rounds each gathered
+ * element to the tensor dtype exactly like bc_pad_ring_nhwc does.  Summation order: cin-unit / tap / channel (K groups of one
+ * workgroup are added in a fixed order: deterministic).
+ * Constraints: Cin % 32 == 0 (16-bit: % 64), Cout % 64 == 0, bs = 4 or a multiple of 8 (<= 248), 16-byte aligned pointers. */
 int bc_conv3x3_ring_nhwc(void *out, const void *features, void *ring, const void *weights_packed,
                          const int32_t *grid_idx, const int32_t *mapping_exec, int n_exec, int N, int Cin, int Cout,
                          int GH, int GW, int bs, int dtype, const float *in_scale, const float *in_shift, int in_relu,
@@ -208,6 +212,14 @@ int bc_nms_sorted(const float *boxes, int n, float iou_thr, unsigned long long *
 int bc_policy_step(const float *logits, int n_total, unsigned long long seed, unsigned long long counter, int multiple,
                    int at_least_one, uint8_t *grid, int32_t *grid_idx, int32_t *mapping_exec, int32_t *counts,
                    int32_t *host_mailbox, void *stream);
+
+/* input features of the policy net in one gather (replaces the four nearest-neighbour F.interpolate calls, casts, -0.5
+ * centring and concat of policy/net.py:82-113): out float32 (N, sum C_k, h, w) contiguous = concat over k = 0..3 of
+ * nearest(src_k) + offset_k, src index = min((int)floorf(dst * scale), in - 1) per axis (ATen's legacy 'nearest').
+ * Per source k: ptrs[k]; strides[4k..] = element strides (n, c, h, w); dims[4k..] = {C, H, W, dtype} with dtype BC_F32 /
+ * BC_F16 / BC_BF16 / 3 = uint8 (bool); scales[3k..] = {scale_h, scale_w, offset}. */
+int bc_policy_features(float *out, int N, int h, int w, const void *const *ptrs, const long long *strides, const int *dims,
+                       const float *scales, void *stream);
 
 /* tuning / A-B knob (measurement infrastructure; defaults are the shipped behaviour): key in
  *   "conv_impl"      1 = first-generation fused conv kernel, 2 = CU-balanced kernel (default)

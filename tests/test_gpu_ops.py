@@ -487,6 +487,56 @@ def test_fused_conv3x3_matches_halo_plus_conv(be, case):
         assert torch.equal(ring_a, ring_b), (case, t)
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 4, 6, 7, 9, 11, 12, 13, 15])
+def test_fused_conv3x3_half_precision(be, cfg, dtype, tol):
+    """The same kernel on v_mfma_f32_32x32x16_f16 / _bf16 (fp32 accumulation, one rounding at the store): forced
+    decompositions and the library's own choice against halo gather (same per-element prologue rounding) + fp64 conv of the
+    16-bit values + fp32 epilogue; ring caches bit-identical."""
+    import torch.nn.functional as F
+
+    rng = np.random.default_rng(900 + cfg)
+    gen = torch.Generator().manual_seed(900 + cfg)
+    be.tune("conv2_cfg", cfg)
+    try:
+        for case, (Cin, Cout, bs, N, GH, GW) in enumerate([(64, 128, 8, 1, 3, 5), (128, 128, 16, 2, 2, 3), (256, 256, 4, 1, 4, 7),
+                                                            (64, 64, 32, 1, 2, 2), (128, 128, 4, 1, 5, 5), (192, 128, 24, 1, 2, 3)]):
+            if cfg in (0, 1, 8, 10) and bs == 4:
+                continue
+            if cfg >= 13 and Cin % 128:
+                continue
+            if cfg in (0, 2, 4, 6, 8, 9, 11, 14) and Cout % 128:
+                continue
+            T = N * GH * GW
+            w = (torch.randn((Cout, Cin, 3, 3), generator=gen) * (2.0 / (9 * Cin)) ** 0.5).cuda().to(dtype)
+            wpk = be.pack_conv3x3_weights(w)
+            ring_a, ring_b = torch.zeros((T, Cin, 4 * bs), dtype=dtype).cuda(), torch.zeros((T, Cin, 4 * bs), dtype=dtype).cuda()
+            for t in range(3):
+                g = np.ones(T, bool) if t == 0 else rng.random(T) < (0.3, 0.5, 0.8)[t]
+                if not g.any():
+                    g[int(rng.integers(T))] = True
+                gi, m = O.c_grid_mappings(g.reshape(N, 1, GH, GW))
+                gi_d, m_d = _dev(gi), _dev(m)
+                feats = _cl(torch.randn((len(m), Cin, bs, bs), generator=gen).cuda().to(dtype))
+                pro = None if t == 0 else ((torch.rand(Cin, generator=gen) + 0.5).cuda(), (torch.randn(Cin, generator=gen) * 0.1).cuda(), t == 2)
+                add = _cl(torch.randn((len(m), Cout, bs, bs), generator=gen).cuda().to(dtype)) if t == 1 else None
+                epi = None if t == 0 else ((torch.rand(Cout, generator=gen) + 0.5).cuda(), (torch.randn(Cout, generator=gen) * 0.1).cuda(), add, t == 1)
+                want = F.conv2d(be.pad_ring(feats, ring_a, gi_d, m_d, 1, pro).double(), w.double())
+                if epi is not None:
+                    want = want * epi[0].view(1, -1, 1, 1) + epi[1].view(1, -1, 1, 1)
+                    if epi[2] is not None:
+                        want = want + epi[2].double()
+                    if epi[3]:
+                        want = torch.relu(want)
+                got = be.conv3x3_ring(feats, ring_b, wpk, Cout, gi_d, m_d, pro, epi)
+                assert got.dtype == dtype and (cfg < 0 or be.tune_get("conv_last_cfg") == cfg)
+                err = (got.double() - want).abs().max().item()
+                assert err <= tol * max(1.0, want.abs().max().item()), (cfg, case, t, err)
+                assert torch.equal(ring_a, ring_b), (cfg, case, t)
+    finally:
+        be.tune("conv2_cfg", -1)
+
+
 @pytest.mark.parametrize("cfg", list(range(16)))
 def test_fused_conv3x3_every_decomposition(be, cfg):
     """The CU-balanced conv kernel (csrc/conv3x3_v2.inc) picks one of 16 decompositions per launch (register blocking

@@ -360,6 +360,12 @@ def test_conv3x3_weight_packing_matches_the_header_formula():
         nb, chunk, tap, cg, lane, j = (int(rng.integers(n)) for n in (Cout // 32, Cin // 32, 9, 4, 64, 4))
         want = w[32 * nb + lane % 32, 32 * chunk + 8 * cg + 4 * (lane // 32) + j, tap // 3, tap % 3]
         assert wpk[nb, chunk, tap, cg, lane, j] == want
+    # 16-bit weights: 8 elements per 16-byte vector, 2 steps per 32-channel unit
+    w16 = torch.arange(Cout * Cin * 9, dtype=torch.float32).reshape(Cout, Cin, 3, 3).to(torch.int16)      # (exact integers; the permutation is dtype-agnostic)
+    wpk16 = HipBackend.pack_conv3x3_weights(w16).reshape(Cout // 32, Cin // 32, 9, 2, 64, 8)
+    for _ in range(500):
+        nb, unit, tap, step, lane, j = (int(rng.integers(n)) for n in (Cout // 32, Cin // 32, 9, 2, 64, 8))
+        assert wpk16[nb, unit, tap, step, lane, j] == w16[32 * nb + lane % 32, 32 * unit + 16 * step + 8 * (lane // 32) + j, tap // 3, tap % 3]
 
 
 def test_fusion_switch_off_gives_the_same_logits(golden_dir, oracle_backend):

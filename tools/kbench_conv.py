@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--cfgs", default="", help="comma list of forced conv2 decompositions to time besides auto (e.g. 0,1,2,3,4,5,6,7)")
     ap.add_argument("--no-lib", action="store_true")
     ap.add_argument("--n", type=int, default=0, help="override the executed-tile count of every case")
+    ap.add_argument("--dtype", default="float32", choices=["float32", "float16", "bfloat16"])
     a = ap.parse_args()
     torch.backends.cudnn.benchmark = True
     be = bk.get_backend()
@@ -44,9 +45,10 @@ def main():
         if a.n:
             n_exec = a.n
         gi, m = grid_tables(N, GH, GW // N if False else GW, n_exec) if N == 1 else grid_tables(2, GH, GW, n_exec)
-        feats = torch.randn((n_exec, Cin, bs, bs), device="cuda").contiguous(memory_format=torch.channels_last)
-        ring = torch.randn((N * GH * GW, Cin, 4 * bs), device="cuda")
-        w = (torch.randn((Cout, Cin, 3, 3), device="cuda") * 0.05).contiguous(memory_format=torch.channels_last)
+        dt = getattr(torch, a.dtype)
+        feats = torch.randn((n_exec, Cin, bs, bs), device="cuda").to(dt).contiguous(memory_format=torch.channels_last)
+        ring = torch.randn((N * GH * GW, Cin, 4 * bs), device="cuda").to(dt)
+        w = (torch.randn((Cout, Cin, 3, 3), device="cuda") * 0.05).to(dt).contiguous(memory_format=torch.channels_last)
         wpk = be.pack_conv3x3_weights(w)
         sc = torch.rand(Cin, device="cuda") + 0.5
         pro = (sc, sc, True)
@@ -62,20 +64,25 @@ def main():
             lib_path()   # MIOpen find
             us_halo = timeit(lambda: be.pad_ring(feats, ring, gi, m, 1, pro), a.iters)
             us_lib = timeit(lib_path, a.iters)
-        be.tune("conv_impl", 1)
-        us_v1 = timeit(fused, a.iters)
-        be.tune("conv_impl", 2)
+        if dt == torch.float32:
+            be.tune("conv_impl", 1)
+            us_v1 = timeit(fused, a.iters)
+            be.tune("conv_impl", 2)
+        else:
+            us_v1 = float("nan")
         us_v2 = timeit(fused, a.iters)
-        extra = ""
+        extra = f" auto=c{be.tune_get('conv_last_cfg')}"
         for c in [int(x) for x in a.cfgs.split(",") if x != ""]:
             be.tune("conv2_cfg", c)
+            if c not in be.conv3x3_candidates(n_exec, Cin, Cout, bs, feats.element_size()):
+                continue
             try:
                 extra += f" c{c}={timeit(fused, a.iters):.1f}"
             finally:
                 be.tune("conv2_cfg", -1)
         tf = lambda us: flops / us / 1e6
         print(f"{name:18s} ({n_exec},{Cin}->{Cout},{bs}x{bs}) {flops / 1e9:6.2f} GFLOP | halo {us_halo:6.1f} + conv {us_lib - us_halo:6.1f} = {us_lib:6.1f} us"
-              f" ({tf(us_lib):5.1f} TF) | v1 {us_v1:6.1f} us ({tf(us_v1) / 157.3:4.0%}) | v2 {us_v2:6.1f} us ({tf(us_v2):5.1f} TF = {tf(us_v2) / 157.3:4.0%} of fp32 MFMA peak)"
+              f" ({tf(us_lib):5.1f} TF) | v1 {us_v1:6.1f} us ({tf(us_v1) / 157.3:4.0%}) | v2 {us_v2:6.1f} us ({tf(us_v2):5.1f} TF = {tf(us_v2) / 157.3:4.0%} of fp32 MFMA peak; 16-bit peak is 16x)"
               f" | v2 vs lib x{us_lib / us_v2:4.2f}, vs v1 x{us_v1 / us_v2:4.2f}{extra}", flush=True)
 
 
