@@ -61,6 +61,9 @@ def parse_args(argv=None):
     ap.add_argument("--miopen-find", type=int, default=1, help="torch.backends.cudnn.benchmark during warm-up")
     ap.add_argument("--cpu-frames", type=int, default=8)
     ap.add_argument("--graph", type=int, default=1, help="hipGraph replay of the packed pipeline (0 = eager launches)")
+    ap.add_argument("--config", default=None, choices=["C2", "C3", "C4", "C5"],
+                    help="BASELINE.json config preset: C2 (default workload), C3 = --policy rl_semseg --target 0.3, C4 = SwiftNet-RN50 "
+                         "2048x4096 block 64 target 0.25, C5 = CSP-ResNet50 pedestrian detector 1024x2048 block 128 target 0.3 (one stream per GPU)")
     ap.add_argument("--upload-variant", type=int, default=1, help="1 (default, N=1): also report the PCIe-inclusive fps of the reference's full loop")
     ap.add_argument("--stub-cpu", action="store_true",
                     help="(tests only) replace the GPU workload by a tiny CPU stand-in so that the launcher, the per-rank "
@@ -68,7 +71,15 @@ def parse_args(argv=None):
     ap.add_argument("--oversubscribe", action="store_true",
                     help="(tests only) let several replicas share a GPU when fewer than --gpus devices are visible")
     ap.add_argument("--launch-timeout", type=float, default=3000.0, help="seconds before the launcher gives up on its replicas")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    args.workload = "swiftnet"
+    if args.config == "C3":
+        args.policy, args.target = "rl_semseg", 0.3
+    elif args.config == "C4":
+        args.backbone, args.height, args.width, args.block_size, args.target = "resnet50", 2048, 4096, 64, 0.25
+    elif args.config == "C5":
+        args.workload, args.target, args.backbone = "csp", 0.3, "csp_resnet50"
+    return args
 
 
 def cpu_dense_baseline(args, n_frames):
@@ -94,8 +105,42 @@ def cpu_dense_baseline(args, n_frames):
                       f"PyTorch CPU oneDNN conv, BN folded, after 1 warm-up frame ({dt:.1f} s)"}
 
 
+class _Detector:
+    """The CSP detector behind the call convention the clip harness uses (model(frame), reset_temporal(), .policy)."""
+
+    def __init__(self, det):
+        self.det = det
+        self.policy = getattr(det, "policy", None)
+
+    def reset_temporal(self):
+        if hasattr(self.det, "reset_temporal"):
+            self.det.reset_temporal()
+
+    def __call__(self, frame):
+        return self.det.simple_test(frame)
+
+
+def build_workload(args, policy, dtype, device, rank, graph=None):
+    """The model of the selected config: SwiftNet behind BlockCopyModel (C2-C4) or the CSP detector (C5); policy 'static' = dense."""
+    from bc_workloads import harness
+
+    graph = args.graph if graph is None else graph
+    if args.workload == "csp":
+        from bc_workloads.csp import build_csp
+
+        kw = {} if policy == "static" else dict(block_size=args.block_size, block_target=args.target, block_graph=graph, seed=1000 * rank)
+        return _Detector(build_csp(block_policy=policy, device=device, dtype=dtype, channels_last=bool(args.channels_last), **kw))
+    if policy == "static":
+        return harness.build_model(args.backbone, block_policy="static", device=device, dtype=dtype, channels_last=bool(args.channels_last))
+    return harness.build_model(args.backbone, block_policy=policy, block_size=args.block_size, block_target=args.target, device=device,
+                               dtype=dtype, seed=1000 * rank, block_graph=graph, block_train_interval=args.train_interval,
+                               channels_last=bool(args.channels_last))
+
+
 def config_name(args):
     """Which BASELINE.json config the arguments correspond to."""
+    if args.workload == "csp":
+        return "C5"
     if args.batch != 1:
         return f"custom(batch {args.batch})"
     base = (args.backbone, args.height, args.width, args.block_size)
@@ -296,16 +341,14 @@ def main(argv=None):
     shape = (args.batch, 3, args.height, args.width)
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
 
-    model = harness.build_model(args.backbone, block_policy=args.policy, block_size=args.block_size, block_target=args.target,
-                                device=device, dtype=dtype, seed=1000 * rank,
-                                block_graph=args.graph, block_train_interval=args.train_interval,
-                                channels_last=bool(args.channels_last))
+    is_csp = args.workload == "csp"
+    model = build_workload(args, args.policy, dtype, device, rank)
     # per-rank clips (clip i of the job lives on rank i mod N); inputs resident in HBM before the clock starts
     n_distinct = 2
     clips = [harness.synthetic_clip(CLIP_LEN, shape, seed=(rank * n_distinct + c) * 100, device=device, dtype=dtype) for c in range(n_distinct)]
 
     t_w0 = time.perf_counter()
-    if args.graph and args.policy != "fixed":
+    if args.graph and args.policy != "fixed" and not is_csp:
         # data-dependent policies visit many executed-tile counts: warm + capture all quantised buckets up front
         harness.run_clip(model, clips[0][:1])
         model.prewarm(clips[0][0])
@@ -341,7 +384,8 @@ def main(argv=None):
         # halo-gather kernel statistics from one extra, untimed clip (events around all 21 launches per frame)
         be.prof_reset()
         be.prof_enable(["pad_ring", "split", "combine"])
-        use_graph, model.use_graph = model.use_graph, False   # per-launch events need eager launches
+        inner = model.det if is_csp else model
+        use_graph, inner.use_graph = inner.use_graph, False   # per-launch events (eager mode, NOT the timed mode) need eager launches
         harness.run_clip(model, clips[0])
         torch.cuda.synchronize(device)
         be.prof_enable([])
@@ -349,7 +393,8 @@ def main(argv=None):
             r = be.prof_read(op)
             if r["launches"]:
                 extra[op] = {"launches_per_frame": r["launches"] / CLIP_LEN, "avg_us": 1e3 * r["total_ms"] / r["launches"],
-                             "GBps": r["total_bytes"] / (r["total_ms"] * 1e-3) / 1e9, "MB_per_frame": r["total_bytes"] / CLIP_LEN / 1e6}
+                             "GBps": r["total_bytes"] / (r["total_ms"] * 1e-3) / 1e9, "MB_per_frame": r["total_bytes"] / CLIP_LEN / 1e6,
+                             "mode": "eager launches (in-library events per launch); the timed region replays hipGraphs"}
         # host-side enqueue cost of one clip (no sync inside): tells whether the frame is CPU- or GPU-bound
         torch.cuda.synchronize(device)
         th = time.perf_counter()
@@ -357,7 +402,7 @@ def main(argv=None):
         host_s = time.perf_counter() - th
         torch.cuda.synchronize(device)
         extra["eager_host_enqueue_ms_per_frame"] = 1e3 * host_s / CLIP_LEN
-        model.use_graph = use_graph
+        inner.use_graph = use_graph
         torch.cuda.synchronize(device)
         th = time.perf_counter()
         harness.run_clip(model, clips[0])
@@ -365,7 +410,7 @@ def main(argv=None):
         torch.cuda.synchronize(device)
         extra["host_enqueue_ms_per_frame"] = 1e3 * host_s / CLIP_LEN
         extra["roofline_large"] = scatter_copy_large(be, device)
-        if world == 1 and args.upload_variant:
+        if world == 1 and args.upload_variant and not is_csp:
             # the reference driver's complete loop: per-frame upload from pinned host memory + last-frame upsample / argmax / .cpu()
             # (test_swiftnet.py:181-197); the headline `value` keeps inputs resident in HBM, these two figures do not
             hclips = [[f.cpu() for f in clips[0]]]
@@ -383,8 +428,7 @@ def main(argv=None):
                                    "us": round(times[best], 1), "library_us": round(times.get("library", float("nan")), 1)}
                                   for k, times, best in fusion.CONV_TUNE_LOG]
         if not args.no_dense and world == 1:
-            dense = harness.build_model(args.backbone, block_policy="static", device=device, dtype=dtype,
-                                        channels_last=bool(args.channels_last))
+            dense = build_workload(args, "static", dtype, device, rank)
             dfps, _, _ = harness.measure_fps(dense, clips[:1], n_clips=max(1, min(args.steps, 3)), warmup_clips=1, device=device)
             extra["dense_gpu_fps"] = dfps
             extra["speedup_vs_dense_gpu"] = fps / dfps
@@ -394,17 +438,15 @@ def main(argv=None):
                 del model
                 torch.cuda.empty_cache()
                 h = torch.float16
-                hm = harness.build_model(args.backbone, block_policy=args.policy, block_size=args.block_size, block_target=args.target,
-                                         device=device, dtype=h, seed=1000 * rank, block_graph=args.graph,
-                                         block_train_interval=args.train_interval, channels_last=bool(args.channels_last))
+                hm = build_workload(args, args.policy, h, device, rank)
                 hclips = [[f.to(h) for f in clips[0]]]
                 hfps, _, _ = harness.measure_fps(hm, hclips, n_clips=max(1, min(args.steps, 3)), warmup_clips=2, device=device)
-                hd = harness.build_model(args.backbone, block_policy="static", device=device, dtype=h, channels_last=bool(args.channels_last))
+                hd = build_workload(args, "static", h, device, rank)
                 hdfps, _, _ = harness.measure_fps(hd, hclips, n_clips=max(1, min(args.steps, 3)), warmup_clips=1, device=device)
                 extra["fp16"] = {"fps": hfps, "dense_gpu_fps": hdfps, "speedup_vs_dense_gpu": hfps / hdfps,
                                  "note": "same workload, weights and masks in float16 (not parity-gated; the headline value is fp32)"}
                 del hm, hd
-                if args.batch == 1:
+                if args.batch == 1 and not is_csp:
                     # secondary measurement: two clips side by side (the reference's speed configs use --batch-size 2)
                     torch.cuda.empty_cache()
                     bshape = (2, 3, args.height, args.width)
@@ -429,7 +471,7 @@ def main(argv=None):
             "metric": METRIC, "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16" if args.half else "f32", "data": "synthetic",
-            "config": {"workload": f"{config_name(args)}: SwiftNet-{args.backbone} {shape[0]}x3x{args.height}x{args.width} synthetic clips of {CLIP_LEN} frames, "
+            "config": {"workload": f"{config_name(args)}: {'CSP-ResNet50 pedestrian detector (backbone + neck + head + decode + NMS)' if is_csp else 'SwiftNet-' + args.backbone} {shape[0]}x3x{args.height}x{args.width} synthetic clips of {CLIP_LEN} frames, "
                                    f"block {args.block_size}, policy {args.policy} target {args.target:.0%} (frame 0 of each clip all-active), "
                                    f"{args.engine} engine{' + hipGraph replay' if args.graph else ''}{', channels-last' if args.channels_last else ''}, name-seeded weights, BN folded; step = 1 clip",
                        "clips_per_rank": args.steps, "parallelism": f"{world} independent replica(s), no collective",
