@@ -424,7 +424,7 @@ def main(argv=None):
             extra["upload_inclusive"] = up
         from blockcopy.core import fusion
         # measured route per padded 3x3 layer shape (fusion.conv3x3_plan): library = halo gather + MIOpen, cN = fused kernel
-        extra["conv3x3_plans"] = [{"n_exec": k[0], "tile": k[1], "cin": k[2], "cout": k[3], "choice": best,
+        extra["conv3x3_plans"] = [{"n_exec": k[0], "tile": k[1], "cin": k[2], "cout": k[3], "stride": k[6], "choice": best,
                                    "us": round(times[best], 1), "library_us": round(times.get("library", float("nan")), 1)}
                                   for k, times, best in fusion.CONV_TUNE_LOG]
         if not args.no_dense and world == 1:

@@ -78,6 +78,8 @@ def load_library(path: str = None) -> ctypes.CDLL:
         "bc_maxpool3x3s2_ring_nhwc": [p, p, p, p, p] + [i] * 7 + [p, p, i, p],
         "bc_pad_ring_add_nhwc": [p, p, p, p, p, p, p] + [i] * 8 + [p, p, i, p],
         "bc_conv3x3_ring_nhwc": [p, p, p, p, p, p] + [i] * 8 + [p, p, i, p, p, p, i, p],
+        "bc_conv3x3s2_ring_nhwc": [p, p, p, p, p, p] + [i] * 8 + [p, p, i, p, p, p, i, p],
+        "bc_conv3x3_candidates": [i, i, i, i, i, i, ctypes.POINTER(i), i],
         "bc_interp_bilinear_nhwc": [p, p, ctypes.c_longlong, i, i, i, i, i, i, ctypes.c_float, ctypes.c_float, i, p],
         "bc_interp_bilinear_act_nhwc": [p, p, ctypes.c_longlong, i, i, i, i, i, i, ctypes.c_float, ctypes.c_float, i, p, p, p, i, p],
         "bc_affine_act": [p, p, p, p, p, i, ctypes.c_longlong, i, ctypes.c_longlong, i, p],
@@ -312,12 +314,15 @@ class HipBackend:
         """Shapes the fused MFMA conv covers (everything else goes halo gather + library conv)."""
         def _one(v):
             return v if isinstance(v, int) else (v[0] if len(set(v)) == 1 else None)
-        bs = data_exec.shape[2]
+        st = _one(stride)
+        if st not in (1, 2) or data_exec.shape[2] % st:
+            return False
+        bs = data_exec.shape[2] // st                                 # output tile size
         cin_unit = 32 if data_exec.dtype == torch.float32 else 64     # 16-bit: two 32-channel units are staged per K iteration
         return (data_exec.dtype in _DTYPE_CODE and weight.dtype == data_exec.dtype and is_nhwc(data_exec)
-                and tuple(weight.shape[2:]) == (3, 3) and _one(stride) == 1 and _one(padding) == 1 and _one(dilation) == 1
+                and tuple(weight.shape[2:]) == (3, 3) and _one(padding) == 1 and _one(dilation) == 1
                 and groups == 1 and weight.shape[1] % cin_unit == 0 and weight.shape[0] % 64 == 0
-                and data_exec.shape[2] == data_exec.shape[3] and (bs == 4 or (bs % 8 == 0 and bs <= 248)))
+                and data_exec.shape[2] == data_exec.shape[3] and (bs == 4 or (bs % 8 == 0 and bs * st <= 248)))
 
     @staticmethod
     def pack_conv3x3_weights(weight):
@@ -331,24 +336,15 @@ class HipBackend:
         w = weight.detach().as_subclass(torch.Tensor).permute(2, 3, 1, 0).reshape(9, Cin // 32, steps, 2, epv, Cout // 32, 32)   # tap, unit, step, h, j, nb, n
         return w.permute(5, 1, 0, 2, 3, 6, 4).contiguous().view(-1)                                    # nb, unit, tap, step, h, n, j
 
-    CONV2_CFGS = ((2, 2, 4, 2, 1), (2, 1, 4, 2, 1), (1, 2, 4, 2, 1), (1, 1, 4, 2, 1), (1, 1, 2, 4, 1), (1, 1, 2, 2, 2), (1, 1, 1, 4, 2),
-                  (1, 1, 1, 2, 4), (2, 2, 2, 2, 2), (2, 2, 1, 2, 4), (2, 1, 2, 2, 2), (2, 1, 1, 4, 2), (2, 1, 1, 2, 4), (2, 1, 1, 1, 8),
-                  (1, 2, 1, 1, 8), (1, 1, 1, 1, 8))    # (RM, RN, WMW, WNW, WKW) of csrc/blockcopy_hip.hip launch_conv3x3_v2
-
-    def conv3x3_candidates(self, n_exec, cin, cout, bs, elem_size=4):
-        """Decomposition indices of the balanced conv kernel that cover this layer shape (same rules as the launcher)."""
-        out = []
-        for c, (rm, rn, wmw, wnw, wkw) in enumerate(self.CONV2_CFGS):
-            if bs == 4:
-                if rm != 1 and wmw != 1:
-                    continue
-            elif bs % 8 or bs % (4 * rm):
-                continue
-            sc = (2 if wkw == 8 else 1) * (1 if elem_size == 4 else 2)
-            if cout % (32 * rn * wnw) or cin % (32 * sc):
-                continue
-            out.append(c)
-        return out
+    def conv3x3_candidates(self, n_exec, cin, cout, bs, elem_size=4, stride=1):
+        """Decomposition indices of the balanced conv kernel that cover this layer shape (bs = input tile size), straight from
+        the library's launcher rules (bc_conv3x3_candidates)."""
+        buf = (ctypes.c_int * 32)()
+        dt = 0 if elem_size == 4 else 1
+        n = self.lib.bc_conv3x3_candidates(dt, int(stride), int(n_exec), int(cin), int(cout), int(bs), buf, 32)
+        if n < 0:
+            return []
+        return [int(buf[k]) for k in range(n)]
 
     @staticmethod
     def time_routes(routes, reps=3, launches=4):
@@ -373,7 +369,7 @@ class HipBackend:
             out[name] = sorted(ts)[len(ts) // 2]
         return out
 
-    def conv3x3_ring(self, data_exec, ring, wpk, cout, grid_idx, mapping_exec, prologue=None, epilogue=None, cfg=None):
+    def conv3x3_ring(self, data_exec, ring, wpk, cout, grid_idx, mapping_exec, prologue=None, epilogue=None, cfg=None, stride=1):
         """Fused halo gather + 3x3/s1/p1 conv (+ optional epilogue) of a channels-last packed batch on the fp32 matrix
         cores.  prologue = (scale, shift, relu) per input channel, epilogue = (scale, shift, add, relu) per output channel."""
         dt = data_exec.dtype
@@ -384,7 +380,8 @@ class HipBackend:
         n_exec = mapping_exec.numel()
         assert n_exec == B and wpk.numel() == 9 * C * cout
         assert tuple(ring.shape) == (N * GH * GW, C, 4 * bs), (ring.shape, (N * GH * GW, C, 4 * bs))
-        out = empty_like_layout((B, cout, bs, bs), data_exec)
+        assert stride in (1, 2) and bs % stride == 0
+        out = empty_like_layout((B, cout, bs // stride, bs // stride), data_exec)
         isc, ish, irelu = prologue if prologue is not None else (None, None, False)
         osc, osh, oadd, orelu = epilogue if epilogue is not None else (None, None, None, False)
         for v, n in ((isc, C), (ish, C), (osc, cout), (osh, cout)):
@@ -397,10 +394,11 @@ class HipBackend:
                 if want != self._conv_cfg:
                     self._check(self.lib.bc_tune_set(b"conv2_cfg", want), "tune_set")
                     self._conv_cfg = want
-                self._check(self.lib.bc_conv3x3_ring_nhwc(out.data_ptr(), data_exec.data_ptr(), ring.data_ptr(), wpk.data_ptr(),
-                                                          grid_idx.data_ptr(), mapping_exec.data_ptr(), n_exec, N, C, cout, GH, GW,
-                                                          bs, _DTYPE_CODE[data_exec.dtype], ptr(isc), ptr(ish), int(bool(irelu)),
-                                                          ptr(osc), ptr(osh), ptr(oadd), int(bool(orelu)), self._stream()),
+                fn = self.lib.bc_conv3x3_ring_nhwc if stride == 1 else self.lib.bc_conv3x3s2_ring_nhwc
+                self._check(fn(out.data_ptr(), data_exec.data_ptr(), ring.data_ptr(), wpk.data_ptr(),
+                               grid_idx.data_ptr(), mapping_exec.data_ptr(), n_exec, N, C, cout, GH, GW,
+                               bs, _DTYPE_CODE[data_exec.dtype], ptr(isc), ptr(ish), int(bool(irelu)),
+                               ptr(osc), ptr(osh), ptr(oadd), int(bool(orelu)), self._stream()),
                             "conv3x3_ring_nhwc")
         return out
 

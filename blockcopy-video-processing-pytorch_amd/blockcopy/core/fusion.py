@@ -131,7 +131,7 @@ def default_native_conv3x3(n_exec: int, bs: int, cin: int, cout: int) -> bool:
     return not (bs <= 4 and n_exec * bs * bs < 1024)
 
 
-def conv3x3_plan(n_exec: int, bs: int, cin: int, cout: int, n_total: int, dtype, tuner=None):
+def conv3x3_plan(n_exec: int, bs: int, cin: int, cout: int, n_total: int, dtype, tuner=None, stride: int = 1):
     """How to run one padded 3x3 / stride 1 conv layer: ``None`` = halo gather + library conv, ``int`` = the fused
     halo+conv kernel with that decomposition (-1: the library's cost model).  In ``auto`` mode a new layer shape is
     MEASURED once (``tuner()`` times the library route and every decomposition on the live tensors) -- the same idea as the
@@ -140,7 +140,7 @@ def conv3x3_plan(n_exec: int, bs: int, cin: int, cout: int, n_total: int, dtype,
         return None
     if CONV_MODE == "native":
         return -1
-    key = (n_exec, bs, cin, cout, n_total, dtype)
+    key = (n_exec, bs, cin, cout, n_total, dtype, stride)
     if key in _conv_plans:
         return _conv_plans[key]
     capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
@@ -152,7 +152,7 @@ def conv3x3_plan(n_exec: int, bs: int, cin: int, cout: int, n_total: int, dtype,
             _conv_plans[key] = plan
             CONV_TUNE_LOG.append((key, times, best))
             return plan
-    return -1 if default_native_conv3x3(n_exec, bs, cin, cout) else None
+    return -1 if default_native_conv3x3(n_exec, bs // stride, cin, cout) else None
 
 
 def batchnorm_affine(running_mean, running_var, weight, bias, eps):

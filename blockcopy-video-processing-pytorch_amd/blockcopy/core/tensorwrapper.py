@@ -730,7 +730,8 @@ class TensorWrapper(torch.Tensor):
                 ring = feats.next_ring(data, padding)
                 feats._pad_memo = None
                 with timings.env("tensorwrapper/conv3x3_fused", 10):
-                    return be.conv3x3_ring(data, ring, wpk, weight.shape[0], grid_idx, mapping_exec, prologue, None, cfg=plan), pend_out
+                    return be.conv3x3_ring(data, ring, wpk, weight.shape[0], grid_idx, mapping_exec, prologue, None, cfg=plan,
+                                           stride=self._conv_stride(args, kwargs)), pend_out
         if feats.engine == "fused" and fuse and op == "max_pool2d" and padding == 1:
             # the ResNet stem pool (3x3, stride 2): halo gather + max in one kernel, no padded tensor
             be = get_backend()
@@ -775,6 +776,11 @@ class TensorWrapper(torch.Tensor):
         with timings.env("tensorwrapper/pad_func", 11):
             return func(*args, **kwargs), pend_out
 
+    @staticmethod
+    def _conv_stride(args, kwargs) -> int:
+        st = kwargs.get("stride", args[3] if len(args) > 3 else 1)
+        return st if isinstance(st, int) else st[0]
+
     def _conv3x3_plan(self, be, data, args, kwargs, grid_idx, mapping_exec, func):
         """None = halo gather + library conv; int = fused halo+conv kernel with that decomposition (fusion.conv3x3_plan)."""
         weight = args[1] if len(args) > 1 else kwargs.get("weight")
@@ -784,6 +790,7 @@ class TensorWrapper(torch.Tensor):
             return None
         n_exec, cin, bs = data.shape[0], data.shape[1], data.shape[2]
         cout, n_total = weight.shape[0], grid_idx.numel()
+        stride = self._conv_stride(args, kwargs)
 
         def tuner():
             if not hasattr(be, "conv3x3_candidates") or not data.is_cuda:
@@ -791,12 +798,12 @@ class TensorWrapper(torch.Tensor):
             w_plain = weight.as_subclass(torch.Tensor) if isinstance(weight, TensorWrapper) else weight
             wpk = fusion.packed_conv3x3_weight(weight, be.pack_conv3x3_weights)
             scratch = torch.zeros((n_total, cin, 4 * bs), dtype=data.dtype, device=data.device)   # a ring nobody else reads
-            routes = {"library": lambda: torch.nn.functional.conv2d(be.pad_ring(data, scratch, grid_idx, mapping_exec, 1, None), w_plain.detach())}
-            for c in be.conv3x3_candidates(n_exec, cin, cout, bs, data.element_size()):
-                routes[str(c)] = (lambda c_: lambda: be.conv3x3_ring(data, scratch, wpk, cout, grid_idx, mapping_exec, None, None, cfg=c_))(c)
+            routes = {"library": lambda: torch.nn.functional.conv2d(be.pad_ring(data, scratch, grid_idx, mapping_exec, 1, None), w_plain.detach(), stride=stride)}
+            for c in be.conv3x3_candidates(n_exec, cin, cout, bs, data.element_size(), stride):
+                routes[str(c)] = (lambda c_: lambda: be.conv3x3_ring(data, scratch, wpk, cout, grid_idx, mapping_exec, None, None, cfg=c_, stride=stride))(c)
             return be.time_routes(routes)
 
-        return fusion.conv3x3_plan(n_exec, bs, cin, cout, n_total, data.dtype, tuner)
+        return fusion.conv3x3_plan(n_exec, bs, cin, cout, n_total, data.dtype, tuner, stride)
 
     def _residual_gather_ok(self, op, x, P, args, kwargs, padding) -> bool:
         """Can the pending residual add of ``x`` be folded into this padded op's halo gather?"""

@@ -16,6 +16,7 @@
 #include <hip/hip_fp16.h>
 #include <hip/hip_bfloat16.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -2091,18 +2092,18 @@ static int device_cu_count()
     return n;
 }
 
-template <int DT, int RM, int RN, int WMW, int WNW, int WKW, int SC, int PW>
+template <int DT, int RM, int RN, int WMW, int WNW, int WKW, int SC, int PW, int S>
 static void launch_conv3x3_v2_cfg(ProfScope &ps, dim3 grid, size_t lds_bytes, hipStream_t st, void *out, const void *features, void *ring,
                                   const void *wpk, const int32_t *grid_idx, const int32_t *mapping_exec, const ConvGeom2 &g,
                                   const Prologue &pr, const EpilogueT &ep)
 {
     static bool attr_set = false;   // > 64 KB of dynamic LDS needs the opt-in once per kernel
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_v2<DT, RM, RN, WMW, WNW, WKW, SC, PW>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_v2<DT, RM, RN, WMW, WNW, WKW, SC, PW, S>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
         attr_set = true;
     }
-    BC_LAUNCH(ps, (k_conv3x3_v2<DT, RM, RN, WMW, WNW, WKW, SC, PW>), grid, dim3(512), lds_bytes, st, (typename CvType<DT>::T *)out,
+    BC_LAUNCH(ps, (k_conv3x3_v2<DT, RM, RN, WMW, WNW, WKW, SC, PW, S>), grid, dim3(512), lds_bytes, st, (typename CvType<DT>::T *)out,
               (const uint4 *)features, (long long)(((const char *)ring - (const char *)features) / 16), (uint4 *)ring, (const uint4 *)wpk,
               grid_idx, mapping_exec, g, pr, ep, g_tune.conv_stamps);
 }
@@ -2112,57 +2113,83 @@ static const Conv2Cfg CONV2_CFGS[] = {{2, 2, 4, 2, 1}, {2, 1, 4, 2, 1}, {1, 2, 4
                                       {2, 2, 2, 2, 2}, {2, 2, 1, 2, 4}, {2, 1, 2, 2, 2}, {2, 1, 1, 4, 2},     // 8-11: 2-block tiles + K groups
                                       {2, 1, 1, 2, 4}, {2, 1, 1, 1, 8}, {1, 2, 1, 1, 8}, {1, 1, 1, 1, 8}};    // 12-15
 
-template <int DT>
+// geometry of one decomposition for a layer (bs = OUTPUT tile size); false if the decomposition does not cover the layer
+struct Conv2Plan { long long wgs; size_t lds_bytes; uint32_t n_rows, patches_per_tile, patches_x; };
+
+static bool conv2_plan(const Conv2Cfg &k, int E, int S, int n_exec, int Cin, int Cout, int bs, Conv2Plan &p)
+{
+    const int pw = bs == 4 ? 4 : 8;
+    const int uv = E == 4 ? 8 : 4, sc_lo = E == 4 ? 1 : 2;
+    const int sc = k.WKW == 8 ? 2 * sc_lo : sc_lo;
+    if (pw == 8 && bs % 8 != 0) return false;
+    if (pw == 4 && k.RM != 1 && k.WMW != 1) return false;       // 4x4 tiles: 4 tile slots per wave row only in single-row workgroups (LDS)
+    if (pw == 8 && bs % (4 * k.RM) != 0) return false;
+    if (Cout % (32 * k.RN * k.WNW) != 0 || Cin % (32 * sc) != 0) return false;
+    const uint32_t ph = pw == 8 ? 4u * k.RM : 4u, tpr = pw == 8 ? 1u : 2u * k.RM;
+    const uint32_t slot_px = (uint32_t)(S * pw + 3 - S) * (S * ph + 3 - S);
+    const size_t img = (size_t)k.WMW * tpr * slot_px * (uv * sc + 1) * 16;
+    const size_t red = (size_t)k.WMW * k.WNW * (k.WKW - 1) * k.RM * k.RN * 16 * 64 * sizeof(float);
+    p.lds_bytes = 2 * img > red ? 2 * img : red;
+    if (p.lds_bytes > 160 * 1024 - 2048 - 1024) return false;   // (static tables of the kernel take < 1 KB)
+    p.patches_x = pw == 8 ? bs / 8 : 1;
+    p.patches_per_tile = pw == 8 ? (bs / 8) * (bs / ph) : 1;
+    p.n_rows = pw == 8 ? (uint32_t)n_exec * p.patches_per_tile : ((uint32_t)n_exec + tpr - 1) / tpr;
+    p.wgs = (long long)((p.n_rows + k.WMW - 1) / k.WMW) * (Cout / (32 * k.RN * k.WNW));
+    return true;
+}
+
+template <int DT, int S>
 static int launch_conv3x3_v2(ProfScope &ps, void *out, const void *features, void *ring, const void *wpk, const int32_t *grid_idx,
                              const int32_t *mapping_exec, int n_exec, int Cin, int Cout, int GH, int GW, int bs,
                              const Prologue &pr, const EpilogueT &ep, hipStream_t st)
 {
-    constexpr int E = CvType<DT>::E, UV = CvType<DT>::UV;
+    constexpr int E = CvType<DT>::E;
     constexpr int SC_LO = DT == BC_F32 ? 1 : 2, SC_HI = 2 * SC_LO;      // 32-channel units staged per iteration (SC_HI with 8 K groups)
     const int force = g_tune.conv2_cfg, min_lds = g_tune.conv2_min_lds;
     const int pw = bs == 4 ? 4 : 8;
-    if (pw == 8 && bs % 8 != 0) return BC_ERR_SHAPE;
     const int cus = device_cu_count();
+    static const bool dbg_model = getenv("BC_CONV2_DEBUG") != nullptr;
     int best = -1;
     double best_t = 0;
+    Conv2Plan plan, best_plan{};
     for (int c = 0; c < (int)(sizeof(CONV2_CFGS) / sizeof(CONV2_CFGS[0])); ++c) {
         const Conv2Cfg &k = CONV2_CFGS[c];
         if (force >= 0 && c != force) continue;
-        if (pw == 4 && k.RM != 1 && k.WMW != 1) continue;      // 4x4 tiles: 4 tile slots per wave row only in single-row workgroups (LDS)
-        if (pw == 8 && bs % (4 * k.RM) != 0) continue;
-        if (Cout % (32 * k.RN * k.WNW) != 0) continue;
-        if (Cin % (32 * (k.WKW == 8 ? SC_HI : SC_LO)) != 0) continue;
-        const long long rows = pw == 8 ? (long long)n_exec * (bs / 8) * (bs / (4 * k.RM)) : ((long long)n_exec + 2 * k.RM - 1) / (2 * k.RM);
-        const long long wgs = ((rows + k.WMW - 1) / k.WMW) * (Cout / (32 * k.RN * k.WNW));
-        const long long rounds = (wgs + cus - 1) / cus;
+        if (!conv2_plan(k, E, S, n_exec, Cin, Cout, bs, plan)) continue;
+        const long long rounds = (plan.wgs + cus - 1) / cus;
         const double mf = (double)k.RM * k.RN * 9.0 * (Cin / 8) * 4.0 / k.WKW;        // fp32 MFMAs per wave (16-bit: the same ranking)
         // per-MFMA slowdown from operand delivery (tools/probes/mfma_probe2: 1x1 tiles ~0.72, 2x1 ~0.79, 2x2 ~0.82 of peak)
         const double eff = k.RM * k.RN >= 4 ? 0.82 : (k.RM * k.RN == 2 ? (k.RM == 2 ? 0.79 : 0.74) : 0.70);
         const double t = rounds * (mf / eff + 70.0 + 12.0 * (k.WKW - 1) * k.RM * k.RN);
-        if (best < 0 || t < best_t) { best = c; best_t = t; }
+        if (dbg_model) fprintf(stderr, "[conv2 model] dt %d S %d n %d %d->%d bs %d: c%d wgs %lld rounds %lld mf %.0f t %.0f (cus %d)\n", DT, S, n_exec, Cin, Cout, bs, c, plan.wgs, rounds, mf, t, cus);
+        if (best < 0 || t < best_t) { best = c; best_t = t; best_plan = plan; }
     }
     if (best < 0) return BC_ERR_SHAPE;
     g_tune.conv_last_cfg = best;
     const Conv2Cfg &k = CONV2_CFGS[best];
     ConvGeom2 g;
     g.Cin = Cin; g.Cout = Cout; g.bs = bs; g.GH = GH; g.GW = GW; g.n_exec = n_exec;
-    g.patches_x = pw == 8 ? bs / 8 : 1;
-    g.patches_per_tile = pw == 8 ? (bs / 8) * (bs / (4 * k.RM)) : 1;
-    g.n_rows = pw == 8 ? (uint32_t)n_exec * g.patches_per_tile : ((uint32_t)n_exec + 2 * k.RM - 1) / (2 * k.RM);
+    g.patches_x = best_plan.patches_x;
+    g.patches_per_tile = best_plan.patches_per_tile;
+    g.n_rows = best_plan.n_rows;
     g.cin_chunks = Cin / CV_CH;
-    const uint32_t slot_px = pw == 8 ? 10u * (4 * k.RM + 2) : 36u, tpr = pw == 8 ? 1u : 2u * k.RM;
-    const uint32_t chp = UV * (k.WKW == 8 ? SC_HI : SC_LO) + 1;        // pixel stride in 16-byte vectors
-    const size_t img = (size_t)k.WMW * tpr * slot_px * chp * 16;
-    const size_t red = (size_t)k.WMW * k.WNW * (k.WKW - 1) * k.RM * k.RN * 16 * 64 * sizeof(float);
-    size_t lds_bytes = 2 * img > red ? 2 * img : red;
+    size_t lds_bytes = best_plan.lds_bytes;
     if (lds_bytes < (size_t)min_lds) lds_bytes = min_lds;      // one workgroup per CU: two waves on every SIMD, no more
-    (void)E;
     const dim3 grid((g.n_rows + k.WMW - 1) / k.WMW, (unsigned)Cout / (32 * k.RN * k.WNW));
+    // (decompositions whose double-buffered patch images cannot fit the LDS are never chosen by conv2_plan and are not compiled)
 #define BC_CV2(RM_, RN_, WMW_, WNW_, WKW_)                                                                                   \
     do {                                                                                                                 \
         constexpr int SC_ = WKW_ == 8 ? SC_HI : SC_LO;                                                                   \
-        if (pw == 8) launch_conv3x3_v2_cfg<DT, RM_, RN_, WMW_, WNW_, WKW_, SC_, 8>(ps, grid, lds_bytes, st, out, features, ring, wpk, grid_idx, mapping_exec, g, pr, ep); \
-        else launch_conv3x3_v2_cfg<DT, (WMW_ == 1 ? RM_ : 1), RN_, WMW_, WNW_, WKW_, SC_, 4>(ps, grid, lds_bytes, st, out, features, ring, wpk, grid_idx, mapping_exec, g, pr, ep); \
+        constexpr int RM4_ = WMW_ == 1 ? RM_ : 1;                                                                        \
+        constexpr size_t img8_ = (size_t)WMW_ * (S * 8 + 3 - S) * (S * 4 * RM_ + 3 - S) * (CvType<DT>::UV * SC_ + 1) * 32;  \
+        constexpr size_t img4_ = (size_t)WMW_ * 2 * RM4_ * (S * 4 + 3 - S) * (S * 4 + 3 - S) * (CvType<DT>::UV * SC_ + 1) * 32; \
+        if (pw == 8) {                                                                                                   \
+            if constexpr (img8_ <= 160 * 1024 - 3072)                                                                    \
+                launch_conv3x3_v2_cfg<DT, RM_, RN_, WMW_, WNW_, WKW_, SC_, 8, S>(ps, grid, lds_bytes, st, out, features, ring, wpk, grid_idx, mapping_exec, g, pr, ep); \
+        } else {                                                                                                         \
+            if constexpr (img4_ <= 160 * 1024 - 3072)                                                                    \
+                launch_conv3x3_v2_cfg<DT, RM4_, RN_, WMW_, WNW_, WKW_, SC_, 4, S>(ps, grid, lds_bytes, st, out, features, ring, wpk, grid_idx, mapping_exec, g, pr, ep); \
+        }                                                                                                                \
     } while (0)
     switch (best) {
     case 0: BC_CV2(2, 2, 4, 2, 1); break;
@@ -2184,6 +2211,19 @@ static int launch_conv3x3_v2(ProfScope &ps, void *out, const void *features, voi
     }
 #undef BC_CV2
     return launch_status();
+}
+
+// which decompositions cover a layer: out[0..n) = their indices, returns n (the engine times exactly these)
+BC_EXPORT int bc_conv3x3_candidates(int dtype, int stride, int n_exec, int Cin, int Cout, int bs_in, int *out, int max_out)
+{
+    if (dtype < BC_F32 || dtype > BC_BF16 || (stride != 1 && stride != 2) || !out || bs_in % stride) return BC_ERR_SHAPE;
+    const int E = dtype == BC_F32 ? 4 : 2, bs = bs_in / stride;
+    if (!(bs == 4 || bs % 8 == 0) || bs > 248 / stride) return 0;
+    int n = 0;
+    Conv2Plan plan;
+    for (int c = 0; c < (int)(sizeof(CONV2_CFGS) / sizeof(CONV2_CFGS[0])) && n < max_out; ++c)
+        if (conv2_plan(CONV2_CFGS[c], E, stride, n_exec, Cin, Cout, bs, plan)) out[n++] = c;
+    return n;
 }
 
 BC_EXPORT int bc_tune_set(const char *key, int value)
@@ -2237,11 +2277,11 @@ BC_EXPORT int bc_conv3x3_ring_nhwc(void *out, const void *features, void *ring, 
         EpilogueT ept{out_scale, out_shift, out_add, out_relu};
         int rc;
         if (dtype == BC_F32)
-            rc = launch_conv3x3_v2<BC_F32>(ps, out, features, ring, weights_packed, grid_idx, mapping_exec, n_exec, Cin, Cout, GH, GW, bs, pr, ept, (hipStream_t)stream);
+            rc = launch_conv3x3_v2<BC_F32, 1>(ps, out, features, ring, weights_packed, grid_idx, mapping_exec, n_exec, Cin, Cout, GH, GW, bs, pr, ept, (hipStream_t)stream);
         else if (dtype == BC_F16)
-            rc = launch_conv3x3_v2<BC_F16>(ps, out, features, ring, weights_packed, grid_idx, mapping_exec, n_exec, Cin, Cout, GH, GW, bs, pr, ept, (hipStream_t)stream);
+            rc = launch_conv3x3_v2<BC_F16, 1>(ps, out, features, ring, weights_packed, grid_idx, mapping_exec, n_exec, Cin, Cout, GH, GW, bs, pr, ept, (hipStream_t)stream);
         else
-            rc = launch_conv3x3_v2<BC_BF16>(ps, out, features, ring, weights_packed, grid_idx, mapping_exec, n_exec, Cin, Cout, GH, GW, bs, pr, ept, (hipStream_t)stream);
+            rc = launch_conv3x3_v2<BC_BF16, 1>(ps, out, features, ring, weights_packed, grid_idx, mapping_exec, n_exec, Cin, Cout, GH, GW, bs, pr, ept, (hipStream_t)stream);
         if (rc != BC_ERR_SHAPE || dtype != BC_F32) return rc;   // fp32 shapes the balanced kernel does not cover fall through
     }
     g_tune.conv_last_cfg = -1;
@@ -2273,6 +2313,31 @@ BC_EXPORT int bc_conv3x3_ring_nhwc(void *out, const void *features, void *ring, 
     else { if (WM_ == 2) BC_CV(4, 2); else BC_CV(4, 1); }
 #undef BC_CV
     return launch_status();
+}
+
+BC_EXPORT int bc_conv3x3s2_ring_nhwc(void *out, const void *features, void *ring, const void *weights_packed,
+                                     const int32_t *grid_idx, const int32_t *mapping_exec, int n_exec, int N, int Cin, int Cout,
+                                     int GH, int GW, int bs, int dtype, const float *in_scale, const float *in_shift, int in_relu,
+                                     const float *out_scale, const float *out_shift, const void *out_add, int out_relu, void *stream)
+{
+    if (dtype < BC_F32 || dtype > BC_BF16) return BC_ERR_ELEM;
+    if (n_exec < 0 || N <= 0 || Cin <= 0 || Cout <= 0 || GH <= 0 || GW <= 0 || bs <= 0 || bs % 2) return BC_ERR_SHAPE;
+    const int bso = bs / 2;
+    if (Cin % CV_CH != 0 || Cout % 64 != 0 || !(bso == 4 || bso % 8 == 0) || bs > 248) return BC_ERR_SHAPE;
+    if (n_exec == 0) return BC_OK;
+    if (!out || !features || !ring || !weights_packed || !grid_idx || !mapping_exec) return BC_ERR_NULL;
+    if ((uint64_t)n_exec * bs * bs * (uint64_t)(Cin > Cout ? Cin : Cout) >= (1ull << 31) ||
+        (uint64_t)N * GH * GW * 4 * bs * Cin >= (1ull << 31)) return BC_ERR_RANGE;
+    if (!aligned(out, 16) || !aligned(features, 16) || !aligned(ring, 16) || !aligned(weights_packed, 16) || !aligned(out_add, 2))
+        return BC_ERR_ALIGN;
+    Prologue pr{in_scale, in_shift, in_relu};
+    EpilogueT ept{out_scale, out_shift, out_add, out_relu};
+    ProfScope ps(BC_OP_CONV3X3, 2.0 * n_exec * bso * bso * 9.0 * Cin * Cout);
+    if (dtype == BC_F32)
+        return launch_conv3x3_v2<BC_F32, 2>(ps, out, features, ring, weights_packed, grid_idx, mapping_exec, n_exec, Cin, Cout, GH, GW, bso, pr, ept, (hipStream_t)stream);
+    if (dtype == BC_F16)
+        return launch_conv3x3_v2<BC_F16, 2>(ps, out, features, ring, weights_packed, grid_idx, mapping_exec, n_exec, Cin, Cout, GH, GW, bso, pr, ept, (hipStream_t)stream);
+    return launch_conv3x3_v2<BC_BF16, 2>(ps, out, features, ring, weights_packed, grid_idx, mapping_exec, n_exec, Cin, Cout, GH, GW, bso, pr, ept, (hipStream_t)stream);
 }
 
 BC_EXPORT int bc_pad_ring_add_nhwc(void *out, void *act_out, const void *features, const void *add, void *ring,

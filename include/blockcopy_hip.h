@@ -172,6 +172,18 @@ int bc_conv3x3_ring_nhwc(void *out, const void *features, void *ring, const void
                          int GH, int GW, int bs, int dtype, const float *in_scale, const float *in_shift, int in_relu,
                          const float *out_scale, const float *out_shift, const void *out_add, int out_relu, void *stream);
 
+/* the same for a 3x3 / STRIDE 2 / pad 1 conv (the first conv of a ResNet stage): features (n_exec, bs, bs, Cin) ->
+ * out (n_exec, bs/2, bs/2, Cout); halo, ring (pad 1, over the INPUT tiles), prologue, epilogue and weight stream as above.
+ * bs even with bs/2 = 4 or a multiple of 8. */
+int bc_conv3x3s2_ring_nhwc(void *out, const void *features, void *ring, const void *weights_packed,
+                           const int32_t *grid_idx, const int32_t *mapping_exec, int n_exec, int N, int Cin, int Cout,
+                           int GH, int GW, int bs, int dtype, const float *in_scale, const float *in_shift, int in_relu,
+                           const float *out_scale, const float *out_shift, const void *out_add, int out_relu, void *stream);
+
+/* decompositions of the fused conv kernel that cover a layer (stride 1 or 2; bs_in = input tile size): indices written to out,
+ * count returned.  What bc_tune_set("conv2_cfg", i) may force; the engine times exactly these when it measures a layer shape. */
+int bc_conv3x3_candidates(int dtype, int stride, int n_exec, int Cin, int Cout, int bs_in, int *out, int max_out);
+
 /* halo gather with a residual-add prologue and a by-product: v = relu?(features*scale[c] + shift[c] + add) is computed while
  * gathering; `out` receives the padded batch of v and `act_out` (n_exec, bs, bs, C) the plain v of every executed tile
  * (what the next block's shortcut reads), so the end of a residual block costs one launch instead of bc_affine_act_nhwc

@@ -537,6 +537,51 @@ def test_fused_conv3x3_half_precision(be, cfg, dtype, tol):
         be.tune("conv2_cfg", -1)
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.float16, 2e-3)])
+def test_fused_conv3x3_stride2(be, dtype, tol):
+    """bc_conv3x3s2_ring_nhwc (first conv of a ResNet stage: 3x3, stride 2, pad 1) == halo gather + strided conv, for every
+    decomposition the library lists for the layer (bc_conv3x3_candidates) and its own choice; ring caches bit-identical
+    (patches of a stride-2 launch share staged rows: the duplicate refreshes must store identical values)."""
+    import torch.nn.functional as F
+
+    rng = np.random.default_rng(31)
+    gen = torch.Generator().manual_seed(31)
+    try:
+        for case, (Cin, Cout, bs, N, GH, GW) in enumerate([(64, 128, 32, 1, 2, 3), (128, 256, 16, 1, 3, 4), (256, 512, 8, 2, 2, 3), (64, 64, 48, 1, 1, 2)]):
+            T = N * GH * GW
+            w = (torch.randn((Cout, Cin, 3, 3), generator=gen) * (2.0 / (9 * Cin)) ** 0.5).cuda().to(dtype)
+            wpk = be.pack_conv3x3_weights(w)
+            cands = be.conv3x3_candidates(T, Cin, Cout, bs, w.element_size(), 2)
+            assert cands, (case, "no decomposition covers this stride-2 layer")
+            for cfg in [-1] + cands:
+                be.tune("conv2_cfg", cfg)
+                ring_a, ring_b = torch.zeros((T, Cin, 4 * bs), dtype=dtype).cuda(), torch.zeros((T, Cin, 4 * bs), dtype=dtype).cuda()
+                for t in range(3):
+                    g = np.ones(T, bool) if t == 0 else rng.random(T) < (0.3, 0.5, 0.8)[t]
+                    if not g.any():
+                        g[int(rng.integers(T))] = True
+                    gi, m = O.c_grid_mappings(g.reshape(N, 1, GH, GW))
+                    gi_d, m_d = _dev(gi), _dev(m)
+                    feats = _cl(torch.randn((len(m), Cin, bs, bs), generator=gen).cuda().to(dtype))
+                    pro = None if t == 0 else ((torch.rand(Cin, generator=gen) + 0.5).cuda(), (torch.randn(Cin, generator=gen) * 0.1).cuda(), t == 2)
+                    add = _cl(torch.randn((len(m), Cout, bs // 2, bs // 2), generator=gen).cuda().to(dtype)) if t == 1 else None
+                    epi = None if t == 0 else ((torch.rand(Cout, generator=gen) + 0.5).cuda(), (torch.randn(Cout, generator=gen) * 0.1).cuda(), add, t == 1)
+                    want = F.conv2d(be.pad_ring(feats, ring_a, gi_d, m_d, 1, pro).double(), w.double(), stride=2)
+                    if epi is not None:
+                        want = want * epi[0].view(1, -1, 1, 1) + epi[1].view(1, -1, 1, 1)
+                        if epi[2] is not None:
+                            want = want + epi[2].double()
+                        if epi[3]:
+                            want = torch.relu(want)
+                    got = be.conv3x3_ring(feats, ring_b, wpk, Cout, gi_d, m_d, pro, epi, stride=2)
+                    assert tuple(got.shape) == (len(m), Cout, bs // 2, bs // 2) and (cfg < 0 or be.tune_get("conv_last_cfg") == cfg)
+                    err = (got.double() - want).abs().max().item()
+                    assert err <= tol * max(1.0, want.abs().max().item()), (case, cfg, t, err)
+                    assert torch.equal(ring_a, ring_b), (case, cfg, t)
+    finally:
+        be.tune("conv2_cfg", -1)
+
+
 @pytest.mark.parametrize("cfg", list(range(16)))
 def test_fused_conv3x3_every_decomposition(be, cfg):
     """The CU-balanced conv kernel (csrc/conv3x3_v2.inc) picks one of 16 decompositions per launch (register blocking

@@ -35,10 +35,14 @@ def main():
     ap.add_argument("--no-lib", action="store_true")
     ap.add_argument("--n", type=int, default=0, help="override the executed-tile count of every case")
     ap.add_argument("--dtype", default="float32", choices=["float32", "float16", "bfloat16"])
+    ap.add_argument("--stride2", action="store_true", help="time the stride-2 form on the stage-entry layer shapes instead")
     a = ap.parse_args()
     torch.backends.cudnn.benchmark = True
     be = bk.get_backend()
-    for name, GH, GW, n_exec, Cin, Cout, bs in CASES:
+    cases = CASES if not a.stride2 else [("C2 layer2.0.conv1 s2", 8, 16, 64, 64, 128, 32), ("C2 layer3.0.conv1 s2", 8, 16, 64, 128, 256, 16),
+                                         ("C2 layer4.0.conv1 s2", 8, 16, 64, 256, 512, 8)]
+    stride = 2 if a.stride2 else 1
+    for name, GH, GW, n_exec, Cin, Cout, bs in cases:
         if a.filter not in name:
             continue
         N = 2 if "batch2" in name else 1
@@ -52,19 +56,19 @@ def main():
         wpk = be.pack_conv3x3_weights(w)
         sc = torch.rand(Cin, device="cuda") + 0.5
         pro = (sc, sc, True)
-        flops = 2.0 * n_exec * bs * bs * 9 * Cin * Cout
+        flops = 2.0 * n_exec * (bs // stride) ** 2 * 9 * Cin * Cout
 
         def lib_path():
-            return F.conv2d(be.pad_ring(feats, ring, gi, m, 1, pro), w)
+            return F.conv2d(be.pad_ring(feats, ring, gi, m, 1, pro), w, stride=stride)
 
-        fused = lambda: be.conv3x3_ring(feats, ring, wpk, Cout, gi, m, pro, None)
+        fused = lambda: be.conv3x3_ring(feats, ring, wpk, Cout, gi, m, pro, None, stride=stride)
         if a.no_lib:
             us_halo = us_lib = float("nan")
         else:
             lib_path()   # MIOpen find
             us_halo = timeit(lambda: be.pad_ring(feats, ring, gi, m, 1, pro), a.iters)
             us_lib = timeit(lib_path, a.iters)
-        if dt == torch.float32:
+        if dt == torch.float32 and stride == 1:
             be.tune("conv_impl", 1)
             us_v1 = timeit(fused, a.iters)
             be.tune("conv_impl", 2)
@@ -73,9 +77,9 @@ def main():
         us_v2 = timeit(fused, a.iters)
         extra = f" auto=c{be.tune_get('conv_last_cfg')}"
         for c in [int(x) for x in a.cfgs.split(",") if x != ""]:
-            be.tune("conv2_cfg", c)
-            if c not in be.conv3x3_candidates(n_exec, Cin, Cout, bs, feats.element_size()):
+            if c not in be.conv3x3_candidates(n_exec, Cin, Cout, bs, feats.element_size(), stride):
                 continue
+            be.tune("conv2_cfg", c)
             try:
                 extra += f" c{c}={timeit(fused, a.iters):.1f}"
             finally:
