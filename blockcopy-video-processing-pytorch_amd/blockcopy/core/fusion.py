@@ -32,14 +32,23 @@ class Pending:
     happened yet (the stored data is an unwritten placeholder of the right shape) and will carry the rest of the record
     as its epilogue, e.g. a decoder's ``x = upsample(x); x += skip`` becomes one kernel."""
 
-    __slots__ = ("scale", "shift", "add", "relu", "interp", "add_version")
+    __slots__ = ("scale", "shift", "add", "relu", "interp", "add_version", "conv")
 
-    def __init__(self, scale=None, shift=None, add=None, relu=False, interp=None, add_version=None):
+    def __init__(self, scale=None, shift=None, add=None, relu=False, interp=None, add_version=None, conv=None):
         self.scale, self.shift, self.add, self.relu, self.interp = scale, shift, add, relu, interp
         self.add_version = add._version if (add is not None and add_version is None) else add_version
+        # deferred fused halo+conv: ``conv = (launch, kwargs)``; like ``interp`` the stored data is an unwritten placeholder and
+        # the launch happens when the value is needed, with the rest of the record as the kernel's epilogue -- the end of a
+        # residual block (conv -> + bias -> + identity -> ReLU) is then ONE launch and no separate elementwise pass
+        self.conv = conv
 
     def copy(self):
-        return Pending(self.scale, self.shift, self.add, self.relu, self.interp, self.add_version)
+        return Pending(self.scale, self.shift, self.add, self.relu, self.interp, self.add_version, self.conv)
+
+    @property
+    def deferred(self):
+        """True when the base value itself has not been computed yet (deferred resampling or conv)."""
+        return self.interp is not None or self.conv is not None
 
     def set_add(self, t):
         """Record the residual operand by alias, together with its version counter: the sum is formed when the record
@@ -117,6 +126,7 @@ def packed_conv3x3_weight(weight: torch.Tensor, pack) -> torch.Tensor:
 CONV_MODE = os.environ.get("BLOCKCOPY_CONV", "auto")   # auto | native | library
 CONV_TUNE = os.environ.get("BLOCKCOPY_CONV_TUNE", "1") != "0"   # auto mode: measure each new layer shape once (eager runs only)
 _conv_plans = {}      # (n_exec, bs, cin, cout, n_total, dtype) -> None (library conv) | decomposition index (-1 = library's own choice)
+DEFER_CONV = os.environ.get("BLOCKCOPY_DEFER_CONV", "1") != "0"   # fused convs launch lazily with the recorded elementwise work as epilogue
 CONV_TUNE_LOG = []    # (key, {candidate: microseconds}, choice) of every measurement, for the bench report
 
 

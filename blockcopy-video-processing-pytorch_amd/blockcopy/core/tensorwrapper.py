@@ -360,7 +360,11 @@ class TensorWrapper(torch.Tensor):
             if add is not None:
                 add = dense_layout(add)
             be = get_backend()
-            if P.interp is not None:      # deferred interpolation: resample now, the rest of the record is its epilogue
+            if P.conv is not None:        # deferred fused halo+conv: launch now, the rest of the record is its epilogue
+                launch, kw = P.conv
+                plain = P.scale is None and P.shift is None and add is None and not P.relu
+                out = launch(epilogue=None if plain else (P.scale, P.shift, add, P.relu), **kw)
+            elif P.interp is not None:    # deferred interpolation: resample now, the rest of the record is its epilogue
                 src, H, W, align, rh, rw = P.interp
                 plain = P.scale is None and P.shift is None and add is None and not P.relu
                 out = be.interp_bilinear(src, H, W, align, rh, rw, None if plain else (P.scale, P.shift, add, P.relu))
@@ -605,11 +609,11 @@ class TensorWrapper(torch.Tensor):
             scale, shift = fusion.batchnorm_affine(rm, rv, w, b, eps)
             if x._pending is not None and not x._pending.affine_only:
                 x._materialize()
-            interp = None
+            interp = conv = None
             if x._pending is not None:
                 scale, shift = fusion.compose_affine(x._pending.scale, x._pending.shift, scale, shift)
-                interp = x._pending.interp    # deferred resampling stays the base of the record (its source, not the placeholder)
-            return x._sibling(fusion.Pending(scale=scale, shift=shift, interp=interp)), None, True
+                interp, conv = x._pending.interp, x._pending.conv    # a deferred producer stays the base of the record (not the placeholder)
+            return x._sibling(fusion.Pending(scale=scale, shift=shift, interp=interp, conv=conv)), None, True
         # residual add:  x (+)= y
         y = args[1] if len(args) > 1 else kwargs.get("other", None)
         alpha = kwargs.get("alpha", args[2] if len(args) > 2 else 1)
@@ -620,7 +624,7 @@ class TensorWrapper(torch.Tensor):
         P = x._pending if inplace else x._pending.copy()
         if isinstance(y, TensorWrapper) and y._pending is not None:
             q = y._pending
-            if q.scale is None and q.affine_only and q.interp is None:      # (raw_y + shift_y): fold the shift, add the raw tensor
+            if q.scale is None and q.affine_only and not q.deferred:      # (raw_y + shift_y): fold the shift, add the raw tensor
                 P.shift = fusion.add_shifts(P.shift, q.shift)
                 P.set_add(y._raw())
             else:
@@ -691,7 +695,7 @@ class TensorWrapper(torch.Tensor):
         residual = None      # pending residual add folded into the halo gather (with the activated tiles as a by-product)
         if isinstance(x, TensorWrapper) and x._pending is not None:
             P = x._pending
-            if fuse and P.add is None and P.interp is None:
+            if fuse and P.add is None and not P.deferred:
                 prologue = (P.scale, P.shift, P.relu)     # folded into the halo gather; x itself stays pending
             elif fuse and feats.engine == "fused" and self._residual_gather_ok(op, x, P, args, kwargs, padding):
                 residual = P
@@ -729,9 +733,18 @@ class TensorWrapper(torch.Tensor):
                 wpk = fusion.packed_conv3x3_weight(weight, be.pack_conv3x3_weights)   # cached per parameter object
                 ring = feats.next_ring(data, padding)
                 feats._pad_memo = None
+                stride = self._conv_stride(args, kwargs)
+                if fusion.DEFER_CONV and data.dtype in getattr(be, "supports_fusion_dtypes", ()):
+                    # deferred: the launch happens when the value is needed, carrying the elementwise work recorded by then (bias,
+                    # residual add, ReLU) as its epilogue.  The placeholder is never read or written; `data` is held by the record.
+                    placeholder = empty_like_layout((data.shape[0], weight.shape[0], data.shape[2] // stride, data.shape[3] // stride), data)
+                    P = pend_out if pend_out is not None else fusion.Pending()
+                    P.conv = (be.conv3x3_ring, dict(data_exec=data, ring=ring, wpk=wpk, cout=weight.shape[0], grid_idx=grid_idx,
+                                                   mapping_exec=mapping_exec, prologue=prologue, cfg=plan, stride=stride))
+                    return placeholder, P
                 with timings.env("tensorwrapper/conv3x3_fused", 10):
                     return be.conv3x3_ring(data, ring, wpk, weight.shape[0], grid_idx, mapping_exec, prologue, None, cfg=plan,
-                                           stride=self._conv_stride(args, kwargs)), pend_out
+                                           stride=stride), pend_out
         if feats.engine == "fused" and fuse and op == "max_pool2d" and padding == 1:
             # the ResNet stem pool (3x3, stride 2): halo gather + max in one kernel, no padded tensor
             be = get_backend()
@@ -808,7 +821,7 @@ class TensorWrapper(torch.Tensor):
     def _residual_gather_ok(self, op, x, P, args, kwargs, padding) -> bool:
         """Can the pending residual add of ``x`` be folded into this padded op's halo gather?"""
         be = get_backend()
-        if not hasattr(be, "pad_ring_add") or P.add is None or P.interp is not None or not isinstance(P.add, torch.Tensor):
+        if not hasattr(be, "pad_ring_add") or P.add is None or P.deferred or not isinstance(P.add, torch.Tensor):
             return False
         raw = x._raw()
         if not (is_nhwc(raw) and be.pad_ring_add_supported(dense_layout(raw), dense_layout(P.add))):

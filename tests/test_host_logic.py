@@ -323,7 +323,7 @@ def test_channels_last_model_matches_reference_on_cpu(golden_dir, oracle_backend
 
     G, cfg = load_golden(golden_dir, name)
     # the engine's MI355X-specific routes must be taken on this model: residual gather (by-product), fused halo+pool
-    chk, hits = bk.get_backend(), {"pad_ring_add": 0, "maxpool3x3s2_ring": 0}
+    chk, hits = bk.get_backend(), {"pad_ring_add": 0, "maxpool3x3s2_ring": 0, "conv3x3_ring": 0}
     for meth in hits:
         orig = getattr(chk, meth)
         setattr(chk, meth, (lambda o, k: lambda *a, **kw: (hits.__setitem__(k, hits[k] + 1), o(*a, **kw))[1])(orig, meth))
@@ -341,7 +341,10 @@ def test_channels_last_model_matches_reference_on_cpu(golden_dir, oracle_backend
                 y = model(seeded.synthetic_frame(cfg["frame_seed0"] + t, (cfg["N"], 3, cfg["H"], cfg["W"])))
                 assert float((y - torch.from_numpy(G[f"logits{t}"])).abs().max()) <= 1e-4, (graph, t)
         assert is_nhwc(y), "the output map should have stayed channels-last"
-    assert hits["pad_ring_add"] >= 7 * cfg["n_frames"] and hits["maxpool3x3s2_ring"] >= cfg["n_frames"], hits
+    # residual block ends go either into the residual gather (library conv route) or into the deferred fused conv's epilogue
+    executed = 2 * (cfg["n_frames"] - 1)        # two passes (eager plumbing, graph-mode plumbing); one frame of the clip executes nothing
+    assert hits["pad_ring_add"] + hits["conv3x3_ring"] >= 8 * executed and hits["conv3x3_ring"] >= 4 * executed, hits
+    assert hits["maxpool3x3s2_ring"] >= executed, hits
 
 
 def test_conv3x3_weight_packing_matches_the_header_formula():

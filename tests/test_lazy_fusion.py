@@ -131,3 +131,47 @@ def test_pad_memo_distinguishes_prologues(oracle_backend):
     memo = blk.get_features()._pad_memo
     F.conv2d(y, conv_w * 2, None, 1, 1)
     assert blk.get_features()._pad_memo is memo
+
+
+@pytest.mark.parametrize("tail", ["plain", "bias_relu", "residual_relu", "bn_residual_relu_conv", "two_consumers", "stride2_residual"])
+def test_deferred_conv_takes_the_recorded_work_as_its_epilogue(oracle_backend, tail):
+    """A fused halo+conv launch is deferred (fusion.Pending.conv) and carries bias / BN / residual add / ReLU recorded after it
+    as its epilogue -- the end of a residual block is one launch.  Same values as the unfused op sequence, incl. a tensor
+    consumed twice (next conv + next shortcut) and a stride-2 conv."""
+    import blockcopy.backend as bk
+    from blockcopy.core import fusion
+
+    g = torch.Generator().manual_seed(11)
+    w1, b1 = torch.randn(8, 8, 3, 3, generator=g) * 0.1, torch.randn(8, generator=g) * 0.1
+    w2 = torch.randn(8, 8, 3, 3, generator=g) * 0.1
+    rm, rv, bw, bb = _bn_params(8, seed=4)
+    launches = []
+    chk = bk.get_backend()
+    orig = chk.conv3x3_ring
+    chk.conv3x3_ring = lambda *a, **k: (launches.append(k.get("epilogue")), orig(*a, **k))[1]
+
+    def fn(blk):
+        st = 2 if tail == "stride2_residual" else 1
+        y = F.conv2d(blk, w1, None if tail == "plain" else b1, st, 1)
+        if tail == "bn_residual_relu_conv":
+            y = F.batch_norm(y, rm, rv, bw, bb, False, 0.1, 1e-5)
+        if "residual" in tail or tail == "two_consumers":
+            y += (blk if st == 1 else F.avg_pool2d(blk._plain(), 2).contiguous(memory_format=torch.channels_last))
+        if tail != "plain":
+            y = F.relu(y, inplace=True)
+        if tail == "bn_residual_relu_conv":
+            y = F.conv2d(y, w2, None, 1, 1)
+        if tail == "two_consumers":
+            y = F.conv2d(y, w2, None, 1, 1) + y
+        return y.combine().to_tensor()
+
+    prev_mode, fusion.CONV_MODE = fusion.CONV_MODE, "native"      # (the tiny tiles of this test would go to the library route)
+    try:
+        fused, plain = _both(fn)
+    finally:
+        chk.conv3x3_ring = orig
+        fusion.CONV_MODE = prev_mode
+    assert torch.isfinite(fused).all() and (fused - plain).abs().max().item() <= 1e-5 * max(1.0, plain.abs().max().item())
+    if tail in ("residual_relu", "stride2_residual"):
+        epi = launches[0]           # the fused pass: ONE conv launch whose epilogue holds bias + identity + ReLU
+        assert epi is not None and epi[1] is not None and epi[2] is not None and epi[3] is True
