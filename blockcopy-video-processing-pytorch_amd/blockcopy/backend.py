@@ -46,6 +46,45 @@ def empty_like_layout(shape, like: torch.Tensor) -> torch.Tensor:
     return torch.empty(shape, dtype=like.dtype, device=like.device, memory_format=fmt)
 
 
+class PinnedRing:
+    """A few reusable pinned host buffers of one shape for per-frame staging (index tables, grids): page-locking memory costs
+    tens of microseconds per allocation, so the engine must not do it every frame.  ``next()`` hands out the buffers round
+    robin; before a buffer is reused, the event recorded after its last asynchronous upload is waited for (normally long
+    past), so a copy still in flight is never overwritten.  On CPU-only runs (test tier) the buffers are ordinary tensors."""
+
+    def __init__(self, numel: int, dtype, pinned: bool, depth: int = 4):
+        self.bufs = [torch.empty(numel, dtype=dtype, pin_memory=pinned) for _ in range(depth)]
+        self.events = [None] * depth
+        self.pos = 0
+        self.pinned = pinned
+
+    def next(self):
+        i = self.pos
+        self.pos = (i + 1) % len(self.bufs)
+        if self.events[i] is not None:
+            self.events[i].synchronize()
+        self._last = i
+        return self.bufs[i]
+
+    def uploaded(self):
+        """Call right after enqueueing the H->D copy of the buffer returned by the last ``next()``."""
+        if self.pinned:
+            ev = self.events[self._last] or torch.cuda.Event()
+            ev.record()
+            self.events[self._last] = ev
+
+
+_pinned_rings = {}
+
+
+def pinned_ring(numel: int, dtype, pinned: bool) -> PinnedRing:
+    key = (int(numel), dtype, bool(pinned))
+    r = _pinned_rings.get(key)
+    if r is None:
+        r = _pinned_rings[key] = PinnedRing(numel, dtype, pinned)
+    return r
+
+
 def _ok(x: torch.Tensor, *dtypes) -> bool:
     # same contract as the reference's cudaok(), utils/cuda.py:42-48 (plus channels-last as a second dense layout)
     assert x.is_cuda, "blockcopy ops need GPU tensors (no CPU path)"

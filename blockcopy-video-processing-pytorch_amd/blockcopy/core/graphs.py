@@ -20,7 +20,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-from ..backend import empty_like_layout, get_backend
+from ..backend import empty_like_layout, get_backend, pinned_ring
 from .tensorwrapper import BlockFeatures, PersistentState, TensorWrapper, _NoDispatch
 
 WARM_RUNS = 1   # eager runs of a new executed-tile count before it is captured (MIOpen solver search, lazy module loads)
@@ -58,10 +58,12 @@ class GraphedFrame:
     def upload(self, inputs: torch.Tensor, grid_host: torch.Tensor) -> int:
         g8 = grid_host.to(torch.bool).contiguous().numpy().view(np.uint8).reshape(-1)
         assert g8.size == self.n_total
-        staging = torch.empty(2 * self.n_total, dtype=torch.int32, pin_memory=self.device.type == "cuda")
+        ring = pinned_ring(2 * self.n_total, torch.int32, self.device.type == "cuda")     # reused pinned staging (no per-frame page-locking)
+        staging = ring.next()
         st = staging.numpy()
         n_exec = get_backend().grid_tables_host(g8, st[:self.n_total], st[self.n_total:], None, None)
         self.tables.copy_(staging, non_blocking=True)
+        ring.uploaded()
         if inputs.data_ptr() != self.static_in.data_ptr():
             self.static_in.copy_(inputs, non_blocking=True)
         return n_exec

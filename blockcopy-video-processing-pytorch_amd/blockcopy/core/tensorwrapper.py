@@ -32,7 +32,7 @@ import numpy as np
 import torch
 
 from . import fusion
-from ..backend import dense_layout, empty_like_layout, get_backend, is_nhwc
+from ..backend import dense_layout, empty_like_layout, get_backend, is_nhwc, pinned_ring
 from ..utils.block_funcs import CombineCopyFunction, CombineFunction, SplitFunction, TransferFunction
 from ..utils.blockpad import pad, pad_ring
 from ..utils.profiler import timings
@@ -183,7 +183,11 @@ class BlockFeatures:
             g8 = grid_host.contiguous().numpy().view(np.uint8).reshape(-1)
             n_total = g8.size
             on_gpu = self.device.type == "cuda"
-            staging = torch.empty(3 * n_total, dtype=torch.int32, pin_memory=on_gpu)
+            if on_gpu:
+                ring = pinned_ring(3 * n_total, torch.int32, True)        # reused pinned staging (no per-frame page-locking)
+                staging = ring.next()
+            else:
+                staging = torch.empty(3 * n_total, dtype=torch.int32)    # CPU tier: the tables ARE this tensor, so it must be fresh
             st = staging.numpy()
             want_transfer = meta_prev is not None and self.engine == "reference"
             n_exec = get_backend().grid_tables_host(
@@ -195,13 +199,15 @@ class BlockFeatures:
             else:
                 assert meta_prev.n_total == n_total, "grid size changed inside a clip"
             dev = staging.to(self.device, non_blocking=True) if on_gpu else staging
+            if on_gpu:
+                ring.uploaded()
             self._grid = grid.to(self.device, dtype=torch.bool)
             self._grid_idx = dev[:n_total].view(grid.shape)
             self._mapping_exec = dev[n_total:n_total + n_exec]
             if want_transfer:
                 self._transfer_idx = dev[2 * n_total:3 * n_total - n_exec]
-            self._grid_idx_host = st[:n_total]
-            self._staging = staging   # keeps the host mirror alive
+            self._grid_idx_host = st[:n_total].copy() if on_gpu else st[:n_total]   # (the pinned staging is reused: keep an own mirror)
+            self._staging = staging
             self.n_exec, self.n_total = n_exec, n_total
             if meta_prev is not None:
                 self.rings = meta_prev.rings   # ring caches persist across frames

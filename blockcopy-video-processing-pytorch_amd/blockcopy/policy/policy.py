@@ -122,9 +122,13 @@ class Policy(torch.nn.Module, metaclass=abc.ABCMeta):
         device = policy_meta["inputs"].device
         grid_host = grid_host.to(torch.bool)
         if device.type == "cuda":
-            pinned = torch.empty(grid_host.shape, dtype=torch.bool, pin_memory=True).copy_(grid_host)
+            from blockcopy.backend import pinned_ring
+
+            ring = pinned_ring(grid_host.numel(), torch.bool, True)      # reused pinned staging (no per-frame page-locking)
+            pinned = ring.next().view(grid_host.shape).copy_(grid_host)
             policy_meta["grid"] = pinned.to(device, non_blocking=True)
-            policy_meta["grid_host"] = pinned
+            ring.uploaded()
+            policy_meta["grid_host"] = grid_host if not grid_host.is_pinned() else grid_host.clone()   # (callers may keep it: never the ring's buffer)
         else:
             policy_meta["grid"] = grid_host
             policy_meta["grid_host"] = grid_host
