@@ -119,6 +119,7 @@ def load_library(path: str = None) -> ctypes.CDLL:
         "bc_conv3x3_ring_nhwc": [p, p, p, p, p, p] + [i] * 8 + [p, p, i, p, p, p, i, p],
         "bc_conv3x3s2_ring_nhwc": [p, p, p, p, p, p] + [i] * 8 + [p, p, i, p, p, p, i, p],
         "bc_conv3x3_candidates": [i, i, i, i, i, i, ctypes.POINTER(i), i],
+        "bc_stem7x7s2_nhwc": [p, p, p, p] + [i] * 7 + [p, p, p, i, p],
         "bc_interp_bilinear_nhwc": [p, p, ctypes.c_longlong, i, i, i, i, i, i, ctypes.c_float, ctypes.c_float, i, p],
         "bc_interp_bilinear_act_nhwc": [p, p, ctypes.c_longlong, i, i, i, i, i, i, ctypes.c_float, ctypes.c_float, i, p, p, p, i, p],
         "bc_affine_act": [p, p, p, p, p, i, ctypes.c_longlong, i, ctypes.c_longlong, i, p],
@@ -439,6 +440,49 @@ class HipBackend:
                                bs, _DTYPE_CODE[data_exec.dtype], ptr(isc), ptr(ish), int(bool(irelu)),
                                ptr(osc), ptr(osh), ptr(oadd), int(bool(orelu)), self._stream()),
                             "conv3x3_ring_nhwc")
+        return out
+
+    # -- network-input stage: window gather from the frame-state map + 7x7 / stride 2 stem conv (csrc/stem7x7.inc)
+    @staticmethod
+    def stem7x7_supported(frame_state, weight, bs, stride=2, padding=3, dilation=1, groups=1):
+        def _one(v):
+            return v if isinstance(v, int) else (v[0] if len(set(v)) == 1 else None)
+        return (frame_state.is_cuda and frame_state.dim() == 4 and frame_state.shape[1] == 3 and frame_state.is_contiguous()
+                and frame_state.dtype in _DTYPE_CODE and weight.dtype == frame_state.dtype and tuple(weight.shape) == (64, 3, 7, 7)
+                and _one(stride) == 2 and _one(padding) == 3 and _one(dilation) == 1 and groups == 1 and bs % 64 == 0
+                and frame_state.shape[2] % bs == 0 and frame_state.shape[3] % bs == 0)
+
+    @staticmethod
+    def pack_stem7x7_weights(weight):
+        """(64, 3, 7, 7) -> the operand stream of bc_stem7x7s2_nhwc (include/blockcopy_hip.h): per output-row tap ky the 21 (kx, c)
+        values as one K segment, zero-padded to 24 (fp32) / 32 (16-bit), in MFMA lane order."""
+        w = weight.detach().as_subclass(torch.Tensor)
+        assert tuple(w.shape) == (64, 3, 7, 7)
+        kseg = 24 if w.element_size() == 4 else 32
+        seg = torch.zeros((64, 7, kseg), dtype=w.dtype, device=w.device)
+        seg[:, :, :21] = w.permute(0, 2, 3, 1).reshape(64, 7, 21)                 # [co][ky][3*kx + c]
+        if w.element_size() == 4:
+            v = seg.reshape(2, 32, 7, 3, 4, 2).permute(0, 2, 3, 5, 1, 4)            # nb, n, ky, t4, j, h -> nb, ky, t4, h, n, j
+        else:
+            v = seg.reshape(2, 32, 7, 2, 2, 8).permute(0, 2, 3, 4, 1, 5)            # nb, n, ky, s, h, j  -> nb, ky, s, h, n, j
+        return v.contiguous().view(-1)
+
+    def stem7x7(self, frame_state, wpk, mapping_exec, bs, epilogue=None):
+        """(n_exec, 64, bs/2, bs/2) channels-last = epilogue(conv7x7 s2 p3 of the (bs+6)^2 windows of ``frame_state``)."""
+        assert _ok(frame_state, *_DTYPE_CODE) and frame_state.is_contiguous() and _ok(wpk, frame_state.dtype) and _ok(mapping_exec, torch.int32)
+        N, C, H, W = frame_state.shape
+        n_exec = mapping_exec.numel()
+        out = torch.empty((n_exec, 64, bs // 2, bs // 2), dtype=frame_state.dtype, device=frame_state.device, memory_format=torch.channels_last)
+        osc, osh, oadd, orelu = epilogue if epilogue is not None else (None, None, None, False)
+        for v in (osc, osh):
+            assert v is None or (_ok(v, torch.float32) and v.numel() == 64)
+        assert oadd is None or (_ok(oadd, frame_state.dtype) and oadd.shape == out.shape and is_nhwc(oadd))
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        if n_exec > 0:
+            with torch.cuda.device_of(frame_state):
+                self._check(self.lib.bc_stem7x7s2_nhwc(out.data_ptr(), frame_state.data_ptr(), wpk.data_ptr(), mapping_exec.data_ptr(), n_exec,
+                                                       N, H, W, int(bs), 64, _DTYPE_CODE[frame_state.dtype], ptr(osc), ptr(osh), ptr(oadd),
+                                                       int(bool(orelu)), self._stream()), "stem7x7s2_nhwc")
         return out
 
     def affine_act(self, data, scale=None, shift=None, add=None, relu=False):

@@ -127,6 +127,7 @@ CONV_MODE = os.environ.get("BLOCKCOPY_CONV", "auto")   # auto | native | library
 CONV_TUNE = os.environ.get("BLOCKCOPY_CONV_TUNE", "1") != "0"   # auto mode: measure each new layer shape once (eager runs only)
 _conv_plans = {}      # (n_exec, bs, cin, cout, n_total, dtype) -> None (library conv) | decomposition index (-1 = library's own choice)
 DEFER_CONV = os.environ.get("BLOCKCOPY_DEFER_CONV", "1") != "0"   # fused convs launch lazily with the recorded elementwise work as epilogue
+STEM_KERNEL = os.environ.get("BLOCKCOPY_STEM", "1") != "0"        # network input: window gather + 7x7 stem conv in one kernel
 CONV_TUNE_LOG = []    # (key, {candidate: microseconds}, choice) of every measurement, for the bench report
 
 

@@ -483,6 +483,7 @@ class TensorWrapper(torch.Tensor):
                 # tiles move: 2*n_exec*C*bs^2*E bytes instead of the 2*N*C*H*W*E of a full copy.
                 buf = ps.next_map(out_shape, blocks.dtype, blocks.device, is_nhwc(blocks))
                 out = CombineFunction.apply(blocks, buf, grid_idx, mapping_exec)
+                self._dense_map = out     # the map now holds these packed tiles in place: a halo window of it IS their padded form
                 return self._wrap_like(out, self, False)
 
             if self._features_prev:
@@ -504,6 +505,8 @@ class TensorWrapper(torch.Tensor):
                 out = CombineFunction.apply(blocks, out, grid_idx, mapping_exec)
 
             self._features.store_features_full(out)
+            if inplace or not self._features_prev:
+                self._dense_map = out     # (see above; an out-of-place combine's map may be handed to the caller and changed)
             return self._wrap_like(out, self, False)
 
     # ------------------------------------------------------------------ reference engine: transfer from previous frame
@@ -697,6 +700,21 @@ class TensorWrapper(torch.Tensor):
                 return func(*args, **kwargs), pend_out
 
         feats = self._features
+        if fuse and op == "conv2d" and padding == 3 and fusion.STEM_KERNEL and isinstance(x, TensorWrapper) and x._pending is None:
+            # network input: the padded tiles are windows of the frame-state map this packed tensor was just scattered into
+            # (combine_), so window gather + 7x7 stem conv run as ONE kernel -- no halo gather, no ring cache, no layout copy
+            be = get_backend()
+            dm = getattr(x, "_dense_map", None)
+            weight = args[1] if len(args) > 1 else kwargs.get("weight")
+            cv = {k: kwargs.get(k, args[i] if len(args) > i else d) for k, i, d in (("stride", 3, 1), ("dilation", 5, 1), ("groups", 6, 1))}
+            if (dm is not None and hasattr(be, "stem7x7") and isinstance(weight, torch.Tensor) and is_nhwc(weight) and feats.engine == "fused"
+                    and be.stem7x7_supported(dm, weight, x.shape[2], cv["stride"], padding, cv["dilation"], cv["groups"])):
+                wpk = fusion.packed_conv3x3_weight(weight, be.pack_stem7x7_weights)
+                placeholder = torch.empty((x.shape[0], 64, x.shape[2] // 2, x.shape[3] // 2), dtype=dm.dtype, device=dm.device,
+                                          memory_format=torch.channels_last)
+                P = pend_out if pend_out is not None else fusion.Pending()
+                P.conv = (be.stem7x7, dict(frame_state=dm, wpk=wpk, mapping_exec=feats._mapping_exec, bs=x.shape[2]))
+                return placeholder, P
         prologue = None
         residual = None      # pending residual add folded into the halo gather (with the activated tiles as a by-product)
         if isinstance(x, TensorWrapper) and x._pending is not None:

@@ -1794,6 +1794,7 @@ int check_halo(const void *out, const void *features, const int32_t *grid_idx, c
 
 #include "conv3x3_mfma.inc"
 #include "conv3x3_v2.inc"
+#include "stem7x7.inc"
 
 }  // namespace
 
@@ -2312,6 +2313,38 @@ BC_EXPORT int bc_conv3x3_ring_nhwc(void *out, const void *features, void *ring, 
     if (g.pw == 8) { if (WM_ == 2) BC_CV(8, 2); else BC_CV(8, 1); }
     else { if (WM_ == 2) BC_CV(4, 2); else BC_CV(4, 1); }
 #undef BC_CV
+    return launch_status();
+}
+
+BC_EXPORT int bc_stem7x7s2_nhwc(void *out, const void *frame_state, const void *weights_packed, const int32_t *mapping_exec, int n_exec,
+                                int N, int H, int W, int bs, int Cout, int dtype, const float *out_scale, const float *out_shift,
+                                const void *out_add, int out_relu, void *stream)
+{
+    if (dtype < BC_F32 || dtype > BC_BF16) return BC_ERR_ELEM;
+    if (n_exec < 0 || N <= 0 || H <= 0 || W <= 0 || bs <= 0 || H % bs || W % bs) return BC_ERR_SHAPE;
+    if (Cout != 64 || bs % 2 || (bs / 2) % ST_OW != 0 || (bs / 2) % ST_OH != 0) return BC_ERR_SHAPE;
+    if (n_exec == 0) return BC_OK;
+    if (!out || !frame_state || !weights_packed || !mapping_exec) return BC_ERR_NULL;
+    if ((uint64_t)N * 3 * H * W >= (1ull << 31) || (uint64_t)n_exec * (bs / 2) * (bs / 2) * 64 >= (1ull << 31)) return BC_ERR_RANGE;
+    if (!aligned(out, 4) || !aligned(frame_state, 4) || !aligned(weights_packed, 16)) return BC_ERR_ALIGN;
+    StemGeom g;
+    g.H = H; g.W = W; g.bs = bs; g.GH = H / bs; g.GW = W / bs; g.n_exec = n_exec;
+    g.patches_x = (bs / 2) / ST_OW;
+    g.patches_per_tile = g.patches_x * ((bs / 2) / ST_OH);
+    EpilogueT ep{out_scale, out_shift, out_add, out_relu};
+    const int E = dtype == BC_F32 ? 4 : 2;
+    const size_t lds = ((size_t)3 * ST_WH * ST_WS + 64) * E + 16;
+    ProfScope ps(BC_OP_CONV3X3, 2.0 * n_exec * (bs / 2) * (bs / 2) * 147.0 * 64);
+    const dim3 grid((unsigned)n_exec * g.patches_per_tile);
+    if (dtype == BC_F32)
+        BC_LAUNCH(ps, (k_stem7x7<BC_F32>), grid, dim3(512), lds, (hipStream_t)stream, (float *)out, (const float *)frame_state,
+                  (const uint4 *)weights_packed, mapping_exec, g, ep);
+    else if (dtype == BC_F16)
+        BC_LAUNCH(ps, (k_stem7x7<BC_F16>), grid, dim3(512), lds, (hipStream_t)stream, (__half *)out, (const __half *)frame_state,
+                  (const uint4 *)weights_packed, mapping_exec, g, ep);
+    else
+        BC_LAUNCH(ps, (k_stem7x7<BC_BF16>), grid, dim3(512), lds, (hipStream_t)stream, (hip_bfloat16 *)out, (const hip_bfloat16 *)frame_state,
+                  (const uint4 *)weights_packed, mapping_exec, g, ep);
     return launch_status();
 }
 

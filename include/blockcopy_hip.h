@@ -180,6 +180,20 @@ int bc_conv3x3s2_ring_nhwc(void *out, const void *features, void *ring, const vo
                            int GH, int GW, int bs, int dtype, const float *in_scale, const float *in_shift, int in_relu,
                            const float *out_scale, const float *out_shift, const void *out_add, int out_relu, void *stream);
 
+/* network-input stage in ONE launch: (bs+6)^2 window gather from the frame-state map + the 7x7 / stride 2 / pad 3 conv of the
+ * 3-channel frame (ResNet stem) + epilogue, on the matrix cores.  Replaces, for the first padded op of the reference pipeline,
+ * split + transfer + repad (p = 3) + F.conv2d (core/tensorwrapper.py:304-381, 529-575; utils/blockpad.py:77-156): for the network
+ * input the halo of a tile IS the frame-state map (the dense map holding the most recently executed pixels of every tile, i.e.
+ * bc_combine of this frame's packed input into last frame's map), zeros beyond the image; no ring cache is involved.
+ *   frame_state (N, 3, H, W) contiguous NCHW; out (n_exec, bs/2, bs/2, 64) channels-last = relu?(conv * out_scale[c] + out_shift[c] + out_add);
+ *   weights_packed: per output-row tap ky the 21 (kx, c) values as one K segment, zero-padded to 24 (fp32) / 32 (16-bit):
+ *     fp32   wpk[nb][ky][t4<3][lane][j<4] = Wseg[32*nb + lane%32][ky][8*t4 + 2*j + lane/32]
+ *     16-bit wpk[nb][ky][s<2][lane][j<8]  = Wseg[32*nb + lane%32][ky][16*s + 8*(lane/32) + j],   Wseg[co][ky][3*kx + c] = W[co][c][ky][kx]
+ *   Cout = 64, bs/2 a multiple of 32. */
+int bc_stem7x7s2_nhwc(void *out, const void *frame_state, const void *weights_packed, const int32_t *mapping_exec, int n_exec,
+                      int N, int H, int W, int bs, int Cout, int dtype, const float *out_scale, const float *out_shift,
+                      const void *out_add, int out_relu, void *stream);
+
 /* decompositions of the fused conv kernel that cover a layer (stride 1 or 2; bs_in = input tile size): indices written to out,
  * count returned.  What bc_tune_set("conv2_cfg", i) may force; the engine times exactly these when it measures a layer shape. */
 int bc_conv3x3_candidates(int dtype, int stride, int n_exec, int Cin, int Cout, int bs_in, int *out, int max_out);

@@ -772,3 +772,46 @@ def test_interp_epilogue_matches_two_kernel_route(be, dtype):
             want = be.affine_act(plain, epi[0], epi[1], epi[2], epi[3])
             got = be.interp_bilinear(x, H, W, align, rh, rw, epi)
             assert torch.equal(got.contiguous(), want.contiguous()), (dtype, (B, C, h, w, H, W), [e is not None for e in epi[:3]], epi[3])
+
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
+def test_stem7x7_window_conv(be, dtype, tol):
+    """bc_stem7x7s2_nhwc (window gather from the frame-state map + 7x7 / stride 2 / pad 3 conv + epilogue in one launch) vs the
+    definition: every executed tile's (bs+6)^2 window of the zero-padded map through an fp64 conv; tiles on all four image
+    borders and corners, batch 2, tile sizes 64 and 128, epilogue with bias / residual / ReLU."""
+    import torch.nn.functional as F
+
+    gen = torch.Generator().manual_seed(17)
+    for (N, GH, GW, bs) in [(1, 2, 3, 64), (2, 1, 2, 128), (1, 3, 2, 64)]:
+        H, W = GH * bs, GW * bs
+        state = torch.randn((N, 3, H, W), generator=gen).cuda().to(dtype)
+        w = (torch.randn((64, 3, 7, 7), generator=gen) * 0.08).cuda().to(dtype)
+        wpk = be.pack_stem7x7_weights(w)
+        assert be.stem7x7_supported(state, w, bs)
+        for mask in (np.ones(N * GH * GW, bool), np.arange(N * GH * GW) % 2 == 0, np.arange(N * GH * GW) == N * GH * GW - 1):
+            gi, m = O.c_grid_mappings(mask.reshape(N, 1, GH, GW))
+            m_d = _dev(m)
+            osc, osh = (torch.rand(64, generator=gen) + 0.5).cuda(), (torch.randn(64, generator=gen) * 0.1).cuda()
+            add = _cl(torch.randn((len(m), 64, bs // 2, bs // 2), generator=gen).cuda().to(dtype))
+            padded = F.pad(state.double(), (3, 3, 3, 3))
+            wins = []
+            for ig in m.tolist():
+                n, r = divmod(ig, GH * GW)
+                gy, gx = divmod(r, GW)
+                wins.append(padded[n:n + 1, :, gy * bs:gy * bs + bs + 6, gx * bs:gx * bs + bs + 6])
+            want0 = F.conv2d(torch.cat(wins), w.double(), stride=2)
+            for epi in (None, (osc, osh, None, True), (None, osh, add, False)):
+                want = want0
+                if epi is not None:
+                    if epi[0] is not None:
+                        want = want * epi[0].view(1, -1, 1, 1)
+                    want = want + epi[1].view(1, -1, 1, 1)
+                    if epi[2] is not None:
+                        want = want + epi[2].double()
+                    if epi[3]:
+                        want = torch.relu(want)
+                got = be.stem7x7(state, wpk, m_d, bs, epi)
+                assert tuple(got.shape) == (len(m), 64, bs // 2, bs // 2) and got.dtype == dtype and not got.is_contiguous()
+                err = (got.double() - want).abs().max().item()
+                assert err <= tol * max(1.0, want.abs().max().item()), (N, GH, GW, bs, int(mask.sum()), epi is not None, err)
