@@ -2075,6 +2075,7 @@ struct TuneState {
     int conv2_cfg = [] { const char *e = getenv("BC_CONV2_CFG"); return e ? atoi(e) : -1; }();             // >= 0: force a decomposition
     unsigned long long *conv_stamps = nullptr;   // device buffer for in-kernel s_memtime stamps (bc_tune_set_ptr), measurement only
     int conv_last_cfg = -2;   // decomposition of the most recent bc_conv3x3_ring_nhwc launch (-1: first-generation kernel)
+    int stem_min_lds = [] { const char *e = getenv("BC_STEM_MINLDS"); return e ? atoi(e) : 84 * 1024; }();
     int conv2_min_lds = [] { const char *e = getenv("BC_CONV2_MINLDS"); return e ? atoi(e) : 84 * 1024; }();   // bytes; > 80 KB = one workgroup per CU
 } g_tune;
 
@@ -2233,6 +2234,7 @@ BC_EXPORT int bc_tune_set(const char *key, int value)
     if (!strcmp(key, "conv_impl")) g_tune.conv_impl = value;
     else if (!strcmp(key, "conv2_cfg")) g_tune.conv2_cfg = value;
     else if (!strcmp(key, "conv2_min_lds")) g_tune.conv2_min_lds = value;
+    else if (!strcmp(key, "stem_min_lds")) g_tune.stem_min_lds = value;
     else return BC_ERR_SHAPE;
     return BC_OK;
 }
@@ -2333,7 +2335,18 @@ BC_EXPORT int bc_stem7x7s2_nhwc(void *out, const void *frame_state, const void *
     g.patches_per_tile = g.patches_x * ((bs / 2) / ST_OH);
     EpilogueT ep{out_scale, out_shift, out_add, out_relu};
     const int E = dtype == BC_F32 ? 4 : 2;
-    const size_t lds = ((size_t)3 * ST_WH * ST_WS + 64) * E + 16;
+    size_t lds = ((size_t)3 * ST_WH * ST_WS + 64) * E + 16;
+    // one workgroup per CU at a time (LDS request > half a CU's): the 67 MB output of a C2 launch is then written by one round
+    // of workgroups while the next round computes, instead of by all of them at the end (stem_min_lds = 0: natural occupancy)
+    // (measured, tools/kbench_stem.py: fp32 67 -> 61 us; 16-bit launches are too short to gain: 19.8 -> 23.3 us, so fp32 only)
+    if (dtype == BC_F32 && lds < (size_t)g_tune.stem_min_lds) lds = g_tune.stem_min_lds;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stem7x7<BC_F32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stem7x7<BC_F16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stem7x7<BC_BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+        attr_set = true;
+    }
     ProfScope ps(BC_OP_CONV3X3, 2.0 * n_exec * (bs / 2) * (bs / 2) * 147.0 * 64);
     const dim3 grid((unsigned)n_exec * g.patches_per_tile);
     if (dtype == BC_F32)
