@@ -2132,6 +2132,7 @@ static bool conv2_plan(const Conv2Cfg &k, int E, int S, int n_exec, int Cin, int
     const size_t img = (size_t)k.WMW * tpr * slot_px * (uv * sc + 1) * 16;
     const size_t red = (size_t)k.WMW * k.WNW * (k.WKW - 1) * k.RM * k.RN * 16 * 64 * sizeof(float);
     p.lds_bytes = 2 * img > red ? 2 * img : red;
+    if (p.lds_bytes < 8 * 4096) p.lds_bytes = 8 * 4096;         // the epilogue transposes through 4 KB per wave
     if (p.lds_bytes > 160 * 1024 - 2048 - 1024) return false;   // (static tables of the kernel take < 1 KB)
     p.patches_x = pw == 8 ? bs / 8 : 1;
     p.patches_per_tile = pw == 8 ? (bs / 8) * (bs / ph) : 1;
