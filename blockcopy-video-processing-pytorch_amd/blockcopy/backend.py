@@ -120,6 +120,8 @@ def load_library(path: str = None) -> ctypes.CDLL:
         "bc_conv3x3s2_ring_nhwc": [p, p, p, p, p, p] + [i] * 8 + [p, p, i, p, p, p, i, p],
         "bc_conv3x3_candidates": [i, i, i, i, i, i, ctypes.POINTER(i), i],
         "bc_stem7x7s2_nhwc": [p, p, p, p] + [i] * 7 + [p, p, p, i, p],
+        "bc_conv1x1_nhwc": [p, p, p] + [i] * 6 + [p, p, i, p, p, p, i, p],
+        "bc_conv1x1_candidates": [i, i, i, i, i, i, ctypes.POINTER(i), i],
         "bc_interp_bilinear_nhwc": [p, p, ctypes.c_longlong, i, i, i, i, i, i, ctypes.c_float, ctypes.c_float, i, p],
         "bc_interp_bilinear_act_nhwc": [p, p, ctypes.c_longlong, i, i, i, i, i, i, ctypes.c_float, ctypes.c_float, i, p, p, p, i, p],
         "bc_affine_act": [p, p, p, p, p, i, ctypes.c_longlong, i, ctypes.c_longlong, i, p],
@@ -259,7 +261,8 @@ class HipBackend:
 
     def pad_ring(self, data_exec, ring, grid_idx, mapping_exec, pad, prologue=None):
         """halo gather over the persistent ring cache (+ refresh of the executed tiles' rings).
-        prologue = (scale, shift, relu): per-channel fp32 affine + ReLU fused into the gather (ring keeps raw values)."""
+        prologue = (scale, shift, relu): per-channel fp32 affine + ReLU fused into the gather (applied to
+        values read from packed tiles; the ring keeps the ACTIVATED values, so records do not depend on the route that wrote them)."""
         assert _ok(data_exec) and _ok(ring, data_exec.dtype) and _ok(mapping_exec, torch.int32) and _ok(grid_idx, torch.int32)
         N, _, GH, GW = grid_idx.shape
         B, C, bs, _ = data_exec.shape
@@ -370,10 +373,10 @@ class HipBackend:
         wpk[nb][unit][tap][step][lane][j] = W[32*nb + lane%32][32*unit + 2*EPV*step + EPV*(lane//32) + j][tap] with EPV = elements
         per 16-byte vector (4 for fp32: 4 steps per 32-channel unit; 8 for fp16 / bf16: 2 steps)."""
         Cout, Cin, kh, kw = weight.shape
-        assert (kh, kw) == (3, 3) and Cin % 32 == 0 and Cout % 32 == 0
+        assert (kh, kw) in ((3, 3), (1, 1)) and Cin % 32 == 0 and Cout % 32 == 0     # (1x1: the same stream with a single tap)
         epv = 16 // weight.element_size()
         steps = 32 // (2 * epv)
-        w = weight.detach().as_subclass(torch.Tensor).permute(2, 3, 1, 0).reshape(9, Cin // 32, steps, 2, epv, Cout // 32, 32)   # tap, unit, step, h, j, nb, n
+        w = weight.detach().as_subclass(torch.Tensor).permute(2, 3, 1, 0).reshape(kh * kw, Cin // 32, steps, 2, epv, Cout // 32, 32)   # tap, unit, step, h, j, nb, n
         return w.permute(5, 1, 0, 2, 3, 6, 4).contiguous().view(-1)                                    # nb, unit, tap, step, h, n, j
 
     def conv3x3_candidates(self, n_exec, cin, cout, bs, elem_size=4, stride=1):
@@ -440,6 +443,62 @@ class HipBackend:
                                bs, _DTYPE_CODE[data_exec.dtype], ptr(isc), ptr(ish), int(bool(irelu)),
                                ptr(osc), ptr(osh), ptr(oadd), int(bool(orelu)), self._stream()),
                             "conv3x3_ring_nhwc")
+        return out
+
+    # -- pointwise conv on the matrix cores (the fused kernel with one tap): prologue / epilogue fusion for 1x1 convs
+    @staticmethod
+    def conv1x1_geometry(data, stride):
+        """(n_tiles, bs) the library is called with, or None: stride 1 = any 8x8 re-tiling of the pixels, stride 2 = the real tiles."""
+        B, C, H, W = data.shape
+        if stride == 1:
+            return ((B * H * W) // 64, 8) if (B * H * W) % 64 == 0 else None
+        if H != W or H % 2 or not ((H // 2) % 8 == 0 or H // 2 == 4) or H > 248:
+            return None
+        return B, H
+
+    def conv1x1_supported(self, data, weight, stride=1, padding=0, dilation=1, groups=1):
+        def _one(v):
+            return v if isinstance(v, int) else (v[0] if len(set(v)) == 1 else None)
+        st = _one(stride)
+        if st not in (1, 2) or _one(padding) != 0 or _one(dilation) != 1 or groups != 1 or data.dim() != 4:
+            return False
+        cin_unit = 32 if data.dtype == torch.float32 else 64
+        nhwc = is_nhwc(data) or (data.is_contiguous() and data.shape[2] * data.shape[3] == 1)
+        return (data.is_cuda and data.dtype in _DTYPE_CODE and weight.dtype == data.dtype and nhwc and tuple(weight.shape[2:]) == (1, 1)
+                and weight.shape[1] % cin_unit == 0 and weight.shape[0] % 64 == 0 and data.shape[1] == weight.shape[1]
+                and self.conv1x1_geometry(data, st) is not None)
+
+    def conv1x1_candidates(self, data, cout, stride=1):
+        geo = self.conv1x1_geometry(data, stride)
+        if geo is None:
+            return []
+        buf = (ctypes.c_int * 32)()
+        n = self.lib.bc_conv1x1_candidates(_DTYPE_CODE[data.dtype], int(stride), geo[0], data.shape[1], int(cout), geo[1], buf, 32)
+        return [int(buf[k]) for k in range(max(n, 0))]
+
+    def conv1x1(self, data, wpk, cout, prologue=None, epilogue=None, cfg=None, stride=1):
+        """relu?(conv1x1(prologue(data)) * scale + shift + add) of a channels-last tensor in one launch (bc_conv1x1_nhwc)."""
+        assert _ok(data, *_DTYPE_CODE) and _ok(wpk, data.dtype)
+        B, C, H, W = data.shape
+        n_tiles, bs = self.conv1x1_geometry(data, stride)
+        out = torch.empty((B, cout, H // stride, W // stride), dtype=data.dtype, device=data.device, memory_format=torch.channels_last)
+        isc, ish, irelu = prologue if prologue is not None else (None, None, False)
+        osc, osh, oadd, orelu = epilogue if epilogue is not None else (None, None, None, False)
+        for v, n in ((isc, C), (ish, C), (osc, cout), (osh, cout)):
+            assert v is None or (_ok(v, torch.float32) and v.numel() == n)
+        if oadd is not None:
+            oadd = oadd.contiguous(memory_format=torch.channels_last)
+            assert oadd.dtype == data.dtype and oadd.shape == out.shape
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        if out.numel() > 0:
+            with torch.cuda.device_of(data):
+                want = int(cfg) if cfg is not None else self._conv_cfg_pinned
+                if want != self._conv_cfg:
+                    self._check(self.lib.bc_tune_set(b"conv2_cfg", want), "tune_set")
+                    self._conv_cfg = want
+                self._check(self.lib.bc_conv1x1_nhwc(out.data_ptr(), data.data_ptr(), wpk.data_ptr(), n_tiles, C, cout, bs, int(stride),
+                                                     _DTYPE_CODE[data.dtype], ptr(isc), ptr(ish), int(bool(irelu)), ptr(osc), ptr(osh),
+                                                     ptr(oadd), int(bool(orelu)), self._stream()), "conv1x1_nhwc")
         return out
 
     # -- network-input stage: window gather from the frame-state map + 7x7 / stride 2 stem conv (csrc/stem7x7.inc)

@@ -127,6 +127,7 @@ CONV_MODE = os.environ.get("BLOCKCOPY_CONV", "auto")   # auto | native | library
 CONV_TUNE = os.environ.get("BLOCKCOPY_CONV_TUNE", "1") != "0"   # auto mode: measure each new layer shape once (eager runs only)
 _conv_plans = {}      # (n_exec, bs, cin, cout, n_total, dtype) -> None (library conv) | decomposition index (-1 = library's own choice)
 DEFER_CONV = os.environ.get("BLOCKCOPY_DEFER_CONV", "1") != "0"   # fused convs launch lazily with the recorded elementwise work as epilogue
+POINTWISE = os.environ.get("BLOCKCOPY_POINTWISE", "1") != "0"     # 1x1 convs through the fused kernel's one-tap form (prologue / epilogue fusion)
 STEM_KERNEL = os.environ.get("BLOCKCOPY_STEM", "1") != "0"        # network input: window gather + 7x7 stem conv in one kernel
 CONV_TUNE_LOG = []    # (key, {candidate: microseconds}, choice) of every measurement, for the bench report
 
@@ -142,7 +143,7 @@ def default_native_conv3x3(n_exec: int, bs: int, cin: int, cout: int) -> bool:
     return not (bs <= 4 and n_exec * bs * bs < 1024)
 
 
-def conv3x3_plan(n_exec: int, bs: int, cin: int, cout: int, n_total: int, dtype, tuner=None, stride: int = 1):
+def conv3x3_plan(n_exec: int, bs: int, cin: int, cout: int, n_total: int, dtype, tuner=None, stride: int = 1, ks: int = 3):
     """How to run one padded 3x3 / stride 1 conv layer: ``None`` = halo gather + library conv, ``int`` = the fused
     halo+conv kernel with that decomposition (-1: the library's cost model).  In ``auto`` mode a new layer shape is
     MEASURED once (``tuner()`` times the library route and every decomposition on the live tensors) -- the same idea as the
@@ -151,7 +152,7 @@ def conv3x3_plan(n_exec: int, bs: int, cin: int, cout: int, n_total: int, dtype,
         return None
     if CONV_MODE == "native":
         return -1
-    key = (n_exec, bs, cin, cout, n_total, dtype, stride)
+    key = (n_exec, bs, cin, cout, n_total, dtype, stride, ks)
     if key in _conv_plans:
         return _conv_plans[key]
     capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
@@ -163,6 +164,8 @@ def conv3x3_plan(n_exec: int, bs: int, cin: int, cout: int, n_total: int, dtype,
             _conv_plans[key] = plan
             CONV_TUNE_LOG.append((key, times, best))
             return plan
+    if ks == 1:
+        return -1 if n_exec * bs * bs >= 4096 else None       # untuned rule for pointwise convs: the library for tiny maps
     return -1 if default_native_conv3x3(n_exec, bs // stride, cin, cout) else None
 
 

@@ -578,9 +578,16 @@ class TensorWrapper(torch.Tensor):
                     warnings.warn(f"Operation {op} might behave differently with TensorWrapper!")
                     ret = func(*args, **kwargs)
             else:
-                if op in OPS["PADDED"]:
-                    _materialize_args(args)
-                ret = func(*args, **kwargs)
+                ret = None
+                if (op == "conv2d" and fusion.ENABLED and fusion.POINTWISE and self._features is not None and self._features.engine == "fused"
+                        and isinstance(args[0], TensorWrapper)):
+                    got = self._dense_pointwise_conv(args, kwargs)     # BN -> ReLU -> 1x1 conv blocks of dense (noblocks) modules
+                    if got is not None:
+                        ret, pend = got
+                if ret is None:
+                    if op in OPS["PADDED"]:
+                        _materialize_args(args)
+                    ret = func(*args, **kwargs)
             out = cls._wrap_result(ret, self)
             if pend is not None:
                 out._pending = pend
@@ -695,6 +702,10 @@ class TensorWrapper(torch.Tensor):
             padding = padding[0]
         padding = int(padding)
         if padding <= 0:
+            if fuse and op == "conv2d":
+                got = self._pointwise_conv(x, args, kwargs, pend_out)
+                if got is not None:
+                    return got
             _materialize_args(args)
             with timings.env("tensorwrapper/pad_func0", 11):
                 return func(*args, **kwargs), pend_out
@@ -841,6 +852,76 @@ class TensorWrapper(torch.Tensor):
             return be.time_routes(routes)
 
         return fusion.conv3x3_plan(n_exec, bs, cin, cout, n_total, data.dtype, tuner, stride)
+
+    def _dense_pointwise_conv(self, args, kwargs):
+        """conv2d on a dense (non-packed) TensorWrapper: 1x1 convs take the fused one-tap kernel; returns (result, pending) or None."""
+        args = list(args)
+        if "padding" in kwargs:
+            padding = kwargs["padding"]
+        else:
+            padding = args[4] if len(args) > 4 else 0
+        if isinstance(padding, (tuple, list)):
+            padding = padding[0] if len(set(padding)) == 1 else -1
+        if padding != 0:
+            return None
+        pend_out = None
+        bias = kwargs["bias"] if "bias" in kwargs else (args[2] if len(args) > 2 else None)
+        got = self._pointwise_conv(args[0], args, kwargs, None, bias=bias)
+        return got
+
+    def _pointwise_conv(self, x, args, kwargs, pend_out, bias=None):
+        """1x1 / pad 0 conv through bc_conv1x1_nhwc where that is the faster route: the pending BN / ReLU of ``x`` becomes the
+        kernel's prologue, the launch is deferred so that what is recorded after it becomes its epilogue.  None = library route."""
+        be = get_backend()
+        weight = args[1] if len(args) > 1 else kwargs.get("weight")
+        if (not fusion.POINTWISE or not hasattr(be, "conv1x1") or not isinstance(weight, torch.Tensor) or not isinstance(x, TensorWrapper)
+                or x.dim() != 4 or tuple(weight.shape[2:]) != (1, 1)):
+            return None
+        cv = {k: kwargs.get(k, args[i] if len(args) > i else d) for k, i, d in (("stride", 3, 1), ("dilation", 5, 1), ("groups", 6, 1))}
+        stride = self._conv_stride(args, kwargs)
+        raw = x._raw()
+        if not be.conv1x1_supported(raw, weight, cv["stride"], 0, cv["dilation"], cv["groups"]):
+            return None
+        P = x._pending
+        foldable = P is not None and P.add is None and not P.deferred
+        n_px, cin, cout = raw.shape[0] * raw.shape[2] * raw.shape[3], raw.shape[1], weight.shape[0]
+
+        def tuner():
+            if not raw.is_cuda:
+                return None
+            w_plain = weight.as_subclass(torch.Tensor) if isinstance(weight, TensorWrapper) else weight
+            wpk = fusion.packed_conv3x3_weight(weight, be.pack_conv3x3_weights)
+            src = dense_layout(raw)
+            pro = (P.scale, P.shift, P.relu) if foldable else None
+            lib = (lambda: torch.nn.functional.conv2d(be.affine_act(src, pro[0], pro[1], None, pro[2]), w_plain.detach(), stride=stride)) if pro is not None \
+                else (lambda: torch.nn.functional.conv2d(src, w_plain.detach(), stride=stride))
+            routes = {"library": lib}
+            for c in be.conv1x1_candidates(src, cout, stride):
+                routes[str(c)] = (lambda c_: lambda: be.conv1x1(src, wpk, cout, pro, None, cfg=c_, stride=stride))(c)
+            return be.time_routes(routes)
+
+        plan = fusion.conv3x3_plan(n_px // 64, 8, cin, cout, int(foldable), raw.dtype, tuner, stride, ks=1)
+        if plan is None:
+            return None
+        if pend_out is None and bias is not None:
+            if raw.dtype not in getattr(be, "supports_fusion_dtypes", ()):
+                return None
+            pend_out = fusion.Pending(shift=fusion.channel_vector(bias))
+        prologue = None
+        if foldable:
+            prologue = (P.scale, P.shift, P.relu)
+        elif P is not None:
+            x._materialize()
+        data = dense_layout(x._raw())
+        wpk = fusion.packed_conv3x3_weight(weight, be.pack_conv3x3_weights)
+        launch_kw = dict(data=data, wpk=wpk, cout=cout, prologue=prologue, cfg=plan, stride=stride)
+        if fusion.DEFER_CONV and data.dtype in getattr(be, "supports_fusion_dtypes", ()):
+            placeholder = torch.empty((data.shape[0], cout, data.shape[2] // stride, data.shape[3] // stride), dtype=data.dtype, device=data.device,
+                                      memory_format=torch.channels_last)
+            Pn = pend_out if pend_out is not None else fusion.Pending()
+            Pn.conv = (be.conv1x1, launch_kw)
+            return placeholder, Pn
+        return be.conv1x1(epilogue=None, **launch_kw), pend_out
 
     def _residual_gather_ok(self, op, x, P, args, kwargs, padding) -> bool:
         """Can the pending residual add of ``x`` be folded into this padded op's halo gather?"""

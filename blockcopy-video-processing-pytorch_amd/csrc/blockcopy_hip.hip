@@ -218,8 +218,10 @@ __global__ __launch_bounds__(WG) void k_transfer(typename VecOf<VB>::type *__res
 // Optional per-channel affine + ReLU applied to every gathered REAL value inside the halo gather
 // (y = relu?(x*scale[c] + shift[c]), fp32 arithmetic): the BN->ReLU prologue of a pre-activation conv or the
 // bias+ReLU epilogue of the producing conv, fused into the copy.  Zeros written beyond the image border stay zero
-// (the padded op pads the ACTIVATED tensor) and the ring cache keeps RAW values, so the same transform applies to
-// values gathered in later frames.  DT: 0 = none (pure copy, bit-exact), 1 = f32, 2 = f16, 3 = bf16.
+// (the padded op pads the ACTIVATED tensor).  The ring cache keeps ACTIVATED values -- what the padded op sees -- so a
+// record is valid whichever route produced it (prologue here, or a producer that had materialised the activation
+// already): values read from a ring record are never transformed again, values read from packed tiles always are.
+// DT: 0 = none (pure copy, bit-exact), 1 = f32, 2 = f16, 3 = bf16.
 struct Prologue {
     const float *scale;   // may be null (= 1)
     const float *shift;   // may be null (= 0)
@@ -442,6 +444,7 @@ __global__ __launch_bounds__(WG) void k_halo_lds(T *__restrict__ out, const T *_
     SV vec[HALO_UM];
     T edge[HALO_UE];
     uint32_t fm[HALO_UM], zm[HALO_UM], rsel[HALO_UM], fe[HALO_UE], ze[HALO_UE], rhs[HALO_UM], rws[HALO_UM];
+    bool gm[HALO_UM], ge[HALO_UE];   // value comes from a ring record (already activated)
     float psm[HALO_UM], ptm[HALO_UM], pse[HALO_UE], pte[HALO_UE];
     long long roff[HALO_UM];
     {
@@ -460,6 +463,7 @@ __global__ __launch_bounds__(WG) void k_halo_lds(T *__restrict__ out, const T *_
             const uint32_t in_tile = c * g.plane + hs * bs + xv * VE;
             const uint32_t z = (uint32_t)nb_zero[s];
             zm[u] = z == 1;
+            gm[u] = z == 2;
             const long long src = z == 1 ? 0 : nb_base[s] + (z == 2 ? c * RS + ring_elem(sy, 1, hs, xv * VE, bs, p) : in_tile);
             vec[u] = *reinterpret_cast<const SV *>(features + src);
             fm[u] = r * BSP + p + xv * VE;
@@ -486,6 +490,7 @@ __global__ __launch_bounds__(WG) void k_halo_lds(T *__restrict__ out, const T *_
             const uint32_t wp = right ? bs + e : e;        // p + bs + (e - p)
             const uint32_t z = (uint32_t)nb_zero[s];
             ze[u] = z == 1;
+            ge[u] = z == 2;
             const long long src = z == 1 ? 0 : nb_base[s] + (z == 2 ? c * RS + ring_elem(sy, right ? 2u : 0u, hs, ws, bs, p)
                                                                        : c * g.plane + hs * bs + ws);
             edge[u] = features[src];
@@ -494,17 +499,22 @@ __global__ __launch_bounds__(WG) void k_halo_lds(T *__restrict__ out, const T *_
     }
 #pragma unroll
     for (int u = 0; u < HALO_UM; ++u) {
-        const T *e = reinterpret_cast<const T *>(&vec[u]);
+        SV av = vec[u];
+        T *e = reinterpret_cast<T *>(&av);
+        if (DT != 0 && !gm[u]) {
+#pragma unroll
+            for (int k = 0; k < VE; ++k) e[k] = ActCvt<DT, T>::apply(e[k], psm[u], ptm[u], pr.relu);
+        }
 #pragma unroll
         for (int k = 0; k < VE; ++k) {
             const uint32_t f = fm[u] + k;
             const uint32_t j = (f >= f0 && f < f1) ? ph + (f - f0) : dummy;
-            img[j] = zm[u] ? (T)0 : ActCvt<DT, T>::apply(e[k], psm[u], ptm[u], pr.relu);
+            img[j] = zm[u] ? (T)0 : e[k];
         }
-        if (RING && rsel[u]) {   // refresh the tile's own compact ring record; the ring keeps RAW values
+        if (RING && rsel[u]) {   // refresh the tile's own compact ring record; the ring keeps ACTIVATED values
             T *rec = ring_w + roff[u];
-            if (rhs[u] < p) *reinterpret_cast<SV *>(rec + rhs[u] * bs + rws[u]) = vec[u];
-            if (rhs[u] >= bs - p) *reinterpret_cast<SV *>(rec + p * bs + (rhs[u] - (bs - p)) * bs + rws[u]) = vec[u];
+            if (rhs[u] < p) *reinterpret_cast<SV *>(rec + rhs[u] * bs + rws[u]) = av;
+            if (rhs[u] >= bs - p) *reinterpret_cast<SV *>(rec + p * bs + (rhs[u] - (bs - p)) * bs + rws[u]) = av;
 #pragma unroll
             for (int k = 0; k < VE; ++k) {
                 const uint32_t w = rws[u] + k;
@@ -517,7 +527,7 @@ __global__ __launch_bounds__(WG) void k_halo_lds(T *__restrict__ out, const T *_
     for (int u = 0; u < HALO_UE; ++u) {
         const uint32_t f = fe[u];
         const uint32_t j = (f >= f0 && f < f1) ? ph + (f - f0) : dummy;
-        img[j] = ze[u] ? (T)0 : ActCvt<DT, T>::apply(edge[u], pse[u], pte[u], pr.relu);
+        img[j] = ze[u] ? (T)0 : (ge[u] ? edge[u] : ActCvt<DT, T>::apply(edge[u], pse[u], pte[u], pr.relu));
     }
     __syncthreads();
 
@@ -610,7 +620,7 @@ __global__ __launch_bounds__(WG) void k_halo_rows(T *__restrict__ out, const T *
     {
         SV vec[HALO_UM];
         uint32_t dst[HALO_UM], rc[HALO_UM], rhs[HALO_UM], rws[HALO_UM];
-        bool zero[HALO_UM], rsel[HALO_UM];
+        bool zero[HALO_UM], rsel[HALO_UM], fr[HALO_UM];
         float ps[HALO_UM], pt[HALO_UM];
 #pragma unroll
         for (int u = 0; u < HALO_UM; ++u) {
@@ -627,6 +637,7 @@ __global__ __launch_bounds__(WG) void k_halo_rows(T *__restrict__ out, const T *
             const long long base = top ? nbb[1] : (bot ? nbb[7] : nbb[4]);
             const uint32_t off = from_ring ? c * RS + ring_elem(top ? 0u : 2u, 1, hs, xv * VE, bs, p) : in_tile;
             vec[u] = *reinterpret_cast<const SV *>(features + (zero[u] ? 0 : base + off));
+            fr[u] = from_ring;
             dst[u] = rr * BSP + p + xv * VE;
             rsel[u] = RING && !top && !bot && (hs < p || hs >= bs - p || xv * VE < p || xv * VE + VE > bs - p);
             rc[u] = c; rhs[u] = hs; rws[u] = xv * VE;
@@ -634,7 +645,12 @@ __global__ __launch_bounds__(WG) void k_halo_rows(T *__restrict__ out, const T *
 #pragma unroll
         for (int u = 0; u < HALO_UM; ++u) {
             SV v = vec[u];
-            if (RING && rsel[u]) {   // refresh the tile's own compact ring record; the ring keeps RAW values
+            if (DT != 0 && !fr[u]) {   // ring records are activated already
+                T *e = reinterpret_cast<T *>(&v);
+#pragma unroll
+                for (int k = 0; k < VE; ++k) e[k] = ActCvt<DT, T>::apply(e[k], ps[u], pt[u], pr.relu);
+            }
+            if (RING && rsel[u]) {   // refresh the tile's own compact ring record; the ring keeps ACTIVATED values
                 T *rec = ring_w + ring_base + (long long)rc[u] * RS;
                 if (rhs[u] < p) *reinterpret_cast<SV *>(rec + rhs[u] * bs + rws[u]) = v;
                 if (rhs[u] >= bs - p) *reinterpret_cast<SV *>(rec + p * bs + (rhs[u] - (bs - p)) * bs + rws[u]) = v;
@@ -645,11 +661,6 @@ __global__ __launch_bounds__(WG) void k_halo_rows(T *__restrict__ out, const T *
                     if (w < p) rec[2 * p * bs + rhs[u] * p + w] = e[k];
                     if (w >= bs - p) rec[2 * p * bs + bs * p + rhs[u] * p + (w - (bs - p))] = e[k];
                 }
-            }
-            if (DT != 0) {
-                T *e = reinterpret_cast<T *>(&v);
-#pragma unroll
-                for (int k = 0; k < VE; ++k) e[k] = ActCvt<DT, T>::apply(e[k], ps[u], pt[u], pr.relu);
             }
             if (zero[u]) v = (SV)0;
             *reinterpret_cast<SVU *>(out_t + dst[u]) = v;
@@ -662,7 +673,7 @@ __global__ __launch_bounds__(WG) void k_halo_rows(T *__restrict__ out, const T *
         for (uint32_t base_it = e0; base_it < e1; base_it += WG * HALO_UE) {
             T val[HALO_UE];
             uint32_t dst[HALO_UE];
-            bool zero[HALO_UE];
+            bool zero[HALO_UE], fr[HALO_UE];
             float ps[HALO_UE], pt[HALO_UE];
 #pragma unroll
             for (int u = 0; u < HALO_UE; ++u) {
@@ -686,10 +697,12 @@ __global__ __launch_bounds__(WG) void k_halo_rows(T *__restrict__ out, const T *
                                                : c * g.plane + hs * bs + ws;
                 const long long src = (right ? br : bl) + off;
                 val[u] = features[zero[u] ? 0 : src];
+                fr[u] = from_ring;
                 dst[u] = rr * BSP + (right ? bs + e : e);
             }
 #pragma unroll
-            for (int u = 0; u < HALO_UE; ++u) out_t[dst[u]] = zero[u] ? (T)0 : ActCvt<DT, T>::apply(val[u], ps[u], pt[u], pr.relu);
+            for (int u = 0; u < HALO_UE; ++u)
+                out_t[dst[u]] = zero[u] ? (T)0 : (fr[u] ? val[u] : ActCvt<DT, T>::apply(val[u], ps[u], pt[u], pr.relu));
         }
     }
 }
@@ -1089,7 +1102,7 @@ __global__ __launch_bounds__(WG) void k_halo_nhwc(typename VecOf<VB>::type *__re
 
     V vec[UNROLL];
     uint32_t fo[UNROLL], kk[UNROLL], hs_[UNROLL], ws_[UNROLL];
-    bool zero[UNROLL], own[UNROLL];
+    bool zero[UNROLL], own[UNROLL], ring[UNROLL];
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
         const uint32_t f = min((blockIdx.x * UNROLL + u) * WG + threadIdx.x, g.per_tile - 1);
@@ -1116,24 +1129,25 @@ __global__ __launch_bounds__(WG) void k_halo_nhwc(typename VecOf<VB>::type *__re
         vec[u] = features[zero[u] ? 0 : base + off];   // inputs are fresh from the producing kernel: streaming loads measured slower here
         fo[u] = f; kk[u] = k; hs_[u] = hs; ws_[u] = ws;
         own[u] = sy == 1 && sx == 1;
+        ring[u] = from_ring;
     }
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
         V v = vec[u];
-        if (RING && own[u]) {   // refresh the tile's own compact ring record (raw values), aligned vector stores
-            const uint32_t hs = hs_[u], ws = ws_[u], k = kk[u];
-            if (hs < p) rec[(hs * bs + ws) * K + k] = v;
-            if (hs >= bs - p) rec[(p * bs + (hs - (bs - p)) * bs + ws) * K + k] = v;
-            if (ws < p) rec[(2 * p * bs + hs * p + ws) * K + k] = v;
-            if (ws >= bs - p) rec[(2 * p * bs + bs * p + hs * p + (ws - (bs - p))) * K + k] = v;
-        }
-        if (DT != 0) {
+        if (DT != 0 && !ring[u]) {   // ring records hold activated values already
             T *e = reinterpret_cast<T *>(&v);
             float sc[VE], sh[VE];
             load_coeffs<VE>(pr.scale, kk[u] * VE, 1.0f, sc);
             load_coeffs<VE>(pr.shift, kk[u] * VE, 0.0f, sh);
 #pragma unroll
             for (int j = 0; j < VE; ++j) e[j] = ActCvt<DT, T>::apply(e[j], sc[j], sh[j], pr.relu);
+        }
+        if (RING && own[u]) {   // refresh the tile's own compact ring record (activated values), aligned vector stores
+            const uint32_t hs = hs_[u], ws = ws_[u], k = kk[u];
+            if (hs < p) rec[(hs * bs + ws) * K + k] = v;
+            if (hs >= bs - p) rec[(p * bs + (hs - (bs - p)) * bs + ws) * K + k] = v;
+            if (ws < p) rec[(2 * p * bs + hs * p + ws) * K + k] = v;
+            if (ws >= bs - p) rec[(2 * p * bs + bs * p + hs * p + (ws - (bs - p))) * K + k] = v;
         }
         if (zero[u]) v = V{};
         out_t[fo[u]] = v;
@@ -1326,7 +1340,7 @@ __global__ __launch_bounds__(WG) void k_maxpool3x3s2_nhwc(typename VecOf<sizeof(
     V *__restrict__ rec = ring_w + (long long)ig * RSV;
 
     V raw[9];
-    bool zero[9];
+    bool zero[9], ring[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         const int y = 2 * (int)oy + t / 3 - 1, x = 2 * (int)ox + t % 3 - 1;   // >= -1, <= bs - 1
@@ -1338,6 +1352,22 @@ __global__ __launch_bounds__(WG) void k_maxpool3x3s2_nhwc(typename VecOf<sizeof(
         zero[t] = k == 0 ? nbz[0] : (k == 1 ? nbz[1] : (k == 2 ? nbz[2] : false));
         const uint32_t pos = from_ring ? ring_elem(sy, sx, hs, ws, bs, 1u) : hs * bs + ws;
         raw[t] = features[zero[t] ? 0 : base + (long long)pos * K + kq];
+        ring[t] = from_ring;
+    }
+    // activation of everything that comes from packed tiles (ring records hold activated values), rounded to T as the
+    // reference pools the ROUNDED activations
+    if (DT != 0) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            if (ring[t]) continue;
+            T *e = reinterpret_cast<T *>(&raw[t]);
+#pragma unroll
+            for (int j = 0; j < VE; ++j) {
+                float x = Cvt<T>::ld(e + j) * sc[j] + sh[j];
+                if (pr.relu) x = fmaxf(x, 0.0f);
+                e[j] = Cvt<T>::st(x);
+            }
+        }
     }
     // ring refresh: this lane owns the 2x2 input block (2oy..2oy+1, 2ox..2ox+1) = taps 4, 5, 7, 8
 #pragma unroll
@@ -1358,11 +1388,6 @@ __global__ __launch_bounds__(WG) void k_maxpool3x3s2_nhwc(typename VecOf<sizeof(
 #pragma unroll
         for (int j = 0; j < VE; ++j) {
             float x = Cvt<T>::ld(e + j);
-            if (DT != 0) {
-                x = Cvt<T>::ld(e + j) * sc[j] + sh[j];
-                if (pr.relu) x = fmaxf(x, 0.0f);
-                x = Cvt<T>::ld_round(x);     // the reference pools the ROUNDED activations
-            }
             if (zero[t]) x = 0.0f;
             best[j] = fmaxf(best[j], x);
         }
@@ -2094,18 +2119,18 @@ static int device_cu_count()
     return n;
 }
 
-template <int DT, int RM, int RN, int WMW, int WNW, int WKW, int SC, int PW, int S>
+template <int DT, int RM, int RN, int WMW, int WNW, int WKW, int SC, int PW, int S, int KS>
 static void launch_conv3x3_v2_cfg(ProfScope &ps, dim3 grid, size_t lds_bytes, hipStream_t st, void *out, const void *features, void *ring,
                                   const void *wpk, const int32_t *grid_idx, const int32_t *mapping_exec, const ConvGeom2 &g,
                                   const Prologue &pr, const EpilogueT &ep)
 {
     static bool attr_set = false;   // > 64 KB of dynamic LDS needs the opt-in once per kernel
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_v2<DT, RM, RN, WMW, WNW, WKW, SC, PW, S>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_v2<DT, RM, RN, WMW, WNW, WKW, SC, PW, S, KS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
         attr_set = true;
     }
-    BC_LAUNCH(ps, (k_conv3x3_v2<DT, RM, RN, WMW, WNW, WKW, SC, PW, S>), grid, dim3(512), lds_bytes, st, (typename CvType<DT>::T *)out,
+    BC_LAUNCH(ps, (k_conv3x3_v2<DT, RM, RN, WMW, WNW, WKW, SC, PW, S, KS>), grid, dim3(512), lds_bytes, st, (typename CvType<DT>::T *)out,
               (const uint4 *)features, (long long)(((const char *)ring - (const char *)features) / 16), (uint4 *)ring, (const uint4 *)wpk,
               grid_idx, mapping_exec, g, pr, ep, g_tune.conv_stamps);
 }
@@ -2118,7 +2143,7 @@ static const Conv2Cfg CONV2_CFGS[] = {{2, 2, 4, 2, 1}, {2, 1, 4, 2, 1}, {1, 2, 4
 // geometry of one decomposition for a layer (bs = OUTPUT tile size); false if the decomposition does not cover the layer
 struct Conv2Plan { long long wgs; size_t lds_bytes; uint32_t n_rows, patches_per_tile, patches_x; };
 
-static bool conv2_plan(const Conv2Cfg &k, int E, int S, int n_exec, int Cin, int Cout, int bs, Conv2Plan &p)
+static bool conv2_plan(const Conv2Cfg &k, int E, int S, int n_exec, int Cin, int Cout, int bs, Conv2Plan &p, int KS = 3)
 {
     const int pw = bs == 4 ? 4 : 8;
     const int uv = E == 4 ? 8 : 4, sc_lo = E == 4 ? 1 : 2;
@@ -2128,7 +2153,7 @@ static bool conv2_plan(const Conv2Cfg &k, int E, int S, int n_exec, int Cin, int
     if (pw == 8 && bs % (4 * k.RM) != 0) return false;
     if (Cout % (32 * k.RN * k.WNW) != 0 || Cin % (32 * sc) != 0) return false;
     const uint32_t ph = pw == 8 ? 4u * k.RM : 4u, tpr = pw == 8 ? 1u : 2u * k.RM;
-    const uint32_t slot_px = (uint32_t)(S * pw + 3 - S) * (S * ph + 3 - S);
+    const uint32_t slot_px = (uint32_t)(S * (pw - 1) + KS) * (S * (ph - 1) + KS);
     const size_t img = (size_t)k.WMW * tpr * slot_px * (uv * sc + 1) * 16;
     const size_t red = (size_t)k.WMW * k.WNW * (k.WKW - 1) * k.RM * k.RN * 16 * 64 * sizeof(float);
     p.lds_bytes = 2 * img > red ? 2 * img : red;
@@ -2141,7 +2166,7 @@ static bool conv2_plan(const Conv2Cfg &k, int E, int S, int n_exec, int Cin, int
     return true;
 }
 
-template <int DT, int S>
+template <int DT, int S, int KS = 3>
 static int launch_conv3x3_v2(ProfScope &ps, void *out, const void *features, void *ring, const void *wpk, const int32_t *grid_idx,
                              const int32_t *mapping_exec, int n_exec, int Cin, int Cout, int GH, int GW, int bs,
                              const Prologue &pr, const EpilogueT &ep, hipStream_t st)
@@ -2158,9 +2183,10 @@ static int launch_conv3x3_v2(ProfScope &ps, void *out, const void *features, voi
     for (int c = 0; c < (int)(sizeof(CONV2_CFGS) / sizeof(CONV2_CFGS[0])); ++c) {
         const Conv2Cfg &k = CONV2_CFGS[c];
         if (force >= 0 && c != force) continue;
-        if (!conv2_plan(k, E, S, n_exec, Cin, Cout, bs, plan)) continue;
+        if (!conv2_plan(k, E, S, n_exec, Cin, Cout, bs, plan, KS)) continue;
+        if (KS == 1 && pw == 4 && S == 1) continue;            // (pointwise stride-1 launches are re-tiled to 8x8 by the caller)
         const long long rounds = (plan.wgs + cus - 1) / cus;
-        const double mf = (double)k.RM * k.RN * 9.0 * (Cin / 8) * 4.0 / k.WKW;        // fp32 MFMAs per wave (16-bit: the same ranking)
+        const double mf = (double)k.RM * k.RN * (double)(KS * KS) * (Cin / 8) * 4.0 / k.WKW;   // fp32 MFMAs per wave (16-bit: the same ranking)
         // per-MFMA slowdown from operand delivery (tools/probes/mfma_probe2: 1x1 tiles ~0.72, 2x1 ~0.79, 2x2 ~0.82 of peak)
         const double eff = k.RM * k.RN >= 4 ? 0.82 : (k.RM * k.RN == 2 ? (k.RM == 2 ? 0.79 : 0.74) : 0.70);
         const double t = rounds * (mf / eff + 70.0 + 12.0 * (k.WKW - 1) * k.RM * k.RN);
@@ -2184,14 +2210,14 @@ static int launch_conv3x3_v2(ProfScope &ps, void *out, const void *features, voi
     do {                                                                                                                 \
         constexpr int SC_ = WKW_ == 8 ? SC_HI : SC_LO;                                                                   \
         constexpr int RM4_ = WMW_ == 1 ? RM_ : 1;                                                                        \
-        constexpr size_t img8_ = (size_t)WMW_ * (S * 8 + 3 - S) * (S * 4 * RM_ + 3 - S) * (CvType<DT>::UV * SC_ + 1) * 32;  \
-        constexpr size_t img4_ = (size_t)WMW_ * 2 * RM4_ * (S * 4 + 3 - S) * (S * 4 + 3 - S) * (CvType<DT>::UV * SC_ + 1) * 32; \
+        constexpr size_t img8_ = (size_t)WMW_ * (S * 7 + KS) * (S * (4 * RM_ - 1) + KS) * (CvType<DT>::UV * SC_ + 1) * 32;  \
+        constexpr size_t img4_ = (size_t)WMW_ * 2 * RM4_ * (S * 3 + KS) * (S * 3 + KS) * (CvType<DT>::UV * SC_ + 1) * 32; \
         if (pw == 8) {                                                                                                   \
             if constexpr (img8_ <= 160 * 1024 - 3072)                                                                    \
-                launch_conv3x3_v2_cfg<DT, RM_, RN_, WMW_, WNW_, WKW_, SC_, 8, S>(ps, grid, lds_bytes, st, out, features, ring, wpk, grid_idx, mapping_exec, g, pr, ep); \
+                launch_conv3x3_v2_cfg<DT, RM_, RN_, WMW_, WNW_, WKW_, SC_, 8, S, KS>(ps, grid, lds_bytes, st, out, features, ring, wpk, grid_idx, mapping_exec, g, pr, ep); \
         } else {                                                                                                         \
-            if constexpr (img4_ <= 160 * 1024 - 3072)                                                                    \
-                launch_conv3x3_v2_cfg<DT, RM4_, RN_, WMW_, WNW_, WKW_, SC_, 4, S>(ps, grid, lds_bytes, st, out, features, ring, wpk, grid_idx, mapping_exec, g, pr, ep); \
+            if constexpr (img4_ <= 160 * 1024 - 3072 && !(KS == 1 && S == 1))                                            \
+                launch_conv3x3_v2_cfg<DT, RM4_, RN_, WMW_, WNW_, WKW_, SC_, 4, S, KS>(ps, grid, lds_bytes, st, out, features, ring, wpk, grid_idx, mapping_exec, g, pr, ep); \
         }                                                                                                                \
     } while (0)
     switch (best) {
@@ -2217,16 +2243,55 @@ static int launch_conv3x3_v2(ProfScope &ps, void *out, const void *features, voi
 }
 
 // which decompositions cover a layer: out[0..n) = their indices, returns n (the engine times exactly these)
-BC_EXPORT int bc_conv3x3_candidates(int dtype, int stride, int n_exec, int Cin, int Cout, int bs_in, int *out, int max_out)
+static int conv_candidates(int dtype, int stride, int ks, int n_exec, int Cin, int Cout, int bs_in, int *out, int max_out)
 {
     if (dtype < BC_F32 || dtype > BC_BF16 || (stride != 1 && stride != 2) || !out || bs_in % stride) return BC_ERR_SHAPE;
     const int E = dtype == BC_F32 ? 4 : 2, bs = bs_in / stride;
     if (!(bs == 4 || bs % 8 == 0) || bs > 248 / stride) return 0;
+    if (ks == 1 && stride == 1 && bs == 4) return 0;
     int n = 0;
     Conv2Plan plan;
     for (int c = 0; c < (int)(sizeof(CONV2_CFGS) / sizeof(CONV2_CFGS[0])) && n < max_out; ++c)
-        if (conv2_plan(CONV2_CFGS[c], E, stride, n_exec, Cin, Cout, bs, plan)) out[n++] = c;
+        if (conv2_plan(CONV2_CFGS[c], E, stride, n_exec, Cin, Cout, bs, plan, ks)) out[n++] = c;
     return n;
+}
+
+BC_EXPORT int bc_conv3x3_candidates(int dtype, int stride, int n_exec, int Cin, int Cout, int bs_in, int *out, int max_out)
+{
+    return conv_candidates(dtype, stride, 3, n_exec, Cin, Cout, bs_in, out, max_out);
+}
+
+BC_EXPORT int bc_conv1x1_candidates(int dtype, int stride, int n_tiles, int Cin, int Cout, int bs_in, int *out, int max_out)
+{
+    return conv_candidates(dtype, stride, 1, n_tiles, Cin, Cout, bs_in, out, max_out);
+}
+
+// pointwise (1x1) conv of a channels-last tensor viewed as n_tiles tiles of bs x bs pixels (any view with n_tiles*bs*bs pixels does
+// for stride 1; stride 2 needs the real tiles): the GEMM of the fused kernel with ONE tap -- no halo, no ring cache, no grid tables
+BC_EXPORT int bc_conv1x1_nhwc(void *out, const void *features, const void *weights_packed, int n_tiles, int Cin, int Cout, int bs, int stride,
+                              int dtype, const float *in_scale, const float *in_shift, int in_relu, const float *out_scale,
+                              const float *out_shift, const void *out_add, int out_relu, void *stream)
+{
+    if (dtype < BC_F32 || dtype > BC_BF16) return BC_ERR_ELEM;
+    if (n_tiles < 0 || Cin <= 0 || Cout <= 0 || bs <= 0 || (stride != 1 && stride != 2) || bs % stride) return BC_ERR_SHAPE;
+    const int bso = bs / stride;
+    if (Cin % CV_CH != 0 || Cout % 64 != 0 || !(bso % 8 == 0 || (bso == 4 && stride == 2)) || bs > 248) return BC_ERR_SHAPE;
+    if (n_tiles == 0) return BC_OK;
+    if (!out || !features || !weights_packed) return BC_ERR_NULL;
+    if ((uint64_t)n_tiles * bs * bs * (uint64_t)(Cin > Cout ? Cin : Cout) >= (1ull << 31)) return BC_ERR_RANGE;
+    if (!aligned(out, 16) || !aligned(features, 16) || !aligned(weights_packed, 16) || !aligned(out_add, 8)) return BC_ERR_ALIGN;
+    Prologue pr{in_scale, in_shift, in_relu};
+    EpilogueT ept{out_scale, out_shift, out_add, out_relu};
+    ProfScope ps(BC_OP_CONV3X3, 2.0 * n_tiles * bso * bso * (double)Cin * Cout);
+    void *ring = const_cast<void *>(features);      // (unused by the one-tap form)
+    hipStream_t st = (hipStream_t)stream;
+#define BC_C1(DT_)                                                                                                         \
+    (stride == 1 ? launch_conv3x3_v2<DT_, 1, 1>(ps, out, features, ring, weights_packed, nullptr, nullptr, n_tiles, Cin, Cout, 1, 1, bso, pr, ept, st) \
+                 : launch_conv3x3_v2<DT_, 2, 1>(ps, out, features, ring, weights_packed, nullptr, nullptr, n_tiles, Cin, Cout, 1, 1, bso, pr, ept, st))
+    if (dtype == BC_F32) return BC_C1(BC_F32);
+    if (dtype == BC_F16) return BC_C1(BC_F16);
+    return BC_C1(BC_BF16);
+#undef BC_C1
 }
 
 BC_EXPORT int bc_tune_set(const char *key, int value)

@@ -120,8 +120,10 @@ int bc_interp_bilinear(void *out, const void *in, long long planes, int h, int w
  *
  * bc_pad_ring_act = bc_pad_ring with an activation PROLOGUE: every gathered real value x of channel c becomes
  * relu?(x*scale[c] + shift[c]) (fp32 arithmetic; scale/shift are float32[C] device vectors, either may be NULL),
- * zeros beyond the image border stay zero, the ring cache keeps raw values.  With scale = shift = NULL and relu = 0
- * it is the pure copy.
+ * zeros beyond the image border stay zero.  The ring cache keeps the ACTIVATED values (what the padded op sees): values read
+ * from packed tiles are transformed, values read from ring records never are, so a record is valid whichever route wrote
+ * it (this prologue, or a plain gather of an input whose activation had been materialised by its producer).  With
+ * scale = shift = NULL and relu = 0 it is the pure copy.
  * bc_affine_act: out = relu?(in*scale[c] + shift[c] + add) over a packed (B,C,hw) tensor; add may be NULL; out may
  * alias in. */
 int bc_pad_ring_act(void *out, const void *features, void *ring, const int32_t *grid_idx,
@@ -155,7 +157,7 @@ int bc_interp_bilinear_act_nhwc(void *out, const void *in, long long planes, int
  * Replaces, for one padded conv layer of the reference (core/tensorwrapper.py:478-527: BlockPad.apply, then the stock
  * F.conv2d with padding 0 on the padded batch), the sequence bc_pad_ring_nhwc + library conv [+ bc_affine_act_nhwc].
  *   features (n_exec, bs, bs, Cin), out (n_exec, bs, bs, Cout), ring (N*GH*GW, 4*bs, Cin) as for bc_pad_ring_nhwc
- *   with pad = 1 (read for non-executed neighbours, refreshed with the RAW border of every executed tile);
+ *   with pad = 1 (read for non-executed neighbours, refreshed with the ACTIVATED (post-prologue) border of every executed tile);
  *   prologue: x -> relu?(x*in_scale[cin] + in_shift[cin]) on real values, zeros beyond the image border stay zero;
  *   epilogue: y -> relu?(y*out_scale[cout] + out_shift[cout] + out_add[pixel, cout]); any of them may be NULL/0.
  *   weights_packed: 9 * Cin * Cout elements of the tensor dtype in the MFMA operand order
@@ -179,6 +181,17 @@ int bc_conv3x3s2_ring_nhwc(void *out, const void *features, void *ring, const vo
                            const int32_t *grid_idx, const int32_t *mapping_exec, int n_exec, int N, int Cin, int Cout,
                            int GH, int GW, int bs, int dtype, const float *in_scale, const float *in_shift, int in_relu,
                            const float *out_scale, const float *out_shift, const void *out_add, int out_relu, void *stream);
+
+/* pointwise (1x1, pad 0) conv of a channels-last tensor on the matrix cores: the GEMM of the fused kernel with one tap, so that the
+ * BN / ReLU recorded BEFORE the conv (prologue) and the bias / residual add / ReLU recorded AFTER it (epilogue) cost no launch of
+ * their own (ResNet bottlenecks and decoder blocks are  ... -> ReLU -> conv1x1 -> ...).  features = n_tiles tiles of bs x bs pixels x Cin
+ * (stride 1: any view with the same number of pixels, e.g. a dense map as 8x8 tiles; stride 2: the real packed tiles, out has
+ * bs/2 x bs/2 per tile); weights_packed: the bc_conv3x3_ring_nhwc stream with a single tap; prologue / epilogue as there.
+ * Cin % 32 == 0 (16-bit: % 64), Cout % 64 == 0, bs/stride a multiple of 8 (or 4 with stride 2). */
+int bc_conv1x1_nhwc(void *out, const void *features, const void *weights_packed, int n_tiles, int Cin, int Cout, int bs, int stride,
+                    int dtype, const float *in_scale, const float *in_shift, int in_relu, const float *out_scale,
+                    const float *out_shift, const void *out_add, int out_relu, void *stream);
+int bc_conv1x1_candidates(int dtype, int stride, int n_tiles, int Cin, int Cout, int bs_in, int *out, int max_out);
 
 /* network-input stage in ONE launch: (bs+6)^2 window gather from the frame-state map + the 7x7 / stride 2 / pad 3 conv of the
  * 3-channel frame (ResNet stem) + epilogue, on the matrix cores.  Replaces, for the first padded op of the reference pipeline,
@@ -211,7 +224,7 @@ int bc_pad_ring_add_nhwc(void *out, void *act_out, const void *features, const v
 /* fused halo gather + max_pool2d(kernel 3, stride 2, padding 1) of a packed channels-last batch (the ResNet stem pool, the
  * one padded op of the path that is not a conv; reference: BlockPad.apply + F.max_pool2d(padding=0),
  * core/tensorwrapper.py:478-527).  features (n_exec, bs, bs, C) -> out (n_exec, bs/2, bs/2, C); ring and prologue exactly
- * as for bc_pad_ring_nhwc with pad = 1 (zeros beyond the image border take part in the max, the ring keeps raw values);
+ * as for bc_pad_ring_nhwc with pad = 1 (zeros beyond the image border take part in the max, the ring keeps the activated values);
  * bit-identical to bc_pad_ring_nhwc followed by a pad-0 pool.  bs even, C*elem_size a multiple of 16 bytes. */
 int bc_maxpool3x3s2_ring_nhwc(void *out, const void *features, void *ring, const int32_t *grid_idx,
                               const int32_t *mapping_exec, int n_exec, int N, int C, int GH, int GW, int bs, int dtype,

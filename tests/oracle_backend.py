@@ -84,20 +84,11 @@ class OracleBackend:
         skipped = torch.nonzero(gi < 0).squeeze(1)
         # skipped tiles, compacted in raster order == row (grid_idx + n_total) of the reference's transfer tensor
         transfer = ring_to_tiles(ring[skipped], bs, pad).contiguous()
-        out = self.pad(data_exec, transfer, grid_idx, mapping_exec, pad)
-        ring[mapping_exec.long()] = tiles_to_ring(data_exec, pad)      # the ring cache keeps RAW values
-        if prologue is not None:
-            # which padded positions hold real data (not image-border zeros)?  gather a tensor of ones the same way
-            real = self.pad(torch.ones_like(data_exec), torch.ones_like(transfer), grid_idx, mapping_exec, pad) == 1
-            scale, shift, relu = prologue
-            y = out.float()
-            if scale is not None:
-                y = y * scale.view(1, -1, 1, 1)
-            if shift is not None:
-                y = y + shift.view(1, -1, 1, 1)
-            if relu:
-                y = torch.relu(y)
-            out = torch.where(real, y.to(out.dtype), torch.zeros_like(out))
+        # the ring cache keeps what the padded op sees (ACTIVATED values): a prologue transforms the packed tiles only, ring
+        # records are never transformed again, and the image-border zeros stay zero because the ACTIVATED tensor is padded
+        act = data_exec if prologue is None else self.affine_act(data_exec, prologue[0], prologue[1], None, prologue[2])
+        out = self.pad(act, transfer, grid_idx, mapping_exec, pad)
+        ring[mapping_exec.long()] = tiles_to_ring(act, pad)
         return out
 
     supports_fusion_dtypes = (torch.float32,)
@@ -153,6 +144,21 @@ class OracleBackend:
             scale, shift, add, relu = epilogue
             y = self.affine_act(y, scale, shift, add.contiguous() if add is not None else None, relu)
         return _like(y, data_exec)
+
+    def conv1x1_supported(self, data, weight, stride=1, padding=0, dilation=1, groups=1):
+        one = lambda v: v if isinstance(v, int) else (v[0] if len(set(v)) == 1 else None)
+        return (data.dim() == 4 and _nhwc(data) and tuple(weight.shape[2:]) == (1, 1) and one(stride) in (1, 2) and one(padding) == 0
+                and one(dilation) == 1 and groups == 1 and data.dtype == torch.float32 and (data.shape[0] * data.shape[2] * data.shape[3]) % 64 == 0)
+
+    def conv1x1(self, data, wpk, cout, prologue=None, epilogue=None, cfg=None, stride=1):
+        x = data
+        if prologue is not None:
+            x = self.affine_act(x, prologue[0], prologue[1], None, prologue[2])
+        y = torch.nn.functional.conv2d(x.contiguous(), wpk.reshape(cout, data.shape[1], 1, 1), stride=stride)
+        if epilogue is not None:
+            scale, shift, add, relu = epilogue
+            y = self.affine_act(y, scale, shift, add.contiguous() if add is not None else None, relu)
+        return y.contiguous(memory_format=torch.channels_last)
 
     supports_interp_dtypes = (torch.float32,)
 
