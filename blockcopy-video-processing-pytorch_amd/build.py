@@ -8,9 +8,14 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = [os.path.join(HERE, "csrc", "blockcopy_hip.hip")]
-HDR = [os.path.join(os.path.dirname(HERE), "include", "blockcopy_hip.h"), os.path.join(HERE, "csrc", "conv3x3_mfma.inc")]
+HDR = [os.path.join(os.path.dirname(HERE), "include", "blockcopy_hip.h")] + [os.path.join(HERE, "csrc", f) for f in
+                                                                             ("conv3x3_mfma.inc", "conv3x3_v2.inc", "stem7x7.inc")]
 OUT = os.path.join(HERE, "lib", "libblockcopy_hip.so")
+OBJ_DIR = os.path.join(HERE, "lib", "obj")
 ARCH = "gfx950"
+# the one source is compiled as 7 translation units (-DBC_PART=n, see ConvV2Args in csrc/blockcopy_hip.hip): part 0 = everything
+# but the decompositions of the fused conv kernel, parts 1..6 = one (dtype, kernel size) slice of them each
+PARTS = list(range(7))
 
 
 def hipcc() -> str:
@@ -30,12 +35,21 @@ def needs_build() -> bool:
 def build_hip_library(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return OUT
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
-           "-Wall", "-Wno-unused-result", "-o", OUT + ".tmp"] + SRC
+    from concurrent.futures import ThreadPoolExecutor
+
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-result", "-Wno-unused-function"]
     if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-    subprocess.check_call(cmd)
+        flags.append("-Rpass-analysis=kernel-resource-usage")
+    objs = [os.path.join(OBJ_DIR, f"part{n}.o") for n in PARTS]
+
+    def compile_part(n):
+        subprocess.check_call([hipcc()] + flags + [f"-DBC_PART={n}", "-c", "-o", objs[n]] + SRC)
+
+    jobs = int(os.environ.get("BC_BUILD_JOBS", "0")) or max(1, min(len(PARTS), os.cpu_count() or 1))
+    with ThreadPoolExecutor(max_workers=jobs) as pool:
+        list(pool.map(compile_part, PARTS))
+    subprocess.check_call([hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-fvisibility=hidden", "-o", OUT + ".tmp"] + objs)
     os.replace(OUT + ".tmp", OUT)
     return OUT
 

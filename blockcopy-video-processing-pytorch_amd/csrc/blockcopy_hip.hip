@@ -11,6 +11,11 @@
 //     index arithmetic stays ~30 VALU ops per 16 B and well under the memory time;
 //   * 64-wide wavefronts, 256-thread workgroups, no LDS needed except the 3x3 neighbour table of the halo
 //     gather.
+// Translation-unit slicing (see ConvV2Args below): no -DBC_PART = the whole library in one unit
+#ifndef BC_PART
+#define BC_MONO 1
+#define BC_PART 0
+#endif
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <hip/hip_fp16.h>
@@ -1823,6 +1828,211 @@ int check_halo(const void *out, const void *features, const int32_t *grid_idx, c
 
 }  // namespace
 
+// ---- host side of conv3x3_v2.inc: choose the decomposition whose workgroup count best fills whole rounds of one
+// 8-wave workgroup per CU with equal MFMA counts per wave, then launch it.
+struct Conv2Cfg { int RM, RN, WMW, WNW, WKW; };
+
+static int device_cu_count()
+{
+    static const int n = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        return cus;
+    }();
+    return n;
+}
+
+static const Conv2Cfg CONV2_CFGS[] = {{2, 2, 4, 2, 1}, {2, 1, 4, 2, 1}, {1, 2, 4, 2, 1}, {1, 1, 4, 2, 1},     // 0-3: many pixels
+                                      {1, 1, 2, 4, 1}, {1, 1, 2, 2, 2}, {1, 1, 1, 4, 2}, {1, 1, 1, 2, 4},     // 4-7: 1x1 wave tiles
+                                      {2, 2, 2, 2, 2}, {2, 2, 1, 2, 4}, {2, 1, 2, 2, 2}, {2, 1, 1, 4, 2},     // 8-11: 2-block tiles + K groups
+                                      {2, 1, 1, 2, 4}, {2, 1, 1, 1, 8}, {1, 2, 1, 1, 8}, {1, 1, 1, 1, 8}};    // 12-15
+
+// geometry of one decomposition for a layer (bs = OUTPUT tile size); false if the decomposition does not cover the layer
+struct Conv2Plan { long long wgs; size_t lds_bytes; uint32_t n_rows, patches_per_tile, patches_x; };
+
+static bool conv2_plan(const Conv2Cfg &k, int E, int S, int n_exec, int Cin, int Cout, int bs, Conv2Plan &p, int KS = 3)
+{
+    const int pw = bs == 4 ? 4 : 8;
+    const int uv = E == 4 ? 8 : 4, sc_lo = E == 4 ? 1 : 2;
+    const int sc = k.WKW == 8 ? 2 * sc_lo : sc_lo;
+    if (pw == 8 && bs % 8 != 0) return false;
+    if (pw == 4 && k.RM != 1 && k.WMW != 1) return false;       // 4x4 tiles: 4 tile slots per wave row only in single-row workgroups (LDS)
+    if (pw == 8 && bs % (4 * k.RM) != 0) return false;
+    if (Cout % (32 * k.RN * k.WNW) != 0 || Cin % (32 * sc) != 0) return false;
+    const uint32_t ph = pw == 8 ? 4u * k.RM : 4u, tpr = pw == 8 ? 1u : 2u * k.RM;
+    const uint32_t slot_px = (uint32_t)(S * (pw - 1) + KS) * (S * (ph - 1) + KS);
+    const size_t img = (size_t)k.WMW * tpr * slot_px * (uv * sc + 1) * 16;
+    const size_t red = (size_t)k.WMW * k.WNW * (k.WKW - 1) * k.RM * k.RN * 16 * 64 * sizeof(float);
+    p.lds_bytes = 2 * img > red ? 2 * img : red;
+    if (p.lds_bytes < 8 * 4096) p.lds_bytes = 8 * 4096;         // the epilogue transposes through 4 KB per wave
+    if (p.lds_bytes > 160 * 1024 - 2048 - 1024) return false;   // (static tables of the kernel take < 1 KB)
+    p.patches_x = pw == 8 ? bs / 8 : 1;
+    p.patches_per_tile = pw == 8 ? (bs / 8) * (bs / ph) : 1;
+    p.n_rows = pw == 8 ? (uint32_t)n_exec * p.patches_per_tile : ((uint32_t)n_exec + tpr - 1) / tpr;
+    p.wgs = (long long)((p.n_rows + k.WMW - 1) / k.WMW) * (Cout / (32 * k.RN * k.WNW));
+    return true;
+}
+
+// ---- how the main translation unit reaches the decompositions of conv3x3_v2.inc.  The ~600 kernel instantiations (3 dtypes x
+// 2 strides x 2 kernel sizes x 16 decompositions x 2 patch widths) take minutes in one translation unit, so build.py compiles
+// this same source several times in parallel: -DBC_PART=0 is everything but them, -DBC_PART=1..6 is one (dtype, kernel size)
+// slice each, exported to part 0 as bc_part_conv_v2_<n>(ConvV2Args *).  Without -DBC_PART the file is the whole library.
+struct ConvV2Args {
+    void *out; const void *features; void *ring; const void *wpk;
+    const int32_t *grid_idx, *mapping_exec;
+    int n_exec, Cin, Cout, GH, GW, bs, stride;
+    Prologue pr; EpilogueT ep;
+    hipStream_t st;
+    int prof_on; hipEvent_t ev_a, ev_b;           // the caller's ProfScope (events attached to the dispatch when profiling)
+    int force_cfg, min_lds;                        // tuning knobs of the caller (g_tune)
+    unsigned long long *stamps;
+    int chosen;                                    // out: the decomposition that was launched
+};
+struct LaunchProf { bool on; struct { hipEvent_t a, b; } rec; };   // what BC_LAUNCH needs of a ProfScope
+
+#if defined(BC_MONO) || BC_PART != 0
+template <int DT, int RM, int RN, int WMW, int WNW, int WKW, int SC, int PW, int S, int KS>
+static void launch_conv3x3_v2_cfg(LaunchProf &ps, dim3 grid, size_t lds_bytes, const ConvV2Args &a, const ConvGeom2 &g)
+{
+    static bool attr_set = false;   // > 64 KB of dynamic LDS needs the opt-in once per kernel
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_v2<DT, RM, RN, WMW, WNW, WKW, SC, PW, S, KS>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+        attr_set = true;
+    }
+    BC_LAUNCH(ps, (k_conv3x3_v2<DT, RM, RN, WMW, WNW, WKW, SC, PW, S, KS>), grid, dim3(512), lds_bytes, a.st, (typename CvType<DT>::T *)a.out,
+              (const uint4 *)a.features, (long long)(((const char *)a.ring - (const char *)a.features) / 16), (uint4 *)a.ring, (const uint4 *)a.wpk,
+              a.grid_idx, a.mapping_exec, g, a.pr, a.ep, a.stamps);
+}
+
+template <int DT, int S, int KS>
+static int conv_v2_run(ConvV2Args &a)
+{
+    constexpr int E = CvType<DT>::E;
+    const int n_exec = a.n_exec, Cin = a.Cin, Cout = a.Cout, GH = a.GH, GW = a.GW, bs = a.bs;
+    LaunchProf ps{a.prof_on != 0, {a.ev_a, a.ev_b}};
+    constexpr int SC_LO = DT == BC_F32 ? 1 : 2, SC_HI = 2 * SC_LO;      // 32-channel units staged per iteration (SC_HI with 8 K groups)
+    const int force = a.force_cfg, min_lds = a.min_lds;
+    const int pw = bs == 4 ? 4 : 8;
+    const int cus = device_cu_count();
+    static const bool dbg_model = getenv("BC_CONV2_DEBUG") != nullptr;
+    int best = -1;
+    double best_t = 0;
+    Conv2Plan plan, best_plan{};
+    for (int c = 0; c < (int)(sizeof(CONV2_CFGS) / sizeof(CONV2_CFGS[0])); ++c) {
+        const Conv2Cfg &k = CONV2_CFGS[c];
+        if (force >= 0 && c != force) continue;
+        if (!conv2_plan(k, E, S, n_exec, Cin, Cout, bs, plan, KS)) continue;
+        if (KS == 1 && pw == 4 && S == 1) continue;            // (pointwise stride-1 launches are re-tiled to 8x8 by the caller)
+        const long long rounds = (plan.wgs + cus - 1) / cus;
+        const double mf = (double)k.RM * k.RN * (double)(KS * KS) * (Cin / 8) * 4.0 / k.WKW;   // fp32 MFMAs per wave (16-bit: the same ranking)
+        // per-MFMA slowdown from operand delivery (tools/probes/mfma_probe2: 1x1 tiles ~0.72, 2x1 ~0.79, 2x2 ~0.82 of peak)
+        const double eff = k.RM * k.RN >= 4 ? 0.82 : (k.RM * k.RN == 2 ? (k.RM == 2 ? 0.79 : 0.74) : 0.70);
+        const double t = rounds * (mf / eff + 70.0 + 12.0 * (k.WKW - 1) * k.RM * k.RN);
+        if (dbg_model) fprintf(stderr, "[conv2 model] dt %d S %d n %d %d->%d bs %d: c%d wgs %lld rounds %lld mf %.0f t %.0f (cus %d)\n", DT, S, n_exec, Cin, Cout, bs, c, plan.wgs, rounds, mf, t, cus);
+        if (best < 0 || t < best_t) { best = c; best_t = t; best_plan = plan; }
+    }
+    if (best < 0) return BC_ERR_SHAPE;
+    a.chosen = best;
+    const Conv2Cfg &k = CONV2_CFGS[best];
+    ConvGeom2 g;
+    g.Cin = Cin; g.Cout = Cout; g.bs = bs; g.GH = GH; g.GW = GW; g.n_exec = n_exec;
+    g.patches_x = best_plan.patches_x;
+    g.patches_per_tile = best_plan.patches_per_tile;
+    g.n_rows = best_plan.n_rows;
+    g.cin_chunks = Cin / CV_CH;
+    size_t lds_bytes = best_plan.lds_bytes;
+    if (lds_bytes < (size_t)min_lds) lds_bytes = min_lds;      // one workgroup per CU: two waves on every SIMD, no more
+    const dim3 grid((g.n_rows + k.WMW - 1) / k.WMW, (unsigned)Cout / (32 * k.RN * k.WNW));
+    // (decompositions whose double-buffered patch images cannot fit the LDS are never chosen by conv2_plan and are not compiled)
+#define BC_CV2(RM_, RN_, WMW_, WNW_, WKW_)                                                                                   \
+    do {                                                                                                                 \
+        constexpr int SC_ = WKW_ == 8 ? SC_HI : SC_LO;                                                                   \
+        constexpr int RM4_ = WMW_ == 1 ? RM_ : 1;                                                                        \
+        constexpr size_t img8_ = (size_t)WMW_ * (S * 7 + KS) * (S * (4 * RM_ - 1) + KS) * (CvType<DT>::UV * SC_ + 1) * 32;  \
+        constexpr size_t img4_ = (size_t)WMW_ * 2 * RM4_ * (S * 3 + KS) * (S * 3 + KS) * (CvType<DT>::UV * SC_ + 1) * 32; \
+        if (pw == 8) {                                                                                                   \
+            if constexpr (img8_ <= 160 * 1024 - 3072)                                                                    \
+                launch_conv3x3_v2_cfg<DT, RM_, RN_, WMW_, WNW_, WKW_, SC_, 8, S, KS>(ps, grid, lds_bytes, a, g); \
+        } else {                                                                                                         \
+            if constexpr (img4_ <= 160 * 1024 - 3072 && !(KS == 1 && S == 1))                                            \
+                launch_conv3x3_v2_cfg<DT, RM4_, RN_, WMW_, WNW_, WKW_, SC_, 4, S, KS>(ps, grid, lds_bytes, a, g); \
+        }                                                                                                                \
+    } while (0)
+    switch (best) {
+    case 0: BC_CV2(2, 2, 4, 2, 1); break;
+    case 1: BC_CV2(2, 1, 4, 2, 1); break;
+    case 2: BC_CV2(1, 2, 4, 2, 1); break;
+    case 3: BC_CV2(1, 1, 4, 2, 1); break;
+    case 4: BC_CV2(1, 1, 2, 4, 1); break;
+    case 5: BC_CV2(1, 1, 2, 2, 2); break;
+    case 6: BC_CV2(1, 1, 1, 4, 2); break;
+    case 7: BC_CV2(1, 1, 1, 2, 4); break;
+    case 8: BC_CV2(2, 2, 2, 2, 2); break;
+    case 9: BC_CV2(2, 2, 1, 2, 4); break;
+    case 10: BC_CV2(2, 1, 2, 2, 2); break;
+    case 11: BC_CV2(2, 1, 1, 4, 2); break;
+    case 12: BC_CV2(2, 1, 1, 2, 4); break;
+    case 13: BC_CV2(2, 1, 1, 1, 8); break;
+    case 14: BC_CV2(1, 2, 1, 1, 8); break;
+    default: BC_CV2(1, 1, 1, 1, 8); break;
+    }
+#undef BC_CV2
+    return launch_status();
+}
+
+#endif
+
+#if BC_PART != 0
+// this slice: dtype (BC_PART - 1) / 2, kernel size 3 (odd parts) or 1 (even parts), both strides
+#define BC_PART_NAME2(n_) bc_part_conv_v2_##n_
+#define BC_PART_NAME(n_) BC_PART_NAME2(n_)
+extern "C" int BC_PART_NAME(BC_PART)(void *p)
+{
+    ConvV2Args &a = *static_cast<ConvV2Args *>(p);
+    constexpr int DT = (BC_PART - 1) / 2, KS = (BC_PART - 1) % 2 == 0 ? 3 : 1;
+    return a.stride == 1 ? conv_v2_run<DT, 1, KS>(a) : conv_v2_run<DT, 2, KS>(a);
+}
+#endif
+
+#if BC_PART == 0
+// ---- tuning knobs (bc_tune_set; defaults may also come from the environment, read once)
+struct TuneState {
+    int conv_impl = [] { const char *e = getenv("BC_CONV_IMPL"); return e ? atoi(e) : 2; }();              // 1 = first-generation conv kernel
+    int conv2_cfg = [] { const char *e = getenv("BC_CONV2_CFG"); return e ? atoi(e) : -1; }();             // >= 0: force a decomposition
+    unsigned long long *conv_stamps = nullptr;   // device buffer for in-kernel s_memtime stamps (bc_tune_set_ptr), measurement only
+    int conv_last_cfg = -2;   // decomposition of the most recent bc_conv3x3_ring_nhwc launch (-1: first-generation kernel)
+    int stem_min_lds = [] { const char *e = getenv("BC_STEM_MINLDS"); return e ? atoi(e) : 84 * 1024; }();
+    int conv2_min_lds = [] { const char *e = getenv("BC_CONV2_MINLDS"); return e ? atoi(e) : 84 * 1024; }();   // bytes; > 80 KB = one workgroup per CU
+} g_tune;
+
+
+#if !defined(BC_MONO)
+extern "C" {
+int bc_part_conv_v2_1(void *); int bc_part_conv_v2_2(void *); int bc_part_conv_v2_3(void *);
+int bc_part_conv_v2_4(void *); int bc_part_conv_v2_5(void *); int bc_part_conv_v2_6(void *);
+}
+#endif
+
+template <int DT, int S, int KS = 3>
+static int launch_conv3x3_v2(ProfScope &ps, void *out, const void *features, void *ring, const void *wpk, const int32_t *grid_idx,
+                             const int32_t *mapping_exec, int n_exec, int Cin, int Cout, int GH, int GW, int bs,
+                             const Prologue &pr, const EpilogueT &ep, hipStream_t st)
+{
+    ConvV2Args a{out, features, ring, wpk, grid_idx, mapping_exec, n_exec, Cin, Cout, GH, GW, bs, S, pr, ep, st,
+                 ps.on ? 1 : 0, ps.rec.a, ps.rec.b, g_tune.conv2_cfg, g_tune.conv2_min_lds, g_tune.conv_stamps, -2};
+#if defined(BC_MONO)
+    const int rc = conv_v2_run<DT, S, KS>(a);
+#else
+    typedef int (*part_fn)(void *);
+    static const part_fn parts[6] = {bc_part_conv_v2_1, bc_part_conv_v2_2, bc_part_conv_v2_3, bc_part_conv_v2_4, bc_part_conv_v2_5, bc_part_conv_v2_6};
+    const int rc = parts[2 * DT + (KS == 3 ? 0 : 1)](&a);
+#endif
+    if (a.chosen >= 0) g_tune.conv_last_cfg = a.chosen;
+    return rc;
+}
+
 // ================================================================================================ C ABI
 BC_EXPORT int bc_abi_version(void) { return BC_ABI_VERSION; }
 
@@ -2091,154 +2301,6 @@ BC_EXPORT int bc_pad_ring_nhwc(void *out, const void *features, void *ring, cons
     else { if (vb == 16) BC_HN(16, uint16_t, 3); else if (vb == 8) BC_HN(8, uint16_t, 3); else if (vb == 4) BC_HN(4, uint16_t, 3); else BC_HN(2, uint16_t, 3); }
 #undef BC_HNV
 #undef BC_HN
-    return launch_status();
-}
-
-// ---- tuning knobs (bc_tune_set; defaults may also come from the environment, read once)
-struct TuneState {
-    int conv_impl = [] { const char *e = getenv("BC_CONV_IMPL"); return e ? atoi(e) : 2; }();              // 1 = first-generation conv kernel
-    int conv2_cfg = [] { const char *e = getenv("BC_CONV2_CFG"); return e ? atoi(e) : -1; }();             // >= 0: force a decomposition
-    unsigned long long *conv_stamps = nullptr;   // device buffer for in-kernel s_memtime stamps (bc_tune_set_ptr), measurement only
-    int conv_last_cfg = -2;   // decomposition of the most recent bc_conv3x3_ring_nhwc launch (-1: first-generation kernel)
-    int stem_min_lds = [] { const char *e = getenv("BC_STEM_MINLDS"); return e ? atoi(e) : 84 * 1024; }();
-    int conv2_min_lds = [] { const char *e = getenv("BC_CONV2_MINLDS"); return e ? atoi(e) : 84 * 1024; }();   // bytes; > 80 KB = one workgroup per CU
-} g_tune;
-
-// ---- host side of conv3x3_v2.inc: choose the decomposition whose workgroup count best fills whole rounds of one
-// 8-wave workgroup per CU with equal MFMA counts per wave, then launch it.
-struct Conv2Cfg { int RM, RN, WMW, WNW, WKW; };
-
-static int device_cu_count()
-{
-    static const int n = [] {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-            cus = 256;
-        return cus;
-    }();
-    return n;
-}
-
-template <int DT, int RM, int RN, int WMW, int WNW, int WKW, int SC, int PW, int S, int KS>
-static void launch_conv3x3_v2_cfg(ProfScope &ps, dim3 grid, size_t lds_bytes, hipStream_t st, void *out, const void *features, void *ring,
-                                  const void *wpk, const int32_t *grid_idx, const int32_t *mapping_exec, const ConvGeom2 &g,
-                                  const Prologue &pr, const EpilogueT &ep)
-{
-    static bool attr_set = false;   // > 64 KB of dynamic LDS needs the opt-in once per kernel
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_v2<DT, RM, RN, WMW, WNW, WKW, SC, PW, S, KS>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
-        attr_set = true;
-    }
-    BC_LAUNCH(ps, (k_conv3x3_v2<DT, RM, RN, WMW, WNW, WKW, SC, PW, S, KS>), grid, dim3(512), lds_bytes, st, (typename CvType<DT>::T *)out,
-              (const uint4 *)features, (long long)(((const char *)ring - (const char *)features) / 16), (uint4 *)ring, (const uint4 *)wpk,
-              grid_idx, mapping_exec, g, pr, ep, g_tune.conv_stamps);
-}
-
-static const Conv2Cfg CONV2_CFGS[] = {{2, 2, 4, 2, 1}, {2, 1, 4, 2, 1}, {1, 2, 4, 2, 1}, {1, 1, 4, 2, 1},     // 0-3: many pixels
-                                      {1, 1, 2, 4, 1}, {1, 1, 2, 2, 2}, {1, 1, 1, 4, 2}, {1, 1, 1, 2, 4},     // 4-7: 1x1 wave tiles
-                                      {2, 2, 2, 2, 2}, {2, 2, 1, 2, 4}, {2, 1, 2, 2, 2}, {2, 1, 1, 4, 2},     // 8-11: 2-block tiles + K groups
-                                      {2, 1, 1, 2, 4}, {2, 1, 1, 1, 8}, {1, 2, 1, 1, 8}, {1, 1, 1, 1, 8}};    // 12-15
-
-// geometry of one decomposition for a layer (bs = OUTPUT tile size); false if the decomposition does not cover the layer
-struct Conv2Plan { long long wgs; size_t lds_bytes; uint32_t n_rows, patches_per_tile, patches_x; };
-
-static bool conv2_plan(const Conv2Cfg &k, int E, int S, int n_exec, int Cin, int Cout, int bs, Conv2Plan &p, int KS = 3)
-{
-    const int pw = bs == 4 ? 4 : 8;
-    const int uv = E == 4 ? 8 : 4, sc_lo = E == 4 ? 1 : 2;
-    const int sc = k.WKW == 8 ? 2 * sc_lo : sc_lo;
-    if (pw == 8 && bs % 8 != 0) return false;
-    if (pw == 4 && k.RM != 1 && k.WMW != 1) return false;       // 4x4 tiles: 4 tile slots per wave row only in single-row workgroups (LDS)
-    if (pw == 8 && bs % (4 * k.RM) != 0) return false;
-    if (Cout % (32 * k.RN * k.WNW) != 0 || Cin % (32 * sc) != 0) return false;
-    const uint32_t ph = pw == 8 ? 4u * k.RM : 4u, tpr = pw == 8 ? 1u : 2u * k.RM;
-    const uint32_t slot_px = (uint32_t)(S * (pw - 1) + KS) * (S * (ph - 1) + KS);
-    const size_t img = (size_t)k.WMW * tpr * slot_px * (uv * sc + 1) * 16;
-    const size_t red = (size_t)k.WMW * k.WNW * (k.WKW - 1) * k.RM * k.RN * 16 * 64 * sizeof(float);
-    p.lds_bytes = 2 * img > red ? 2 * img : red;
-    if (p.lds_bytes < 8 * 4096) p.lds_bytes = 8 * 4096;         // the epilogue transposes through 4 KB per wave
-    if (p.lds_bytes > 160 * 1024 - 2048 - 1024) return false;   // (static tables of the kernel take < 1 KB)
-    p.patches_x = pw == 8 ? bs / 8 : 1;
-    p.patches_per_tile = pw == 8 ? (bs / 8) * (bs / ph) : 1;
-    p.n_rows = pw == 8 ? (uint32_t)n_exec * p.patches_per_tile : ((uint32_t)n_exec + tpr - 1) / tpr;
-    p.wgs = (long long)((p.n_rows + k.WMW - 1) / k.WMW) * (Cout / (32 * k.RN * k.WNW));
-    return true;
-}
-
-template <int DT, int S, int KS = 3>
-static int launch_conv3x3_v2(ProfScope &ps, void *out, const void *features, void *ring, const void *wpk, const int32_t *grid_idx,
-                             const int32_t *mapping_exec, int n_exec, int Cin, int Cout, int GH, int GW, int bs,
-                             const Prologue &pr, const EpilogueT &ep, hipStream_t st)
-{
-    constexpr int E = CvType<DT>::E;
-    constexpr int SC_LO = DT == BC_F32 ? 1 : 2, SC_HI = 2 * SC_LO;      // 32-channel units staged per iteration (SC_HI with 8 K groups)
-    const int force = g_tune.conv2_cfg, min_lds = g_tune.conv2_min_lds;
-    const int pw = bs == 4 ? 4 : 8;
-    const int cus = device_cu_count();
-    static const bool dbg_model = getenv("BC_CONV2_DEBUG") != nullptr;
-    int best = -1;
-    double best_t = 0;
-    Conv2Plan plan, best_plan{};
-    for (int c = 0; c < (int)(sizeof(CONV2_CFGS) / sizeof(CONV2_CFGS[0])); ++c) {
-        const Conv2Cfg &k = CONV2_CFGS[c];
-        if (force >= 0 && c != force) continue;
-        if (!conv2_plan(k, E, S, n_exec, Cin, Cout, bs, plan, KS)) continue;
-        if (KS == 1 && pw == 4 && S == 1) continue;            // (pointwise stride-1 launches are re-tiled to 8x8 by the caller)
-        const long long rounds = (plan.wgs + cus - 1) / cus;
-        const double mf = (double)k.RM * k.RN * (double)(KS * KS) * (Cin / 8) * 4.0 / k.WKW;   // fp32 MFMAs per wave (16-bit: the same ranking)
-        // per-MFMA slowdown from operand delivery (tools/probes/mfma_probe2: 1x1 tiles ~0.72, 2x1 ~0.79, 2x2 ~0.82 of peak)
-        const double eff = k.RM * k.RN >= 4 ? 0.82 : (k.RM * k.RN == 2 ? (k.RM == 2 ? 0.79 : 0.74) : 0.70);
-        const double t = rounds * (mf / eff + 70.0 + 12.0 * (k.WKW - 1) * k.RM * k.RN);
-        if (dbg_model) fprintf(stderr, "[conv2 model] dt %d S %d n %d %d->%d bs %d: c%d wgs %lld rounds %lld mf %.0f t %.0f (cus %d)\n", DT, S, n_exec, Cin, Cout, bs, c, plan.wgs, rounds, mf, t, cus);
-        if (best < 0 || t < best_t) { best = c; best_t = t; best_plan = plan; }
-    }
-    if (best < 0) return BC_ERR_SHAPE;
-    g_tune.conv_last_cfg = best;
-    const Conv2Cfg &k = CONV2_CFGS[best];
-    ConvGeom2 g;
-    g.Cin = Cin; g.Cout = Cout; g.bs = bs; g.GH = GH; g.GW = GW; g.n_exec = n_exec;
-    g.patches_x = best_plan.patches_x;
-    g.patches_per_tile = best_plan.patches_per_tile;
-    g.n_rows = best_plan.n_rows;
-    g.cin_chunks = Cin / CV_CH;
-    size_t lds_bytes = best_plan.lds_bytes;
-    if (lds_bytes < (size_t)min_lds) lds_bytes = min_lds;      // one workgroup per CU: two waves on every SIMD, no more
-    const dim3 grid((g.n_rows + k.WMW - 1) / k.WMW, (unsigned)Cout / (32 * k.RN * k.WNW));
-    // (decompositions whose double-buffered patch images cannot fit the LDS are never chosen by conv2_plan and are not compiled)
-#define BC_CV2(RM_, RN_, WMW_, WNW_, WKW_)                                                                                   \
-    do {                                                                                                                 \
-        constexpr int SC_ = WKW_ == 8 ? SC_HI : SC_LO;                                                                   \
-        constexpr int RM4_ = WMW_ == 1 ? RM_ : 1;                                                                        \
-        constexpr size_t img8_ = (size_t)WMW_ * (S * 7 + KS) * (S * (4 * RM_ - 1) + KS) * (CvType<DT>::UV * SC_ + 1) * 32;  \
-        constexpr size_t img4_ = (size_t)WMW_ * 2 * RM4_ * (S * 3 + KS) * (S * 3 + KS) * (CvType<DT>::UV * SC_ + 1) * 32; \
-        if (pw == 8) {                                                                                                   \
-            if constexpr (img8_ <= 160 * 1024 - 3072)                                                                    \
-                launch_conv3x3_v2_cfg<DT, RM_, RN_, WMW_, WNW_, WKW_, SC_, 8, S, KS>(ps, grid, lds_bytes, st, out, features, ring, wpk, grid_idx, mapping_exec, g, pr, ep); \
-        } else {                                                                                                         \
-            if constexpr (img4_ <= 160 * 1024 - 3072 && !(KS == 1 && S == 1))                                            \
-                launch_conv3x3_v2_cfg<DT, RM4_, RN_, WMW_, WNW_, WKW_, SC_, 4, S, KS>(ps, grid, lds_bytes, st, out, features, ring, wpk, grid_idx, mapping_exec, g, pr, ep); \
-        }                                                                                                                \
-    } while (0)
-    switch (best) {
-    case 0: BC_CV2(2, 2, 4, 2, 1); break;
-    case 1: BC_CV2(2, 1, 4, 2, 1); break;
-    case 2: BC_CV2(1, 2, 4, 2, 1); break;
-    case 3: BC_CV2(1, 1, 4, 2, 1); break;
-    case 4: BC_CV2(1, 1, 2, 4, 1); break;
-    case 5: BC_CV2(1, 1, 2, 2, 2); break;
-    case 6: BC_CV2(1, 1, 1, 4, 2); break;
-    case 7: BC_CV2(1, 1, 1, 2, 4); break;
-    case 8: BC_CV2(2, 2, 2, 2, 2); break;
-    case 9: BC_CV2(2, 2, 1, 2, 4); break;
-    case 10: BC_CV2(2, 1, 2, 2, 2); break;
-    case 11: BC_CV2(2, 1, 1, 4, 2); break;
-    case 12: BC_CV2(2, 1, 1, 2, 4); break;
-    case 13: BC_CV2(2, 1, 1, 1, 8); break;
-    case 14: BC_CV2(1, 2, 1, 1, 8); break;
-    default: BC_CV2(1, 1, 1, 1, 8); break;
-    }
-#undef BC_CV2
     return launch_status();
 }
 
@@ -2690,3 +2752,4 @@ BC_EXPORT int bc_prof_read(int op, long long *launches, double *total_ms, double
     if (total_bytes) *total_bytes = g_prof.bytes[op];
     return BC_OK;
 }
+#endif  // BC_PART == 0
