@@ -382,9 +382,9 @@ class HipBackend:
     def conv3x3_candidates(self, n_exec, cin, cout, bs, elem_size=4, stride=1):
         """Decomposition indices of the balanced conv kernel that cover this layer shape (bs = input tile size), straight from
         the library's launcher rules (bc_conv3x3_candidates)."""
-        buf = (ctypes.c_int * 32)()
+        buf = (ctypes.c_int * 64)()
         dt = 0 if elem_size == 4 else 1
-        n = self.lib.bc_conv3x3_candidates(dt, int(stride), int(n_exec), int(cin), int(cout), int(bs), buf, 32)
+        n = self.lib.bc_conv3x3_candidates(dt, int(stride), int(n_exec), int(cin), int(cout), int(bs), buf, 64)
         if n < 0:
             return []
         return [int(buf[k]) for k in range(n)]
@@ -472,8 +472,8 @@ class HipBackend:
         geo = self.conv1x1_geometry(data, stride)
         if geo is None:
             return []
-        buf = (ctypes.c_int * 32)()
-        n = self.lib.bc_conv1x1_candidates(_DTYPE_CODE[data.dtype], int(stride), geo[0], data.shape[1], int(cout), geo[1], buf, 32)
+        buf = (ctypes.c_int * 64)()
+        n = self.lib.bc_conv1x1_candidates(_DTYPE_CODE[data.dtype], int(stride), geo[0], data.shape[1], int(cout), geo[1], buf, 64)
         return [int(buf[k]) for k in range(max(n, 0))]
 
     def conv1x1(self, data, wpk, cout, prologue=None, epilogue=None, cfg=None, stride=1):

@@ -1913,7 +1913,10 @@ static int conv_v2_run(ConvV2Args &a)
     const int n_exec = a.n_exec, Cin = a.Cin, Cout = a.Cout, GH = a.GH, GW = a.GW, bs = a.bs;
     LaunchProf ps{a.prof_on != 0, {a.ev_a, a.ev_b}};
     constexpr int SC_LO = DT == BC_F32 ? 1 : 2, SC_HI = 2 * SC_LO;      // 32-channel units staged per iteration (SC_HI with 8 K groups)
-    const int force = a.force_cfg, min_lds = a.min_lds;
+    // forced decomposition: bits 0-7 = index into CONV2_CFGS, bit 8 = no LDS floor (two workgroups may share a CU: the prologue /
+    // epilogue bursts of one overlap the matrix phase of the other; pays when the launch is several rounds of workgroups)
+    const int force = a.force_cfg < 0 ? -1 : (a.force_cfg & 0xff);
+    const int min_lds = (a.force_cfg >= 0 && (a.force_cfg & 0x100)) ? 0 : a.min_lds;
     const int pw = bs == 4 ? 4 : 8;
     const int cus = device_cu_count();
     static const bool dbg_model = getenv("BC_CONV2_DEBUG") != nullptr;
@@ -2313,8 +2316,13 @@ static int conv_candidates(int dtype, int stride, int ks, int n_exec, int Cin, i
     if (ks == 1 && stride == 1 && bs == 4) return 0;
     int n = 0;
     Conv2Plan plan;
-    for (int c = 0; c < (int)(sizeof(CONV2_CFGS) / sizeof(CONV2_CFGS[0])) && n < max_out; ++c)
+    const int n_cfg = (int)(sizeof(CONV2_CFGS) / sizeof(CONV2_CFGS[0]));
+    for (int c = 0; c < n_cfg && n < max_out; ++c)
         if (conv2_plan(CONV2_CFGS[c], E, stride, n_exec, Cin, Cout, bs, plan, ks)) out[n++] = c;
+    // the same decompositions without the one-workgroup-per-CU LDS floor, where two workgroups fit a CU at all
+    for (int c = 0; c < n_cfg && n < max_out; ++c)
+        if (conv2_plan(CONV2_CFGS[c], E, stride, n_exec, Cin, Cout, bs, plan, ks) && plan.lds_bytes <= (size_t)78 * 1024 && plan.wgs > device_cu_count())
+            out[n++] = c | 0x100;
     return n;
 }
 

@@ -207,8 +207,10 @@ int bc_stem7x7s2_nhwc(void *out, const void *frame_state, const void *weights_pa
                       int N, int H, int W, int bs, int Cout, int dtype, const float *out_scale, const float *out_shift,
                       const void *out_add, int out_relu, void *stream);
 
-/* decompositions of the fused conv kernel that cover a layer (stride 1 or 2; bs_in = input tile size): indices written to out,
- * count returned.  What bc_tune_set("conv2_cfg", i) may force; the engine times exactly these when it measures a layer shape. */
+/* decompositions of the fused conv kernel that cover a layer (stride 1 or 2; bs_in = input tile size): codes written to out,
+ * count returned.  What bc_tune_set("conv2_cfg", code) may force; the engine times exactly these when it measures a layer shape.
+ * code = decomposition index (bits 0-7) | 0x100 if the launch runs without the one-workgroup-per-CU LDS floor (two workgroups
+ * may then share a CU; listed only for multi-round launches whose workgroups need <= 78 KB).  At most 32 codes. */
 int bc_conv3x3_candidates(int dtype, int stride, int n_exec, int Cin, int Cout, int bs_in, int *out, int max_out);
 
 /* halo gather with a residual-add prologue and a by-product: v = relu?(features*scale[c] + shift[c] + add) is computed while
