@@ -388,7 +388,7 @@ def main(argv=None):
     if rank == 0:
         # halo-gather kernel statistics from one extra, untimed clip (events around all 21 launches per frame)
         be.prof_reset()
-        be.prof_enable(["pad_ring", "split", "combine"])
+        be.prof_enable(["pad_ring", "split", "combine", "conv3x3"])
         inner = model.det if is_csp else model
         use_graph, inner.use_graph = inner.use_graph, False   # per-launch events (eager mode, NOT the timed mode) need eager launches
         harness.run_clip(model, clips[0])
@@ -400,6 +400,17 @@ def main(argv=None):
                 extra[op] = {"launches_per_frame": r["launches"] / CLIP_LEN, "avg_us": 1e3 * r["total_ms"] / r["launches"],
                              "GBps": r["total_bytes"] / (r["total_ms"] * 1e-3) / 1e9, "MB_per_frame": r["total_bytes"] / CLIP_LEN / 1e6,
                              "mode": "eager launches (in-library events per launch); the timed region replays hipGraphs"}
+        r = be.prof_read("conv3x3")
+        if r["launches"]:
+            # the fused conv kernel (3x3 halo form, its stride-2 and one-tap forms): FLOPs of all its launches of one clip over their
+            # summed execution time, against the dense MFMA peak of the compute dtype (MI355X_MICROARCH.md: fp32 157.3, 16-bit 2516 TFLOP/s)
+            peak = 157.3 if dtype == torch.float32 else 2516.0
+            tf = r["total_bytes"] / (r["total_ms"] * 1e-3) / 1e12
+            extra["roofline_conv"] = {"kernel": "k_conv3x3_v2 (fused halo gather + conv: 3x3, 3x3 stride 2 and 1x1 forms) + k_stem7x7", "bound": "mfma",
+                                      "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "traffic": None,
+                                      "launches_per_frame": r["launches"] / CLIP_LEN, "ms_per_frame": r["total_ms"] / CLIP_LEN,
+                                      "GFLOP_per_frame": r["total_bytes"] / CLIP_LEN / 1e9,
+                                      "mode": "eager launches (events attached to each dispatch); the timed region replays the same kernels from hipGraphs"}
         # host-side enqueue cost of one clip (no sync inside): tells whether the frame is CPU- or GPU-bound
         torch.cuda.synchronize(device)
         th = time.perf_counter()

@@ -1846,7 +1846,8 @@ static int device_cu_count()
 static const Conv2Cfg CONV2_CFGS[] = {{2, 2, 4, 2, 1}, {2, 1, 4, 2, 1}, {1, 2, 4, 2, 1}, {1, 1, 4, 2, 1},     // 0-3: many pixels
                                       {1, 1, 2, 4, 1}, {1, 1, 2, 2, 2}, {1, 1, 1, 4, 2}, {1, 1, 1, 2, 4},     // 4-7: 1x1 wave tiles
                                       {2, 2, 2, 2, 2}, {2, 2, 1, 2, 4}, {2, 1, 2, 2, 2}, {2, 1, 1, 4, 2},     // 8-11: 2-block tiles + K groups
-                                      {2, 1, 1, 2, 4}, {2, 1, 1, 1, 8}, {1, 2, 1, 1, 8}, {1, 1, 1, 1, 8}};    // 12-15
+                                      {2, 1, 1, 2, 4}, {2, 1, 1, 1, 8}, {1, 2, 1, 1, 8}, {1, 1, 1, 1, 8},     // 12-15
+                                      {2, 2, 4, 1, 2}, {2, 2, 2, 1, 4}, {1, 2, 4, 1, 2}, {1, 2, 2, 1, 4}};    // 16-19: one 64-channel column (2x2 / 1x2 wave tiles)
 
 // geometry of one decomposition for a layer (bs = OUTPUT tile size); false if the decomposition does not cover the layer
 struct Conv2Plan { long long wgs; size_t lds_bytes; uint32_t n_rows, patches_per_tile, patches_x; };
@@ -1979,7 +1980,11 @@ static int conv_v2_run(ConvV2Args &a)
     case 12: BC_CV2(2, 1, 1, 2, 4); break;
     case 13: BC_CV2(2, 1, 1, 1, 8); break;
     case 14: BC_CV2(1, 2, 1, 1, 8); break;
-    default: BC_CV2(1, 1, 1, 1, 8); break;
+    case 15: BC_CV2(1, 1, 1, 1, 8); break;
+    case 16: BC_CV2(2, 2, 4, 1, 2); break;
+    case 17: BC_CV2(2, 2, 2, 1, 4); break;
+    case 18: BC_CV2(1, 2, 4, 1, 2); break;
+    default: BC_CV2(1, 2, 2, 1, 4); break;
     }
 #undef BC_CV2
     return launch_status();

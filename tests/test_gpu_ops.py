@@ -620,9 +620,9 @@ def test_fused_conv3x3_stride2(be, dtype, tol):
         be.tune("conv2_cfg", -1)
 
 
-@pytest.mark.parametrize("cfg", list(range(16)))
+@pytest.mark.parametrize("cfg", list(range(20)))
 def test_fused_conv3x3_every_decomposition(be, cfg):
-    """The CU-balanced conv kernel (csrc/conv3x3_v2.inc) picks one of 16 decompositions per launch (register blocking
+    """The CU-balanced conv kernel (csrc/conv3x3_v2.inc) picks one of 20 decompositions per launch (register blocking
     RM x RN, wave grid, in-workgroup split-K); here each one is FORCED in turn on shapes it covers -- incl. ragged wave
     rows, 4x4 tiles, prologue, epilogue with residual, ring cache from a previous frame -- against halo gather + fp64 conv
     (2e-5 relative: fp32 summation order), with the ring cache left bit-identical."""
@@ -634,8 +634,8 @@ def test_fused_conv3x3_every_decomposition(be, cfg):
     try:
         for case, (Cin, Cout, bs, N, GH, GW) in enumerate([(64, 128, 8, 1, 3, 5), (32, 128, 16, 2, 2, 3), (96, 256, 4, 1, 4, 7),
                                                             (64, 128, 32, 1, 2, 2), (128, 128, 4, 1, 5, 5), (160, 128, 24, 1, 2, 3)]):
-            if (cfg in (0, 1, 8, 10) and bs == 4) or (cfg >= 13 and Cin % 64):
-                continue      # multi-row RM = 2 decompositions need 8-row patches; 8 K groups stage 64 channels at a time
+            if cfg not in be.conv3x3_candidates(T, Cin, Cout, bs, 4, 1):
+                continue      # (multi-row RM = 2 decompositions need 8-row patches; 8 K groups stage 64 channels at a time)
             T = N * GH * GW
             w = (torch.randn((Cout, Cin, 3, 3), generator=gen) * (2.0 / (9 * Cin)) ** 0.5).cuda()
             wpk = be.pack_conv3x3_weights(w)

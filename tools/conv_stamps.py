@@ -35,8 +35,12 @@ def main():
             be.conv3x3_ring(feats, ring, wpk, Cout, gi, m, None, None)
         torch.cuda.synchronize()
         be.tune_ptr("conv_stamps", stamps)
+        be.prof_reset()
+        be.prof_enable(["conv3x3"])
         be.conv3x3_ring(feats, ring, wpk, Cout, gi, m, None, None)
         torch.cuda.synchronize()
+        be.prof_enable([])
+        us = be.prof_read("conv3x3")["total_ms"] * 1e3      # execution time of this one dispatch (events attached to the packet)
         be.tune_ptr("conv_stamps", None)
         cfg = be.tune_get("conv_last_cfg")
         s = stamps.view(-1, 8).cpu()
@@ -46,7 +50,13 @@ def main():
         seg = rel[:, 1:] - rel[:, :-1]
         names = ["tables", "first stage", "main loop", "reduction", "stores"]
         print(f"{name} n={a.n} cfg {cfg}: {s.shape[0]} workgroups; start skew max {rel[:, 0].max():.0f} cyc; end: mean {rel[:, 5].mean():.0f} max {rel[:, 5].max():.0f} cyc"
-              f" (s_memtime ticks = 100 MHz? see below)")
+              f"")
+        per_wg = float((s[:, 5] - s[:, 0]).double().mean())      # ticks one workgroup lives (one round: that is the whole launch)
+        rounds = max(1.0, s.shape[0] / 256.0)
+        flops = 2.0 * a.n * bs * bs * 9 * Cin * Cout
+        ghz = per_wg * rounds / us / 1e3
+        print(f"   dispatch {us:.1f} us; a workgroup lives {per_wg:.0f} s_memtime ticks x {rounds:.2f} rounds => ~{ghz:.2f} GHz shader clock during the launch; "
+              f"{flops / us / 1e6:.1f} TFLOP/s = {flops / us / 1e6 / 157.3:.0%} of the 2.4 GHz peak = {flops / us / 1e6 / (157.3 * ghz / 2.4):.0%} of the MFMA issue slots at that clock")
         print("   " + " | ".join(f"{n} {seg[:, i].mean():.0f} (max {seg[:, i].max():.0f})" for i, n in enumerate(names)))
 
 
