@@ -125,6 +125,7 @@ def load_library(path: str = None) -> ctypes.CDLL:
         "bc_interp_bilinear_nhwc": [p, p, ctypes.c_longlong, i, i, i, i, i, i, ctypes.c_float, ctypes.c_float, i, p],
         "bc_interp_bilinear_act_nhwc": [p, p, ctypes.c_longlong, i, i, i, i, i, i, ctypes.c_float, ctypes.c_float, i, p, p, p, i, p],
         "bc_affine_act": [p, p, p, p, p, i, ctypes.c_longlong, i, ctypes.c_longlong, i, p],
+        "bc_group_norm_affine_nhwc": [p, ctypes.c_longlong, i, i, i, ctypes.c_float, p, p, p, p, p, ctypes.c_longlong, p],
         "bc_nms_sorted": [p, i, ctypes.c_float, p, p, p, p],
         "bc_policy_step": [p, i, ctypes.c_ulonglong, ctypes.c_ulonglong, i, i, p, p, p, p, p, p],
         "bc_policy_features": [p, i, i, i, p, p, p, p, p],
@@ -500,6 +501,34 @@ class HipBackend:
                                                      _DTYPE_CODE[data.dtype], ptr(isc), ptr(ish), int(bool(irelu)), ptr(osc), ptr(osh),
                                                      ptr(oadd), int(bool(orelu)), self._stream()), "conv1x1_nhwc")
         return out
+
+    # -- group_norm over all executed tiles as a per-channel affine map (one read of the tensor)
+    @staticmethod
+    def group_norm_affine_supported(data, groups):
+        if not (data.is_cuda and data.dim() == 4 and data.dtype in _DTYPE_CODE and data.numel() > 0):
+            return False
+        C = data.shape[1]
+        if not (is_nhwc(data) or (data.is_contiguous() and (C == 1 or data.shape[2] * data.shape[3] == 1))):
+            return False
+        ve = 16 // data.element_size()
+        return C % groups == 0 and C % ve == 0 and C // ve <= 256 and 256 % (C // ve) == 0
+
+    def group_norm_affine(self, data, groups, weight=None, bias=None, eps=1e-5):
+        """(scale, shift), float32[C]: group_norm of the channels-last packed tiles ``data`` (statistics over all tiles, the
+        reference's batched form, core/tensorwrapper.py:600-633) == data * scale[c] + shift[c]  (bc_group_norm_affine_nhwc)."""
+        assert self.group_norm_affine_supported(data, groups)
+        B, C, H, W = data.shape
+        dev = data.device
+        scale, shift = torch.empty(C, dtype=torch.float32, device=dev), torch.empty(C, dtype=torch.float32, device=dev)
+        ws = torch.empty(512 * C * 2, dtype=torch.float32, device=dev)
+        for v in (weight, bias):
+            assert v is None or (_ok(v, torch.float32) and v.numel() == C)
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        with torch.cuda.device_of(data):
+            self._check(self.lib.bc_group_norm_affine_nhwc(data.data_ptr(), B * H * W, C, int(groups), _DTYPE_CODE[data.dtype], float(eps), ptr(weight),
+                                                           ptr(bias), scale.data_ptr(), shift.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()),
+                        "group_norm_affine_nhwc")
+        return scale, shift
 
     # -- network-input stage: window gather from the frame-state map + 7x7 / stride 2 stem conv (csrc/stem7x7.inc)
     @staticmethod

@@ -128,6 +128,7 @@ CONV_TUNE = os.environ.get("BLOCKCOPY_CONV_TUNE", "1") != "0"   # auto mode: mea
 _conv_plans = {}      # (n_exec, bs, cin, cout, n_total, dtype) -> None (library conv) | decomposition index (-1 = library's own choice)
 DEFER_CONV = os.environ.get("BLOCKCOPY_DEFER_CONV", "1") != "0"   # fused convs launch lazily with the recorded elementwise work as epilogue
 POINTWISE = os.environ.get("BLOCKCOPY_POINTWISE", "1") != "0"     # 1x1 convs through the fused kernel's one-tap form (prologue / epilogue fusion)
+GROUP_NORM = os.environ.get("BLOCKCOPY_GROUP_NORM", "1") != "0"   # group_norm on packed tiles as a recorded per-channel affine map (one stats pass)
 STEM_KERNEL = os.environ.get("BLOCKCOPY_STEM", "1") != "0"        # network input: window gather + 7x7 stem conv in one kernel
 CONV_TUNE_LOG = []    # (key, {candidate: microseconds}, choice) of every measurement, for the bench report
 

@@ -567,7 +567,7 @@ class TensorWrapper(torch.Tensor):
                 elif op in OPS["INTERPOLATE"]:
                     ret, pend = self._func_interpolate(func, args, kwargs)
                 elif op in OPS["BATCHED"]:
-                    ret = self._func_batched(func, args, kwargs)
+                    ret, pend = self._func_batched(op, func, args, kwargs)
                 elif op in OPS["CHANNELONLY"]:
                     if kwargs.get("dim", None) != 1:
                         print(f"Operation {op} might behave differently with TensorWrapper when dim != 1!")
@@ -980,12 +980,23 @@ class TensorWrapper(torch.Tensor):
             return placeholder, fusion.Pending(interp=(src, H, W, align, rh, rw))
         return be.interp_bilinear(src, H, W, align, rh, rw), None
 
-    def _func_batched(self, func, args, kwargs):
+    def _func_batched(self, op, func, args, kwargs):
         """Ops with per-sample statistics (group_norm): fold the tile axis into the spatial axis so statistics
-        run over all executed tiles of the (batch-size-1) frame, as the reference does (:600-633)."""
+        run over all executed tiles of the (batch-size-1) frame, as the reference does (:600-633).
+        Returns (result, pending-for-the-result)."""
         args = list(args)
         data = args[0].as_subclass(torch.Tensor)
         B, C, H, W = data.shape
+        if op == "group_norm" and fusion.ENABLED and fusion.GROUP_NORM and self._features.engine == "fused":
+            # channels-last packed tiles: the op is a per-channel affine map whose coefficients cost one read of the tensor
+            # (bc_group_norm_affine_nhwc); recorded as pending work, i.e. applied by whatever consumes the result
+            be = get_backend()
+            gn = {k: kwargs.get(k, args[i] if len(args) > i else d) for k, i, d in (("num_groups", 1, None), ("weight", 2, None), ("bias", 3, None), ("eps", 4, 1e-5))}
+            if (hasattr(be, "group_norm_affine") and gn["num_groups"] is not None and data.dtype in getattr(be, "supports_fusion_dtypes", ())
+                    and be.group_norm_affine_supported(dense_layout(data), gn["num_groups"])):
+                vec = lambda v: None if v is None else fusion.channel_vector(v)
+                scale, shift = be.group_norm_affine(dense_layout(data), gn["num_groups"], vec(gn["weight"]), vec(gn["bias"]), gn["eps"])
+                return args[0]._sibling(fusion.Pending(scale=scale, shift=shift)), None     # (a sibling: the input tensor keeps its own value)
         args[0] = data.permute(1, 0, 2, 3).reshape(1, C, B * H * W, 1)
         out = func(*args, **kwargs)
-        return out.reshape(C, B, H, W).permute(1, 0, 2, 3).contiguous()
+        return out.reshape(C, B, H, W).permute(1, 0, 2, 3).contiguous(), None

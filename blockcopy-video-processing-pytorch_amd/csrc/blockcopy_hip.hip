@@ -1404,6 +1404,84 @@ __global__ __launch_bounds__(WG) void k_maxpool3x3s2_nhwc(typename VecOf<sizeof(
     out[(size_t)b * g.per_tile + f] = res;
 }
 
+// ------------------------------------------------------------------------------------------ GroupNorm over all executed tiles (NHWC)
+// The reference runs group_norm on packed tiles by folding the tile axis into the spatial axis, so that the statistics of a group
+// run over ALL executed tiles of the frame (core/tensorwrapper.py:600-633: (B,C,h,w) -> (1,C,B*h*w,1)).  On channels-last packed
+// tiles that is a plain (n_pix, C) matrix, and the result of the op is a per-CHANNEL affine map y = x*a[c] + b[c] with
+// a = gamma*rstd[g(c)], b = beta - mean[g(c)]*a -- exactly what the engine's lazy fusion records and the next kernel applies as
+// its prologue.  So the op costs ONE read of the tensor: k_group_stats (per-workgroup per-channel partial sums, fixed ranges) and
+// k_group_finalize (one workgroup per group sums the partials in double precision in a fixed order -- deterministic, no atomics --
+// and writes a, b).  The stock route on this layout: two layout copies + RowwiseMoments + the elementwise normalisation + a third
+// copy back (5 passes over the tensor).
+template <typename T, int VE>
+__global__ __launch_bounds__(WG) void k_group_stats(const typename VecOf<sizeof(T) * VE>::type *__restrict__ x, uint32_t n_pix, uint32_t K /* vectors per pixel */,
+                                                    uint32_t rows_per_wg, float *__restrict__ partial /* [wg][C][2] */)
+{
+    typedef typename VecOf<sizeof(T) * VE>::type V;
+    __shared__ float red[WG][2 * VE + 1];
+    const uint32_t lanes_per_row = K;                    // one lane per vector of a pixel; WG / K pixel rows in flight
+    const uint32_t rpw = WG / lanes_per_row;             // (host guarantees K <= WG and WG % K == 0)
+    const uint32_t k = threadIdx.x % lanes_per_row, r = threadIdx.x / lanes_per_row;
+    const uint32_t p0 = blockIdx.x * rows_per_wg, p1 = min(p0 + rows_per_wg, n_pix);
+    float s1[VE], s2[VE];
+#pragma unroll
+    for (int j = 0; j < VE; ++j) { s1[j] = 0.0f; s2[j] = 0.0f; }
+    for (uint32_t p = p0 + r; p < p1; p += rpw) {
+        const V v = x[(size_t)p * K + k];
+        const T *e = reinterpret_cast<const T *>(&v);
+#pragma unroll
+        for (int j = 0; j < VE; ++j) {
+            const float f = Cvt<T>::ld(e + j);
+            s1[j] += f;
+            s2[j] = fmaf(f, f, s2[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < VE; ++j) { red[threadIdx.x][2 * j] = s1[j]; red[threadIdx.x][2 * j + 1] = s2[j]; }
+    __syncthreads();
+    if (threadIdx.x < lanes_per_row) {     // fixed-order sum over the pixel rows of this workgroup
+#pragma unroll
+        for (int j = 0; j < VE; ++j) {
+            float a = 0.0f, b = 0.0f;
+            for (uint32_t q = 0; q < rpw; ++q) { a += red[q * lanes_per_row + threadIdx.x][2 * j]; b += red[q * lanes_per_row + threadIdx.x][2 * j + 1]; }
+            const size_t o = ((size_t)blockIdx.x * K * VE + (size_t)threadIdx.x * VE + j) * 2;
+            partial[o] = a;
+            partial[o + 1] = b;
+        }
+    }
+}
+
+__global__ __launch_bounds__(WG) void k_group_finalize(const float *__restrict__ partial, uint32_t n_wg, uint32_t C, uint32_t cpg, double count,
+                                                       float eps, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                       float *__restrict__ scale, float *__restrict__ shift)
+{
+    __shared__ double r1[WG], r2[WG];
+    const uint32_t g = blockIdx.x;
+    double a = 0.0, b = 0.0;
+    // thread t owns the (workgroup, channel-of-group) items t, t + WG, ...: a fixed assignment, then a fixed-shape tree
+    for (uint32_t it = threadIdx.x; it < n_wg * cpg; it += WG) {
+        const uint32_t w = it / cpg, c = g * cpg + it % cpg;
+        a += (double)partial[((size_t)w * C + c) * 2];
+        b += (double)partial[((size_t)w * C + c) * 2 + 1];
+    }
+    r1[threadIdx.x] = a; r2[threadIdx.x] = b;
+    __syncthreads();
+    for (uint32_t st = WG / 2; st > 0; st >>= 1) {
+        if (threadIdx.x < st) { r1[threadIdx.x] += r1[threadIdx.x + st]; r2[threadIdx.x] += r2[threadIdx.x + st]; }
+        __syncthreads();
+    }
+    const double mean = r1[0] / count;
+    double var = r2[0] / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    for (uint32_t c = threadIdx.x; c < cpg; c += WG) {
+        const uint32_t ch = g * cpg + c;
+        const float sc = (gamma ? gamma[ch] : 1.0f) * rstd;
+        scale[ch] = sc;
+        shift[ch] = (beta ? beta[ch] : 0.0f) - (float)mean * sc;
+    }
+}
+
 // channels-last fused epilogue: channel index runs fastest
 template <typename T, int Q>
 __global__ __launch_bounds__(WG) void k_affine_act_nhwc(T *__restrict__ out, const T *__restrict__ in, const T *__restrict__ add,
@@ -2617,6 +2695,39 @@ BC_EXPORT int bc_affine_act_nhwc(void *out, const void *in, const void *add, con
     else BC_ANQ(hip_bfloat16, 8);
 #undef BC_ANQ
 #undef BC_AN
+    return launch_status();
+}
+
+/* GroupNorm statistics over ALL pixels of a channels-last (n_pix, C) matrix (= the packed tiles of one frame), returned as the
+ * per-channel affine map of the normalisation: scale[c] = gamma[c]*rstd[g], shift[c] = beta[c] - mean[g]*scale[c]. */
+BC_EXPORT int bc_group_norm_affine_nhwc(const void *features, long long n_pix, int C, int groups, int dtype, float eps, const float *gamma,
+                                        const float *beta, float *scale, float *shift, float *workspace, long long workspace_floats, void *stream)
+{
+    if (dtype < BC_F32 || dtype > BC_BF16) return BC_ERR_ELEM;
+    if (n_pix <= 0 || C <= 0 || groups <= 0 || C % groups != 0 || n_pix >= (1ll << 31)) return BC_ERR_SHAPE;
+    const int E = dtype == BC_F32 ? 4 : 2, VE = 16 / E;
+    if (C % VE != 0) return BC_ERR_SHAPE;
+    const uint32_t K = (uint32_t)(C / VE);
+    if (K > WG || WG % K != 0) return BC_ERR_SHAPE;
+    if (!features || !scale || !shift || !workspace) return BC_ERR_NULL;
+    if (!aligned(features, 16)) return BC_ERR_ALIGN;
+    const uint32_t rpw = WG / K;
+    // ~2 workgroups per CU, each at least 8 steps of its pixel rows
+    uint32_t n_wg = 512;
+    while (n_wg > 1 && (uint64_t)n_wg * rpw * 8 > (uint64_t)n_pix) n_wg >>= 1;
+    const uint32_t rows_per_wg = (uint32_t)((n_pix + n_wg - 1) / n_wg);
+    n_wg = (uint32_t)((n_pix + rows_per_wg - 1) / rows_per_wg);
+    if ((long long)n_wg * C * 2 > workspace_floats) return BC_ERR_RANGE;
+    ProfScope ps(BC_OP_AFFINE, (double)n_pix * C * E);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == BC_F32)
+        BC_LAUNCH(ps, (k_group_stats<float, 4>), dim3(n_wg), dim3(WG), 0, st, (const VecOf<16>::type *)features, (uint32_t)n_pix, K, rows_per_wg, workspace);
+    else if (dtype == BC_F16)
+        BC_LAUNCH(ps, (k_group_stats<__half, 8>), dim3(n_wg), dim3(WG), 0, st, (const VecOf<16>::type *)features, (uint32_t)n_pix, K, rows_per_wg, workspace);
+    else
+        BC_LAUNCH(ps, (k_group_stats<hip_bfloat16, 8>), dim3(n_wg), dim3(WG), 0, st, (const VecOf<16>::type *)features, (uint32_t)n_pix, K, rows_per_wg, workspace);
+    hipLaunchKernelGGL(k_group_finalize, dim3(groups), dim3(WG), 0, st, (const float *)workspace, n_wg, (uint32_t)C, (uint32_t)(C / groups),
+                       (double)n_pix * (C / groups), eps, gamma, beta, scale, shift);
     return launch_status();
 }
 

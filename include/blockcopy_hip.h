@@ -207,6 +207,16 @@ int bc_stem7x7s2_nhwc(void *out, const void *frame_state, const void *weights_pa
                       int N, int H, int W, int bs, int Cout, int dtype, const float *out_scale, const float *out_shift,
                       const void *out_add, int out_relu, void *stream);
 
+/* group_norm on packed tiles.  The reference folds the tile axis into the spatial axis so that the statistics of a group run over
+ * ALL executed tiles of the frame (core/tensorwrapper.py:600-633: F.group_norm on the (1, C, B*h*w, 1) view).  On channels-last
+ * packed tiles (a contiguous (n_pix, C) matrix) the op is a per-channel affine map; this entry computes it in one read of the
+ * tensor: scale[c] = gamma[c] * rstd[g(c)], shift[c] = beta[c] - mean[g(c)] * scale[c] (biased variance, fp32 partial sums per
+ * workgroup, combined in double in a fixed order: deterministic).  The engine records (scale, shift) as pending work: the next
+ * kernel applies it as its prologue.  C * elem_size a multiple of 16 and <= 4096 bytes with 256 % (C*elem_size/16) == 0;
+ * gamma / beta may be NULL; workspace: >= 512 * C * 2 floats of scratch. */
+int bc_group_norm_affine_nhwc(const void *features, long long n_pix, int C, int groups, int dtype, float eps, const float *gamma,
+                              const float *beta, float *scale, float *shift, float *workspace, long long workspace_floats, void *stream);
+
 /* decompositions of the fused conv kernel that cover a layer (stride 1 or 2; bs_in = input tile size): codes written to out,
  * count returned.  What bc_tune_set("conv2_cfg", code) may force; the engine times exactly these when it measures a layer shape.
  * code = decomposition index (bits 0-7) | 0x100 if the launch runs without the one-workgroup-per-CU LDS floor (two workgroups

@@ -160,6 +160,22 @@ class OracleBackend:
             y = self.affine_act(y, scale, shift, add.contiguous() if add is not None else None, relu)
         return y.contiguous(memory_format=torch.channels_last)
 
+    @staticmethod
+    def group_norm_affine_supported(data, groups):
+        return data.dim() == 4 and _nhwc(data) and data.shape[1] % groups == 0 and data.dtype == torch.float32
+
+    def group_norm_affine(self, data, groups, weight=None, bias=None, eps=1e-5):
+        """the batched group_norm (statistics over all tiles) as its per-channel affine map, from the definition in fp64"""
+        B, C, H, W = data.shape
+        x = data.double().permute(1, 0, 2, 3).reshape(groups, -1)
+        mean, var = x.mean(1), x.var(1, unbiased=False)
+        rstd = (var + eps).rsqrt().repeat_interleave(C // groups)
+        mean = mean.repeat_interleave(C // groups)
+        g = weight.double() if weight is not None else torch.ones(C, dtype=torch.float64)
+        b = bias.double() if bias is not None else torch.zeros(C, dtype=torch.float64)
+        scale = g * rstd
+        return scale.float(), (b - mean * scale).float()
+
     supports_interp_dtypes = (torch.float32,)
 
     @staticmethod

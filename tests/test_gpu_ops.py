@@ -895,3 +895,29 @@ def test_pointwise_conv(be, dtype, tol):
                 err = (got.double() - want).abs().max().item()
                 assert err <= tol * max(1.0, want.abs().max().item()), (B, Cin, Cout, H, stride, cfg, pro is not None, err)
     be.tune("conv2_cfg", -1)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
+def test_group_norm_affine_matches_the_batched_group_norm(be, dtype, tol):
+    """bc_group_norm_affine_nhwc: group_norm over ALL executed tiles (the reference's batched form, core/tensorwrapper.py:600-633:
+    F.group_norm on the (1, C, B*h*w, 1) view) as a per-channel affine map: data * scale + shift == the stock op on that view;
+    deterministic (two launches give identical coefficients); offsets much larger than the spread keep their precision."""
+    import torch.nn.functional as F
+
+    g = torch.Generator().manual_seed(21)
+    for (B, C, h, w, G, offset) in [(38, 256, 32, 32, 32, 0.0), (5, 64, 8, 8, 32, 3.0), (1, 32, 4, 4, 32, 0.0), (7, 128, 16, 16, 4, -20.0),
+                                     (3, 512, 2, 2, 32, 0.5), (2, 1024, 1, 1, 32, 0.0)]:
+        x = (torch.randn((B, C, h, w), generator=g) * (torch.rand(C, generator=g).view(1, -1, 1, 1) + 0.5) + offset).to(dtype)
+        gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+        xd = _cl(x.cuda())
+        if not be.group_norm_affine_supported(xd, G):
+            assert dtype != torch.float32 or C // 4 > 256, (B, C, h, w)
+            continue
+        scale, shift = be.group_norm_affine(xd, G, gamma.cuda(), beta.cuda(), 1e-5)
+        scale2, shift2 = be.group_norm_affine(xd, G, gamma.cuda(), beta.cuda(), 1e-5)
+        assert torch.equal(scale, scale2) and torch.equal(shift, shift2)
+        got = x.double() * scale.cpu().double().view(1, -1, 1, 1) + shift.cpu().double().view(1, -1, 1, 1)
+        view = x.double().permute(1, 0, 2, 3).reshape(1, C, B * h * w, 1)
+        want = F.group_norm(view, G, gamma.double(), beta.double(), 1e-5).reshape(C, B, h, w).permute(1, 0, 2, 3)
+        err = float((got - want).abs().max())
+        assert err <= (tol if dtype != torch.float32 else 2e-5 * max(1.0, abs(offset))) * max(1.0, float(want.abs().max())), ((B, C, h, w, G), err)

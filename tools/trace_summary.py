@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 --kernel-trace CSV of bench.py: per-frame kernel time inside the timed clips.
 
-usage: trace_summary.py <kernel_trace.csv> <frames_in_window> [skip_last_frames]
-The window is delimited by the gather (k_tiles<.., true>) launches: two per frame (network input + SPP output)."""
+usage: trace_summary.py <kernel_trace.csv> <frames_in_window> [skip_last_frames] [gathers_per_frame]
+The window is delimited by the gather (k_tiles<.., true>) launches: two per SwiftNet frame (network input + SPP output), one per
+CSP frame (network input)."""
 import collections
 import csv
 import sys
@@ -14,7 +15,7 @@ def main():
     rows = list(csv.DictReader(open(path)))
     ks = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows)
     marks = [s for s, e, n in ks if "k_tiles<" in n and ", true" in n]
-    per_frame = 2
+    per_frame = int(sys.argv[4]) if len(sys.argv) > 4 else 2
     fe = marks[-per_frame * skip] if skip else ks[-1][1] + 1
     fs = marks[-per_frame * (skip + n_frames)]
     sel = [(s, e, n) for s, e, n in ks if fs <= s < fe]
