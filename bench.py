@@ -501,6 +501,9 @@ def main(argv=None):
                          "algorithmic_bytes_per_launch": (cc["total_bytes"] / cc["launches"]) if cc["launches"] else None},
             "kernels": extra,
         }
+        if "roofline_conv" in extra:
+            # the kernel that DOMINATES the frame by time (the fused conv, MFMA-bound); `roofline` above is the kernel the metric names
+            out["roofline_conv"] = extra.pop("roofline_conv")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_dense_baseline(args, args.cpu_frames)
         print(json.dumps(out), flush=True)

@@ -32,18 +32,20 @@ class Pending:
     happened yet (the stored data is an unwritten placeholder of the right shape) and will carry the rest of the record
     as its epilogue, e.g. a decoder's ``x = upsample(x); x += skip`` becomes one kernel."""
 
-    __slots__ = ("scale", "shift", "add", "relu", "interp", "add_version", "conv")
+    __slots__ = ("scale", "shift", "add", "relu", "interp", "add_version", "conv", "src_guard")
 
-    def __init__(self, scale=None, shift=None, add=None, relu=False, interp=None, add_version=None, conv=None):
+    def __init__(self, scale=None, shift=None, add=None, relu=False, interp=None, add_version=None, conv=None, src_guard=None):
         self.scale, self.shift, self.add, self.relu, self.interp = scale, shift, add, relu, interp
         self.add_version = add._version if (add is not None and add_version is None) else add_version
+        # (tensor, version) of the input a deferred producer will read at launch time (see checked_source)
+        self.src_guard = src_guard if src_guard is not None else ((interp[0], interp[0]._version) if interp is not None else None)
         # deferred fused halo+conv: ``conv = (launch, kwargs)``; like ``interp`` the stored data is an unwritten placeholder and
         # the launch happens when the value is needed, with the rest of the record as the kernel's epilogue -- the end of a
         # residual block (conv -> + bias -> + identity -> ReLU) is then ONE launch and no separate elementwise pass
         self.conv = conv
 
     def copy(self):
-        return Pending(self.scale, self.shift, self.add, self.relu, self.interp, self.add_version, self.conv)
+        return Pending(self.scale, self.shift, self.add, self.relu, self.interp, self.add_version, self.conv, self.src_guard)
 
     @property
     def deferred(self):
@@ -63,6 +65,19 @@ class Pending:
                                "before the sum was consumed; materialise the sum first (e.g. call .clone() on it) or set "
                                "BLOCKCOPY_FUSE=0")
         return self.add
+
+    def defer_conv(self, launch, kwargs, source):
+        """Record a deferred producer launch (``launch(epilogue=..., **kwargs)``) that will read ``source`` when it runs."""
+        self.conv = (launch, kwargs)
+        self.src_guard = (source, source._version)
+        return self
+
+    def check_source(self):
+        """Loud error if the input of a deferred producer (conv / resampling) was written in place after the op was recorded:
+        the launch happens when the value is needed, so it would silently see the new contents."""
+        if self.src_guard is not None and self.src_guard[0]._version != self.src_guard[1]:
+            raise RuntimeError("blockcopy lazy fusion: the input of a deferred conv / interpolation was modified in place before the "
+                               "result was consumed; consume the result first or set BLOCKCOPY_DEFER_CONV=0 / BLOCKCOPY_FUSE=0")
 
     @property
     def affine_only(self):

@@ -366,6 +366,7 @@ class TensorWrapper(torch.Tensor):
             if add is not None:
                 add = dense_layout(add)
             be = get_backend()
+            P.check_source()
             if P.conv is not None:        # deferred fused halo+conv: launch now, the rest of the record is its epilogue
                 launch, kw = P.conv
                 plain = P.scale is None and P.shift is None and add is None and not P.relu
@@ -629,7 +630,8 @@ class TensorWrapper(torch.Tensor):
             if x._pending is not None:
                 scale, shift = fusion.compose_affine(x._pending.scale, x._pending.shift, scale, shift)
                 interp, conv = x._pending.interp, x._pending.conv    # a deferred producer stays the base of the record (not the placeholder)
-            return x._sibling(fusion.Pending(scale=scale, shift=shift, interp=interp, conv=conv)), None, True
+            return x._sibling(fusion.Pending(scale=scale, shift=shift, interp=interp, conv=conv,
+                                             src_guard=x._pending.src_guard if x._pending is not None else None)), None, True
         # residual add:  x (+)= y
         y = args[1] if len(args) > 1 else kwargs.get("other", None)
         alpha = kwargs.get("alpha", args[2] if len(args) > 2 else 1)
@@ -724,7 +726,7 @@ class TensorWrapper(torch.Tensor):
                 placeholder = torch.empty((x.shape[0], 64, x.shape[2] // 2, x.shape[3] // 2), dtype=dm.dtype, device=dm.device,
                                           memory_format=torch.channels_last)
                 P = pend_out if pend_out is not None else fusion.Pending()
-                P.conv = (be.stem7x7, dict(frame_state=dm, wpk=wpk, mapping_exec=feats._mapping_exec, bs=x.shape[2]))
+                P.defer_conv(be.stem7x7, dict(frame_state=dm, wpk=wpk, mapping_exec=feats._mapping_exec, bs=x.shape[2]), dm)
                 return placeholder, P
         prologue = None
         residual = None      # pending residual add folded into the halo gather (with the activated tiles as a by-product)
@@ -774,8 +776,8 @@ class TensorWrapper(torch.Tensor):
                     # residual add, ReLU) as its epilogue.  The placeholder is never read or written; `data` is held by the record.
                     placeholder = empty_like_layout((data.shape[0], weight.shape[0], data.shape[2] // stride, data.shape[3] // stride), data)
                     P = pend_out if pend_out is not None else fusion.Pending()
-                    P.conv = (be.conv3x3_ring, dict(data_exec=data, ring=ring, wpk=wpk, cout=weight.shape[0], grid_idx=grid_idx,
-                                                   mapping_exec=mapping_exec, prologue=prologue, cfg=plan, stride=stride))
+                    P.defer_conv(be.conv3x3_ring, dict(data_exec=data, ring=ring, wpk=wpk, cout=weight.shape[0], grid_idx=grid_idx,
+                                                       mapping_exec=mapping_exec, prologue=prologue, cfg=plan, stride=stride), data)
                     return placeholder, P
                 with timings.env("tensorwrapper/conv3x3_fused", 10):
                     return be.conv3x3_ring(data, ring, wpk, weight.shape[0], grid_idx, mapping_exec, prologue, None, cfg=plan,
@@ -919,7 +921,7 @@ class TensorWrapper(torch.Tensor):
             placeholder = torch.empty((data.shape[0], cout, data.shape[2] // stride, data.shape[3] // stride), dtype=data.dtype, device=data.device,
                                       memory_format=torch.channels_last)
             Pn = pend_out if pend_out is not None else fusion.Pending()
-            Pn.conv = (be.conv1x1, launch_kw)
+            Pn.defer_conv(be.conv1x1, launch_kw, data)
             return placeholder, Pn
         return be.conv1x1(epilogue=None, **launch_kw), pend_out
 

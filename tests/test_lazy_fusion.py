@@ -175,3 +175,27 @@ def test_deferred_conv_takes_the_recorded_work_as_its_epilogue(oracle_backend, t
     if tail in ("residual_relu", "stride2_residual"):
         epi = launches[0]           # the fused pass: ONE conv launch whose epilogue holds bias + identity + ReLU
         assert epi is not None and epi[1] is not None and epi[2] is not None and epi[3] is True
+
+
+def test_deferred_conv_input_modified_in_place_is_a_loud_error(oracle_backend):
+    """A deferred conv / resampling reads its input when the value is needed, not where the op was called: a real in-place
+    write to that input in between must not silently change the result (same rule as the recorded residual operand)."""
+    from blockcopy.core import fusion
+
+    w1 = torch.randn(8, 8, 3, 3, generator=torch.Generator().manual_seed(3)) * 0.1
+    prev_mode, fusion.CONV_MODE = fusion.CONV_MODE, "native"
+    try:
+        blk = _packed()
+        y = F.conv2d(blk, w1, None, 1, 1)
+        assert y._pending is not None and y._pending.conv is not None     # recorded, not launched
+        blk.as_subclass(torch.Tensor).mul_(2.0)                            # a real in-place write to the conv's input
+        with pytest.raises(RuntimeError, match="modified in place"):
+            y.combine()
+        blk2 = _packed()
+        z = F.interpolate(blk2, scale_factor=2, mode="bilinear", align_corners=False)
+        assert z._pending is not None and z._pending.interp is not None
+        blk2.as_subclass(torch.Tensor).add_(1.0)
+        with pytest.raises(RuntimeError, match="modified in place"):
+            z.combine()
+    finally:
+        fusion.CONV_MODE = prev_mode
