@@ -125,6 +125,8 @@ def load_library(path: str = None) -> ctypes.CDLL:
         "bc_interp_bilinear_nhwc": [p, p, ctypes.c_longlong, i, i, i, i, i, i, ctypes.c_float, ctypes.c_float, i, p],
         "bc_interp_bilinear_act_nhwc": [p, p, ctypes.c_longlong, i, i, i, i, i, i, ctypes.c_float, ctypes.c_float, i, p, p, p, i, p],
         "bc_affine_act": [p, p, p, p, p, i, ctypes.c_longlong, i, ctypes.c_longlong, i, p],
+        "bc_bn_train_fwd": [p, p, i, i, ctypes.c_longlong, p, p, p, p, p, p, p, ctypes.c_float, ctypes.c_float, i, p, ctypes.c_longlong, p],
+        "bc_bn_train_stats_nhwc": [p, ctypes.c_longlong, i, i, ctypes.c_float, p, p, p, p, p, ctypes.c_float, p, p, p, p, p, ctypes.c_longlong, p],
         "bc_group_norm_affine_nhwc": [p, ctypes.c_longlong, i, i, i, ctypes.c_float, p, p, p, p, p, ctypes.c_longlong, p],
         "bc_nms_sorted": [p, i, ctypes.c_float, p, p, p, p],
         "bc_policy_step": [p, i, ctypes.c_ulonglong, ctypes.c_ulonglong, i, i, p, p, p, p, p, p],
@@ -501,6 +503,43 @@ class HipBackend:
                                                      _DTYPE_CODE[data.dtype], ptr(isc), ptr(ish), int(bool(irelu)), ptr(osc), ptr(osh),
                                                      ptr(oadd), int(bool(orelu)), self._stream()), "conv1x1_nhwc")
         return out
+
+    # -- training-mode BatchNorm forward of the policy net (two launches instead of five)
+    @staticmethod
+    def bn_train_supported(x):
+        if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and 0 < x.numel() < 2 ** 32 and x.shape[0] * x.shape[2] * x.shape[3] < 2 ** 31):
+            return False
+        if x.is_contiguous():
+            return True
+        C = x.shape[1]
+        return is_nhwc(x) and C % 4 == 0 and C // 4 <= 256 and 256 % (C // 4) == 0
+
+    def bn_train(self, x, weight, bias, running_mean, running_var, num_batches_tracked, momentum, eps, relu=False):
+        """(y, save_mean, save_invstd) of training-mode batch_norm(+ReLU) on fp32 ``x`` (NCHW: bc_bn_train_fwd; channels-last:
+        bc_bn_train_stats_nhwc + bc_affine_act_nhwc); running statistics and the batch counter are updated in place."""
+        assert self.bn_train_supported(x)
+        N, C, H, W = x.shape
+        dev = x.device
+        save_mean, save_invstd = torch.empty(C, dtype=torch.float32, device=dev), torch.empty(C, dtype=torch.float32, device=dev)
+        for v in (weight, bias, running_mean, running_var):
+            assert v is None or (_ok(v, torch.float32) and v.numel() == C)
+        assert num_batches_tracked is None or (num_batches_tracked.dtype == torch.int64 and num_batches_tracked.is_cuda)
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        if x.is_contiguous():
+            y = torch.empty_like(x)
+            ws = torch.empty(C * 64 * 2, dtype=torch.float32, device=dev)
+            with torch.cuda.device_of(x):
+                self._check(self.lib.bc_bn_train_fwd(y.data_ptr(), x.data_ptr(), N, C, H * W, ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var),
+                                                     ptr(num_batches_tracked), save_mean.data_ptr(), save_invstd.data_ptr(), float(momentum), float(eps),
+                                                     int(bool(relu)), ws.data_ptr(), ws.numel(), self._stream()), "bn_train_fwd")
+            return y, save_mean, save_invstd
+        scale, shift = torch.empty(C, dtype=torch.float32, device=dev), torch.empty(C, dtype=torch.float32, device=dev)
+        ws = torch.empty(512 * C * 2, dtype=torch.float32, device=dev)
+        with torch.cuda.device_of(x):
+            self._check(self.lib.bc_bn_train_stats_nhwc(x.data_ptr(), N * H * W, C, _DTYPE_CODE[x.dtype], float(eps), ptr(weight), ptr(bias), ptr(running_mean),
+                                                        ptr(running_var), ptr(num_batches_tracked), float(momentum), save_mean.data_ptr(), save_invstd.data_ptr(),
+                                                        scale.data_ptr(), shift.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()), "bn_train_stats_nhwc")
+        return self.affine_act(x, scale, shift, None, relu), save_mean, save_invstd
 
     # -- group_norm over all executed tiles as a per-channel affine map (one read of the tensor)
     @staticmethod

@@ -18,6 +18,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from blockcopy.policy.fused_bn import PolicyBatchNorm2d
 from blockcopy.policy.resnet import resnet8
 from blockcopy.utils.profiler import timings
 
@@ -32,7 +33,7 @@ def _head_stage(cin: int, cout: int, last: bool) -> nn.Sequential:
     """3x3 stride-2 conv; every stage but the last is followed by BN (slow running stats) and ReLU and has no bias."""
     mods: List[nn.Module] = [nn.Conv2d(cin, cout, kernel_size=3, stride=2, padding=1, bias=last)]
     if not last:
-        mods += [nn.BatchNorm2d(cout, momentum=0.02), nn.ReLU(inplace=False)]
+        mods += [PolicyBatchNorm2d(cout, momentum=0.02), nn.ReLU(inplace=False)]
     return nn.Sequential(*mods)
 
 

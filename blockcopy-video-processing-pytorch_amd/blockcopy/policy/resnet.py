@@ -12,13 +12,15 @@ from typing import Sequence
 
 import torch.nn as nn
 
+from blockcopy.policy.fused_bn import PolicyBatchNorm2d
+
 BN_MOMENTUM = 0.02          # slow running statistics: the policy trains online on single frames
 STAGE_WIDTHS = (16, 32, 64)  # x width_factor
 STAGE_STRIDES = (1, 2, 2)
 
 
 def _bn(channels: int) -> nn.BatchNorm2d:
-    return nn.BatchNorm2d(channels, momentum=BN_MOMENTUM)
+    return PolicyBatchNorm2d(channels, momentum=BN_MOMENTUM)     # nn.BatchNorm2d with a two-launch training forward (fused_bn.py)
 
 
 class BasicBlock(nn.Module):
@@ -37,7 +39,7 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        y = self.bn2(self.conv2(self.relu(self.bn1(self.conv1(x)))))
+        y = self.bn2(self.conv2(self.bn1(self.conv1(x), relu=True)))      # (bn1 + self.relu in one pass)
         y += x if self.downsample is None else self.downsample(x)
         return self.relu(y)
 
@@ -79,7 +81,7 @@ class ResNet_32x32(nn.Module):
                 nn.init.zeros_(m.bias)
 
     def forward(self, x):
-        x = self.relu(self.bn1(self.conv1(x)))
+        x = self.bn1(self.conv1(x), relu=True)
         return self.layer3(self.layer2(self.layer1(x)))
 
 

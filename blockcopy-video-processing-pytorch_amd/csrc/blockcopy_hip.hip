@@ -1451,9 +1451,15 @@ __global__ __launch_bounds__(WG) void k_group_stats(const typename VecOf<sizeof(
     }
 }
 
+struct BnExtra {          // batch-norm bookkeeping of the training forward (cpg == 1: a "group" is a channel); all optional
+    float *save_mean, *save_invstd, *running_mean, *running_var;
+    long long *batches;
+    float momentum;
+};
+
 __global__ __launch_bounds__(WG) void k_group_finalize(const float *__restrict__ partial, uint32_t n_wg, uint32_t C, uint32_t cpg, double count,
                                                        float eps, const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                       float *__restrict__ scale, float *__restrict__ shift)
+                                                       float *__restrict__ scale, float *__restrict__ shift, BnExtra bn)
 {
     __shared__ double r1[WG], r2[WG];
     const uint32_t g = blockIdx.x;
@@ -1474,11 +1480,111 @@ __global__ __launch_bounds__(WG) void k_group_finalize(const float *__restrict__
     double var = r2[0] / count - mean * mean;
     if (var < 0.0) var = 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (threadIdx.x == 0) {
+        if (bn.save_mean) bn.save_mean[g] = (float)mean;
+        if (bn.save_invstd) bn.save_invstd[g] = rstd;
+        if (bn.running_mean) bn.running_mean[g] = (1.0f - bn.momentum) * bn.running_mean[g] + bn.momentum * (float)mean;
+        if (bn.running_var) bn.running_var[g] = (1.0f - bn.momentum) * bn.running_var[g] + bn.momentum * (float)(count > 1.0 ? var * count / (count - 1.0) : var);
+        if (bn.batches && g == 0) *bn.batches += 1;
+    }
     for (uint32_t c = threadIdx.x; c < cpg; c += WG) {
         const uint32_t ch = g * cpg + c;
         const float sc = (gamma ? gamma[ch] : 1.0f) * rstd;
         scale[ch] = sc;
         shift[ch] = (beta ? beta[ch] : 0.0f) - (float)mean * sc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ training-mode BatchNorm forward (policy net)
+// The online-RL policy keeps its small CNN in TRAINING mode on every frame (reference policy/policy.py: the net is
+// trained online, batch statistics of the single frame), i.e. ten batch-statistics BatchNorms per frame on 4-17 MB maps.  The stock
+// route is three library kernels + a momentum update + a counter increment per layer (32 us on average).  Here: k_bn_stats (per-chunk
+// partial sums of a channel plane) + k_bn_apply (every workgroup re-reduces the <= 64 partials of its channel in double -- fixed
+// order, deterministic -- then normalises its chunk with optional ReLU; chunk 0 also writes save_mean / save_invstd for the backward
+// pass and the running statistics, workgroup (0,0) the batch counter).  NCHW fp32, contiguous.
+struct BnGeom {
+    uint32_t N, C, HW;
+    uint32_t L;          // elements (of the N*HW of a channel) per chunk, a multiple of 4
+    uint32_t chunks;
+};
+
+__global__ __launch_bounds__(WG) void k_bn_stats(const float *__restrict__ x, float2 *__restrict__ partial, BnGeom g)
+{
+    __shared__ float r1[WG], r2[WG];
+    const uint32_t c = blockIdx.y, j = blockIdx.x;
+    const uint32_t total = g.N * g.HW;
+    const uint32_t e0 = j * g.L, e1 = min(e0 + g.L, total);
+    float s1 = 0.0f, s2 = 0.0f;
+    if (g.HW % 4 == 0) {
+        for (uint32_t e = e0 + threadIdx.x * 4; e < e1; e += WG * 4) {
+            const uint32_t n = e / g.HW, hw = e - n * g.HW;
+            const float4 v = *reinterpret_cast<const float4 *>(x + ((size_t)n * g.C + c) * g.HW + hw);
+            s1 += (v.x + v.y) + (v.z + v.w);
+            s2 = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, s2))));
+        }
+    } else {
+        for (uint32_t e = e0 + threadIdx.x; e < e1; e += WG) {
+            const uint32_t n = e / g.HW, hw = e - n * g.HW;
+            const float v = x[((size_t)n * g.C + c) * g.HW + hw];
+            s1 += v;
+            s2 = fmaf(v, v, s2);
+        }
+    }
+    r1[threadIdx.x] = s1; r2[threadIdx.x] = s2;
+    __syncthreads();
+    for (uint32_t st = WG / 2; st > 0; st >>= 1) {
+        if (threadIdx.x < st) { r1[threadIdx.x] += r1[threadIdx.x + st]; r2[threadIdx.x] += r2[threadIdx.x + st]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[(size_t)c * g.chunks + j] = make_float2(r1[0], r2[0]);
+}
+
+__global__ __launch_bounds__(WG) void k_bn_apply(float *__restrict__ y, const float *__restrict__ x, const float2 *__restrict__ partial,
+                                                 const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ running_mean,
+                                                 float *__restrict__ running_var, long long *__restrict__ batches, float *__restrict__ save_mean,
+                                                 float *__restrict__ save_invstd, float momentum, float eps, int relu, BnGeom g)
+{
+    __shared__ float coef[2];
+    const uint32_t c = blockIdx.y, j = blockIdx.x;
+    const uint32_t total = g.N * g.HW;
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+        for (uint32_t q = 0; q < g.chunks; ++q) { const float2 p = partial[(size_t)c * g.chunks + q]; a += (double)p.x; b += (double)p.y; }
+        const double mean = a / total;
+        double var = b / total - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = (gamma ? gamma[c] : 1.0f) * invstd;
+        coef[0] = sc;
+        coef[1] = (beta ? beta[c] : 0.0f) - (float)mean * sc;
+        if (j == 0) {
+            if (save_mean) save_mean[c] = (float)mean;
+            if (save_invstd) save_invstd[c] = invstd;
+            if (running_mean) running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
+            if (running_var) running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)(total > 1 ? var * total / (total - 1.0) : var);
+            if (batches && c == 0) *batches += 1;
+        }
+    }
+    __syncthreads();
+    const float sc = coef[0], sh = coef[1];
+    const uint32_t e0 = j * g.L, e1 = min(e0 + g.L, total);
+    if (g.HW % 4 == 0) {
+        for (uint32_t e = e0 + threadIdx.x * 4; e < e1; e += WG * 4) {
+            const uint32_t n = e / g.HW, hw = e - n * g.HW;
+            const size_t o = ((size_t)n * g.C + c) * g.HW + hw;
+            float4 v = *reinterpret_cast<const float4 *>(x + o);
+            v.x = fmaf(v.x, sc, sh); v.y = fmaf(v.y, sc, sh); v.z = fmaf(v.z, sc, sh); v.w = fmaf(v.w, sc, sh);
+            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<float4 *>(y + o) = v;
+        }
+    } else {
+        for (uint32_t e = e0 + threadIdx.x; e < e1; e += WG) {
+            const uint32_t n = e / g.HW, hw = e - n * g.HW;
+            const size_t o = ((size_t)n * g.C + c) * g.HW + hw;
+            float v = fmaf(x[o], sc, sh);
+            if (relu) v = fmaxf(v, 0.f);
+            y[o] = v;
+        }
     }
 }
 
@@ -2698,10 +2804,8 @@ BC_EXPORT int bc_affine_act_nhwc(void *out, const void *in, const void *add, con
     return launch_status();
 }
 
-/* GroupNorm statistics over ALL pixels of a channels-last (n_pix, C) matrix (= the packed tiles of one frame), returned as the
- * per-channel affine map of the normalisation: scale[c] = gamma[c]*rstd[g], shift[c] = beta[c] - mean[g]*scale[c]. */
-BC_EXPORT int bc_group_norm_affine_nhwc(const void *features, long long n_pix, int C, int groups, int dtype, float eps, const float *gamma,
-                                        const float *beta, float *scale, float *shift, float *workspace, long long workspace_floats, void *stream)
+static int launch_group_stats(const void *features, long long n_pix, int C, int groups, int dtype, float eps, const float *gamma, const float *beta,
+                              float *scale, float *shift, float *workspace, long long workspace_floats, const BnExtra &bn, hipStream_t st)
 {
     if (dtype < BC_F32 || dtype > BC_BF16) return BC_ERR_ELEM;
     if (n_pix <= 0 || C <= 0 || groups <= 0 || C % groups != 0 || n_pix >= (1ll << 31)) return BC_ERR_SHAPE;
@@ -2719,7 +2823,6 @@ BC_EXPORT int bc_group_norm_affine_nhwc(const void *features, long long n_pix, i
     n_wg = (uint32_t)((n_pix + rows_per_wg - 1) / rows_per_wg);
     if ((long long)n_wg * C * 2 > workspace_floats) return BC_ERR_RANGE;
     ProfScope ps(BC_OP_AFFINE, (double)n_pix * C * E);
-    hipStream_t st = (hipStream_t)stream;
     if (dtype == BC_F32)
         BC_LAUNCH(ps, (k_group_stats<float, 4>), dim3(n_wg), dim3(WG), 0, st, (const VecOf<16>::type *)features, (uint32_t)n_pix, K, rows_per_wg, workspace);
     else if (dtype == BC_F16)
@@ -2727,7 +2830,51 @@ BC_EXPORT int bc_group_norm_affine_nhwc(const void *features, long long n_pix, i
     else
         BC_LAUNCH(ps, (k_group_stats<hip_bfloat16, 8>), dim3(n_wg), dim3(WG), 0, st, (const VecOf<16>::type *)features, (uint32_t)n_pix, K, rows_per_wg, workspace);
     hipLaunchKernelGGL(k_group_finalize, dim3(groups), dim3(WG), 0, st, (const float *)workspace, n_wg, (uint32_t)C, (uint32_t)(C / groups),
-                       (double)n_pix * (C / groups), eps, gamma, beta, scale, shift);
+                       (double)n_pix * (C / groups), eps, gamma, beta, scale, shift, bn);
+    return launch_status();
+}
+
+/* GroupNorm statistics over ALL pixels of a channels-last (n_pix, C) matrix (= the packed tiles of one frame), returned as the
+ * per-channel affine map of the normalisation: scale[c] = gamma[c]*rstd[g], shift[c] = beta[c] - mean[g]*scale[c]. */
+BC_EXPORT int bc_group_norm_affine_nhwc(const void *features, long long n_pix, int C, int groups, int dtype, float eps, const float *gamma,
+                                        const float *beta, float *scale, float *shift, float *workspace, long long workspace_floats, void *stream)
+{
+    return launch_group_stats(features, n_pix, C, groups, dtype, eps, gamma, beta, scale, shift, workspace, workspace_floats,
+                              BnExtra{nullptr, nullptr, nullptr, nullptr, nullptr, 0.0f}, (hipStream_t)stream);
+}
+
+/* channels-last form of the training-mode BatchNorm statistics: the same two kernels with one channel per group; also writes what the
+ * backward pass and the module state need.  The normalisation itself is bc_affine_act_nhwc with the returned (scale, shift). */
+BC_EXPORT int bc_bn_train_stats_nhwc(const void *features, long long n_pix, int C, int dtype, float eps, const float *gamma, const float *beta,
+                                     float *running_mean, float *running_var, long long *num_batches_tracked, float momentum, float *save_mean,
+                                     float *save_invstd, float *scale, float *shift, float *workspace, long long workspace_floats, void *stream)
+{
+    return launch_group_stats(features, n_pix, C, C, dtype, eps, gamma, beta, scale, shift, workspace, workspace_floats,
+                              BnExtra{save_mean, save_invstd, running_mean, running_var, num_batches_tracked, momentum}, (hipStream_t)stream);
+}
+
+/* training-mode BatchNorm2d forward of an NCHW fp32 tensor (batch statistics; optional fused ReLU): see k_bn_stats / k_bn_apply */
+BC_EXPORT int bc_bn_train_fwd(void *y, const void *x, int N, int C, long long HW, const float *gamma, const float *beta, float *running_mean,
+                              float *running_var, long long *num_batches_tracked, float *save_mean, float *save_invstd, float momentum,
+                              float eps, int relu, float *workspace, long long workspace_floats, void *stream)
+{
+    if (N <= 0 || C <= 0 || HW <= 0 || (uint64_t)N * HW >= (1ull << 31) || (uint64_t)N * C * HW >= (1ull << 32)) return BC_ERR_SHAPE;
+    if (!y || !x || !workspace) return BC_ERR_NULL;
+    if (!aligned(y, 16) || !aligned(x, 16)) return BC_ERR_ALIGN;
+    BnGeom g;
+    g.N = N; g.C = C; g.HW = (uint32_t)HW;
+    const uint32_t total = (uint32_t)N * g.HW;
+    uint32_t chunks = (total + 8191) / 8192;
+    if (chunks > 64) chunks = 64;
+    if (chunks < 1) chunks = 1;
+    g.L = ((total + chunks - 1) / chunks + 3) / 4 * 4;
+    g.chunks = (total + g.L - 1) / g.L;
+    if ((long long)C * g.chunks * 2 > workspace_floats) return BC_ERR_RANGE;
+    ProfScope ps(BC_OP_AFFINE, 3.0 * N * C * (double)HW * 4);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_bn_stats, dim3(g.chunks, C), dim3(WG), 0, st, (const float *)x, (float2 *)workspace, g);
+    BC_LAUNCH(ps, k_bn_apply, dim3(g.chunks, C), dim3(WG), 0, st, (float *)y, (const float *)x, (const float2 *)workspace, gamma, beta, running_mean,
+              running_var, num_batches_tracked, save_mean, save_invstd, momentum, eps, relu, g);
     return launch_status();
 }
 

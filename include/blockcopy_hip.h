@@ -217,6 +217,22 @@ int bc_stem7x7s2_nhwc(void *out, const void *frame_state, const void *weights_pa
 int bc_group_norm_affine_nhwc(const void *features, long long n_pix, int C, int groups, int dtype, float eps, const float *gamma,
                               const float *beta, float *scale, float *shift, float *workspace, long long workspace_floats, void *stream);
 
+/* training-mode BatchNorm2d forward (batch statistics) of a contiguous NCHW float32 tensor, optional fused ReLU: the per-frame
+ * normalisation of the online-RL policy net (reference policy/policy.py keeps the net in train() mode; policy/net.py, resnet.py).
+ * y = relu?((x - mean[c]) * invstd[c] * gamma[c] + beta[c]); save_mean / save_invstd (what aten::native_batch_norm_backward
+ * takes), running_mean / running_var (momentum update, unbiased variance) and num_batches_tracked (+1) are updated when non-NULL.
+ * Two launches (partial sums; normalise) instead of the library's five; deterministic.  workspace: >= C * 64 * 2 floats. */
+int bc_bn_train_fwd(void *y, const void *x, int N, int C, long long HW, const float *gamma, const float *beta, float *running_mean,
+                    float *running_var, long long *num_batches_tracked, float *save_mean, float *save_invstd, float momentum,
+                    float eps, int relu, float *workspace, long long workspace_floats, void *stream);
+
+/* channels-last form of the above, statistics only: per-channel scale = gamma*invstd, shift = beta - mean*scale of a (n_pix, C)
+ * matrix (+ save_mean / save_invstd / running statistics / batch counter), to be applied with bc_affine_act_nhwc(relu).  Same two
+ * kernels as bc_group_norm_affine_nhwc with one channel per group.  workspace: >= 512 * C * 2 floats. */
+int bc_bn_train_stats_nhwc(const void *features, long long n_pix, int C, int dtype, float eps, const float *gamma, const float *beta,
+                           float *running_mean, float *running_var, long long *num_batches_tracked, float momentum, float *save_mean,
+                           float *save_invstd, float *scale, float *shift, float *workspace, long long workspace_floats, void *stream);
+
 /* decompositions of the fused conv kernel that cover a layer (stride 1 or 2; bs_in = input tile size): codes written to out,
  * count returned.  What bc_tune_set("conv2_cfg", code) may force; the engine times exactly these when it measures a layer shape.
  * code = decomposition index (bits 0-7) | 0x100 if the launch runs without the one-workgroup-per-CU LDS floor (two workgroups

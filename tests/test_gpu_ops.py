@@ -634,9 +634,9 @@ def test_fused_conv3x3_every_decomposition(be, cfg):
     try:
         for case, (Cin, Cout, bs, N, GH, GW) in enumerate([(64, 128, 8, 1, 3, 5), (32, 128, 16, 2, 2, 3), (96, 256, 4, 1, 4, 7),
                                                             (64, 128, 32, 1, 2, 2), (128, 128, 4, 1, 5, 5), (160, 128, 24, 1, 2, 3)]):
+            T = N * GH * GW
             if cfg not in be.conv3x3_candidates(T, Cin, Cout, bs, 4, 1):
                 continue      # (multi-row RM = 2 decompositions need 8-row patches; 8 K groups stage 64 channels at a time)
-            T = N * GH * GW
             w = (torch.randn((Cout, Cin, 3, 3), generator=gen) * (2.0 / (9 * Cin)) ** 0.5).cuda()
             wpk = be.pack_conv3x3_weights(w)
             ring_a, ring_b = torch.zeros((T, Cin, 4 * bs)).cuda(), torch.zeros((T, Cin, 4 * bs)).cuda()
@@ -921,3 +921,42 @@ def test_group_norm_affine_matches_the_batched_group_norm(be, dtype, tol):
         want = F.group_norm(view, G, gamma.double(), beta.double(), 1e-5).reshape(C, B, h, w).permute(1, 0, 2, 3)
         err = float((got - want).abs().max())
         assert err <= (tol if dtype != torch.float32 else 2e-5 * max(1.0, abs(offset))) * max(1.0, float(want.abs().max())), ((B, C, h, w, G), err)
+
+
+def test_policy_batchnorm_training_forward_and_backward(be, monkeypatch):
+    """bc_bn_train_fwd behind PolicyBatchNorm2d == nn.BatchNorm2d in train() mode: output (with and without the fused ReLU),
+    running statistics, batch counter, and the gradients ATen's backward forms from the saved statistics; shapes of the policy
+    net (single frame, 4-17 MB maps) plus ragged ones (HW not a multiple of 4, batch 3, one chunk)."""
+    from blockcopy.policy import fused_bn
+    from blockcopy.policy.fused_bn import PolicyBatchNorm2d
+
+    monkeypatch.setattr(fused_bn, "FUSED_BN_GRAD", True)      # (by default only the no-grad decision forward takes the fused route)
+    g = torch.Generator().manual_seed(8)
+    for (N, C, H, W, relu, cl) in [(1, 32, 256, 512, True, False), (1, 64, 128, 256, False, False), (1, 128, 64, 128, True, False), (3, 16, 9, 7, True, False),
+                                    (2, 8, 5, 5, False, False), (1, 128, 16, 32, True, False), (1, 32, 256, 512, True, True), (1, 64, 128, 256, False, True),
+                                    (1, 128, 64, 128, True, True), (3, 16, 9, 7, True, True), (1, 128, 16, 32, False, True)]:
+        x = (torch.randn((N, C, H, W), generator=g) * 2.0 + 0.7).cuda()
+        if cl:
+            x = x.contiguous(memory_format=torch.channels_last)
+        ref, mine = torch.nn.BatchNorm2d(C, momentum=0.02).cuda().train(), PolicyBatchNorm2d(C, momentum=0.02).cuda().train()
+        with torch.no_grad():
+            ref.weight.copy_(torch.rand(C, generator=g) + 0.5); ref.bias.copy_(torch.randn(C, generator=g))
+            ref.running_mean.copy_(torch.randn(C, generator=g)); ref.running_var.copy_(torch.rand(C, generator=g) + 0.5)
+        mine.load_state_dict(ref.state_dict())
+        xr, xm = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        for step in range(2):
+            yr = ref(xr)
+            yr = torch.relu(yr) if relu else yr
+            ym = mine(xm, relu=relu)
+            assert float((yr - ym).abs().max()) <= 2e-5 * max(1.0, float(yr.abs().max())), (N, C, H, W, cl)
+        for k in ("running_mean", "running_var"):
+            assert float((getattr(ref, k) - getattr(mine, k)).abs().max()) <= 1e-5, k
+        assert int(ref.num_batches_tracked) == int(mine.num_batches_tracked) == 2
+        go = torch.randn(yr.shape, generator=g).cuda()
+        yr.backward(go)
+        ym.backward(go)
+        for a, b in ((xr.grad, xm.grad), (ref.weight.grad, mine.weight.grad), (ref.bias.grad, mine.bias.grad)):
+            assert float((a - b).abs().max()) <= 1e-4 * max(1.0, float(a.abs().max()))
+        # eval mode takes the stock path (same op on running statistics that agree to 1e-5)
+        mine.eval(); ref.eval()
+        assert float((mine(x) - ref(x)).abs().max()) <= 1e-4 * max(1.0, float(ref(x).abs().max()))
