@@ -379,8 +379,18 @@ class HipBackend:
         assert (kh, kw) in ((3, 3), (1, 1)) and Cin % 32 == 0 and Cout % 32 == 0     # (1x1: the same stream with a single tap)
         epv = 16 // weight.element_size()
         steps = 32 // (2 * epv)
-        w = weight.detach().as_subclass(torch.Tensor).permute(2, 3, 1, 0).reshape(kh * kw, Cin // 32, steps, 2, epv, Cout // 32, 32)   # tap, unit, step, h, j, nb, n
-        return w.permute(5, 1, 0, 2, 3, 6, 4).contiguous().view(-1)                                    # nb, unit, tap, step, h, n, j
+        w0 = weight.detach().as_subclass(torch.Tensor)
+        w = w0.permute(2, 3, 1, 0).reshape(kh * kw, Cin // 32, steps, 2, epv, Cout // 32, 32)   # tap, unit, step, h, j, nb, n
+        direct = w.permute(5, 1, 0, 2, 3, 6, 4).contiguous().view(-1)                                    # nb, unit, tap, step, h, n, j
+        if (kh, kw) != (3, 3) or w0.dtype != torch.float32:
+            return direct
+        # fp32 3x3: the Winograd F(2x2,3x3) stream of csrc/conv3x3_wino.inc follows (16 values per (cin, cout)): U = G g Gt computed
+        # in fp64, wino[nb16][chunk][step][q][lane = 16*kq + n][w] = U[f][32*chunk + 8*step + 2*kq + t][16*nb16 + n], 2*f + t = 4*q + w
+        G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64, device=w0.device)
+        U = torch.einsum("xi,ocij,yj->xyco", G, w0.double(), G).reshape(16, Cin, Cout).float()             # f = 4*xi + nu, cin, cout
+        U = U.reshape(16, Cin // 32, 4, 4, 2, Cout // 16, 16).permute(5, 1, 2, 0, 4, 3, 6)                  # nb, chunk, step, f, t, kq, n
+        U = U.reshape(Cout // 16, Cin // 32, 4, 8, 4, 4, 16).permute(0, 1, 2, 3, 5, 6, 4)                   # nb, chunk, step, q, kq, n, w
+        return torch.cat([direct, U.contiguous().view(-1)])
 
     def conv3x3_candidates(self, n_exec, cin, cout, bs, elem_size=4, stride=1):
         """Decomposition indices of the balanced conv kernel that cover this layer shape (bs = input tile size), straight from
@@ -424,7 +434,7 @@ class HipBackend:
         N, _, GH, GW = grid_idx.shape
         B, C, bs, _ = data_exec.shape
         n_exec = mapping_exec.numel()
-        assert n_exec == B and wpk.numel() == 9 * C * cout
+        assert n_exec == B and wpk.numel() in (9 * C * cout, 25 * C * cout)     # (fp32: direct + Winograd streams)
         assert tuple(ring.shape) == (N * GH * GW, C, 4 * bs), (ring.shape, (N * GH * GW, C, 4 * bs))
         assert stride in (1, 2) and bs % stride == 0
         out = empty_like_layout((B, cout, bs // stride, bs // stride), data_exec)

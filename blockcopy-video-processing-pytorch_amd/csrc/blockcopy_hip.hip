@@ -2008,6 +2008,7 @@ int check_halo(const void *out, const void *features, const int32_t *grid_idx, c
 
 #include "conv3x3_mfma.inc"
 #include "conv3x3_v2.inc"
+#include "conv3x3_wino.inc"
 #include "stem7x7.inc"
 
 }  // namespace
@@ -2076,7 +2077,7 @@ struct ConvV2Args {
 };
 struct LaunchProf { bool on; struct { hipEvent_t a, b; } rec; };   // what BC_LAUNCH needs of a ProfScope
 
-#if defined(BC_MONO) || BC_PART != 0
+#if defined(BC_MONO) || (BC_PART != 0 && BC_PART != 7)
 template <int DT, int RM, int RN, int WMW, int WNW, int WKW, int SC, int PW, int S, int KS>
 static void launch_conv3x3_v2_cfg(LaunchProf &ps, dim3 grid, size_t lds_bytes, const ConvV2Args &a, const ConvGeom2 &g)
 {
@@ -2176,7 +2177,78 @@ static int conv_v2_run(ConvV2Args &a)
 
 #endif
 
-#if BC_PART != 0
+// ---- host side of conv3x3_wino.inc (Winograd F(2x2,3x3), fp32 / stride 1): decompositions (MB, WMW, WNW, WKW); code 0x200 | index
+struct WinoCfg { int MB, WMW, WNW, WKW; };
+static const WinoCfg WINO_CFGS[] = {{2, 2, 4, 1}, {2, 2, 2, 2}, {2, 1, 4, 2}, {2, 1, 2, 4}, {1, 2, 4, 1}, {1, 4, 2, 1}, {1, 2, 2, 2}, {1, 1, 4, 2}, {1, 1, 2, 4}};
+constexpr int WINO_N = (int)(sizeof(WINO_CFGS) / sizeof(WINO_CFGS[0]));
+
+struct WinoPlan { long long wgs; size_t lds_bytes; uint32_t n_rows; };
+static bool wino_plan(const WinoCfg &k, int n_exec, int Cin, int Cout, int bs, WinoPlan &p)
+{
+    if (bs % 8 != 0 || bs > 248 || Cin % 32 != 0 || Cout % (16 * k.WNW) != 0) return false;
+    const size_t img = (size_t)k.WMW * k.MB * 100 * 9 * 16;
+    const size_t red = (size_t)k.WMW * k.WNW * (k.WKW - 1) * k.MB * 16 * 64 * sizeof(float);
+    p.lds_bytes = 2 * img > red ? 2 * img : red;
+    if (p.lds_bytes > 160 * 1024 - 2048 - 1024) return false;
+    const long long slots = (long long)n_exec * (bs / 8) * (bs / 8);
+    p.n_rows = (uint32_t)((slots + k.MB - 1) / k.MB);
+    p.wgs = (long long)((p.n_rows + k.WMW - 1) / k.WMW) * (Cout / (16 * k.WNW));
+    return true;
+}
+
+#if defined(BC_MONO) || BC_PART == 7
+template <int MB, int WMW, int WNW, int WKW>
+static void launch_wino_cfg(LaunchProf &ps, dim3 grid, size_t lds_bytes, const ConvV2Args &a, const ConvGeom2 &g)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_wino<MB, WMW, WNW, WKW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+        attr_set = true;
+    }
+    // the Winograd weight stream follows the direct one in the packed buffer (pack_conv3x3_weights: 9 + 16 values per (cin, cout))
+    const float4 *wino_w = reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(a.wpk) + (size_t)9 * a.Cin * a.Cout);
+    BC_LAUNCH(ps, (k_conv3x3_wino<MB, WMW, WNW, WKW>), grid, dim3(512), lds_bytes, a.st, (float *)a.out, (const uint4 *)a.features,
+              (long long)(((const char *)a.ring - (const char *)a.features) / 16), (uint4 *)a.ring, wino_w, a.grid_idx, a.mapping_exec, g, a.pr, a.ep);
+}
+
+static int conv_wino_run(ConvV2Args &a)
+{
+    const int c = a.force_cfg & 0xff;
+    if (c >= WINO_N) return BC_ERR_SHAPE;
+    const WinoCfg &k = WINO_CFGS[c];
+    WinoPlan plan;
+    if (!wino_plan(k, a.n_exec, a.Cin, a.Cout, a.bs, plan)) return BC_ERR_SHAPE;
+    LaunchProf ps{a.prof_on != 0, {a.ev_a, a.ev_b}};
+    ConvGeom2 g;
+    g.Cin = a.Cin; g.Cout = a.Cout; g.bs = a.bs; g.GH = a.GH; g.GW = a.GW; g.n_exec = a.n_exec;
+    g.patches_x = a.bs / 8;
+    g.patches_per_tile = (a.bs / 8) * (a.bs / 8);
+    g.n_rows = plan.n_rows;
+    g.cin_chunks = a.Cin / 32;
+    size_t lds_bytes = plan.lds_bytes;
+    if (!(a.force_cfg & 0x100) && lds_bytes < (size_t)a.min_lds) lds_bytes = a.min_lds;
+    const dim3 grid((plan.n_rows + k.WMW - 1) / k.WMW, (unsigned)a.Cout / (16 * k.WNW));
+    switch (c) {
+    case 0: launch_wino_cfg<2, 2, 4, 1>(ps, grid, lds_bytes, a, g); break;
+    case 1: launch_wino_cfg<2, 2, 2, 2>(ps, grid, lds_bytes, a, g); break;
+    case 2: launch_wino_cfg<2, 1, 4, 2>(ps, grid, lds_bytes, a, g); break;
+    case 3: launch_wino_cfg<2, 1, 2, 4>(ps, grid, lds_bytes, a, g); break;
+    case 4: launch_wino_cfg<1, 2, 4, 1>(ps, grid, lds_bytes, a, g); break;
+    case 5: launch_wino_cfg<1, 4, 2, 1>(ps, grid, lds_bytes, a, g); break;
+    case 6: launch_wino_cfg<1, 2, 2, 2>(ps, grid, lds_bytes, a, g); break;
+    case 7: launch_wino_cfg<1, 1, 4, 2>(ps, grid, lds_bytes, a, g); break;
+    default: launch_wino_cfg<1, 1, 2, 4>(ps, grid, lds_bytes, a, g); break;
+    }
+    a.chosen = a.force_cfg & 0x3ff;
+    return launch_status();
+}
+#endif
+
+#if BC_PART == 7
+extern "C" int bc_part_conv_wino(void *p) { return conv_wino_run(*static_cast<ConvV2Args *>(p)); }
+#endif
+
+#if BC_PART != 0 && BC_PART != 7
 // this slice: dtype (BC_PART - 1) / 2, kernel size 3 (odd parts) or 1 (even parts), both strides
 #define BC_PART_NAME2(n_) bc_part_conv_v2_##n_
 #define BC_PART_NAME(n_) BC_PART_NAME2(n_)
@@ -2204,6 +2276,7 @@ struct TuneState {
 extern "C" {
 int bc_part_conv_v2_1(void *); int bc_part_conv_v2_2(void *); int bc_part_conv_v2_3(void *);
 int bc_part_conv_v2_4(void *); int bc_part_conv_v2_5(void *); int bc_part_conv_v2_6(void *);
+int bc_part_conv_wino(void *);
 }
 #endif
 
@@ -2214,6 +2287,15 @@ static int launch_conv3x3_v2(ProfScope &ps, void *out, const void *features, voi
 {
     ConvV2Args a{out, features, ring, wpk, grid_idx, mapping_exec, n_exec, Cin, Cout, GH, GW, bs, S, pr, ep, st,
                  ps.on ? 1 : 0, ps.rec.a, ps.rec.b, g_tune.conv2_cfg, g_tune.conv2_min_lds, g_tune.conv_stamps, -2};
+    if (DT == BC_F32 && S == 1 && KS == 3 && a.force_cfg >= 0 && (a.force_cfg & 0x200)) {       // Winograd form (conv3x3_wino.inc)
+#if defined(BC_MONO)
+        const int rcw = conv_wino_run(a);
+#else
+        const int rcw = bc_part_conv_wino(&a);
+#endif
+        if (a.chosen >= 0) g_tune.conv_last_cfg = a.chosen;
+        return rcw;
+    }
 #if defined(BC_MONO)
     const int rc = conv_v2_run<DT, S, KS>(a);
 #else
@@ -2512,6 +2594,15 @@ static int conv_candidates(int dtype, int stride, int ks, int n_exec, int Cin, i
     for (int c = 0; c < n_cfg && n < max_out; ++c)
         if (conv2_plan(CONV2_CFGS[c], E, stride, n_exec, Cin, Cout, bs, plan, ks) && plan.lds_bytes <= (size_t)78 * 1024 && plan.wgs > device_cu_count())
             out[n++] = c | 0x100;
+    // the Winograd form (fp32, 3x3, stride 1, tiles of a multiple of 8 pixels)
+    if (dtype == BC_F32 && stride == 1 && ks == 3) {
+        WinoPlan wp;
+        for (int c = 0; c < WINO_N && n < max_out; ++c)
+            if (wino_plan(WINO_CFGS[c], n_exec, Cin, Cout, bs, wp)) {
+                out[n++] = c | 0x200;
+                if (n < max_out && wp.lds_bytes <= (size_t)78 * 1024 && wp.wgs > device_cu_count()) out[n++] = c | 0x300;
+            }
+    }
     return n;
 }
 

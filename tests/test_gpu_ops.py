@@ -620,12 +620,13 @@ def test_fused_conv3x3_stride2(be, dtype, tol):
         be.tune("conv2_cfg", -1)
 
 
-@pytest.mark.parametrize("cfg", list(range(20)))
+@pytest.mark.parametrize("cfg", list(range(20)) + [0x200 | w for w in range(9)])
 def test_fused_conv3x3_every_decomposition(be, cfg):
     """The CU-balanced conv kernel (csrc/conv3x3_v2.inc) picks one of 20 decompositions per launch (register blocking
     RM x RN, wave grid, in-workgroup split-K); here each one is FORCED in turn on shapes it covers -- incl. ragged wave
     rows, 4x4 tiles, prologue, epilogue with residual, ring cache from a previous frame -- against halo gather + fp64 conv
-    (2e-5 relative: fp32 summation order), with the ring cache left bit-identical."""
+    (2e-5 relative: fp32 summation order), with the ring cache left bit-identical.  Codes 0x200 | w: the Winograd F(2x2,3x3)
+    form of the same layer (csrc/conv3x3_wino.inc), same bar."""
     import torch.nn.functional as F
 
     rng = np.random.default_rng(500 + cfg)
