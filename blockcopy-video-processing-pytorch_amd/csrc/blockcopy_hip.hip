@@ -2185,30 +2185,41 @@ constexpr int WINO_N = (int)(sizeof(WINO_CFGS) / sizeof(WINO_CFGS[0]));
 struct WinoPlan { long long wgs; size_t lds_bytes; uint32_t n_rows; };
 static bool wino_plan(const WinoCfg &k, int n_exec, int Cin, int Cout, int bs, WinoPlan &p)
 {
-    if (bs % 8 != 0 || bs > 248 || Cin % 32 != 0 || Cout % (16 * k.WNW) != 0) return false;
-    const size_t img = (size_t)k.WMW * k.MB * 100 * 9 * 16;
+    if (!(bs % 8 == 0 || bs == 4) || bs > 248 || Cin % 32 != 0 || Cout % (16 * k.WNW) != 0) return false;
+    if (bs == 4 && k.MB * k.WMW > 2) return false;
+    const size_t img = (size_t)k.WMW * k.MB * (bs == 4 ? 4 * 36 : 100) * 9 * 16;
     const size_t red = (size_t)k.WMW * k.WNW * (k.WKW - 1) * k.MB * 16 * 64 * sizeof(float);
     p.lds_bytes = 2 * img > red ? 2 * img : red;
     if (p.lds_bytes > 160 * 1024 - 2048 - 1024) return false;
-    const long long slots = (long long)n_exec * (bs / 8) * (bs / 8);
+    const long long slots = bs == 4 ? ((long long)n_exec + 3) / 4 : (long long)n_exec * (bs / 8) * (bs / 8);     // M-blocks
     p.n_rows = (uint32_t)((slots + k.MB - 1) / k.MB);
     p.wgs = (long long)((p.n_rows + k.WMW - 1) / k.WMW) * (Cout / (16 * k.WNW));
     return true;
 }
 
 #if defined(BC_MONO) || BC_PART == 7
-template <int MB, int WMW, int WNW, int WKW>
-static void launch_wino_cfg(LaunchProf &ps, dim3 grid, size_t lds_bytes, const ConvV2Args &a, const ConvGeom2 &g)
+template <int MB, int WMW, int WNW, int WKW, int TS>
+static void launch_wino_ts(LaunchProf &ps, dim3 grid, size_t lds_bytes, const ConvV2Args &a, const ConvGeom2 &g)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_wino<MB, WMW, WNW, WKW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_wino<MB, WMW, WNW, WKW, TS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
         attr_set = true;
     }
     // the Winograd weight stream follows the direct one in the packed buffer (pack_conv3x3_weights: 9 + 16 values per (cin, cout))
     const float4 *wino_w = reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(a.wpk) + (size_t)9 * a.Cin * a.Cout);
-    BC_LAUNCH(ps, (k_conv3x3_wino<MB, WMW, WNW, WKW>), grid, dim3(512), lds_bytes, a.st, (float *)a.out, (const uint4 *)a.features,
+    BC_LAUNCH(ps, (k_conv3x3_wino<MB, WMW, WNW, WKW, TS>), grid, dim3(512), lds_bytes, a.st, (float *)a.out, (const uint4 *)a.features,
               (long long)(((const char *)a.ring - (const char *)a.features) / 16), (uint4 *)a.ring, wino_w, a.grid_idx, a.mapping_exec, g, a.pr, a.ep);
+}
+
+template <int MB, int WMW, int WNW, int WKW>
+static void launch_wino_cfg(LaunchProf &ps, dim3 grid, size_t lds_bytes, const ConvV2Args &a, const ConvGeom2 &g)
+{
+    if (a.bs == 4) {
+        if constexpr (MB * WMW <= 2) launch_wino_ts<MB, WMW, WNW, WKW, 4>(ps, grid, lds_bytes, a, g);     // (4 tile slots per M-block: LDS)
+    } else {
+        launch_wino_ts<MB, WMW, WNW, WKW, 8>(ps, grid, lds_bytes, a, g);
+    }
 }
 
 static int conv_wino_run(ConvV2Args &a)
@@ -2221,8 +2232,8 @@ static int conv_wino_run(ConvV2Args &a)
     LaunchProf ps{a.prof_on != 0, {a.ev_a, a.ev_b}};
     ConvGeom2 g;
     g.Cin = a.Cin; g.Cout = a.Cout; g.bs = a.bs; g.GH = a.GH; g.GW = a.GW; g.n_exec = a.n_exec;
-    g.patches_x = a.bs / 8;
-    g.patches_per_tile = (a.bs / 8) * (a.bs / 8);
+    g.patches_x = a.bs == 4 ? 1 : a.bs / 8;
+    g.patches_per_tile = a.bs == 4 ? 1 : (a.bs / 8) * (a.bs / 8);
     g.n_rows = plan.n_rows;
     g.cin_chunks = a.Cin / 32;
     size_t lds_bytes = plan.lds_bytes;

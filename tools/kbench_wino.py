@@ -12,7 +12,7 @@ import torch
 import blockcopy.backend as bk
 from kbench import grid_tables, timeit
 be = bk.get_backend()
-for name, n, Cin, Cout, bs in [("layer1", 64, 64, 64, 32), ("layer2", 64, 128, 128, 16), ("layer3", 64, 256, 256, 8), ("up1/8", 64, 128, 128, 16), ("up1/4", 64, 128, 128, 32), ("up1/16", 64, 128, 128, 8),
+for name, n, Cin, Cout, bs in [("layer1", 64, 64, 64, 32), ("layer2", 64, 128, 128, 16), ("layer3", 64, 256, 256, 8), ("layer4", 64, 512, 512, 4), ("up1/8", 64, 128, 128, 16), ("up1/4", 64, 128, 128, 32), ("up1/16", 64, 128, 128, 8),
                                ("layer1 n128", 128, 64, 64, 32), ("layer2 n128", 128, 128, 128, 16), ("csp head n38", 38, 768, 256, 32)]:
     gi, m = grid_tables(1, 8, 16, n)
     feats = torch.relu(torch.randn((n, Cin, bs, bs), device="cuda")).contiguous(memory_format=torch.channels_last)
