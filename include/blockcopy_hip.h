@@ -236,7 +236,11 @@ int bc_bn_train_stats_nhwc(const void *features, long long n_pix, int C, int dty
 /* decompositions of the fused conv kernel that cover a layer (stride 1 or 2; bs_in = input tile size): codes written to out,
  * count returned.  What bc_tune_set("conv2_cfg", code) may force; the engine times exactly these when it measures a layer shape.
  * code = decomposition index (bits 0-7) | 0x100 if the launch runs without the one-workgroup-per-CU LDS floor (two workgroups
- * may then share a CU; listed only for multi-round launches whose workgroups need <= 78 KB).  At most 32 codes. */
+ * may then share a CU; listed only for multi-round launches whose workgroups need <= 78 KB) | 0x200 for the Winograd F(2x2,3x3)
+ * form (fp32, stride 1, 3x3: csrc/conv3x3_wino.inc; index = its own decomposition table).  At most 64 codes.
+ * The Winograd form reads a second weight stream placed behind the direct one in weights_packed (fp32 3x3 only):
+ *   wino[nb16][chunk][step < 4][q < 8][lane = 16*kq + n][e < 4] = (G g Gt)[f][cin = 32*chunk + 8*step + 2*kq + t][cout = 16*nb16 + n],
+ *   2*f + t = 4*q + e, f = 4*xi + nu, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]  (16 * Cin * Cout floats after the 9 * Cin * Cout). */
 int bc_conv3x3_candidates(int dtype, int stride, int n_exec, int Cin, int Cout, int bs_in, int *out, int max_out);
 
 /* halo gather with a residual-add prologue and a by-product: v = relu?(features*scale[c] + shift[c] + add) is computed while
