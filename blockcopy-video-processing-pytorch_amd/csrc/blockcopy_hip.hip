@@ -2209,7 +2209,7 @@ static void launch_wino_ts(LaunchProf &ps, dim3 grid, size_t lds_bytes, const Co
     // the Winograd weight stream follows the direct one in the packed buffer (pack_conv3x3_weights: 9 + 16 values per (cin, cout))
     const float4 *wino_w = reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(a.wpk) + (size_t)9 * a.Cin * a.Cout);
     BC_LAUNCH(ps, (k_conv3x3_wino<MB, WMW, WNW, WKW, TS>), grid, dim3(512), lds_bytes, a.st, (float *)a.out, (const uint4 *)a.features,
-              (long long)(((const char *)a.ring - (const char *)a.features) / 16), (uint4 *)a.ring, wino_w, a.grid_idx, a.mapping_exec, g, a.pr, a.ep);
+              (long long)(((const char *)a.ring - (const char *)a.features) / 16), (uint4 *)a.ring, wino_w, a.grid_idx, a.mapping_exec, g, a.pr, a.ep, a.stamps);
 }
 
 template <int MB, int WMW, int WNW, int WKW>

@@ -43,6 +43,8 @@ def main():
         us = be.prof_read("conv3x3")["total_ms"] * 1e3      # execution time of this one dispatch (events attached to the packet)
         be.tune_ptr("conv_stamps", None)
         cfg = be.tune_get("conv_last_cfg")
+        if a.cfg >= 0 and cfg != a.cfg:
+            continue      # (the forced decomposition does not cover this layer)
         s = stamps.view(-1, 8).cpu()
         s = s[s[:, 0] != 0]
         t0 = s[:, 0].min()
@@ -52,7 +54,7 @@ def main():
         print(f"{name} n={a.n} cfg {cfg}: {s.shape[0]} workgroups; start skew max {rel[:, 0].max():.0f} cyc; end: mean {rel[:, 5].mean():.0f} max {rel[:, 5].max():.0f} cyc"
               f"")
         per_wg = float((s[:, 5] - s[:, 0]).double().mean())      # ticks one workgroup lives (one round: that is the whole launch)
-        rounds = max(1.0, s.shape[0] / 256.0)
+        rounds = max(1.0, s.shape[0] / 256.0) if not (a.cfg >= 0 and a.cfg & 0x100) else max(1.0, s.shape[0] / 512.0)
         flops = 2.0 * a.n * bs * bs * 9 * Cin * Cout
         ghz = per_wg * rounds / us / 1e3
         print(f"   dispatch {us:.1f} us; a workgroup lives {per_wg:.0f} s_memtime ticks x {rounds:.2f} rounds => ~{ghz:.2f} GHz shader clock during the launch; "
