@@ -9,9 +9,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int MODE>
-__global__ __launch_bounds__(512) void probe(float *out, int steps, float seed)
+__global__ __launch_bounds__(512) void probe(float *out, int steps, float seed, unsigned long long *stamps = nullptr)
 {
     const int tid = threadIdx.x;
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
     f32x4 acc[16];
     for (int f = 0; f < 16; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
     float a[16], b[16];
@@ -30,6 +31,7 @@ __global__ __launch_bounds__(512) void probe(float *out, int steps, float seed)
     float sum = 0.f;
     for (int f = 0; f < 16; ++f) sum += acc[f][0] + acc[f][1] + acc[f][2] + acc[f][3];
     if (sum == 12345.678f) out[tid] = sum;
+    if (stamps && tid == 0) stamps[blockIdx.x] = __builtin_amdgcn_s_memtime() - t_begin;      // ticks this workgroup lived
 }
 
 __global__ __launch_bounds__(512) void probe32(float *out, int steps, float seed)
@@ -80,5 +82,25 @@ int main()
     run("16x16x4, 16 accumulators + 2 VALU ops per MFMA", [&] { hipLaunchKernelGGL((probe<1>), dim3(256), dim3(512), 0, 0, out, steps, 1.0f); }, (double)steps * 16 * 1024);
     run("16x16x4, 16 accumulators x 2 dependent", [&] { hipLaunchKernelGGL((probe<2>), dim3(256), dim3(512), 0, 0, out, steps, 1.0f); }, (double)steps * 32 * 1024);
     run("16x16x4, 16 accumulators x 2 dependent + 1 VALU op per MFMA", [&] { hipLaunchKernelGGL((probe<3>), dim3(256), dim3(512), 0, 0, out, steps, 1.0f); }, (double)steps * 32 * 1024);
+    // what does s_memtime count?  ticks of a workgroup's life vs the event-timed duration of a one-round launch of the register-only loop
+    unsigned long long *st;
+    hipMalloc(&st, 256 * 8);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL((probe<0>), dim3(256), dim3(512), 0, 0, out, 4096, 1.0f, st);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        unsigned long long h[256];
+        hipMemcpy(h, st, sizeof(h), hipMemcpyDeviceToHost);
+        double mean = 0;
+        for (int i = 0; i < 256; ++i) mean += (double)h[i] / 256;
+        printf("s_memtime: a workgroup of the register-only loop lives %.0f ticks in a %.1f us launch => %.3f ticks/ns; its %d MFMAs x 32 cycles x 2 waves per SIMD = %.0f cycles => %.2f GHz\n",
+               mean, ms * 1e3, mean / (ms * 1e6), 4096 * 16, 4096.0 * 16 * 32 * 2, 4096.0 * 16 * 32 * 2 / (ms * 1e6));
+    }
     return 0;
 }
