@@ -2611,7 +2611,8 @@ static int conv_candidates(int dtype, int stride, int ks, int n_exec, int Cin, i
         for (int c = 0; c < WINO_N && n < max_out; ++c)
             if (wino_plan(WINO_CFGS[c], n_exec, Cin, Cout, bs, wp)) {
                 out[n++] = c | 0x200;
-                if (n < max_out && wp.lds_bytes <= (size_t)78 * 1024 && wp.wgs > device_cu_count()) out[n++] = c | 0x300;
+                // (no 0x100 variant: at 208-255 VGPRs per lane a second 8-wave workgroup cannot join the CU whatever the LDS size.
+                //  Four-wave workgroups -- two independent ones per CU -- were tried and lost 5-20 %: profiles/r02 README)
             }
     }
     return n;
