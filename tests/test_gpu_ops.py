@@ -690,13 +690,16 @@ def test_fused_conv3x3_generations_agree(be):
     assert (outs[0] - outs[1]).abs().max().item() <= 2e-5 * max(1.0, outs[0].abs().max().item())
 
 
-def test_fused_conv3x3_random_geometries(be):
+@pytest.mark.parametrize("form", ["library_choice", "winograd"])
+def test_fused_conv3x3_random_geometries(be, form):
     """20 random (Cin, Cout, tile size, grid, batch) cases x 3 frames with random masks, prologue and epilogue: the fused
-    kernel against halo gather + an fp64 conv of the padded batch; ring caches must stay bit-identical."""
+    kernel against halo gather + an fp64 conv of the padded batch; ring caches must stay bit-identical.  "winograd": the same
+    sweep with a randomly chosen decomposition of the Winograd F(2x2,3x3) form forced on every launch it covers."""
     import torch.nn.functional as F
 
     rng = np.random.default_rng(99)
     gen = torch.Generator().manual_seed(99)
+    forced = 0
     for case in range(20):
         Cin, Cout = int(rng.choice([32, 64, 96, 160])), int(rng.choice([64, 128, 192]))
         bs = int(rng.choice([4, 8, 16, 24, 40]))
@@ -722,10 +725,17 @@ def test_fused_conv3x3_random_geometries(be):
                     want = want + epi[2]
                 if epi[3]:
                     want = torch.relu(want)
-            got = be.conv3x3_ring(feats, ring_b, wpk, Cout, gi_d, m_d, pro, epi)
+            cfg = None
+            if form == "winograd":
+                wino = [c for c in be.conv3x3_candidates(len(m), Cin, Cout, bs, 4, 1) if c & 0x200]
+                if wino:
+                    cfg = int(rng.choice(wino))
+                    forced += 1
+            got = be.conv3x3_ring(feats, ring_b, wpk, Cout, gi_d, m_d, pro, epi, cfg=cfg)
             err = (got.double() - want).abs().max().item()
-            assert err <= 2e-5 * max(1.0, want.abs().max().item()), (case, (Cin, Cout, bs, N, GH, GW), t, err)
+            assert err <= 2e-5 * max(1.0, want.abs().max().item()), (case, (Cin, Cout, bs, N, GH, GW), t, cfg, err)
             assert torch.equal(ring_a, ring_b), (case, t)
+    assert form != "winograd" or forced >= 30
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
