@@ -13,6 +13,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from blockcopy import blockcopy_noblocks
+from blockcopy.core.tensorwrapper import TensorWrapper
 from blockcopy.utils.profiler import timings
 
 
@@ -168,9 +169,11 @@ class SpatialPyramidPooling(nn.Module):
             ar = size[1] / size[0]
             x = self.spp[0](x)
             levels = [x]
-            # adaptive pooling of a channels-last map is ~5x slower than of an NCHW one on ROCm; the map is tiny
-            # (stride 32), so pool from one NCHW copy (values are identical)
-            x_pool = x if x.is_contiguous() else x.contiguous()
+            # the stock adaptive pooling of a channels-last map is ~5x slower than of an NCHW one on ROCm; the map is tiny
+            # (stride 32), so plain tensors pool from one NCHW copy (values are identical).  Inside the block engine the map
+            # is a TensorWrapper and the library pools channels-last maps itself (bc_adaptive_avg_pool_nhwc): no copy.
+            engine_pools = isinstance(x, TensorWrapper) and x.is_cuda
+            x_pool = x if (engine_pools or x.is_contiguous()) else x.contiguous()
             for i in range(1, len(self.spp) - 1):
                 g = self.grids[i - 1]
                 pooled = F.adaptive_avg_pool2d(x_pool, (g, max(1, round(ar * g))))

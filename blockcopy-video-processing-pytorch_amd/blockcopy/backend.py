@@ -127,6 +127,7 @@ def load_library(path: str = None) -> ctypes.CDLL:
         "bc_affine_act": [p, p, p, p, p, i, ctypes.c_longlong, i, ctypes.c_longlong, i, p],
         "bc_bn_train_fwd": [p, p, i, i, ctypes.c_longlong, p, p, p, p, p, p, p, ctypes.c_float, ctypes.c_float, i, p, ctypes.c_longlong, p],
         "bc_bn_train_stats_nhwc": [p, ctypes.c_longlong, i, i, ctypes.c_float, p, p, p, p, p, ctypes.c_float, p, p, p, p, p, ctypes.c_longlong, p],
+        "bc_adaptive_avg_pool_nhwc": [p, p, i, i, i, i, i, i, i, p],
         "bc_group_norm_affine_nhwc": [p, ctypes.c_longlong, i, i, i, ctypes.c_float, p, p, p, p, p, ctypes.c_longlong, p],
         "bc_nms_sorted": [p, i, ctypes.c_float, p, p, p, p],
         "bc_policy_step": [p, i, ctypes.c_ulonglong, ctypes.c_ulonglong, i, i, p, p, p, p, p, p],
@@ -512,6 +513,25 @@ class HipBackend:
                 self._check(self.lib.bc_conv1x1_nhwc(out.data_ptr(), data.data_ptr(), wpk.data_ptr(), n_tiles, C, cout, bs, int(stride),
                                                      _DTYPE_CODE[data.dtype], ptr(isc), ptr(ish), int(bool(irelu)), ptr(osc), ptr(osh),
                                                      ptr(oadd), int(bool(orelu)), self._stream()), "conv1x1_nhwc")
+        return out
+
+    # -- adaptive average pooling of dense channels-last maps (pyramid pooling)
+    @staticmethod
+    def adaptive_avg_pool_supported(x):
+        if not (x.is_cuda and x.dim() == 4 and x.dtype in _DTYPE_CODE and is_nhwc(x) and 0 < x.numel() < 2 ** 31):
+            return False
+        kv = x.shape[1] * x.element_size()
+        return kv % 16 == 0 and kv // 16 <= 256 and 256 % (kv // 16) == 0
+
+    def adaptive_avg_pool(self, x, out_hw):
+        """F.adaptive_avg_pool2d(x, out_hw) of a channels-last tensor (bc_adaptive_avg_pool_nhwc)."""
+        assert self.adaptive_avg_pool_supported(x)
+        N, C, H, W = x.shape
+        OH, OW = int(out_hw[0]), int(out_hw[1])
+        out = torch.empty((N, C, OH, OW), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        with torch.cuda.device_of(x):
+            self._check(self.lib.bc_adaptive_avg_pool_nhwc(out.data_ptr(), x.data_ptr(), N, C, H, W, OH, OW, _DTYPE_CODE[x.dtype], self._stream()),
+                        "adaptive_avg_pool_nhwc")
         return out
 
     # -- training-mode BatchNorm forward of the policy net (two launches instead of five)

@@ -585,6 +585,16 @@ class TensorWrapper(torch.Tensor):
                     got = self._dense_pointwise_conv(args, kwargs)     # BN -> ReLU -> 1x1 conv blocks of dense (noblocks) modules
                     if got is not None:
                         ret, pend = got
+                if (ret is None and op == "adaptive_avg_pool2d" and fusion.ENABLED and fusion.ADAPTIVE_POOL and self._features is not None
+                        and self._features.engine == "fused" and isinstance(args[0], TensorWrapper) and not args[0]._is_blocks):
+                    # pyramid pooling on a dense map (blockcopy_noblocks): one workgroup per output bin instead of the stock kernel
+                    be = get_backend()
+                    size = kwargs.get("output_size", args[1] if len(args) > 1 else None)
+                    size = (size, size) if isinstance(size, int) else size
+                    raw = args[0]._raw()
+                    if (hasattr(be, "adaptive_avg_pool") and size is not None and len(size) == 2 and all(isinstance(v, int) and v > 0 for v in size)
+                            and be.adaptive_avg_pool_supported(raw)):
+                        ret = be.adaptive_avg_pool(raw, size)
                 if ret is None:
                     if op in OPS["PADDED"]:
                         _materialize_args(args)

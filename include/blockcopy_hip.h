@@ -233,6 +233,12 @@ int bc_bn_train_stats_nhwc(const void *features, long long n_pix, int C, int dty
                            float *running_mean, float *running_var, long long *num_batches_tracked, float momentum, float *save_mean,
                            float *save_invstd, float *scale, float *shift, float *workspace, long long workspace_floats, void *stream);
 
+/* F.adaptive_avg_pool2d(in, (OH, OW)) of a channels-last (N, C, H, W) tensor (ATen's bin limits: start = floor(i*H/OH),
+ * end = ceil((i+1)*H/OH)); out (N, C, OH, OW) channels-last.  The pyramid pooling of SwiftNet runs on a dense map inside a
+ * blockcopy_noblocks module (reference semantic_segmentation models; core/blockcopy.py:104-139): three calls per frame that cost
+ * 11.5 us each with the stock kernel.  C * elem_size a multiple of 16 bytes, <= 4096, 256 % (C*elem_size/16) == 0. */
+int bc_adaptive_avg_pool_nhwc(void *out, const void *in, int N, int C, int H, int W, int OH, int OW, int dtype, void *stream);
+
 /* decompositions of the fused conv kernel that cover a layer (stride 1 or 2; bs_in = input tile size): codes written to out,
  * count returned.  What bc_tune_set("conv2_cfg", code) may force; the engine times exactly these when it measures a layer shape.
  * code = decomposition index (bits 0-7) | 0x100 if the launch runs without the one-workgroup-per-CU LDS floor (two workgroups

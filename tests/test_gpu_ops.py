@@ -971,3 +971,21 @@ def test_policy_batchnorm_training_forward_and_backward(be, monkeypatch):
         # eval mode takes the stock path (same op on running statistics that agree to 1e-5)
         mine.eval(); ref.eval()
         assert float((mine(x) - ref(x)).abs().max()) <= 1e-4 * max(1.0, float(ref(x).abs().max()))
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.float16, 1e-3), (torch.bfloat16, 8e-3)])
+def test_adaptive_avg_pool_nhwc(be, dtype, tol):
+    """bc_adaptive_avg_pool_nhwc == F.adaptive_avg_pool2d on channels-last maps: SwiftNet's pyramid grids on the stride-32 map
+    (32x64 -> 8x16, 4x8, 2x4), non-dividing grids (ATen's floor / ceil bin limits), batch 2, bins of one pixel."""
+    import torch.nn.functional as F
+
+    g = torch.Generator().manual_seed(4)
+    for (N, C, H, W, oh, ow) in [(1, 128, 32, 64, 8, 16), (1, 128, 32, 64, 4, 8), (1, 128, 32, 64, 2, 4), (2, 64, 7, 9, 3, 4), (1, 32, 5, 5, 5, 5),
+                                  (1, 512, 16, 32, 1, 2), (1, 128, 33, 65, 6, 3)]:
+        x = _cl(torch.randn((N, C, H, W), generator=g).to(dtype).cuda())
+        if not be.adaptive_avg_pool_supported(x):
+            continue
+        got = be.adaptive_avg_pool(x, (oh, ow))
+        want = F.adaptive_avg_pool2d(x.float(), (oh, ow))
+        assert got.shape == want.shape and got.dtype == dtype
+        assert float((got.float() - want).abs().max()) <= tol * max(1.0, float(want.abs().max())), (N, C, H, W, oh, ow)
