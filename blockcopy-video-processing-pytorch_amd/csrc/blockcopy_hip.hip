@@ -2107,9 +2107,10 @@ static bool conv2_plan(const Conv2Cfg &k, int E, int S, int n_exec, int Cin, int
 }
 
 // ---- how the main translation unit reaches the decompositions of conv3x3_v2.inc.  The ~600 kernel instantiations (3 dtypes x
-// 2 strides x 2 kernel sizes x 16 decompositions x 2 patch widths) take minutes in one translation unit, so build.py compiles
+// 2 strides x 2 kernel sizes x 20 decompositions x 2 patch widths, plus the Winograd form) take minutes in one translation unit, so build.py compiles
 // this same source several times in parallel: -DBC_PART=0 is everything but them, -DBC_PART=1..6 is one (dtype, kernel size)
-// slice each, exported to part 0 as bc_part_conv_v2_<n>(ConvV2Args *).  Without -DBC_PART the file is the whole library.
+// slice each, exported to part 0 as bc_part_conv_v2_<n>(ConvV2Args *), -DBC_PART=7 the Winograd form (bc_part_conv_wino).
+// Without -DBC_PART the file is the whole library.
 struct ConvV2Args {
     void *out; const void *features; void *ring; const void *wpk;
     const int32_t *grid_idx, *mapping_exec;
