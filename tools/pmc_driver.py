@@ -77,6 +77,23 @@ def main():
         wpk = be.pack_conv3x3_weights(torch.randn((Cout, Cin, 3, 3), device="cuda") * 0.05)
         alg = 4.0 * (n * Cin * ((bs + 2) ** 2 + 4 * bs) + n * Cout * bs * bs + 9 * Cin * Cout)
         run(f"{name} ({n},{Cin}->{Cout},{bs}x{bs})", alg, lambda: be.conv3x3_ring(feats, ring, wpk, Cout, gi, m, None, None))
+    # the Winograd F(2x2,3x3) form of the same layers (decomposition codes 0x200 | w as the engine's plan picks them); algorithmic bytes
+    # as for the direct form: the 16/9 larger transformed weight stream shows up as extra reads
+    for (Cin, Cout, bs, code, name) in [(64, 64, 32, 0x204, "winograd layer1"), (128, 128, 16, 0x204, "winograd layer2"), (256, 256, 8, 0x207, "winograd layer3"),
+                                        (512, 512, 4, 0x208, "winograd layer4"), (128, 128, 32, 0x204, "winograd up 1/4")]:
+        feats = cl(torch.randn((n, Cin, bs, bs), device="cuda"))
+        ring = torch.randn((128, Cin, 4 * bs), device="cuda")
+        wpk = be.pack_conv3x3_weights(torch.randn((Cout, Cin, 3, 3), device="cuda") * 0.05)
+        alg = 4.0 * (n * Cin * ((bs + 2) ** 2 + 4 * bs) + n * Cout * bs * bs + 9 * Cin * Cout)
+        run(f"{name} ({n},{Cin}->{Cout},{bs}x{bs})", alg, lambda: be.conv3x3_ring(feats, ring, wpk, Cout, gi, m, None, None, cfg=code))
+    # network-input stage (window gather + 7x7 stem conv): frame-state windows in, packed stem output out
+    state = torch.randn((1, 3, 1024, 2048), device="cuda")
+    wst = be.pack_stem7x7_weights(cl(torch.randn((64, 3, 7, 7), device="cuda") * 0.05))
+    run("stem7x7 (64 tiles of 128x128 -> 64x64x64)", 4.0 * (n * 3 * (128 + 6) ** 2 + n * 64 * 64 * 64 + 64 * 3 * 49),
+        lambda: be.stem7x7(state, wst, m, 128, None))
+    # the pyramid pooling of SwiftNet
+    xp = cl(torch.randn((1, 128, 32, 64), device="cuda"))
+    run("adaptive_avg_pool_nhwc (1,128,32,64) -> 8x16", 4.0 * (xp.numel() + 128 * 8 * 16), lambda: be.adaptive_avg_pool(xp, (8, 16)))
     # fused epilogue pass and per-tile bilinear resampling
     x = cl(torch.randn((n, 128, 16, 16), device="cuda"))
     sc = torch.rand(128, device="cuda")
