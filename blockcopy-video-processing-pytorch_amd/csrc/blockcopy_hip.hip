@@ -2226,7 +2226,8 @@ static int conv_v2_run(ConvV2Args &a)
 
 // ---- host side of conv3x3_wino.inc (Winograd F(2x2,3x3), fp32 / stride 1): decompositions (MB, WMW, WNW, WKW); code 0x200 | index
 struct WinoCfg { int MB, WMW, WNW, WKW; };
-static const WinoCfg WINO_CFGS[] = {{2, 2, 4, 1}, {2, 2, 2, 2}, {2, 1, 4, 2}, {2, 1, 2, 4}, {1, 2, 4, 1}, {1, 4, 2, 1}, {1, 2, 2, 2}, {1, 1, 4, 2}, {1, 1, 2, 4}};
+static const WinoCfg WINO_CFGS[] = {{2, 2, 4, 1}, {2, 2, 2, 2}, {2, 1, 4, 2}, {2, 1, 2, 4}, {1, 2, 4, 1}, {1, 4, 2, 1}, {1, 2, 2, 2}, {1, 1, 4, 2}, {1, 1, 2, 4},
+                                    {1, 1, 8, 1}, {2, 1, 8, 1}};     // 9, 10: 128 output channels per workgroup (the patches of a 128-channel layer are staged once)
 constexpr int WINO_N = (int)(sizeof(WINO_CFGS) / sizeof(WINO_CFGS[0]));
 
 struct WinoPlan { long long wgs; size_t lds_bytes; uint32_t n_rows; };
@@ -2295,7 +2296,9 @@ static int conv_wino_run(ConvV2Args &a)
     case 5: launch_wino_cfg<1, 4, 2, 1>(ps, grid, lds_bytes, a, g); break;
     case 6: launch_wino_cfg<1, 2, 2, 2>(ps, grid, lds_bytes, a, g); break;
     case 7: launch_wino_cfg<1, 1, 4, 2>(ps, grid, lds_bytes, a, g); break;
-    default: launch_wino_cfg<1, 1, 2, 4>(ps, grid, lds_bytes, a, g); break;
+    case 8: launch_wino_cfg<1, 1, 2, 4>(ps, grid, lds_bytes, a, g); break;
+    case 9: launch_wino_cfg<1, 1, 8, 1>(ps, grid, lds_bytes, a, g); break;
+    default: launch_wino_cfg<2, 1, 8, 1>(ps, grid, lds_bytes, a, g); break;
     }
     a.chosen = a.force_cfg & 0x3ff;
     return launch_status();
