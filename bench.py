@@ -6,7 +6,12 @@ dense baseline.
     python bench.py --gpus N --steps K --warmup W
 
 N > 1 run directly: bench.py starts its own N worker processes (one per GPU) before anything touches the GPU; under
-``torch.distributed.run`` (WORLD_SIZE already set) it is a worker.
+``torch.distributed.run`` (WORLD_SIZE already set) it is a worker.  Every worker pins itself to its own slice of the host
+cores and gets its own MIOpen user-db / cache directory before torch is imported; all workers read the same conv plan
+table (blockcopy/plans/gfx950.json), so no rank re-tunes and all ranks run the same kernel forms.
+
+The printed JSON line stays small (< 4 KB); the per-layer plan list, the PMC traffic table and the per-rank numbers go
+to gpurun_out/bench_details_<config>.json.
 
 A *step* is one 20-frame clip (reset_temporal(); frame 0 executes all 128 tiles, frames 1..19 execute a seeded 64 of
 128) with every frame already resident in HBM.  fps = frames / wall, device-synchronised on both sides, exactly as the
@@ -20,6 +25,7 @@ import argparse
 import json
 import os
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -71,6 +77,9 @@ def parse_args(argv=None):
     ap.add_argument("--oversubscribe", action="store_true",
                     help="(tests only) let several replicas share a GPU when fewer than --gpus devices are visible")
     ap.add_argument("--launch-timeout", type=float, default=3000.0, help="seconds before the launcher gives up on its replicas")
+    ap.add_argument("--save-plan", default=None, metavar="FILE",
+                    help="after the run write the conv plan table (loaded + measured entries) to FILE (tools/tune_plans.py)")
+    ap.add_argument("--details", default=None, metavar="FILE", help="side file for the long tables (default gpurun_out/bench_details_<config>.json)")
     args = ap.parse_args(argv)
     args.workload = "swiftnet"
     if args.config == "C3":
@@ -216,13 +225,29 @@ def launch_replicas(args, argv):
     world = args.gpus
     port = _free_port()
     procs = []
+
+    def die_with_parent():
+        # child side, between fork and exec (nothing has touched the GPU in either process): if the launcher is killed outright
+        # (SIGKILL by a driver timeout), the kernel sends the worker SIGTERM instead of leaving it holding a GPU in its own session
+        try:
+            import ctypes
+            ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, signal.SIGTERM, 0, 0, 0)      # PR_SET_PDEATHSIG
+        except Exception:
+            pass
+
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BC_BENCH_WORKER="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or world) // world)))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, start_new_session=True))
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, start_new_session=True,
+                                      preexec_fn=die_with_parent))
+
+    def stop_workers(signum, frame):
+        raise KeyboardInterrupt(f"signal {signum}")
+
+    for sig in (signal.SIGTERM, signal.SIGHUP):      # a driver timeout stops the launcher with SIGTERM: take the workers down too
+        signal.signal(sig, stop_workers)
     import threading
 
     chunks = []
@@ -268,7 +293,44 @@ def launch_replicas(args, argv):
     return rc
 
 
-def stub_cpu_worker(args, rank, world):
+def isolate_rank(rank, local, local_world):
+    """Per-rank host setup, BEFORE torch / MIOpen are loaded: a disjoint slice of the host cores (N Python processes that each
+    enqueue ~1000 launches per ms-frame must not migrate over each other) and a private MIOpen user database / kernel cache
+    (eight processes opening the same sqlite files at start-up serialise on its lock, and a find-db written by one rank mid-run
+    must not change another rank's solver choice).  Returns what was set, for the details file."""
+    info = {}
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+        per = max(1, len(cores) // max(1, local_world))
+        mine = cores[local * per:(local + 1) * per] if local_world > 1 else cores
+        if mine and local_world > 1:
+            os.sched_setaffinity(0, mine)
+        info["cpu_cores"] = len(mine)
+        info["cpu_first"] = mine[0] if mine else None
+        os.environ.setdefault("OMP_NUM_THREADS", str(len(mine)))
+    except (AttributeError, OSError):
+        pass
+    if local_world > 1:
+        base = os.environ.get("BC_BENCH_MIOPEN_DIR") or os.path.join(tempfile.gettempdir(), f"bc_bench_miopen_{os.getuid()}")
+        for var, sub in (("MIOPEN_USER_DB_PATH", "db"), ("MIOPEN_CUSTOM_CACHE_DIR", "cache")):
+            if var not in os.environ:
+                d = os.path.join(base, f"rank{rank}", sub)
+                os.makedirs(d, exist_ok=True)
+                os.environ[var] = d
+            info[var] = os.environ[var]
+    return info
+
+
+def details_path(args):
+    if args.details:
+        return args.details
+    d = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    tag = config_name(args).split("(")[0].replace(" ", "") + ("_f16" if args.half else "") + (f"_n{args.gpus}" if args.gpus > 1 else "")
+    return os.path.join(d, f"bench_details_{tag}.json")
+
+
+def stub_cpu_worker(args, rank, world, rank_env=None):
     """Test stand-in for the GPU workload (``--stub-cpu``): same launcher, environment, clock bracket and JSON schema,
     with a small dense conv on the CPU as a 'frame'."""
     from bc_workloads import replicas
@@ -289,14 +351,19 @@ def stub_cpu_worker(args, rank, world):
             conv(x)
         replicas.barrier(world)
         elapsed = time.perf_counter() - t0
+    local_fps = args.steps * CLIP_LEN / elapsed
     fps, elapsed, frames = replicas.job_throughput(args.steps * CLIP_LEN, elapsed, world)
+    per_rank = replicas.gather_scalars(local_fps, world)
+    cores = replicas.gather_scalars(float((rank_env or {}).get("cpu_first") or 0), world)
     if rank == 0:
         print(json.dumps({"metric": METRIC, "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                           "config": {"workload": "STUB (cpu conv, launcher test only)", "frames_total": frames,
                                      "local_rank": int(os.environ.get("LOCAL_RANK", "-1")),
-                                     "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}"}}), flush=True)
+                                     "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}"},
+                          "per_rank_fps": {"min": min(per_rank), "max": max(per_rank), "all": [round(v, 1) for v in per_rank]},
+                          "rank_env": dict(rank_env or {}, first_core_of_each_rank=[int(c) for c in cores])}), flush=True)
     if world > 1:
         replicas.barrier(world)
         torch.distributed.destroy_process_group()
@@ -313,13 +380,15 @@ def main(argv=None):
     if env_world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but the environment says WORLD_SIZE={env_world}")
 
+    rank_env = isolate_rank(int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+                            int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
     import torch as _torch
     torch = _torch
     from bc_workloads import replicas
 
     rank, world, local = replicas.dist_env()
     if args.stub_cpu:
-        return stub_cpu_worker(args, rank, world)
+        return stub_cpu_worker(args, rank, world, rank_env)
     assert torch.cuda.is_available(), "bench.py needs the GPU"
     n_dev = torch.cuda.device_count()
     if local >= n_dev:
@@ -366,7 +435,11 @@ def main(argv=None):
     timings.set_level(args.timings)
     timings.reset()
     be.prof_reset()
-    be.prof_enable(["combine_copy"])
+    be.prof_enable(["combine_copy"])       # eager launches (graph off, first frame ever): events attached to the dispatch
+    inner0 = model.det if is_csp else model
+    gfs = list(getattr(inner0, "_graphed", {}).values())
+    for gf in gfs:                         # in-graph scatter+copy node: one device timing record per frame of the timed region
+        gf.timing_start(args.steps * CLIP_LEN)
     replicas.barrier(world, device)
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -375,16 +448,32 @@ def main(argv=None):
     elapsed = time.perf_counter() - t0
     be.prof_enable([])
     cc = be.prof_read("combine_copy")
+    cc["method"] = "HIP events attached to each eager dispatch (hipExtLaunchKernelGGL) over the timed region"
+    stamp_us, stamp_bytes = [], 0.0
+    for gf in gfs:
+        us, nb = gf.timing_read()
+        stamp_us += us
+        stamp_bytes = nb or stamp_bytes
+    if stamp_us:
+        # graph kernel nodes cannot carry events: the node stamps the constant 100 MHz clock itself (min workgroup entry, max
+        # workgroup exit; include/blockcopy_hip.h bc_combine_copy_indirect), one record per frame of the timed region
+        cc = {"launches": len(stamp_us) + cc["launches"], "total_ms": sum(stamp_us) * 1e-3 + cc["total_ms"],
+              "total_bytes": stamp_bytes * len(stamp_us) + cc["total_bytes"],
+              "method": "in-kernel s_memrealtime stamps of the hipGraph node k_combine_copy_ind (first workgroup entry -> last workgroup "
+                        "exit, 10 ns ticks), every frame of the timed region; profiles/ holds the rocprofv3 trace of the same command",
+              "p50_us": sorted(stamp_us)[len(stamp_us) // 2], "min_us": min(stamp_us), "max_us": max(stamp_us)}
     if args.timings and rank == 0:
         timings.add_cnt(args.steps * CLIP_LEN)
         print(timings, file=sys.stderr)
     timings.set_level(0)
 
     # whole-job throughput: all ranks' frames / slowest rank's time (no collective on the data path)
+    elapsed_local = elapsed
     fps, elapsed, frames_total = replicas.job_throughput(args.steps * CLIP_LEN * args.batch, elapsed, world, device)
     exec_frac = model.policy.stats.get_exec_percentage()
 
-    extra = {}
+    extra, details = {}, {}
+    per_rank = replicas.gather_scalars(args.steps * CLIP_LEN * args.batch / elapsed_local, world)
     if rank == 0:
         # halo-gather kernel statistics from one extra, untimed clip (events around all 21 launches per frame)
         be.prof_reset()
@@ -405,11 +494,16 @@ def main(argv=None):
             # the fused conv kernel (3x3 halo form, its stride-2 and one-tap forms): FLOPs of all its launches of one clip over their
             # summed execution time, against the dense MFMA peak of the compute dtype (MI355X_MICROARCH.md: fp32 157.3, 16-bit 2516 TFLOP/s)
             peak = 157.3 if dtype == torch.float32 else 2516.0
-            tf = r["total_bytes"] / (r["total_ms"] * 1e-3) / 1e12
-            extra["roofline_conv"] = {"kernel": "k_conv3x3_v2 (fused halo gather + conv: 3x3, 3x3 stride 2 and 1x1 forms) + k_stem7x7", "bound": "mfma",
-                                      "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "traffic": None,
+            tf = r["total_aux"] / (r["total_ms"] * 1e-3) / 1e12          # matrix FLOPs actually issued
+            tf_alg = r["total_bytes"] / (r["total_ms"] * 1e-3) / 1e12    # FLOPs of the direct definition 2*px*k*k*Cin*Cout
+            extra["roofline_conv"] = {"kernel": "k_conv3x3_wino (Winograd F(2x2,3x3): 16/36 of the direct multiplications) + k_conv3x3_v2 (direct: "
+                                                "3x3, 3x3 stride 2, 1x1 forms) + k_stem7x7; per-layer form: details file",
+                                      "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "issued_frac": tf / peak,
+                                      "effective_TFLOPs": tf_alg, "effective_frac": tf_alg / peak, "traffic": None,
                                       "launches_per_frame": r["launches"] / CLIP_LEN, "ms_per_frame": r["total_ms"] / CLIP_LEN,
-                                      "GFLOP_per_frame": r["total_bytes"] / CLIP_LEN / 1e9,
+                                      "GFLOP_issued_per_frame": r["total_aux"] / CLIP_LEN / 1e9, "GFLOP_algorithmic_per_frame": r["total_bytes"] / CLIP_LEN / 1e9,
+                                      "note": "achieved / frac = ISSUED matrix FLOPs over the summed kernel time; effective_* = FLOPs of the direct "
+                                              "definition over the same time (what the layer is worth, not what the matrix cores did)",
                                       "mode": "eager launches (events attached to each dispatch); the timed region replays the same kernels from hipGraphs"}
         # host-side enqueue cost of one clip (no sync inside): tells whether the frame is CPU- or GPU-bound
         torch.cuda.synchronize(device)
@@ -439,10 +533,14 @@ def main(argv=None):
                           "upsample to input size + argmax + .cpu() (reference test_swiftnet.py:190-197). PCIe-inclusive: never `value`")
             extra["upload_inclusive"] = up
         from blockcopy.core import fusion
-        # measured route per padded 3x3 layer shape (fusion.conv3x3_plan): library = halo gather + MIOpen, cN = fused kernel
-        extra["conv3x3_plans"] = [{"n_exec": k[0], "tile": k[1], "cin": k[2], "cout": k[3], "stride": k[6], "choice": best,
-                                   "us": round(times[best], 1), "library_us": round(times.get("library", float("nan")), 1)}
-                                  for k, times, best in fusion.CONV_TUNE_LOG]
+        # route per padded 3x3 / pointwise layer shape (fusion.conv3x3_plan): null = halo gather + MIOpen, code = fused kernel decomposition
+        # (codes with 0x200 = Winograd form).  The table comes from blockcopy/plans/gfx950.json; shapes it lacked were measured live.
+        details["conv_plans_measured_live"] = [{"n_exec": k[0], "tile": k[1], "cin": k[2], "cout": k[3], "stride": k[6], "ks": k[7], "choice": best,
+                                                "us": round(times[best], 1), "library_us": round(times.get("library", float("nan")), 1)}
+                                               for k, times, best in fusion.CONV_TUNE_LOG]
+        details["conv_plan_table"] = {fusion._key_to_str(k): v for k, v in fusion._conv_plans.items()}
+        extra["conv_plan"] = {"hash": fusion.conv_plan_hash(), "entries": len(fusion._conv_plans), "file": os.path.relpath(fusion.PLAN_FILE, ROOT) if fusion.PLAN_FILE else None,
+                              "decisions": dict(fusion.PLAN_STATS), "mode": fusion.CONV_MODE}
         if not args.no_dense and world == 1:
             dense = build_workload(args, "static", dtype, device, rank)
             dfps, _, _ = harness.measure_fps(dense, clips[:1], n_clips=max(1, min(args.steps, 3)), warmup_clips=1, device=device)
@@ -484,7 +582,7 @@ def main(argv=None):
         traffic, traffic_src, traffic_kernels = pmc_traffic()
         if traffic_kernels:
             # committed PMC measurement (profiles/traffic_latest.json: rocprofv3 --pmc passes of tools/pmc_driver.py at these shapes)
-            extra["pmc_traffic"] = traffic_kernels
+            details["pmc_traffic"] = traffic_kernels
         out = {
             "metric": METRIC, "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -494,11 +592,15 @@ def main(argv=None):
                                    f"{args.engine} engine{' + hipGraph replay' if args.graph else ''}{', channels-last' if args.channels_last else ''}, name-seeded weights, BN folded; step = 1 clip",
                        "clips_per_rank": args.steps, "parallelism": f"{world} independent replica(s), no collective",
                        "exec_fraction": exec_frac, "warmup_s": warm_s},
-            "roofline": {"kernel": "k_combine_copy (fused scatter+copy of the logits map)", "bound": "hbm", "achieved": achieved,
+            "roofline": {"kernel": "k_combine_copy_ind (fused scatter+copy of the logits map, a node of the frame's hipGraph)" if stamp_us
+                         else "k_combine_copy (fused scatter+copy of the logits map)", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src,
                          "launches": cc["launches"], "avg_launch_us": (1e3 * cc["total_ms"] / cc["launches"]) if cc["launches"] else None,
-                         "algorithmic_bytes_per_launch": (cc["total_bytes"] / cc["launches"]) if cc["launches"] else None},
+                         "p50_us": cc.get("p50_us"), "min_us": cc.get("min_us"), "max_us": cc.get("max_us"),
+                         "algorithmic_bytes_per_launch": (cc["total_bytes"] / cc["launches"]) if cc["launches"] else None,
+                         "method": cc["method"]},
+            "per_rank_fps": {"min": min(per_rank), "max": max(per_rank), "all": [round(v, 1) for v in per_rank]},
             "kernels": extra,
         }
         if "roofline_conv" in extra:
@@ -506,7 +608,17 @@ def main(argv=None):
             out["roofline_conv"] = extra.pop("roofline_conv")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_dense_baseline(args, args.cpu_frames)
-        print(json.dumps(out), flush=True)
+        details["rank_env"] = rank_env
+        dpath = details_path(args)
+        out["details_file"] = os.path.relpath(dpath, ROOT)
+        line = json.dumps(out)
+        with open(dpath, "w") as f:
+            json.dump({"bench_line": out, **details}, f, indent=1)
+        assert len(line) < 6000, f"bench line grew to {len(line)} bytes: move tables to the details file"
+        print(line, flush=True)
+    if args.save_plan and rank == 0:
+        from blockcopy.core import fusion
+        fusion.save_conv_plans(args.save_plan, note="conv plan table measured by bench.py on " + torch.cuda.get_device_name(device))
 
     if world > 1:
         replicas.barrier(world, device)

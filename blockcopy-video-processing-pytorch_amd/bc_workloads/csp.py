@@ -270,7 +270,8 @@ class CSPBlockCopy(CSP):
                     self.block_temporal_features = x.process_temporal_features(self.block_temporal_features)
                     x = x.to_blocks(self.policy_meta["grid"], self.policy_meta.get("grid_host", None))
                     self.policy_meta["frame_state"] = x.combine_().to_tensor()
-                    maps = self._maps_from_blocks(x)
+                    maps = blockcopy.to_tensor(self._maps_from_blocks(x))
+                    self.block_temporal_features.flush_deferred()
                 self.head_out = maps
                 if decode:
                     dets, labels = self.bbox_head.get_bboxes(*maps, img_shape=img.shape[-2:])

@@ -51,3 +51,12 @@ def job_throughput(frames_local: int, elapsed_local: float, world: int, device="
     torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     torch.distributed.all_reduce(f, op=torch.distributed.ReduceOp.SUM)
     return float(f.item()) / float(t.item()), float(t.item()), int(f.item())
+
+
+def gather_scalars(value: float, world: int) -> List[float]:
+    """One host scalar per rank, on every rank (clock-bracket group only; used for the per-rank fps of the report)."""
+    if world == 1:
+        return [float(value)]
+    bufs = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    torch.distributed.all_gather(bufs, torch.tensor([float(value)], dtype=torch.float64))
+    return [float(b.item()) for b in bufs]

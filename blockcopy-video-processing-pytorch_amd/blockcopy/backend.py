@@ -22,11 +22,14 @@ LIB_PATH = os.environ.get("BLOCKCOPY_HIP_LIB", os.path.join(_PKG_ROOT, "lib", "l
 OP_SPLIT, OP_COMBINE, OP_TRANSFER, OP_PAD, OP_COMBINE_COPY, OP_PAD_RING, OP_GRID_TABLES, OP_INTERP, OP_AFFINE = range(9)
 OP_NAMES = ("split", "combine", "transfer", "pad", "combine_copy", "pad_ring", "grid_tables", "interp", "affine", "nms", "conv3x3")
 _DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class BlockCopyBackendError(RuntimeError):
-    pass
+    code = None   # the library's return code (negative BC_ERR_*, positive hipError_t) when the error came from a launch
+
+
+BC_ERR_SHAPE = -2
 
 
 def is_nhwc(x: torch.Tensor) -> bool:
@@ -105,6 +108,7 @@ def load_library(path: str = None) -> ctypes.CDLL:
         "bc_split": [p, p, p] + [i] * 7 + [p],
         "bc_combine": [p, p, p] + [i] * 7 + [p],
         "bc_combine_copy": [p, p, p, p] + [i] * 6 + [p],
+        "bc_combine_copy_indirect": [p, p, p] + [i] * 7 + [p],
         "bc_transfer": [p, p, p, p] + [i] * 8 + [p],
         "bc_pad": [p, p, p, p, p] + [i] * 8 + [p],
         "bc_pad_ring": [p, p, p, p, p] + [i] * 8 + [p],
@@ -139,6 +143,7 @@ def load_library(path: str = None) -> ctypes.CDLL:
         "bc_prof_enable": [u],
         "bc_prof_reset": [],
         "bc_prof_read": [i, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)],
+        "bc_prof_read_aux": [i, ctypes.POINTER(ctypes.c_double)],
     }
     for name, argtypes in sig.items():
         fn = getattr(lib, name)
@@ -166,7 +171,9 @@ class HipBackend:
     # -- helpers
     def _check(self, rc: int, op: str):
         if rc != 0:
-            raise BlockCopyBackendError(f"bc_{op} failed: {self.lib.bc_error_string(rc).decode()} (code {rc})")
+            err = BlockCopyBackendError(f"bc_{op} failed: {self.lib.bc_error_string(rc).decode()} (code {rc})")
+            err.code = rc
+            raise err
 
     @staticmethod
     def _stream() -> int:
@@ -262,6 +269,24 @@ class HipBackend:
                                                  grid_idx.data_ptr(), N, Ck, H, W, bs, Ek, self._stream()),
                         "combine_copy")
         return out
+
+    SLOT_WORDS = 3     # uint64 words of a bc_combine_copy_indirect slot buffer: prev, out, timing record
+
+    def combine_copy_indirect(self, blocks, slots, grid_idx, out_shape, targets=None):
+        """combine_copy as a hipGraph node: ``prev`` / ``out`` are read at run time from ``slots`` (device int64[3]: prev address,
+        out address, timing record or 0; include/blockcopy_hip.h bc_combine_copy_indirect), so a captured launch serves a fresh
+        output tensor every replay.  ``out_shape`` = (N,C,H,W) of the dense maps, which share the layout of ``blocks``;
+        ``targets`` (the tensors behind the two addresses) is for checker backends only and ignored here."""
+        assert _ok(blocks) and _ok(slots, torch.int64) and slots.numel() >= self.SLOT_WORDS and _ok(grid_idx, torch.int32)
+        N, C, H, W = out_shape
+        _, Cb, bs, _ = blocks.shape
+        _, _, GH, GW = grid_idx.shape
+        assert Cb == C and GH * bs == H and GW * bs == W and grid_idx.size(0) == N and blocks.numel() > 0
+        Ck, Ek = (1, C * blocks.element_size()) if is_nhwc(blocks) else (C, blocks.element_size())
+        with torch.cuda.device_of(blocks):
+            # torch's caching allocator hands out 512-byte aligned blocks; the maps are whole allocations
+            self._check(self.lib.bc_combine_copy_indirect(blocks.data_ptr(), slots.data_ptr(), grid_idx.data_ptr(), N, Ck, H, W, bs, Ek, 256,
+                                                          self._stream()), "combine_copy_indirect")
 
     def pad_ring(self, data_exec, ring, grid_idx, mapping_exec, pad, prologue=None):
         """halo gather over the persistent ring cache (+ refresh of the executed tiles' rings).
@@ -404,15 +429,20 @@ class HipBackend:
         return [int(buf[k]) for k in range(n)]
 
     @staticmethod
-    def time_routes(routes, reps=3, launches=4):
-        """{name: median microseconds per call} of each callable, measured with events on the current stream."""
+    def time_routes(routes, reps=None, launches=4):
+        """{name: median microseconds per call} of each callable, measured with events on the current stream.  A candidate the
+        library rejects for this shape (BC_ERR_SHAPE: a decomposition that does not fit) is skipped; any other failure of a
+        candidate is an error of the kernel, not a reason to pick another one, and propagates."""
         out = {}
+        reps = reps or int(os.environ.get("BLOCKCOPY_CONV_TUNE_REPS", "3"))
         torch.cuda.synchronize()
         for name, fn in routes.items():
             try:
                 fn()
                 fn()
-            except Exception:
+            except BlockCopyBackendError as e:
+                if e.code != BC_ERR_SHAPE:
+                    raise
                 continue
             ts = []
             for _ in range(reps):
@@ -822,7 +852,9 @@ class HipBackend:
         op = OP_NAMES.index(op) if isinstance(op, str) else int(op)
         n, ms, by = ctypes.c_longlong(0), ctypes.c_double(0), ctypes.c_double(0)
         self._check(self.lib.bc_prof_read(op, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(by)), "prof_read")
-        return dict(op=OP_NAMES[op], launches=n.value, total_ms=ms.value, total_bytes=by.value)
+        aux = ctypes.c_double(0)
+        self._check(self.lib.bc_prof_read_aux(op, ctypes.byref(aux)), "prof_read_aux")
+        return dict(op=OP_NAMES[op], launches=n.value, total_ms=ms.value, total_bytes=by.value, total_aux=aux.value)
 
 
 _backend = None

@@ -80,6 +80,7 @@ class BlockCopyModel(nn.Module):
                 self.policy_meta["frame_state"] = blocks.combine_().to_tensor()
                 out = self.base_model(blocks, **kwargs)
                 out = out.combine().to_tensor()
+                self.block_temporal_features.flush_deferred()
 
             self.policy_meta["outputs_prev"] = self.policy_meta["outputs"]
             self.policy_meta["outputs"] = out

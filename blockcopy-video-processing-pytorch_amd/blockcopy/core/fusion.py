@@ -66,10 +66,15 @@ class Pending:
                                "BLOCKCOPY_FUSE=0")
         return self.add
 
-    def defer_conv(self, launch, kwargs, source):
-        """Record a deferred producer launch (``launch(epilogue=..., **kwargs)``) that will read ``source`` when it runs."""
-        self.conv = (launch, kwargs)
+    def defer_conv(self, launch, kwargs, source, registry=None):
+        """Record a deferred producer launch (``launch(epilogue=..., **kwargs)``) that will read ``source`` when it runs.
+        ``conv = (launch, kwargs, state)``; copies of the record share ``state`` (``state["launched"]``).  A launch with a side
+        effect on temporal state (the fused halo+conv refreshes its layer's ring cache) is also put on ``registry`` -- the
+        frame's list of outstanding producers -- so that the frame can run it even if nobody ever asks for its value."""
         self.src_guard = (source, source._version)
+        self.conv = (launch, kwargs, {"launched": False, "guard": self.src_guard})
+        if registry is not None:
+            registry.append(self.conv)
         return self
 
     def check_source(self):
@@ -138,20 +143,97 @@ def packed_conv3x3_weight(weight: torch.Tensor, pack) -> torch.Tensor:
     return v
 
 
-CONV_MODE = os.environ.get("BLOCKCOPY_CONV", "auto")   # auto | native | library
-CONV_TUNE = os.environ.get("BLOCKCOPY_CONV_TUNE", "1") != "0"   # auto mode: measure each new layer shape once (eager runs only)
-_conv_plans = {}      # (n_exec, bs, cin, cout, n_total, dtype) -> None (library conv) | decomposition index (-1 = library's own choice)
+CONV_MODE = os.environ.get("BLOCKCOPY_CONV", "auto")   # auto | native | winograd | library
+CONV_TUNE = os.environ.get("BLOCKCOPY_CONV_TUNE", "1") != "0"   # auto mode: measure a layer shape the plan table does not know (eager runs only)
+_conv_plans = {}      # (n_exec, bs, cin, cout, n_total, dtype, stride, ks) -> None (library conv) | decomposition code (-1 = library's own choice)
 DEFER_CONV = os.environ.get("BLOCKCOPY_DEFER_CONV", "1") != "0"   # fused convs launch lazily with the recorded elementwise work as epilogue
 POINTWISE = os.environ.get("BLOCKCOPY_POINTWISE", "1") != "0"     # 1x1 convs through the fused kernel's one-tap form (prologue / epilogue fusion)
 GROUP_NORM = os.environ.get("BLOCKCOPY_GROUP_NORM", "1") != "0"   # group_norm on packed tiles as a recorded per-channel affine map (one stats pass)
 ADAPTIVE_POOL = os.environ.get("BLOCKCOPY_ADAPTIVE_POOL", "1") != "0"   # adaptive_avg_pool2d of dense channels-last maps (pyramid pooling) in the library's kernel
 STEM_KERNEL = os.environ.get("BLOCKCOPY_STEM", "1") != "0"        # network input: window gather + 7x7 stem conv in one kernel
 CONV_TUNE_LOG = []    # (key, {candidate: microseconds}, choice) of every measurement, for the bench report
+WINOGRAD_FLAG = 0x200  # decomposition codes with this bit run the Winograd F(2x2,3x3) form (csrc/conv3x3_wino.inc)
+
+# Plan table persistence.  A plan decides which KERNEL FORM a layer runs in (library conv / direct MFMA form / Winograd form), and
+# the forms differ by fp32 rounding, so a run is only reproducible -- from run to run and from rank to rank -- with a fixed table.
+# The package ships one measured on MI355X for the BASELINE configs (plans/gfx950.json, written by tools/tune_plans.py); it is
+# loaded at import.  BLOCKCOPY_CONV_PLAN=<file> loads another one instead, BLOCKCOPY_CONV_PLAN=none starts empty.  Shapes the table
+# does not know are measured once (BLOCKCOPY_CONV_TUNE=1, default) or follow a fixed rule (=0); `save_conv_plans` writes the table
+# back.  PLAN_STATS counts where this process's decisions came from.
+DEFAULT_PLAN_FILE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "plans", "gfx950.json")
+PLAN_FILE = os.environ.get("BLOCKCOPY_CONV_PLAN", DEFAULT_PLAN_FILE)
+PLAN_STATS = {"from_table": 0, "tuned_live": 0, "fixed_rule": 0}
+_DTYPE_NAMES = {torch.float32: "f32", torch.float16: "f16", torch.bfloat16: "bf16"}
+_DTYPE_BY_NAME = {v: k for k, v in _DTYPE_NAMES.items()}
+_loaded_keys = set()
+
+
+def _key_to_str(key):
+    n_exec, bs, cin, cout, n_total, dtype, stride, ks = key
+    return f"{n_exec},{bs},{cin},{cout},{n_total},{_DTYPE_NAMES[dtype]},{stride},{ks}"
+
+
+def _key_from_str(text):
+    f = text.split(",")
+    return (int(f[0]), int(f[1]), int(f[2]), int(f[3]), int(f[4]), _DTYPE_BY_NAME[f[5]], int(f[6]), int(f[7]))
 
 
 def clear_conv_plans():
     _conv_plans.clear()
+    _loaded_keys.clear()
     del CONV_TUNE_LOG[:]
+    for k in PLAN_STATS:
+        PLAN_STATS[k] = 0
+
+
+def load_conv_plans(path, replace=False):
+    """Read a plan table written by ``save_conv_plans``; returns the number of entries.  Entries of the file win over
+    plans already in memory."""
+    import json
+
+    with open(path) as f:
+        doc = json.load(f)
+    if replace:
+        clear_conv_plans()
+    for text, plan in doc["plans"].items():
+        key = _key_from_str(text)
+        _conv_plans[key] = None if plan is None else int(plan)
+        _loaded_keys.add(key)
+    return len(doc["plans"])
+
+
+def save_conv_plans(path, note=None):
+    """Write every plan this process knows (loaded and measured) as JSON: {"plans": {"n_exec,bs,cin,cout,n_total,dtype,stride,ks":
+    code | null}} with null = halo gather + library conv."""
+    import json
+
+    doc = {"format": 1, "note": note or "blockcopy conv plan table (fusion.conv3x3_plan)",
+           "plans": {_key_to_str(k): v for k, v in sorted(_conv_plans.items(), key=lambda kv: _key_to_str(kv[0]))}}
+    tmp = f"{path}.tmp{os.getpid()}"
+    with open(tmp, "w") as f:
+        json.dump(doc, f, indent=0, sort_keys=True)
+        f.write("\n")
+    os.replace(tmp, path)
+    return len(doc["plans"])
+
+
+def conv_plan_hash():
+    """Short digest of the plan table in memory (bench.py prints it: equal hashes = equal kernel forms per layer)."""
+    import hashlib
+
+    text = ";".join(f"{_key_to_str(k)}={v}" for k, v in sorted(_conv_plans.items(), key=lambda kv: _key_to_str(kv[0])))
+    return hashlib.sha256(text.encode()).hexdigest()[:16]
+
+
+def _load_default_plans():
+    if PLAN_FILE and PLAN_FILE.lower() != "none":
+        if os.path.exists(PLAN_FILE):
+            load_conv_plans(PLAN_FILE)
+        elif PLAN_FILE != DEFAULT_PLAN_FILE:
+            raise FileNotFoundError(f"BLOCKCOPY_CONV_PLAN={PLAN_FILE} does not exist")
+
+
+_load_default_plans()
 
 
 def default_native_conv3x3(n_exec: int, bs: int, cin: int, cout: int) -> bool:
@@ -160,17 +242,28 @@ def default_native_conv3x3(n_exec: int, bs: int, cin: int, cout: int) -> bool:
     return not (bs <= 4 and n_exec * bs * bs < 1024)
 
 
-def conv3x3_plan(n_exec: int, bs: int, cin: int, cout: int, n_total: int, dtype, tuner=None, stride: int = 1, ks: int = 3):
-    """How to run one padded 3x3 / stride 1 conv layer: ``None`` = halo gather + library conv, ``int`` = the fused
-    halo+conv kernel with that decomposition (-1: the library's cost model).  In ``auto`` mode a new layer shape is
-    MEASURED once (``tuner()`` times the library route and every decomposition on the live tensors) -- the same idea as the
-    conv library's own solver search -- but never during graph capture; until measured, a fixed rule decides."""
+def conv3x3_plan(n_exec: int, bs: int, cin: int, cout: int, n_total: int, dtype, tuner=None, stride: int = 1, ks: int = 3, candidates=None):
+    """How to run one padded 3x3 conv layer (or, ``ks=1``, one pointwise conv): ``None`` = halo gather + library conv, ``int`` =
+    the fused halo+conv kernel with that decomposition code (-1: the library's cost model; codes with WINOGRAD_FLAG: Winograd form).
+
+    ``BLOCKCOPY_CONV`` = ``library`` | ``native`` (direct MFMA form everywhere) | ``winograd`` (every layer that lists a Winograd
+    candidate runs its first one, the rest the direct form) | ``auto``: the plan table decides (see PLAN_FILE above); a shape it
+    does not know is MEASURED once (``tuner()`` times the library route and every decomposition on the live tensors -- the conv
+    library's own solver-search idea -- never during graph capture) or, untuned, follows a fixed rule."""
     if CONV_MODE == "library":
         return None
     if CONV_MODE == "native":
         return -1
+    if CONV_MODE == "winograd":
+        if ks == 3 and stride == 1 and dtype == torch.float32 and candidates is not None:
+            wino = [c for c in candidates() if c >= 0 and (c & WINOGRAD_FLAG)]
+            if wino:
+                return wino[0]
+        return -1
     key = (n_exec, bs, cin, cout, n_total, dtype, stride, ks)
     if key in _conv_plans:
+        if key in _loaded_keys:
+            PLAN_STATS["from_table"] += 1
         return _conv_plans[key]
     capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
     if tuner is not None and CONV_TUNE and not capturing:
@@ -180,7 +273,9 @@ def conv3x3_plan(n_exec: int, bs: int, cin: int, cout: int, n_total: int, dtype,
             plan = None if best == "library" else int(best)
             _conv_plans[key] = plan
             CONV_TUNE_LOG.append((key, times, best))
+            PLAN_STATS["tuned_live"] += 1
             return plan
+    PLAN_STATS["fixed_rule"] += 1
     if ks == 1:
         return -1 if n_exec * bs * bs >= 4096 else None       # untuned rule for pointwise convs: the library for tiny maps
     return -1 if default_native_conv3x3(n_exec, bs // stride, cin, cout) else None

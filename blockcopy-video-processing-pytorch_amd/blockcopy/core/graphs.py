@@ -10,29 +10,39 @@ buffers with fixed addresses:
     persistent ring caches, MIOpen convs, per-tile resampling, dense SPP ...] -> packed output tiles
 
 Per frame the host then does: policy -> index tables (C loop, pinned) -> one H->D copy into the static table buffer ->
-one D->D copy of the frame -> ``graph.replay()`` -> the final fused scatter+copy into a fresh output tensor (eager, so
-callers may keep every frame's output, as with the reference).  No Python runs per layer and nothing synchronises.
+one D->D copy of the frame -> ``graph.replay()``.  No Python runs per layer and nothing synchronises.
+
+The final out-of-place combine (fused scatter+copy of the output map) is a node of the same graph although its output must
+be a FRESH tensor every frame (callers may keep every frame's result, as with the reference) and its ``prev`` operand is
+last frame's output: the kernel reads both addresses from three slot words that travel with the index tables
+(``bc_combine_copy_indirect``).  As the one eager launch of the frame it used to start cold behind the graph's end-of-launch
+release fence (5.7-6.1 us for the 19.9 MB logits map of C2 against 3.5 us back to back).
 
 Reference behaviour being reproduced: BlockCopyModel._forward_blockcopy, core/blockcopy.py:62-79.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
-from ..backend import empty_like_layout, get_backend, pinned_ring
+from ..backend import empty_like_layout, get_backend, is_nhwc, pinned_ring
 from .tensorwrapper import BlockFeatures, PersistentState, TensorWrapper, _NoDispatch
 
 WARM_RUNS = 1   # eager runs of a new executed-tile count before it is captured (MIOpen solver search, lazy module loads)
+GRAPH_COMBINE = os.environ.get("BLOCKCOPY_GRAPH_COMBINE", "1") != "0"   # final scatter+copy as a graph node (0: the eager launch of rounds 1-2)
+SLOT_WORDS = 3  # uint64 words behind the index tables: prev address, out address, timing record (bc_combine_copy_indirect)
 
 
 class _Bucket:
-    __slots__ = ("warm", "graph", "out_blocks")
+    __slots__ = ("warm", "graph", "out_blocks", "combined")
 
     def __init__(self):
         self.warm = 0
         self.graph = None
         self.out_blocks = None
+        self.combined = False    # the captured body ends with the scatter+copy into the frame's output map
 
 
 class GraphedFrame:
@@ -46,22 +56,31 @@ class GraphedFrame:
         self.n_total = N * (H // block_size) * (W // block_size)
         self.device = inputs.device
         self.static_in = torch.empty_like(inputs, memory_format=torch.contiguous_format)
-        self.tables = torch.zeros(2 * self.n_total, dtype=torch.int32, device=self.device)   # [grid_idx | mapping_exec]
+        # [grid_idx | mapping_exec | slot words of the in-graph scatter+copy]: ONE buffer, one H->D copy per frame
+        self.tables = torch.zeros(2 * self.n_total + 2 * SLOT_WORDS, dtype=torch.int32, device=self.device)
         self.grid_idx = self.tables[:self.n_total].view(self.grid_shape)
+        self.slots = self.tables[2 * self.n_total:].view(torch.int64)
         self.state = PersistentState()
         self.buckets = {}
         self.pool = None
         self.prev_out = None      # previous frame's dense output (None at the start of a clip)
         self.frame_state = None
+        self.out_meta = None      # (shape, dtype, channels-last) of the dense output map, known after the first frame
+        self.cur_out = None       # this frame's output map (allocated before the replay that fills it)
+        self._combined = False    # the body that just ran has filled cur_out
+        self.stamps = None        # measurement: device uint64 (K, 2) timing records of the in-graph scatter+copy, one per frame
+        self.stamp_pos = 0
 
     # ------------------------------------------------------------------ per-frame host work
     def upload(self, inputs: torch.Tensor, grid_host: torch.Tensor) -> int:
         g8 = grid_host.to(torch.bool).contiguous().numpy().view(np.uint8).reshape(-1)
         assert g8.size == self.n_total
-        ring = pinned_ring(2 * self.n_total, torch.int32, self.device.type == "cuda")     # reused pinned staging (no per-frame page-locking)
+        ring = pinned_ring(2 * self.n_total + 2 * SLOT_WORDS, torch.int32, self.device.type == "cuda")     # reused pinned staging (no per-frame page-locking)
         staging = ring.next()
         st = staging.numpy()
-        n_exec = get_backend().grid_tables_host(g8, st[:self.n_total], st[self.n_total:], None, None)
+        n_exec = get_backend().grid_tables_host(g8, st[:self.n_total], st[self.n_total:2 * self.n_total], None, None)
+        words = self._next_out()
+        st[2 * self.n_total:].view(np.int64)[:] = words if words is not None else 0
         self.tables.copy_(staging, non_blocking=True)
         ring.uploaded()
         if inputs.data_ptr() != self.static_in.data_ptr():
@@ -69,12 +88,56 @@ class GraphedFrame:
         return n_exec
 
     def upload_tables(self, inputs: torch.Tensor, tables: torch.Tensor, n_exec: int) -> int:
-        """Per-frame work when the policy already built the index tables on the device (bc_policy_step): two D->D copies."""
+        """Per-frame work when the policy already built the index tables on the device (bc_policy_step): two D->D copies (+ the
+        24-byte slot words of the in-graph scatter+copy)."""
         assert tables.numel() == 2 * self.n_total and tables.dtype == torch.int32
-        self.tables.copy_(tables, non_blocking=True)
+        self.tables[:2 * self.n_total].copy_(tables, non_blocking=True)
+        words = self._next_out()
+        if words is not None:
+            ring = pinned_ring(SLOT_WORDS, torch.int64, self.device.type == "cuda")
+            staging = ring.next()
+            staging.numpy()[:] = words
+            self.slots.copy_(staging, non_blocking=True)
+            ring.uploaded()
         if inputs.data_ptr() != self.static_in.data_ptr():
             self.static_in.copy_(inputs, non_blocking=True)
         return int(n_exec)
+
+    def _next_out(self):
+        """Allocate this frame's output map and return the slot words that point the in-graph scatter+copy at it (None until the
+        output geometry is known, i.e. on the very first frame, and for models that do not return packed tiles)."""
+        self.cur_out = None
+        if self.out_meta is None or not GRAPH_COMBINE or not hasattr(get_backend(), "combine_copy_indirect"):
+            return None
+        shape, dtype, nhwc = self.out_meta
+        out = torch.empty(shape, dtype=dtype, device=self.device, memory_format=torch.channels_last if nhwc else torch.contiguous_format)
+        self.cur_out = out
+        prev = self.prev_out if self.prev_out is not None else out     # start of a clip: every tile is executed, prev is never read
+        stamp = 0
+        if self.stamps is not None and self.stamp_pos < self.stamps.shape[0]:
+            stamp = self.stamps.data_ptr() + 16 * self.stamp_pos
+            self.stamp_pos += 1
+        return (prev.data_ptr(), out.data_ptr(), stamp)
+
+    # ------------------------------------------------------------------ measurement of the in-graph scatter+copy
+    def timing_start(self, capacity: int):
+        """Give each of the next ``capacity`` frames a timing record for its in-graph scatter+copy launch."""
+        st = torch.zeros((capacity, 2), dtype=torch.int64, device=self.device)
+        st[:, 0] = -1            # UINT64_MAX: the kernel keeps the minimum entry time
+        self.stamps, self.stamp_pos = st, 0
+
+    def timing_read(self):
+        """(durations in microseconds of the recorded launches, algorithmic bytes per launch); synchronises."""
+        if self.stamps is None or self.out_meta is None:
+            return [], 0.0
+        torch.cuda.synchronize(self.device)
+        st = self.stamps[:self.stamp_pos].cpu().numpy()
+        self.stamps = None
+        ok = (st[:, 0] != -1) & (st[:, 1] != 0)
+        ticks = (st[ok, 1].astype(np.uint64) - st[ok, 0].astype(np.uint64)).astype(np.float64)
+        shape, dtype, _ = self.out_meta
+        nbytes = 2.0 * float(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+        return list(ticks * 0.01), nbytes      # s_memrealtime: constant 100 MHz
 
     # ------------------------------------------------------------------ the capturable body
     def body(self, base_model, n_exec: int, grid: torch.Tensor, **kwargs):
@@ -93,10 +156,21 @@ class GraphedFrame:
         frame_state = blocks.combine_()._plain()
         out = base_model(blocks, **kwargs)
         if isinstance(out, TensorWrapper) and out.is_blocks:
-            return out._plain(), frame_state          # packed output tiles: combined eagerly by finish()
+            plain = out._plain()
+            feats.flush_deferred()
+            N, _, GH, GW = self.grid_shape
+            self.out_meta = ((N, plain.shape[1], GH * plain.shape[2], GW * plain.shape[3]), plain.dtype, is_nhwc(plain))
+            if self.cur_out is not None and tuple(self.cur_out.shape) == self.out_meta[0] and self.cur_out.dtype == plain.dtype:
+                # final out-of-place combine as part of the body: prev / out addresses come from the slot words of this frame
+                prev = self.prev_out if self.prev_out is not None else self.cur_out
+                get_backend().combine_copy_indirect(plain, self.slots, self.grid_idx, self.out_meta[0], targets=(prev, self.cur_out))
+                return plain, frame_state, True
+            return plain, frame_state, False          # (first frame ever: geometry unknown until now) combined eagerly by finish()
         # models that combine inside (e.g. the CSP head): dense maps living in the persistent state / graph pool
         from .tensorwrapper import to_tensor
-        return to_tensor(out), frame_state
+        dense = to_tensor(out)
+        feats.flush_deferred()
+        return dense, frame_state, False
 
     def run(self, base_model, n_exec: int, grid: torch.Tensor, **kwargs):
         """Outputs of ``base_model(packed tiles)`` for this frame -- packed output tiles, or whatever dense structure
@@ -106,7 +180,7 @@ class GraphedFrame:
         b = self.buckets.setdefault(n_exec, _Bucket())
         if b.graph is None and (b.warm < WARM_RUNS or self.device.type != "cuda"):   # (no graphs off-GPU: test hook only)
             b.warm += 1
-            out_blocks, self.frame_state = self.body(base_model, n_exec, grid, **kwargs)
+            out_blocks, self.frame_state, self._combined = self.body(base_model, n_exec, grid, **kwargs)
             return out_blocks
         if b.graph is None:
             if self.pool is None:
@@ -114,19 +188,28 @@ class GraphedFrame:
             torch.cuda.synchronize(self.device)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=self.pool):
-                b.out_blocks, self.frame_state = self.body(base_model, n_exec, grid, **kwargs)
+                b.out_blocks, self.frame_state, b.combined = self.body(base_model, n_exec, grid, **kwargs)
             b.graph = g
             self.state.frozen = True
+        if b.combined and self.cur_out is None:
+            raise AssertionError("a graph that ends with the scatter+copy node was replayed without an output map (GRAPH_COMBINE toggled after capture?)")
         b.graph.replay()
+        self._combined = b.combined
         return b.out_blocks
 
     def finish(self, out_blocks: torch.Tensor) -> torch.Tensor:
-        """Final out-of-place combine: fused scatter+copy against the previous frame's output (eager: every frame's
-        output is a fresh tensor the caller may keep)."""
+        """The frame's dense output (a fresh tensor the caller may keep): filled by the body's scatter+copy node, or -- first
+        frame ever, GRAPH_COMBINE off -- by an eager fused scatter+copy against the previous frame's output."""
+        if self._combined:      # the body (eager run or graph replay) has already filled this frame's map
+            out, self.cur_out, self._combined = self.cur_out, None, False
+            self.prev_out = out
+            return out
         be = get_backend()
         n_exec, C, bs, _ = out_blocks.shape
         N, _, GH, GW = self.grid_shape
-        out = empty_like_layout((N, C, GH * bs, GW * bs), out_blocks)
+        shape = (N, C, GH * bs, GW * bs)
+        out = self.cur_out if (self.cur_out is not None and tuple(self.cur_out.shape) == shape) else empty_like_layout(shape, out_blocks)
+        self.cur_out = None
         if self.prev_out is None:
             be.combine(out_blocks, out, self.grid_idx, self.tables[self.n_total:self.n_total + n_exec])
         else:

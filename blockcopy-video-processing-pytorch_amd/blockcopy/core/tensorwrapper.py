@@ -169,6 +169,7 @@ class BlockFeatures:
         self.rings = []              # fused engine: persistent ring caches (shared list object across frames)
         self._ring_pos = 0
         self._pad_memo = None        # (source, padding, prologue key, padded): consecutive padded ops on the SAME tensor share one gather
+        self._deferred = []          # deferred producers of this frame whose launch also refreshes a ring cache (fusion.Pending.defer_conv)
         self.persistent = None       # PersistentState when running as a graph-capturable body (core/graphs.py)
 
     # ------------------------------------------------------------------ grid -> index tables
@@ -230,6 +231,24 @@ class BlockFeatures:
             raise AssertionError(f"padded op #{k}: expected tiles {tuple(ring.shape)}/{ring.dtype}, got {shape}/{data.dtype}; "
                                  "the model must run the same op sequence every frame")
         return ring
+
+    def flush_deferred(self) -> int:
+        """End of the frame body: run every deferred fused conv nobody asked the value of.  Its output is dropped, but its
+        launch is what refreshes the layer's ring cache for the executed tiles -- without it a later frame that skips those
+        tiles would gather this layer's halo from stale records.  Returns the number of launches made."""
+        n = 0
+        for launch, kw, state in self._deferred:
+            if not state["launched"]:
+                src, version = state["guard"]
+                if src._version != version:
+                    del self._deferred[:]
+                    raise RuntimeError("blockcopy lazy fusion: the input of a deferred conv was modified in place before the end of the "
+                                       "frame and its result was never consumed; set BLOCKCOPY_DEFER_CONV=0 / BLOCKCOPY_FUSE=0")
+                launch(epilogue=None, **kw)
+                state["launched"] = True
+                n += 1
+        del self._deferred[:]
+        return n
 
     # ------------------------------------------------------------------ reference engine: FIFO of tensor pairs
     def store_features(self, data_computed, data_transfer, padding: int = -1) -> None:
@@ -368,9 +387,10 @@ class TensorWrapper(torch.Tensor):
             be = get_backend()
             P.check_source()
             if P.conv is not None:        # deferred fused halo+conv: launch now, the rest of the record is its epilogue
-                launch, kw = P.conv
+                launch, kw, state = P.conv
                 plain = P.scale is None and P.shift is None and add is None and not P.relu
                 out = launch(epilogue=None if plain else (P.scale, P.shift, add, P.relu), **kw)
+                state["launched"] = True
             elif P.interp is not None:    # deferred interpolation: resample now, the rest of the record is its epilogue
                 src, H, W, align, rh, rw = P.interp
                 plain = P.scale is None and P.shift is None and add is None and not P.relu
@@ -787,7 +807,8 @@ class TensorWrapper(torch.Tensor):
                     placeholder = empty_like_layout((data.shape[0], weight.shape[0], data.shape[2] // stride, data.shape[3] // stride), data)
                     P = pend_out if pend_out is not None else fusion.Pending()
                     P.defer_conv(be.conv3x3_ring, dict(data_exec=data, ring=ring, wpk=wpk, cout=weight.shape[0], grid_idx=grid_idx,
-                                                       mapping_exec=mapping_exec, prologue=prologue, cfg=plan, stride=stride), data)
+                                                       mapping_exec=mapping_exec, prologue=prologue, cfg=plan, stride=stride), data,
+                                 registry=feats._deferred)
                     return placeholder, P
                 with timings.env("tensorwrapper/conv3x3_fused", 10):
                     return be.conv3x3_ring(data, ring, wpk, weight.shape[0], grid_idx, mapping_exec, prologue, None, cfg=plan,
@@ -863,7 +884,10 @@ class TensorWrapper(torch.Tensor):
                 routes[str(c)] = (lambda c_: lambda: be.conv3x3_ring(data, scratch, wpk, cout, grid_idx, mapping_exec, None, None, cfg=c_, stride=stride))(c)
             return be.time_routes(routes)
 
-        return fusion.conv3x3_plan(n_exec, bs, cin, cout, n_total, data.dtype, tuner, stride)
+        def candidates():
+            return be.conv3x3_candidates(n_exec, cin, cout, bs, data.element_size(), stride) if hasattr(be, "conv3x3_candidates") else []
+
+        return fusion.conv3x3_plan(n_exec, bs, cin, cout, n_total, data.dtype, tuner, stride, candidates=candidates)
 
     def _dense_pointwise_conv(self, args, kwargs):
         """conv2d on a dense (non-packed) TensorWrapper: 1x1 convs take the fused one-tap kernel; returns (result, pending) or None."""

@@ -183,6 +183,44 @@ __global__ __launch_bounds__(WG) void k_combine_copy(const typename VecOf<VB>::t
     nt_store(nt_load(blocks + off), out + v);
 }
 
+// The same pass as a hipGraph NODE.  A captured kernel node has frozen arguments, but the output of this op must be a fresh tensor
+// every frame (callers may keep every frame's result, reference core/tensorwrapper.py:421-433) and `prev` is last frame's output, so
+// both addresses change per replay.  This form reads them from a small device buffer the host refreshes with the frame's index
+// tables (the one H->D copy the frame has anyway): slots[0] = prev, slots[1] = out, slots[2] = optional timing record (below).
+// The launch then sits inside the frame's graph, directly behind the kernel that produced `blocks`, instead of starting cold behind
+// the graph's end-of-launch release fence as the one eager launch of the frame.
+//
+// Timing record (measurement only; NULL in production): hipGraph kernel nodes cannot carry start/stop events, so when slots[2] is
+// set every workgroup stamps the constant 100 MHz clock (s_memrealtime) into it: stamp[0] = min over workgroups of the entry time,
+// stamp[1] = max of the exit time.  bench.py hands every frame of the timed region its own record and reads them afterwards.
+template <int VB>
+__global__ __launch_bounds__(WG) void k_combine_copy_ind(const typename VecOf<VB>::type *__restrict__ blocks,
+                                                         const unsigned long long *__restrict__ slots,
+                                                         const int32_t *__restrict__ grid_idx, DenseGeom g)
+{
+    typedef typename VecOf<VB>::type V;
+    const V *prev = reinterpret_cast<const V *>(slots[0]);
+    V *__restrict__ out = reinterpret_cast<V *>(slots[1]);
+    unsigned long long *stamp = reinterpret_cast<unsigned long long *>(slots[2]);
+    if (stamp && threadIdx.x == 0) atomicMin(stamp, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    const long long prev_delta = prev - blocks;
+    const uint32_t v = min(blockIdx.x * WG + threadIdx.x, g.total - 1);
+    uint32_t r, xw, r2, y, n, c, gw, xv, gh, h;
+    fd_divmod(v, g.vprW, r, xw);
+    fd_divmod(r, g.H, r2, y);
+    fd_divmod(r2, g.C, n, c);
+    fd_divmod(xw, g.vpr, gw, xv);
+    fd_divmod(y, g.bs, gh, h);
+    const int32_t idx = grid_idx[(n * g.GH + gh) * g.GW + gw];
+    const uint32_t inner = (c * g.bs.d + h) * g.vpr.d + xv;
+    const long long off = idx >= 0 ? (long long)((uint32_t)idx * g.C.d * g.bs.d * g.vpr.d + inner) : prev_delta + (long long)v;
+    nt_store(nt_load(blocks + off), out + v);
+    if (stamp) {
+        __builtin_amdgcn_s_waitcnt(0);      // (the record wants the time the data left the wave, not the time the store was issued)
+        if (threadIdx.x == 0) atomicMax(stamp + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    }
+}
+
 // ------------------------------------------------------------------------------------------ border-ring transfer
 struct TransferGeom {
     FastDiv vpr, bs, C;
@@ -1832,6 +1870,7 @@ struct ProfState {
     long long launches[BC_OP_COUNT] = {0};
     double ms[BC_OP_COUNT] = {0};
     double bytes[BC_OP_COUNT] = {0};
+    double aux[BC_OP_COUNT] = {0};     // second per-op total (conv3x3: matrix FLOPs actually ISSUED -- the Winograd form issues 16/36 of the direct count)
 } g_prof;
 
 // When an op is being profiled its kernel is launched with hipExtLaunchKernelGGL, which attaches the start/stop events
@@ -1855,6 +1894,12 @@ struct ProfScope {
         }
         g_prof.bytes[op] += bytes;
         on = true;
+    }
+    void add_aux(double v) const
+    {
+        if (!on) return;
+        std::lock_guard<std::mutex> lk(g_prof.mu);
+        g_prof.aux[op] += v;
     }
     ~ProfScope()
     {
@@ -2348,7 +2393,9 @@ static int launch_conv3x3_v2(ProfScope &ps, void *out, const void *features, voi
 {
     ConvV2Args a{out, features, ring, wpk, grid_idx, mapping_exec, n_exec, Cin, Cout, GH, GW, bs, S, pr, ep, st,
                  ps.on ? 1 : 0, ps.rec.a, ps.rec.b, g_tune.conv2_cfg, g_tune.conv2_min_lds, g_tune.conv_stamps, -2};
+    const double direct_flops = 2.0 * n_exec * (double)(bs / S) * (bs / S) * (KS * KS) * (double)Cin * Cout;
     if (DT == BC_F32 && S == 1 && KS == 3 && a.force_cfg >= 0 && (a.force_cfg & 0x200)) {       // Winograd form (conv3x3_wino.inc)
+        ps.add_aux(direct_flops * 16.0 / 36.0);     // F(2x2,3x3): 16 multiplications per 2x2 outputs instead of 36
 #if defined(BC_MONO)
         const int rcw = conv_wino_run(a);
 #else
@@ -2357,6 +2404,7 @@ static int launch_conv3x3_v2(ProfScope &ps, void *out, const void *features, voi
         if (a.chosen >= 0) g_tune.conv_last_cfg = a.chosen;
         return rcw;
     }
+    ps.add_aux(direct_flops);
 #if defined(BC_MONO)
     const int rc = conv_v2_run<DT, S, KS>(a);
 #else
@@ -2443,6 +2491,33 @@ BC_EXPORT int bc_combine_copy(const void *blocks, const void *prev, void *out, c
         break;
     switch (vb) { BC_CC(16) BC_CC(8) BC_CC(4) BC_CC(2) BC_CC(1) }
 #undef BC_CC
+    return launch_status();
+}
+
+BC_EXPORT int bc_combine_copy_indirect(const void *blocks, const void *slots, const int32_t *grid_idx,
+                                       int N, int C, int H, int W, int bs, int E, int align, void *stream)
+{
+    int rc = check_dense(N, C, H, W, bs, E);
+    if (rc != BC_OK) return rc;
+    if (!blocks || !slots || !grid_idx) return BC_ERR_NULL;
+    if (align <= 0 || (align & (align - 1))) return BC_ERR_ALIGN;
+    if (!aligned(blocks, E) || !aligned(slots, 8)) return BC_ERR_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    // the dense maps' addresses are not known here: `align` is the caller's promise about them (any future prev / out)
+    const int vb = pick_vb((size_t)bs * E, {blocks, reinterpret_cast<const void *>((uintptr_t)(align > 16 ? 16 : align))});
+    DenseGeom g;
+    const uint32_t vpr = (uint32_t)((size_t)bs * E / vb), vprW = (uint32_t)((size_t)W * E / vb);
+    g.vprW = make_fd(vprW); g.H = make_fd(H); g.C = make_fd(C); g.vpr = make_fd(vpr); g.bs = make_fd(bs);
+    g.GH = H / bs; g.GW = W / bs;
+    g.total = (uint32_t)((uint64_t)N * C * H * vprW);
+    const int grid = grid_exact(g.total, 1);
+#define BC_CI(VB_)                                                                                             \
+    case VB_:                                                                                                  \
+        hipLaunchKernelGGL((k_combine_copy_ind<VB_>), dim3(grid), dim3(WG), 0, st, (const VecOf<VB_>::type *)blocks, \
+                           (const unsigned long long *)slots, grid_idx, g);                                    \
+        break;
+    switch (vb) { BC_CI(16) BC_CI(8) BC_CI(4) BC_CI(2) BC_CI(1) }
+#undef BC_CI
     return launch_status();
 }
 
@@ -2766,6 +2841,7 @@ BC_EXPORT int bc_conv3x3_ring_nhwc(void *out, const void *features, void *ring, 
         if (rc != BC_ERR_SHAPE || dtype != BC_F32) return rc;   // fp32 shapes the balanced kernel does not cover fall through
     }
     g_tune.conv_last_cfg = -1;
+    ps.add_aux(2.0 * n_exec * bs * bs * 9.0 * Cin * Cout);
     Epilogue ep{out_scale, out_shift, (const float *)out_add, out_relu};
     // workgroup = 32*WM pixels x 64 output channels.  64-pixel items halve the weight traffic and the halo overhead; 32-pixel
     // items balance better over the 256 CUs when there are few of them (measured, profiles/r01/kbench_conv_*.txt).
@@ -2826,6 +2902,8 @@ BC_EXPORT int bc_stem7x7s2_nhwc(void *out, const void *frame_state, const void *
         attr_set = true;
     }
     ProfScope ps(BC_OP_CONV3X3, 2.0 * n_exec * (bs / 2) * (bs / 2) * 147.0 * 64);
+    // issued: 7 row taps x a K segment of 24 (fp32, 11 of its 12 k pairs: the all-padding pair is skipped) / 32 (16-bit) instead of 21
+    ps.add_aux(2.0 * n_exec * (bs / 2) * (bs / 2) * (dtype == BC_F32 ? 154.0 : 224.0) * 64);
     const dim3 grid((unsigned)n_exec * g.patches_per_tile);
     if (dtype == BC_F32)
         BC_LAUNCH(ps, (k_stem7x7<BC_F32>), grid, dim3(512), lds, (hipStream_t)stream, (float *)out, (const float *)frame_state,
@@ -3185,7 +3263,17 @@ BC_EXPORT int bc_prof_reset(void)
         g_prof.launches[op] = 0;
         g_prof.ms[op] = 0;
         g_prof.bytes[op] = 0;
+        g_prof.aux[op] = 0;
     }
+    return BC_OK;
+}
+
+BC_EXPORT int bc_prof_read_aux(int op, double *total_aux)
+{
+    if (op < 0 || op >= BC_OP_COUNT) return BC_ERR_SHAPE;
+    if (!total_aux) return BC_ERR_NULL;
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    *total_aux = g_prof.aux[op];
     return BC_OK;
 }
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BC_ABI_VERSION 1
+#define BC_ABI_VERSION 2   /* 2: ring caches keep ACTIVATED values; round-2/3 entry points (conv / stem / policy / indirect scatter+copy) */
 
 enum {
     BC_OK = 0,
@@ -79,6 +79,19 @@ int bc_pad(void *out, const void *features, const void *transfer, const int32_t 
  * prev.  prev may be NULL only if every tile is executed. */
 int bc_combine_copy(const void *blocks, const void *prev, void *out, const int32_t *grid_idx,
                     int N, int C, int H, int W, int bs, int elem_size, void *stream);
+
+/* The same pass as a hipGraph node.  The op's contract makes `out` a fresh map every frame (the reference hands a new tensor to
+ * the caller, core/tensorwrapper.py:421-433) and `prev` the map of the frame before, but the arguments of a captured kernel node
+ * are frozen; this form therefore reads both addresses from device memory at run time:
+ *     slots (device, 8-byte aligned, 3 x uint64): [0] = prev, [1] = out, [2] = timing record or 0.
+ * The caller refreshes `slots` before every replay (the engine sends it with the frame's index tables: one H->D copy).
+ * `align` = power of two that every future prev / out address is a multiple of (>= 16 for full-width vectors).
+ * prev is never dereferenced when every tile is executed (it must still be a valid address or equal to out).
+ * Timing record (measurement only): two uint64 the caller initialises to {UINT64_MAX, 0}; the launch leaves
+ * {min workgroup entry, max workgroup exit} of the constant 100 MHz clock (s_memrealtime) in it -- graph kernel nodes
+ * cannot carry start / stop events. */
+int bc_combine_copy_indirect(const void *blocks, const void *slots, const int32_t *grid_idx,
+                             int N, int C, int H, int W, int bs, int elem_size, int align, void *stream);
 
 /* halo gather over a persistent ring cache.  `ring` is a (N*GH*GW, C, 4*pad*bs) device buffer owned by the
  * caller and kept across frames for one padded layer: per grid position and channel the four contiguous segments
@@ -327,6 +340,9 @@ const char *bc_op_name(int op);
 int bc_prof_enable(unsigned op_mask);
 int bc_prof_reset(void);
 int bc_prof_read(int op, long long *launches, double *total_ms, double *total_bytes);
+/* second total of the same launches; BC_OP_CONV3X3: matrix FLOPs actually ISSUED (total_bytes holds the FLOPs of the direct
+ * definition 2*px*k*k*Cin*Cout; the Winograd form issues 16/36 of them, the stem kernel its zero-padded K segments) */
+int bc_prof_read_aux(int op, double *total_aux);
 
 #ifdef __cplusplus
 }

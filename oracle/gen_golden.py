@@ -158,12 +158,16 @@ def scenario_grids(N, GH, GW, seed):
     return gs
 
 
-def gen_swiftnet(ref, tag, backbone, N, H, W, bs, n_frames, seed, store_frame_state):
+def gen_swiftnet(ref, tag, backbone, N, H, W, bs, n_frames, seed, store_frame_state, subsample=None):
+    """``subsample=(step, offsets)``: store ``logits[..., o::step, o::step]`` for every offset instead of the full map (full-size
+    clips: the lattices are chosen so that both border pixels of every logits tile are among the samples)."""
     grids = scenario_grids(N, H // bs, W // bs, seed)[:n_frames]
     model, _ = build_ref_swiftnet(ref, backbone, bs, grids)
     model.reset_temporal()
-    out = {"cfg": np.frombuffer(json.dumps(dict(backbone=backbone, N=N, H=H, W=W, block_size=bs, n_frames=n_frames,
-                                                frame_seed0=seed * 1000)).encode(), dtype=np.uint8)}
+    cfg = dict(backbone=backbone, N=N, H=H, W=W, block_size=bs, n_frames=n_frames, frame_seed0=seed * 1000)
+    if subsample is not None:
+        cfg["subsample"] = dict(step=subsample[0], offsets=list(subsample[1]))
+    out = {"cfg": np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8)}
     import warnings
     with torch.no_grad(), warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -171,7 +175,13 @@ def gen_swiftnet(ref, tag, backbone, N, H, W, bs, n_frames, seed, store_frame_st
             x = seeded.synthetic_frame(seed * 1000 + t, (N, 3, H, W))
             y = model(x)
             out[f"grid{t}"] = grids[t].numpy()
-            out[f"logits{t}"] = y.detach().numpy().copy()
+            if subsample is None:
+                out[f"logits{t}"] = y.detach().numpy().copy()
+            else:
+                for o in subsample[1]:
+                    out[f"logits{t}_o{o}"] = y.detach()[:, :, o::subsample[0], o::subsample[0]].numpy().copy()
+                out[f"logits{t}_absmax"] = np.float32(y.detach().abs().max())
+                out[f"logits{t}_chansum"] = y.detach().double().sum(dim=(0, 2, 3)).numpy()
             if store_frame_state:
                 out[f"frame_state{t}"] = model.policy_meta["frame_state"].detach().numpy().copy()
     np.savez_compressed(os.path.join(GOLD, f"swiftnet_{tag}.npz"), **out)
@@ -437,6 +447,20 @@ def gen_io_metrics(ref):
     print("io_metrics.npz", rels, "mIoU", res[-1]["Mean IoU"], "GMACs dense", g["dense_avg"] / 1e9, "block avg", g["block_avg"] / 1e9, g["exec"])
 
 
+def gen_swiftnet_rn18_c(ref):
+    """BASELINE config C2's TILE GEOMETRY (block 128: the stem on 128-px tiles, then 32x32 ... 4x4 tiles, the SPP on a
+    2x4 grid) at a size the CPU reference finishes in seconds: 256x512, grid 2x4, masks all / half / one / all-but-one /
+    none / quarter.  Build order as semantic_segmentation/test_swiftnet.py:104-115."""
+    gen_swiftnet(ref, "rn18_c", "resnet18", 1, 256, 512, 128, 6, 6, False)
+
+
+def gen_swiftnet_rn18_c2(ref):
+    """BASELINE config C2 at its FULL size through the reference: SwiftNet-RN18, 1x3x1024x2048, block 128 (grid 8x16), masks all /
+    64 of 128 / one / all-but-one.  The 10 MB logits map of a frame is stored as two 8-strided lattices (offsets 0 and 7: rows /
+    columns 0 and 31 of every 32x32 logits tile are sampled) plus its absolute maximum and per-class sums."""
+    gen_swiftnet(ref, "rn18_c2", "resnet18", 1, 1024, 2048, 128, 4, 8, False, subsample=(8, (0, 7)))
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     ref = ref_loader.load_reference()
@@ -456,6 +480,8 @@ def main():
     gen_swiftnet(ref, "rn18_b", "resnet18", 1, 256, 512, 64, 4, 5, False)
     gen_swiftnet(ref, "rn18_n2", "resnet18", 2, 128, 128, 32, 4, 9, False)
     gen_swiftnet(ref, "rn50_a", "resnet50", 1, 128, 256, 32, 3, 4, False)
+    gen_swiftnet_rn18_c(ref)
+    gen_swiftnet_rn18_c2(ref)
 
 
 if __name__ == "__main__":

@@ -76,6 +76,18 @@ class OracleBackend:
         out.copy_(tmp)
         return out
 
+    def combine_copy_indirect(self, blocks, slots, grid_idx, out_shape, targets=None):
+        """Checker form of the in-graph scatter+copy: the slot words must hold the addresses of ``targets`` (what the HIP kernel
+        would dereference); the arithmetic is combine_copy on those tensors."""
+        prev, out = targets
+        words = slots.tolist()
+        assert words[0] == prev.data_ptr() and words[1] == out.data_ptr(), "slot words do not point at this frame's prev / out maps"
+        assert tuple(out.shape) == tuple(out_shape)
+        if prev is out:      # start of a clip: every tile executed, prev never read
+            assert bool((grid_idx >= 0).all())
+            prev = torch.zeros_like(out)
+        return self.combine_copy(blocks, prev, out, grid_idx)
+
     def pad_ring(self, data_exec, ring, grid_idx, mapping_exec, pad, prologue=None):
         if _nhwc(data_exec):   # ring records are opaque to the host: the checker keeps its own (NCHW-style) convention
             return _like(self.pad_ring(data_exec.contiguous(), ring, grid_idx, mapping_exec, pad, prologue), data_exec)

@@ -38,7 +38,7 @@ def test_binding_covers_the_header(lib):
 
 
 def test_abi_version_and_strings(lib):
-    assert lib.bc_abi_version() == 1
+    assert lib.bc_abi_version() == 2     # 2: ring caches keep activated values; round-2/3 entry points
     assert lib.bc_error_string(0) == b"ok"
     assert b"NULL" in lib.bc_error_string(-1)
     assert [lib.bc_op_name(i).decode() for i in range(11)] == ["split", "combine", "transfer", "pad", "combine_copy", "pad_ring", "grid_tables", "interp", "affine", "nms", "conv3x3"]
@@ -56,6 +56,8 @@ def test_argument_validation_needs_no_gpu(lib):
     assert lib.bc_split(N, N, N, 0, 1, 3, 8, 8, 4, 4, N) == 0            # nothing to do
     assert lib.bc_combine(N, N, N, 4, 1, 1 << 12, 1 << 10, 1 << 10, 4, 4, N) == -4   # >= 2^31 elements
     assert lib.bc_combine_copy(N, N, N, N, 1, 3, 8, 8, 4, 4, N) == -1
+    assert lib.bc_combine_copy_indirect(N, N, N, 1, 3, 8, 8, 4, 4, 256, N) == -1
+    assert lib.bc_combine_copy_indirect(N, N, N, 1, 3, 8, 10, 4, 4, 256, N) == -2
     assert lib.bc_transfer(N, N, N, N, 3, 1, 3, 2, 2, 4, 1, 4, N) == -1
     assert lib.bc_transfer(N, N, N, N, 0, 1, 3, 2, 2, 4, 1, 4, N) == 0
     assert lib.bc_pad(N, N, N, N, N, 2, 1, 3, 2, 2, 4, 0, 4, N) == -2     # pad < 1

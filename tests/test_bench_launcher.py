@@ -80,3 +80,52 @@ def test_launcher_parent_never_imports_torch():
     r = _run([sys.executable, "-c", code])
     assert r.returncode == 0, r.stderr[-2000:]
     assert len(_json_lines(r.stdout)) == 1
+
+
+def test_eight_replicas_get_disjoint_cores_and_private_miopen_dirs(tmp_path):
+    """The 8-GPU shape of the launcher (stub workload): every rank pins itself to its own slice of the host cores and gets its
+    own MIOpen user-db / cache directory BEFORE torch is imported; rank 0's line carries per-rank fps with min / max."""
+    r = _run([sys.executable, BENCH, "--gpus", "8", "--steps", "1", "--warmup", "0", "--stub-cpu"], env={"BC_BENCH_MIOPEN_DIR": str(tmp_path)}, timeout=400)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = _json_lines(r.stdout)[0]
+    assert out["n_gpus"] == 8 and out["config"]["frames_total"] == 8 * 20
+    pr = out["per_rank_fps"]
+    assert len(pr["all"]) == 8 and pr["min"] <= pr["max"] and pr["min"] > 0
+    firsts = out["rank_env"]["first_core_of_each_rank"]
+    n_cores = len(os.sched_getaffinity(0))
+    if n_cores >= 8:
+        assert len(set(firsts)) == 8, firsts          # disjoint slices
+    assert out["rank_env"]["MIOPEN_USER_DB_PATH"].startswith(str(tmp_path)) and out["rank_env"]["MIOPEN_USER_DB_PATH"].endswith("rank0/db")
+    for rank in range(8):
+        assert os.path.isdir(tmp_path / f"rank{rank}" / "db") and os.path.isdir(tmp_path / f"rank{rank}" / "cache")
+
+
+def test_sigterm_to_the_launcher_stops_the_workers():
+    """A driver timeout ends the launcher with SIGTERM: the workers (own sessions) must not be orphaned holding GPUs."""
+    import signal
+
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    p = subprocess.Popen([sys.executable, BENCH, "--gpus", "2", "--steps", "100000", "--warmup", "0", "--stub-cpu"], env=e, cwd=ROOT,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+
+    def workers():
+        out = subprocess.run(["ps", "-eo", "pid,ppid,args"], capture_output=True, text=True).stdout.splitlines()
+        return [int(l.split()[0]) for l in out if len(l.split()) > 2 and l.split()[1] == str(p.pid) and "bench.py" in l]
+
+    deadline = time.time() + 60
+    while time.time() < deadline and len(workers()) < 2:
+        time.sleep(0.2)
+    kids = workers()
+    assert len(kids) == 2, kids
+    time.sleep(1.0)
+    p.send_signal(signal.SIGTERM)
+    p.wait(timeout=60)
+    assert p.returncode != 0
+    deadline = time.time() + 30
+    alive = kids
+    while time.time() < deadline and alive:
+        alive = [k for k in alive if os.path.exists(f"/proc/{k}") and "zombie" not in open(f"/proc/{k}/status").read().lower()]
+        time.sleep(0.2)
+    assert not alive, f"workers survived the launcher: {alive}"

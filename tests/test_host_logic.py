@@ -102,7 +102,7 @@ def test_tinynet_matches_reference(golden_dir, oracle_backend, engine):
 
 
 @pytest.mark.parametrize("engine", ["fused", "reference"])
-@pytest.mark.parametrize("name", ["swiftnet_rn18_a.npz", "swiftnet_rn18_n2.npz", "swiftnet_rn50_a.npz"])
+@pytest.mark.parametrize("name", ["swiftnet_rn18_a.npz", "swiftnet_rn18_n2.npz", "swiftnet_rn50_a.npz", "swiftnet_rn18_c.npz"])
 def test_swiftnet_matches_reference_on_cpu(golden_dir, oracle_backend, name, engine):
     """Whole SwiftNet clip through OUR BlockCopyModel/TensorWrapper/SwiftNet/BN-fold vs the reference's logits.
     Includes an all-skipped frame (num_exec == 0 returns the cached output) and single-tile / all-but-one masks."""

@@ -199,3 +199,36 @@ def test_deferred_conv_input_modified_in_place_is_a_loud_error(oracle_backend):
             z.combine()
     finally:
         fusion.CONV_MODE = prev_mode
+
+
+def test_unconsumed_deferred_conv_still_refreshes_its_ring(oracle_backend):
+    """a deferred fused conv takes its layer's ring cache when it is RECORDED but refreshes it when it is
+    LAUNCHED; a result nobody consumes must still be launched by the end of the frame body (BlockFeatures.flush_deferred),
+    or later frames that skip those tiles would gather stale halo records for the layer."""
+    from blockcopy.core import fusion
+
+    w1 = torch.randn(8, 8, 3, 3, generator=torch.Generator().manual_seed(3)) * 0.1
+    prev_mode, fusion.CONV_MODE = fusion.CONV_MODE, "native"
+    try:
+        blk = _packed()
+        feats = blk.get_features()
+        y = F.conv2d(blk, w1, None, 1, 1)
+        assert y._pending is not None and y._pending.conv is not None and len(feats._deferred) == 1
+        ring = feats.rings[0]
+        ring.fill_(float("nan"))
+        del y                                            # the value is never asked for
+        assert feats.flush_deferred() == 1 and not feats._deferred
+        assert torch.isfinite(ring).all()                # every tile was executed: every record refreshed
+        # consumed results are not launched twice
+        blk2 = _packed()
+        z = F.conv2d(blk2, w1, None, 1, 1)
+        z.combine()
+        assert blk2.get_features().flush_deferred() == 0
+        # and the flush honours the in-place guard of the deferred input
+        blk3 = _packed()
+        u = F.conv2d(blk3, w1, None, 1, 1)
+        blk3.as_subclass(torch.Tensor).mul_(2.0)
+        with pytest.raises(RuntimeError, match="modified in place"):
+            blk3.get_features().flush_deferred()
+    finally:
+        fusion.CONV_MODE = prev_mode
