@@ -109,6 +109,7 @@ def load_library(path: str = None) -> ctypes.CDLL:
         "bc_combine": [p, p, p] + [i] * 7 + [p],
         "bc_combine_copy": [p, p, p, p] + [i] * 6 + [p],
         "bc_combine_copy_indirect": [p, p, p] + [i] * 7 + [p],
+        "bc_combine_copy_cells": [p] + [i] * 7,
         "bc_transfer": [p, p, p, p] + [i] * 8 + [p],
         "bc_pad": [p, p, p, p, p] + [i] * 8 + [p],
         "bc_pad_ring": [p, p, p, p, p] + [i] * 8 + [p],
@@ -287,6 +288,16 @@ class HipBackend:
             # torch's caching allocator hands out 512-byte aligned blocks; the maps are whole allocations
             self._check(self.lib.bc_combine_copy_indirect(blocks.data_ptr(), slots.data_ptr(), grid_idx.data_ptr(), N, Ck, H, W, bs, Ek, 256,
                                                           self._stream()), "combine_copy_indirect")
+
+    def combine_copy_cells(self, blocks, out_shape):
+        """Timing cells (16 bytes each) one bc_combine_copy_indirect launch of this geometry writes when slot word 2 is set."""
+        N, C, H, W = out_shape
+        bs = blocks.shape[2]
+        Ck, Ek = (1, C * blocks.element_size()) if is_nhwc(blocks) else (C, blocks.element_size())
+        n = self.lib.bc_combine_copy_cells(blocks.data_ptr(), N, Ck, H, W, bs, Ek, 256)
+        if n < 0:
+            self._check(n, "combine_copy_cells")
+        return n
 
     def pad_ring(self, data_exec, ring, grid_idx, mapping_exec, pad, prologue=None):
         """halo gather over the persistent ring cache (+ refresh of the executed tiles' rings).

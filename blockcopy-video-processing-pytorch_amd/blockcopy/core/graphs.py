@@ -66,6 +66,7 @@ class GraphedFrame:
         self.prev_out = None      # previous frame's dense output (None at the start of a clip)
         self.frame_state = None
         self.out_meta = None      # (shape, dtype, channels-last) of the dense output map, known after the first frame
+        self.out_blocks_like = None   # a packed output tensor of some frame (geometry / alignment template for the timing cells)
         self.cur_out = None       # this frame's output map (allocated before the replay that fills it)
         self._combined = False    # the body that just ran has filled cur_out
         self.stamps = None        # measurement: device uint64 (K, 2) timing records of the in-graph scatter+copy, one per frame
@@ -115,16 +116,17 @@ class GraphedFrame:
         prev = self.prev_out if self.prev_out is not None else out     # start of a clip: every tile is executed, prev is never read
         stamp = 0
         if self.stamps is not None and self.stamp_pos < self.stamps.shape[0]:
-            stamp = self.stamps.data_ptr() + 16 * self.stamp_pos
+            stamp = self.stamps.data_ptr() + 16 * self.stamps.shape[1] * self.stamp_pos
             self.stamp_pos += 1
         return (prev.data_ptr(), out.data_ptr(), stamp)
 
     # ------------------------------------------------------------------ measurement of the in-graph scatter+copy
     def timing_start(self, capacity: int):
         """Give each of the next ``capacity`` frames a timing record for its in-graph scatter+copy launch."""
-        st = torch.zeros((capacity, 2), dtype=torch.int64, device=self.device)
-        st[:, 0] = -1            # UINT64_MAX: the kernel keeps the minimum entry time
-        self.stamps, self.stamp_pos = st, 0
+        if self.out_meta is None or self.out_blocks_like is None:
+            return
+        cells = get_backend().combine_copy_cells(self.out_blocks_like, self.out_meta[0])
+        self.stamps, self.stamp_pos = torch.zeros((capacity, cells, 2), dtype=torch.int64, device=self.device), 0
 
     def timing_read(self):
         """(durations in microseconds of the recorded launches, algorithmic bytes per launch); synchronises."""
@@ -133,8 +135,8 @@ class GraphedFrame:
         torch.cuda.synchronize(self.device)
         st = self.stamps[:self.stamp_pos].cpu().numpy()
         self.stamps = None
-        ok = (st[:, 0] != -1) & (st[:, 1] != 0)
-        ticks = (st[ok, 1].astype(np.uint64) - st[ok, 0].astype(np.uint64)).astype(np.float64)
+        ok = st[:, 0, 1] != 0                      # frames whose graph ended with the node (cell 0 written)
+        ticks = (st[ok, :, 1].max(axis=1) - st[ok, :, 0].min(axis=1)).astype(np.float64)
         shape, dtype, _ = self.out_meta
         nbytes = 2.0 * float(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
         return list(ticks * 0.01), nbytes      # s_memrealtime: constant 100 MHz
@@ -160,6 +162,7 @@ class GraphedFrame:
             feats.flush_deferred()
             N, _, GH, GW = self.grid_shape
             self.out_meta = ((N, plain.shape[1], GH * plain.shape[2], GW * plain.shape[3]), plain.dtype, is_nhwc(plain))
+            self.out_blocks_like = plain
             if self.cur_out is not None and tuple(self.cur_out.shape) == self.out_meta[0] and self.cur_out.dtype == plain.dtype:
                 # final out-of-place combine as part of the body: prev / out addresses come from the slot words of this frame
                 prev = self.prev_out if self.prev_out is not None else self.cur_out

@@ -191,8 +191,10 @@ __global__ __launch_bounds__(WG) void k_combine_copy(const typename VecOf<VB>::t
 // the graph's end-of-launch release fence as the one eager launch of the frame.
 //
 // Timing record (measurement only; NULL in production): hipGraph kernel nodes cannot carry start/stop events, so when slots[2] is
-// set every workgroup stamps the constant 100 MHz clock (s_memrealtime) into it: stamp[0] = min over workgroups of the entry time,
-// stamp[1] = max of the exit time.  bench.py hands every frame of the timed region its own record and reads them afterwards.
+// set, wave 0 of every workgroup stores {entry time, time its store was acknowledged} of the constant 100 MHz clock
+// (s_memrealtime) into its own 16-byte cell stamp[blockIdx.x] -- plain stores, 78 KB per 19.9 MB launch.  (A first version kept
+// min / max with two atomics per workgroup: ~10 k same-address device-scope atomics stretched the 6 us launch to 55 us.)
+// bench.py hands every frame of the timed region its own record and reduces min(entry) / max(exit) afterwards.
 template <int VB>
 __global__ __launch_bounds__(WG) void k_combine_copy_ind(const typename VecOf<VB>::type *__restrict__ blocks,
                                                          const unsigned long long *__restrict__ slots,
@@ -201,8 +203,9 @@ __global__ __launch_bounds__(WG) void k_combine_copy_ind(const typename VecOf<VB
     typedef typename VecOf<VB>::type V;
     const V *prev = reinterpret_cast<const V *>(slots[0]);
     V *__restrict__ out = reinterpret_cast<V *>(slots[1]);
-    unsigned long long *stamp = reinterpret_cast<unsigned long long *>(slots[2]);
-    if (stamp && threadIdx.x == 0) atomicMin(stamp, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    ulonglong2 *stamp = reinterpret_cast<ulonglong2 *>(slots[2]);
+    unsigned long long t0 = 0;
+    if (stamp) t0 = __builtin_amdgcn_s_memrealtime();
     const long long prev_delta = prev - blocks;
     const uint32_t v = min(blockIdx.x * WG + threadIdx.x, g.total - 1);
     uint32_t r, xw, r2, y, n, c, gw, xv, gh, h;
@@ -215,9 +218,9 @@ __global__ __launch_bounds__(WG) void k_combine_copy_ind(const typename VecOf<VB
     const uint32_t inner = (c * g.bs.d + h) * g.vpr.d + xv;
     const long long off = idx >= 0 ? (long long)((uint32_t)idx * g.C.d * g.bs.d * g.vpr.d + inner) : prev_delta + (long long)v;
     nt_store(nt_load(blocks + off), out + v);
-    if (stamp) {
-        __builtin_amdgcn_s_waitcnt(0);      // (the record wants the time the data left the wave, not the time the store was issued)
-        if (threadIdx.x == 0) atomicMax(stamp + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    if (stamp && threadIdx.x < 64) {
+        __builtin_amdgcn_s_waitcnt(0);      // (the record wants the time the data was accepted by memory, not the issue time)
+        if (threadIdx.x == 0) stamp[blockIdx.x] = make_ulonglong2(t0, (unsigned long long)__builtin_amdgcn_s_memrealtime());
     }
 }
 
@@ -2519,6 +2522,15 @@ BC_EXPORT int bc_combine_copy_indirect(const void *blocks, const void *slots, co
     switch (vb) { BC_CI(16) BC_CI(8) BC_CI(4) BC_CI(2) BC_CI(1) }
 #undef BC_CI
     return launch_status();
+}
+
+BC_EXPORT int bc_combine_copy_cells(const void *blocks, int N, int C, int H, int W, int bs, int E, int align)
+{
+    int rc = check_dense(N, C, H, W, bs, E);
+    if (rc != BC_OK) return rc;
+    if (align <= 0 || (align & (align - 1))) return BC_ERR_ALIGN;
+    const int vb = pick_vb((size_t)bs * E, {blocks, reinterpret_cast<const void *>((uintptr_t)(align > 16 ? 16 : align))});
+    return grid_exact((uint64_t)N * C * H * ((size_t)W * E / vb), 1);
 }
 
 BC_EXPORT int bc_transfer(void *out, const void *prev_computed, const void *prev_transfer,

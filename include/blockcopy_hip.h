@@ -87,11 +87,13 @@ int bc_combine_copy(const void *blocks, const void *prev, void *out, const int32
  * The caller refreshes `slots` before every replay (the engine sends it with the frame's index tables: one H->D copy).
  * `align` = power of two that every future prev / out address is a multiple of (>= 16 for full-width vectors).
  * prev is never dereferenced when every tile is executed (it must still be a valid address or equal to out).
- * Timing record (measurement only): two uint64 the caller initialises to {UINT64_MAX, 0}; the launch leaves
- * {min workgroup entry, max workgroup exit} of the constant 100 MHz clock (s_memrealtime) in it -- graph kernel nodes
- * cannot carry start / stop events. */
+ * Timing record (measurement only): an array of ceil(vectors / 256) cells of two uint64 (bc_combine_copy_cells gives the
+ * count); workgroup i leaves {its entry time, the time its store was acknowledged} of the constant 100 MHz clock
+ * (s_memrealtime) in cell i -- graph kernel nodes cannot carry start / stop events; launch time = max(exit) - min(entry). */
 int bc_combine_copy_indirect(const void *blocks, const void *slots, const int32_t *grid_idx,
                              int N, int C, int H, int W, int bs, int elem_size, int align, void *stream);
+/* number of timing cells (= workgroups) such a launch writes, or a negative error code */
+int bc_combine_copy_cells(const void *blocks, int N, int C, int H, int W, int bs, int elem_size, int align);
 
 /* halo gather over a persistent ring cache.  `ring` is a (N*GH*GW, C, 4*pad*bs) device buffer owned by the
  * caller and kept across frames for one padded layer: per grid position and channel the four contiguous segments

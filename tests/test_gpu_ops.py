@@ -89,6 +89,23 @@ def test_split_combine_combine_copy(be, case, dtype):
         be.combine_copy(_dev(blocks), _dev(prev), fused, _dev(gi))
         assert torch.equal(fused.cpu(), want_out)
 
+        # the hipGraph-node form: prev / out addresses (and an optional timing record) read from device slot words
+        for cl in (False, True):
+            lay = (lambda t: t.contiguous(memory_format=torch.channels_last)) if cl else (lambda t: t)
+            d_blocks, d_prev = lay(_dev(blocks)), lay(_dev(prev))
+            if len(m) == 0:
+                continue
+            d_out = lay(torch.full((N, C, H, W), 5.0, dtype=dtype).cuda())
+            cells = be.combine_copy_cells(d_blocks, (N, C, H, W))
+            stamps = torch.zeros((cells, 2), dtype=torch.int64, device="cuda")
+            for rec in (0, stamps.data_ptr()):
+                d_out.fill_(5.0)
+                slots = torch.tensor([d_prev.data_ptr(), d_out.data_ptr(), rec], dtype=torch.int64).cuda()
+                be.combine_copy_indirect(d_blocks, slots, _dev(gi), (N, C, H, W))
+                assert torch.equal(d_out.cpu(), want_out), (cl, rec != 0)
+            st = stamps.cpu().numpy()
+            assert (st[:, 0] > 0).all() and (st[:, 1] >= st[:, 0]).all()      # every workgroup left its entry / exit time
+
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", CASES)
