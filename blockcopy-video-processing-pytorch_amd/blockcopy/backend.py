@@ -20,7 +20,7 @@ _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("BLOCKCOPY_HIP_LIB", os.path.join(_PKG_ROOT, "lib", "libblockcopy_hip.so"))
 
 OP_SPLIT, OP_COMBINE, OP_TRANSFER, OP_PAD, OP_COMBINE_COPY, OP_PAD_RING, OP_GRID_TABLES, OP_INTERP, OP_AFFINE = range(9)
-OP_NAMES = ("split", "combine", "transfer", "pad", "combine_copy", "pad_ring", "grid_tables", "interp", "affine", "nms", "conv3x3")
+OP_NAMES = ("split", "combine", "transfer", "pad", "combine_copy", "pad_ring", "grid_tables", "interp", "affine", "nms", "conv3x3", "head1x1")
 _DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 ABI_VERSION = 2
 
@@ -110,6 +110,7 @@ def load_library(path: str = None) -> ctypes.CDLL:
         "bc_combine_copy": [p, p, p, p] + [i] * 6 + [p],
         "bc_combine_copy_indirect": [p, p, p] + [i] * 7 + [p],
         "bc_combine_copy_cells": [p] + [i] * 7,
+        "bc_head1x1_scatter_nhwc": [p] * 7 + [i] * 8 + [p, p, i, p, i, p],
         "bc_transfer": [p, p, p, p] + [i] * 8 + [p],
         "bc_pad": [p, p, p, p, p] + [i] * 8 + [p],
         "bc_pad_ring": [p, p, p, p, p] + [i] * 8 + [p],
@@ -554,6 +555,72 @@ class HipBackend:
                 self._check(self.lib.bc_conv1x1_nhwc(out.data_ptr(), data.data_ptr(), wpk.data_ptr(), n_tiles, C, cout, bs, int(stride),
                                                      _DTYPE_CODE[data.dtype], ptr(isc), ptr(ish), int(bool(irelu)), ptr(osc), ptr(osh),
                                                      ptr(oadd), int(bool(orelu)), self._stream()), "conv1x1_nhwc")
+        return out
+
+    # -- the network's last stage: activation prologue + pointwise conv to <= 32 channels (+ out-of-place combine), csrc/head1x1.inc
+    @staticmethod
+    def head1x1_supported(data, weight, stride=1, padding=0, dilation=1, groups=1):
+        def _one(v):
+            return v if isinstance(v, int) else (v[0] if len(set(v)) == 1 else None)
+        if data.dim() != 4 or weight.dim() != 4 or _one(stride) != 1 or _one(padding) != 0 or _one(dilation) != 1 or groups != 1:
+            return False
+        cin_ok = (64, 128) if data.dtype == torch.float32 else (64, 128, 256)
+        bs = data.shape[2]
+        return (data.is_cuda and data.dtype in _DTYPE_CODE and weight.dtype == data.dtype and is_nhwc(data) and tuple(weight.shape[2:]) == (1, 1)
+                and weight.shape[1] == data.shape[1] and data.shape[1] in cin_ok and 1 <= weight.shape[0] <= 32 and data.shape[2] == data.shape[3]
+                and bs % 8 == 0 and (bs <= 32 or bs % 32 == 0))
+
+    def pack_head1x1_weights(self, weight):
+        """(Cout <= 32, Cin, 1, 1) -> the one-tap operand stream of bc_head1x1_scatter_nhwc: zero-padded to 32 output channels."""
+        w = weight.detach().as_subclass(torch.Tensor)
+        full = torch.zeros((32, w.shape[1], 1, 1), dtype=w.dtype, device=w.device)
+        full[:w.shape[0]] = w
+        return self.pack_conv3x3_weights(full)
+
+    def _head_launch(self, out, data, wpk, cout, prologue, bias, scatter, grid_idx=None, mapping_exec=None, prev=None, slots=None):
+        B, C, bs, _ = data.shape
+        isc, ish, irelu = prologue if prologue is not None else (None, None, False)
+        for v, n in ((isc, C), (ish, C), (bias, cout)):
+            assert v is None or (_ok(v, torch.float32) and v.numel() == n)
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        if scatter:
+            N, _, GH, GW = grid_idx.shape
+        else:
+            N, GH, GW = 1, 1, max(B, 1)
+        with torch.cuda.device_of(data):
+            self._check(self.lib.bc_head1x1_scatter_nhwc(ptr(out), data.data_ptr() if B else None, wpk.data_ptr(), ptr(prev), ptr(slots), ptr(grid_idx),
+                                                         ptr(mapping_exec), B, N, C, cout, GH, GW, bs, _DTYPE_CODE[data.dtype], ptr(isc), ptr(ish),
+                                                         int(bool(irelu)), ptr(bias), int(bool(scatter)), self._stream()), "head1x1_scatter_nhwc")
+
+    def head1x1(self, data, wpk, cout, prologue=None, epilogue=None, cfg=None, stride=1):
+        """Packed tiles (B, cout, bs, bs) channels-last = conv1x1(prologue(data)) [+ epilogue]; a per-channel shift (the conv bias) runs
+        inside the kernel, anything else recorded after the conv as one bc_affine_act pass on the small result."""
+        assert _ok(data, *_DTYPE_CODE) and is_nhwc(data) and _ok(wpk, data.dtype) and stride == 1
+        B, C, bs, _ = data.shape
+        out = torch.empty((B, cout, bs, bs), dtype=data.dtype, device=data.device, memory_format=torch.channels_last)
+        osc, osh, oadd, orelu = epilogue if epilogue is not None else (None, None, None, False)
+        bias_only = osc is None and oadd is None and not orelu
+        if B > 0:
+            self._head_launch(out, data, wpk, cout, prologue, osh if bias_only else None, False)
+        if not bias_only:
+            out = self.affine_act(out, osc, osh, oadd, orelu)
+        return out
+
+    def head1x1_scatter(self, data, wpk, cout, prologue, bias, grid_idx, mapping_exec, prev=None, out=None, slots=None, targets=None):
+        """The fresh dense map (N, cout, H, W) channels-last <- executed tiles conv1x1(prologue(data)) + bias at their grid positions,
+        skipped tiles from ``prev``.  Either ``out`` (+ ``prev`` unless every tile is executed) or ``slots`` (hipGraph node: device
+        int64 words [prev address, out address, ...]; ``targets`` = the tensors behind them, for checker backends only)."""
+        assert _ok(data, *_DTYPE_CODE) and is_nhwc(data) and _ok(wpk, data.dtype) and _ok(grid_idx, torch.int32) and _ok(mapping_exec, torch.int32)
+        B, C, bs, _ = data.shape
+        N, _, GH, GW = grid_idx.shape
+        assert mapping_exec.numel() == B
+        if slots is None:
+            assert out is not None and tuple(out.shape) == (N, cout, GH * bs, GW * bs) and out.dtype == data.dtype and (is_nhwc(out) or cout == 1)
+            assert prev is None or (prev.shape == out.shape and prev.dtype == out.dtype and is_nhwc(prev) == is_nhwc(out) and prev.data_ptr() != out.data_ptr())
+            assert prev is not None or B == N * GH * GW, "skipped tiles need the previous frame's map"
+        else:
+            assert _ok(slots, torch.int64) and slots.numel() >= 2
+        self._head_launch(out if slots is None else None, data, wpk, cout, prologue, bias, True, grid_idx, mapping_exec, prev if slots is None else None, slots)
         return out
 
     # -- adaptive average pooling of dense channels-last maps (pyramid pooling)

@@ -151,6 +151,7 @@ POINTWISE = os.environ.get("BLOCKCOPY_POINTWISE", "1") != "0"     # 1x1 convs th
 GROUP_NORM = os.environ.get("BLOCKCOPY_GROUP_NORM", "1") != "0"   # group_norm on packed tiles as a recorded per-channel affine map (one stats pass)
 ADAPTIVE_POOL = os.environ.get("BLOCKCOPY_ADAPTIVE_POOL", "1") != "0"   # adaptive_avg_pool2d of dense channels-last maps (pyramid pooling) in the library's kernel
 STEM_KERNEL = os.environ.get("BLOCKCOPY_STEM", "1") != "0"        # network input: window gather + 7x7 stem conv in one kernel
+HEAD_KERNEL = os.environ.get("BLOCKCOPY_HEAD", "1") != "0"        # network output: prologue + 1x1 conv to <= 32 channels + out-of-place combine in one kernel
 CONV_TUNE_LOG = []    # (key, {candidate: microseconds}, choice) of every measurement, for the bench report
 WINOGRAD_FLAG = 0x200  # decomposition codes with this bit run the Winograd F(2x2,3x3) form (csrc/conv3x3_wino.inc)
 

@@ -158,14 +158,25 @@ class GraphedFrame:
         frame_state = blocks.combine_()._plain()
         out = base_model(blocks, **kwargs)
         if isinstance(out, TensorWrapper) and out.is_blocks:
+            head = out._head_record()      # network output stage still deferred: prologue + 1x1 conv + bias + combine in one launch
+            like = out._raw()              # (a deferred producer's placeholder has the result's shape, dtype and layout)
+            N, _, GH, GW = self.grid_shape
+            self.out_meta = ((N, like.shape[1], GH * like.shape[2], GW * like.shape[3]), like.dtype, is_nhwc(like) or head is not None)
+            ready = self.cur_out is not None and tuple(self.cur_out.shape) == self.out_meta[0] and self.cur_out.dtype == like.dtype
+            prev = self.prev_out if self.prev_out is not None else self.cur_out
+            if ready and head is not None:
+                kw, bias, state = head
+                get_backend().head1x1_scatter(kw["data"], kw["wpk"], kw["cout"], kw["prologue"], bias, self.grid_idx, feats._mapping_exec,
+                                              slots=self.slots, targets=(prev, self.cur_out))
+                state["launched"] = True
+                self.out_blocks_like = None
+                feats.flush_deferred()
+                return like, frame_state, True
             plain = out._plain()
             feats.flush_deferred()
-            N, _, GH, GW = self.grid_shape
-            self.out_meta = ((N, plain.shape[1], GH * plain.shape[2], GW * plain.shape[3]), plain.dtype, is_nhwc(plain))
             self.out_blocks_like = plain
-            if self.cur_out is not None and tuple(self.cur_out.shape) == self.out_meta[0] and self.cur_out.dtype == plain.dtype:
+            if ready:
                 # final out-of-place combine as part of the body: prev / out addresses come from the slot words of this frame
-                prev = self.prev_out if self.prev_out is not None else self.cur_out
                 get_backend().combine_copy_indirect(plain, self.slots, self.grid_idx, self.out_meta[0], targets=(prev, self.cur_out))
                 return plain, frame_state, True
             return plain, frame_state, False          # (first frame ever: geometry unknown until now) combined eagerly by finish()

@@ -409,6 +409,15 @@ class TensorWrapper(torch.Tensor):
             self.data = out
         return self
 
+    def _head_record(self):
+        """(launch kwargs, bias, state) when this packed tensor is the not-yet-launched output stage of the network (deferred
+        bc_head1x1 conv whose recorded epilogue is at most a per-channel shift), else None."""
+        P = self._pending
+        if P is None or P.conv is None or not P.conv[2].get("head") or P.scale is not None or P.add is not None or P.relu or P.interp is not None:
+            return None
+        P.check_source()
+        return P.conv[1], P.shift, P.conv[2]
+
     def _sibling(self, pending) -> "TensorWrapper":
         """New TensorWrapper over the same stored data with its own pending record."""
         with _NoDispatch():
@@ -491,6 +500,22 @@ class TensorWrapper(torch.Tensor):
             _, C, BS, _ = self.shape
             N, _, GH, GW = grid_idx.shape
             out_shape = (N, C, GH * BS, GW * BS)
+            head = None if inplace else self._head_record()
+            if head is not None and self._features.persistent is None and self._features.engine == "fused":
+                # the network's output stage: prologue + pointwise conv + bias + out-of-place combine in ONE launch (csrc/head1x1.inc)
+                kw, bias, state = head
+                raw = self._raw()
+                if self._features_prev:
+                    prev = self._features_prev.get_features_full()
+                    assert out_shape == tuple(prev.shape), (out_shape, prev.shape)
+                else:
+                    prev = None
+                    assert mapping_exec.numel() == grid_idx.numel()
+                out = torch.empty(out_shape, dtype=raw.dtype, device=raw.device, memory_format=torch.channels_last)
+                get_backend().head1x1_scatter(kw["data"], kw["wpk"], kw["cout"], kw["prologue"], bias, grid_idx, mapping_exec, prev=prev, out=out)
+                state["launched"] = True
+                self._features.store_features_full(out)
+                return self._wrap_like(out, self, False)
             if self._pending is not None:
                 self._materialize()
             blocks = dense_layout(self.as_subclass(torch.Tensor))
@@ -916,6 +941,28 @@ class TensorWrapper(torch.Tensor):
         cv = {k: kwargs.get(k, args[i] if len(args) > i else d) for k, i, d in (("stride", 3, 1), ("dilation", 5, 1), ("groups", 6, 1))}
         stride = self._conv_stride(args, kwargs)
         raw = x._raw()
+        if (fusion.HEAD_KERNEL and fusion.DEFER_CONV and x._is_blocks and hasattr(be, "head1x1") and weight.shape[0] <= 32
+                and be.head1x1_supported(raw, weight, cv["stride"], 0, cv["dilation"], cv["groups"])
+                and raw.dtype in getattr(be, "supports_fusion_dtypes", ())):
+            # the network's output stage (few output channels): deferred like every fused conv; if the value is consumed by an
+            # out-of-place combine -- the normal end of a frame -- prologue, conv, bias and scatter+copy are ONE launch (combine())
+            P = x._pending
+            prologue = None
+            if P is not None and P.add is None and not P.deferred:
+                prologue = (P.scale, P.shift, P.relu)
+            elif P is not None:
+                x._materialize()
+            if pend_out is None and bias is not None:
+                pend_out = fusion.Pending(shift=fusion.channel_vector(bias))
+            data = dense_layout(x._raw())
+            wpk = fusion.packed_conv3x3_weight(weight, be.pack_head1x1_weights)
+            cout = weight.shape[0]
+            placeholder = torch.empty((data.shape[0], cout, data.shape[2], data.shape[3]), dtype=data.dtype, device=data.device,
+                                      memory_format=torch.channels_last)
+            Pn = pend_out if pend_out is not None else fusion.Pending()
+            Pn.defer_conv(be.head1x1, dict(data=data, wpk=wpk, cout=cout, prologue=prologue), data)
+            Pn.conv[2]["head"] = True
+            return placeholder, Pn
         if not be.conv1x1_supported(raw, weight, cv["stride"], 0, cv["dilation"], cv["groups"]):
             return None
         P = x._pending

@@ -2104,6 +2104,7 @@ int check_halo(const void *out, const void *features, const int32_t *grid_idx, c
 #include "conv3x3_v2.inc"
 #include "conv3x3_wino.inc"
 #include "stem7x7.inc"
+#include "head1x1.inc"
 
 }  // namespace
 
@@ -2437,7 +2438,7 @@ BC_EXPORT const char *bc_error_string(int code)
 
 BC_EXPORT const char *bc_op_name(int op)
 {
-    static const char *names[BC_OP_COUNT] = {"split", "combine", "transfer", "pad", "combine_copy", "pad_ring", "grid_tables", "interp", "affine", "nms", "conv3x3"};
+    static const char *names[BC_OP_COUNT] = {"split", "combine", "transfer", "pad", "combine_copy", "pad_ring", "grid_tables", "interp", "affine", "nms", "conv3x3", "head1x1"};
     return (op >= 0 && op < BC_OP_COUNT) ? names[op] : "?";
 }
 
@@ -2522,6 +2523,67 @@ BC_EXPORT int bc_combine_copy_indirect(const void *blocks, const void *slots, co
     switch (vb) { BC_CI(16) BC_CI(8) BC_CI(4) BC_CI(2) BC_CI(1) }
 #undef BC_CI
     return launch_status();
+}
+
+template <int DT, int CIN>
+static int launch_head1x1(ProfScope &ps, void *out, const void *features, const void *wpk, const void *prev, const void *slots,
+                          const int32_t *grid_idx, const int32_t *mapping_exec, const HeadGeom &g, const Prologue &pr,
+                          const float *out_shift, hipStream_t st)
+{
+    typedef typename CvType<DT>::T T;
+    constexpr size_t lds_bytes = (size_t)4 * 32 * (CIN * CvType<DT>::E / 16 + 1) * 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_head1x1<DT, CIN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        attr_set = true;
+    }
+    const dim3 grid(g.n_copy_wgs + g.n_waves / 4);
+    BC_LAUNCH(ps, (k_head1x1<DT, CIN>), grid, dim3(256), lds_bytes, st, (T *)out, (const uint4 *)features, (const uint4 *)wpk, (const T *)prev,
+              (const unsigned long long *)slots, grid_idx, mapping_exec, g, pr, out_shift);
+    return launch_status();
+}
+
+BC_EXPORT int bc_head1x1_scatter_nhwc(void *out, const void *features, const void *weights_packed, const void *prev, const void *slots,
+                                      const int32_t *grid_idx, const int32_t *mapping_exec, int n_exec, int N, int Cin, int Cout,
+                                      int GH, int GW, int bs, int dtype, const float *in_scale, const float *in_shift, int in_relu,
+                                      const float *out_shift, int scatter, void *stream)
+{
+    if (dtype < BC_F32 || dtype > BC_BF16) return BC_ERR_ELEM;
+    if (n_exec < 0 || N <= 0 || Cin <= 0 || Cout <= 0 || Cout > 32 || GH <= 0 || GW <= 0 || bs <= 0) return BC_ERR_SHAPE;
+    if (bs % 8 != 0 || (bs > 32 && bs % 32 != 0) || ((long long)bs * bs) % 32 != 0) return BC_ERR_SHAPE;
+    const bool cin_ok = dtype == BC_F32 ? (Cin == 64 || Cin == 128) : (Cin == 64 || Cin == 128 || Cin == 256);
+    if (!cin_ok) return BC_ERR_SHAPE;
+    if (scatter && n_exec > N * GH * GW) return BC_ERR_SHAPE;
+    if (n_exec == 0 && !scatter) return BC_OK;
+    if (!features && n_exec > 0) return BC_ERR_NULL;
+    if (!weights_packed || (!out && !slots)) return BC_ERR_NULL;
+    if (scatter && (!grid_idx || (!mapping_exec && n_exec > 0))) return BC_ERR_NULL;
+    if (scatter && !slots && !prev && n_exec < N * GH * GW) return BC_ERR_NULL;     // skipped tiles need the previous map
+    const int E = dtype == BC_F32 ? 4 : 2;
+    if ((uint64_t)N * GH * GW * bs * bs * (uint64_t)(Cin > Cout ? Cin : Cout) >= (1ull << 31)) return BC_ERR_RANGE;
+    if (!aligned(out, 16) || !aligned(features, 16) || !aligned(weights_packed, 16) || !aligned(prev, 16) || !aligned(slots, 8)) return BC_ERR_ALIGN;
+    HeadGeom g;
+    g.n_exec = n_exec; g.bs = bs; g.Cout = Cout; g.GH = GH; g.GW = GW;
+    g.blocks_per_tile = bs * bs / 32;
+    g.n_mblocks = (uint32_t)n_exec * g.blocks_per_tile;
+    g.scatter = scatter ? 1 : 0;
+    g.n_copy_wgs = (scatter && n_exec < N * GH * GW) ? (uint32_t)(N * GH * GW) : 0;
+    const uint32_t want = g.n_mblocks < 2048u ? g.n_mblocks : 2048u;          // 256 CUs x 2 workgroups x 4 waves: one round
+    g.n_waves = ((want + 3) / 4) * 4;
+    g.run_px = bs < 32 ? bs : 32;
+    g.runs = 32 / g.run_px;
+    Prologue pr{in_scale, in_shift, in_relu};
+    const double px = (double)n_exec * bs * bs;
+    ProfScope ps(BC_OP_HEAD, px * Cin * E + (scatter ? 2.0 * N * GH * GW * (double)bs * bs * Cout * E : px * Cout * E));
+    ps.add_aux(2.0 * px * Cin * 32.0);
+    hipStream_t st = (hipStream_t)stream;
+#define BC_HD(DT_, CIN_) return launch_head1x1<DT_, CIN_>(ps, out, features, weights_packed, prev, slots, grid_idx, mapping_exec, g, pr, out_shift, st)
+    if (dtype == BC_F32) { if (Cin == 64) BC_HD(BC_F32, 64); BC_HD(BC_F32, 128); }
+    if (dtype == BC_F16) { if (Cin == 64) BC_HD(BC_F16, 64); if (Cin == 128) BC_HD(BC_F16, 128); BC_HD(BC_F16, 256); }
+    if (Cin == 64) BC_HD(BC_BF16, 64);
+    if (Cin == 128) BC_HD(BC_BF16, 128);
+    BC_HD(BC_BF16, 256);
+#undef BC_HD
 }
 
 BC_EXPORT int bc_combine_copy_cells(const void *blocks, int N, int C, int H, int W, int bs, int E, int align)

@@ -92,6 +92,25 @@ int bc_combine_copy(const void *blocks, const void *prev, void *out, const int32
  * (s_memrealtime) in cell i -- graph kernel nodes cannot carry start / stop events; launch time = max(exit) - min(entry). */
 int bc_combine_copy_indirect(const void *blocks, const void *slots, const int32_t *grid_idx,
                              int N, int C, int H, int W, int bs, int elem_size, int align, void *stream);
+/* The network's last stage in one launch (csrc/head1x1.inc): activation prologue + pointwise conv to Cout <= 32 channels + the
+ * out-of-place combine.  Replaces, for a model whose head is BN -> ReLU -> 1x1 conv on packed tiles followed by
+ * `out.combine()` (SwiftNet logits: semantic_segmentation/lib/models/swiftnet/swiftnet.py via util.py:40-55, then
+ * core/blockcopy.py:79 / core/tensorwrapper.py:421-433), the elementwise pass, the library conv and bc_combine_copy.
+ *   features        packed channels-last tiles (n_exec, bs, bs, Cin); Cin in {64, 128} (fp32) / {64, 128, 256} (16-bit)
+ *   weights_packed  the (Cout, Cin, 1, 1) weight zero-padded to 32 output channels in the one-tap operand order of
+ *                   bc_conv1x1_nhwc (nb = 1): wpk[step][lane][j] = W[lane % 32][2*EPV*step + EPV*(lane / 32) + j]
+ *   in_scale/in_shift/in_relu   per input channel prologue relu?(x*scale + shift) (fp32, NULL = identity)
+ *   out_shift       per output channel bias (fp32[Cout]) or NULL
+ *   scatter = 0     out = packed tiles (n_exec, bs, bs, Cout); prev, slots, grid_idx, mapping_exec unused
+ *   scatter = 1     out = the fresh dense map (N, GH*bs, GW*bs, Cout) channels-last: executed tiles are written at their grid
+ *                   position (mapping_exec), every skipped tile (grid_idx < 0) is copied from `prev` (same shape; may be NULL
+ *                   only if every tile is executed).  slots != NULL: prev / out are read from slots[0] / slots[1] at run time
+ *                   as in bc_combine_copy_indirect (hipGraph node), the out / prev arguments are ignored.
+ * bs: multiple of 8, and of 32 when larger than 32.  Results: fp32 accumulation over Cin in matrix-core order, one rounding. */
+int bc_head1x1_scatter_nhwc(void *out, const void *features, const void *weights_packed, const void *prev, const void *slots,
+                            const int32_t *grid_idx, const int32_t *mapping_exec, int n_exec, int N, int Cin, int Cout,
+                            int GH, int GW, int bs, int dtype, const float *in_scale, const float *in_shift, int in_relu,
+                            const float *out_shift, int scatter, void *stream);
 /* number of timing cells (= workgroups) such a launch writes, or a negative error code */
 int bc_combine_copy_cells(const void *blocks, int N, int C, int H, int W, int bs, int elem_size, int align);
 
@@ -330,7 +349,7 @@ int bc_tune_get(const char *key, int *value);
  * ------------------------------------------------------------------------------------------- */
 
 enum { BC_OP_SPLIT = 0, BC_OP_COMBINE = 1, BC_OP_TRANSFER = 2, BC_OP_PAD = 3,
-       BC_OP_COMBINE_COPY = 4, BC_OP_PAD_RING = 5, BC_OP_GRID_TABLES = 6, BC_OP_INTERP = 7, BC_OP_AFFINE = 8, BC_OP_NMS = 9, BC_OP_CONV3X3 = 10, BC_OP_COUNT = 11 };
+       BC_OP_COMBINE_COPY = 4, BC_OP_PAD_RING = 5, BC_OP_GRID_TABLES = 6, BC_OP_INTERP = 7, BC_OP_AFFINE = 8, BC_OP_NMS = 9, BC_OP_CONV3X3 = 10, BC_OP_HEAD = 11, BC_OP_COUNT = 12 };
 
 int bc_abi_version(void);
 const char *bc_error_string(int code);

@@ -173,6 +173,34 @@ class OracleBackend:
         return y.contiguous(memory_format=torch.channels_last)
 
     @staticmethod
+    def head1x1_supported(data, weight, stride=1, padding=0, dilation=1, groups=1):
+        one = lambda v: v if isinstance(v, int) else (v[0] if len(set(v)) == 1 else None)
+        return (data.dim() == 4 and _nhwc(data) and tuple(weight.shape[2:]) == (1, 1) and one(stride) == 1 and one(padding) == 0 and one(dilation) == 1
+                and groups == 1 and data.dtype == torch.float32 and weight.shape[0] <= 32 and data.shape[2] == data.shape[3])
+
+    @staticmethod
+    def pack_head1x1_weights(weight):
+        return weight.detach().clone()
+
+    def head1x1(self, data, wpk, cout, prologue=None, epilogue=None, cfg=None, stride=1):
+        return self.conv1x1(data, wpk, cout, prologue, epilogue)
+
+    def head1x1_scatter(self, data, wpk, cout, prologue, bias, grid_idx, mapping_exec, prev=None, out=None, slots=None, targets=None):
+        """Checker form: pointwise conv by composition, then clone + scatter (the reference's non-in-place combine)."""
+        if slots is not None:
+            prev, out = targets
+            words = slots.tolist()
+            assert words[0] == prev.data_ptr() and words[1] == out.data_ptr(), "slot words do not point at this frame's prev / out maps"
+            if prev is out:
+                prev = None
+        y = self.conv1x1(data, wpk, cout, prologue, None if bias is None else (None, bias, None, False))
+        if prev is None:
+            assert bool((grid_idx >= 0).all())
+            prev = torch.zeros_like(out)
+        self.combine_copy(y, prev, out, grid_idx)
+        return out
+
+    @staticmethod
     def group_norm_affine_supported(data, groups):
         return data.dim() == 4 and _nhwc(data) and data.shape[1] % groups == 0 and data.dtype == torch.float32
 

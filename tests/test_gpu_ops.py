@@ -1006,3 +1006,61 @@ def test_adaptive_avg_pool_nhwc(be, dtype, tol):
         want = F.adaptive_avg_pool2d(x.float(), (oh, ow))
         assert got.shape == want.shape and got.dtype == dtype
         assert float((got.float() - want).abs().max()) <= tol * max(1.0, float(want.abs().max())), (N, C, H, W, oh, ow)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
+@pytest.mark.parametrize("geo", [(1, 2, 4, 32, 128, 19), (2, 3, 2, 8, 64, 1), (1, 2, 3, 16, 128, 32), (1, 1, 2, 64, 64, 5), (1, 4, 4, 8, 256, 19)])
+def test_head1x1_prologue_conv_bias_scatter_copy(be, geo, dtype, tol):
+    """bc_head1x1_scatter_nhwc (csrc/head1x1.inc): the network's output stage in one launch.  (a) packed mode == BN/ReLU prologue ->
+    1x1 conv -> bias from the definition in fp64; (b) scatter mode: executed tiles carry the SAME bits at their grid positions,
+    skipped tiles are bit-exact copies of the previous map, i.e. the result equals the oracle's clone + scatter of (a); (c) the
+    hipGraph-node form (prev / out read from slot words) gives the same bits; (d) all-active frames need no previous map."""
+    N, GH, GW, bs, cin, cout = geo
+    if dtype == torch.float32 and cin == 256:
+        pytest.skip("fp32: Cin in {64, 128}")
+    g = torch.Generator().manual_seed(sum(geo))
+    total = N * GH * GW
+    w = (torch.randn((cout, cin, 1, 1), generator=g) / cin ** 0.5).to(dtype).cuda()
+    scale, shift = (torch.rand(cin, generator=g) + 0.5).cuda(), (torch.randn(cin, generator=g) * 0.2).cuda()
+    bias = torch.randn(cout, generator=g).cuda()
+    wpk = be.pack_head1x1_weights(w)
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last)
+    for n_exec, pro, with_bias in ((total, True, True), (max(1, total // 2), True, True), (1, False, False), (total - 1 if total > 1 else 1, False, True)):
+        grid = np.zeros(total, bool)
+        grid[np.random.default_rng(n_exec).permutation(total)[:n_exec]] = True
+        gi, m = O.c_grid_mappings(grid.reshape(N, 1, GH, GW))
+        x = cl(torch.randn((n_exec, cin, bs, bs), generator=g).to(dtype).cuda())
+        assert be.head1x1_supported(x, w)
+        prologue = (scale, shift, True) if pro else None
+        b = bias if with_bias else None
+        # (a) packed mode vs the definition
+        got = be.head1x1(x, wpk, cout, prologue, None if b is None else (None, b, None, False))
+        xr = x.double()
+        if pro:
+            xr = torch.relu(xr * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)).to(dtype).double()   # rounded like the halo gather does
+        want = torch.nn.functional.conv2d(xr, w.double()) + (b.double().view(1, -1, 1, 1) if b is not None else 0.0)
+        err = float((got.double() - want).abs().max()) / max(1.0, float(want.abs().max()))
+        assert tuple(got.shape) == (n_exec, cout, bs, bs) and err <= tol, (geo, n_exec, err)
+        # (b) scatter mode == clone + scatter of (a), bit for bit
+        prev = cl(torch.randn((N, cout, GH * bs, GW * bs), generator=g).to(dtype).cuda())
+        want_map = prev.contiguous().cpu().clone()
+        O.c_combine(got.contiguous().cpu(), want_map, m)
+        out = cl(torch.full((N, cout, GH * bs, GW * bs), 7.0, dtype=dtype).cuda())
+        be.head1x1_scatter(x, wpk, cout, prologue, b, _dev(gi), _dev(m), prev=prev, out=out)
+        assert torch.equal(out.contiguous().cpu(), want_map), (geo, n_exec)
+        # (c) graph-node form
+        out2 = cl(torch.full((N, cout, GH * bs, GW * bs), 9.0, dtype=dtype).cuda())
+        slots = torch.tensor([prev.data_ptr(), out2.data_ptr(), 0], dtype=torch.int64).cuda()
+        be.head1x1_scatter(x, wpk, cout, prologue, b, _dev(gi), _dev(m), slots=slots)
+        assert torch.equal(out2, out)
+        # (d) all-active: prev may be absent
+        if n_exec == total:
+            out3 = cl(torch.full((N, cout, GH * bs, GW * bs), 3.0, dtype=dtype).cuda())
+            be.head1x1_scatter(x, wpk, cout, prologue, b, _dev(gi), _dev(m), prev=None, out=out3)
+            assert torch.equal(out3, out)
+    # other epilogues (scale / add / ReLU recorded after the conv) still give the right value through the extra elementwise pass
+    x = cl(torch.randn((2, cin, bs, bs), generator=g).to(dtype).cuda())
+    osc, add = (torch.rand(cout, generator=g) + 0.5).cuda(), cl(torch.randn((2, cout, bs, bs), generator=g).to(dtype).cuda())
+    got = be.head1x1(x, wpk, cout, None, (osc, bias, add, True))
+    want = torch.relu(torch.nn.functional.conv2d(x.double(), w.double()) * osc.double().view(1, -1, 1, 1) + bias.double().view(1, -1, 1, 1) + add.double())
+    assert float((got.double() - want).abs().max()) / max(1.0, float(want.abs().max())) <= 2 * tol

@@ -323,7 +323,7 @@ def test_channels_last_model_matches_reference_on_cpu(golden_dir, oracle_backend
 
     G, cfg = load_golden(golden_dir, name)
     # the engine's MI355X-specific routes must be taken on this model: residual gather (by-product), fused halo+pool
-    chk, hits = bk.get_backend(), {"pad_ring_add": 0, "maxpool3x3s2_ring": 0, "conv3x3_ring": 0}
+    chk, hits = bk.get_backend(), {"pad_ring_add": 0, "maxpool3x3s2_ring": 0, "conv3x3_ring": 0, "head1x1_scatter": 0, "combine_copy": 0}
     for meth in hits:
         orig = getattr(chk, meth)
         setattr(chk, meth, (lambda o, k: lambda *a, **kw: (hits.__setitem__(k, hits[k] + 1), o(*a, **kw))[1])(orig, meth))
@@ -345,6 +345,11 @@ def test_channels_last_model_matches_reference_on_cpu(golden_dir, oracle_backend
     executed = 2 * (cfg["n_frames"] - 1)        # two passes (eager plumbing, graph-mode plumbing); one frame of the clip executes nothing
     assert hits["pad_ring_add"] + hits["conv3x3_ring"] >= 8 * executed and hits["conv3x3_ring"] >= 4 * executed, hits
     assert hits["maxpool3x3s2_ring"] >= executed, hits
+    # the output stage (BN -> ReLU -> 1x1 conv to 19 classes -> out-of-place combine) is ONE launch on every executed frame, in the eager
+    # engine (TensorWrapper.combine) and in the graph body (slot words); the stand-alone scatter+copy is only called from inside it
+    # (graph mode learns the output geometry on its very first frame, which therefore still ends with a stand-alone combine)
+    ran = 2 * sum(1 for t in range(cfg["n_frames"]) if G[f"grid{t}"].any())
+    assert hits["head1x1_scatter"] == ran - 1 and hits["combine_copy"] == ran - 1, hits
 
 
 def test_conv3x3_weight_packing_matches_the_header_formula():
