@@ -201,12 +201,13 @@ __global__ __launch_bounds__(WG) void k_combine_copy_ind(const typename VecOf<VB
                                                          const int32_t *__restrict__ grid_idx, DenseGeom g)
 {
     typedef typename VecOf<VB>::type V;
-    const V *prev = reinterpret_cast<const V *>(slots[0]);
-    V *__restrict__ out = reinterpret_cast<V *>(slots[1]);
+    // (addresses formed as `blocks + offset`: a pointer cast from an integer would be a generic pointer and the accesses flat_*)
+    const unsigned long long b_addr = reinterpret_cast<unsigned long long>(blocks);
+    V *__restrict__ out = const_cast<V *>(blocks) + (long long)(slots[1] - b_addr) / (long long)sizeof(V);
     ulonglong2 *stamp = reinterpret_cast<ulonglong2 *>(slots[2]);
     unsigned long long t0 = 0;
     if (stamp) t0 = __builtin_amdgcn_s_memrealtime();
-    const long long prev_delta = prev - blocks;
+    const long long prev_delta = (long long)(slots[0] - b_addr) / (long long)sizeof(V);
     const uint32_t v = min(blockIdx.x * WG + threadIdx.x, g.total - 1);
     uint32_t r, xw, r2, y, n, c, gw, xv, gh, h;
     fd_divmod(v, g.vprW, r, xw);
@@ -2531,13 +2532,14 @@ static int launch_head1x1(ProfScope &ps, void *out, const void *features, const 
                           const float *out_shift, hipStream_t st)
 {
     typedef typename CvType<DT>::T T;
-    constexpr size_t lds_bytes = (size_t)4 * 32 * (CIN * CvType<DT>::E / 16 + 1) * 16;
+    constexpr int PXV_ = CIN * CvType<DT>::E / 16;
+    constexpr size_t lds_bytes = (size_t)4 * 32 * ((PXV_ < 16 ? PXV_ : 16) + 1) * 16;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_head1x1<DT, CIN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         attr_set = true;
     }
-    const dim3 grid(g.n_copy_wgs + g.n_waves / 4);
+    const dim3 grid(g.n_waves / 4);
     BC_LAUNCH(ps, (k_head1x1<DT, CIN>), grid, dim3(256), lds_bytes, st, (T *)out, (const uint4 *)features, (const uint4 *)wpk, (const T *)prev,
               (const unsigned long long *)slots, grid_idx, mapping_exec, g, pr, out_shift);
     return launch_status();
@@ -2567,8 +2569,11 @@ BC_EXPORT int bc_head1x1_scatter_nhwc(void *out, const void *features, const voi
     g.blocks_per_tile = bs * bs / 32;
     g.n_mblocks = (uint32_t)n_exec * g.blocks_per_tile;
     g.scatter = scatter ? 1 : 0;
-    g.n_copy_wgs = (scatter && n_exec < N * GH * GW) ? (uint32_t)(N * GH * GW) : 0;
-    const uint32_t want = g.n_mblocks < 2048u ? g.n_mblocks : 2048u;          // 256 CUs x 2 workgroups x 4 waves: one round
+    g.copy_rows = (scatter && n_exec < N * GH * GW) ? (uint32_t)(N * GH * GW) * (uint32_t)bs : 0;
+    // one round of 256 CUs x 2 workgroups x 4 waves at most; at least one wave per M-block or per two tile rows to look at
+    uint32_t want = g.n_mblocks > (g.copy_rows + 1) / 2 ? g.n_mblocks : (g.copy_rows + 1) / 2;
+    if (want > 2048u) want = 2048u;
+    if (want < 1u) want = 1u;
     g.n_waves = ((want + 3) / 4) * 4;
     g.run_px = bs < 32 ? bs : 32;
     g.runs = 32 / g.run_px;

@@ -93,7 +93,7 @@ def test_split_combine_combine_copy(be, case, dtype):
         for cl in (False, True):
             lay = (lambda t: t.contiguous(memory_format=torch.channels_last)) if cl else (lambda t: t)
             d_blocks, d_prev = lay(_dev(blocks)), lay(_dev(prev))
-            if len(m) == 0:
+            if len(m) == 0 or (cl and (bs == 1 or C == 1)):      # (1x1 tiles / one channel: both layouts are the same bytes)
                 continue
             d_out = lay(torch.full((N, C, H, W), 5.0, dtype=dtype).cuda())
             cells = be.combine_copy_cells(d_blocks, (N, C, H, W))
