@@ -427,8 +427,12 @@ class HipBackend:
         G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64, device=w0.device)
         U = torch.einsum("xi,ocij,yj->xyco", G, w0.double(), G).reshape(16, Cin, Cout).float()             # f = 4*xi + nu, cin, cout
         U = U.reshape(16, Cin // 32, 4, 4, 2, Cout // 16, 16).permute(5, 1, 2, 0, 4, 3, 6)                  # nb, chunk, step, f, t, kq, n
-        U = U.reshape(Cout // 16, Cin // 32, 4, 8, 4, 4, 16).permute(0, 1, 2, 3, 5, 6, 4)                   # nb, chunk, step, q, kq, n, w
-        return torch.cat([direct, U.contiguous().view(-1)])
+        U16 = U.reshape(Cout // 16, Cin // 32, 4, 8, 4, 4, 16).permute(0, 1, 2, 3, 5, 6, 4)                 # nb, chunk, step, q, kq, n, w
+        # third stream: the wide wave tile of csrc/conv3x3_wino32.inc (32 output channels per wave, 4-channel sub-steps):
+        # wino32[nb32][chunk][ss][q][lane = 32*h + n][w] = U[f][32*chunk + 4*ss + 2*h + t][32*nb32 + n], 2*f + t = 4*q + w
+        V = torch.einsum("xi,ocij,yj->xyco", G, w0.double(), G).reshape(8, 2, Cin // 32, 8, 2, 2, Cout // 32, 32).float()   # q, f%2, chunk, ss, h, t, nb, n
+        V = V.permute(6, 2, 3, 0, 4, 7, 1, 5)                                                               # nb, chunk, ss, q, h, n, f%2, t
+        return torch.cat([direct, U16.contiguous().view(-1), V.contiguous().view(-1)])
 
     def conv3x3_candidates(self, n_exec, cin, cout, bs, elem_size=4, stride=1):
         """Decomposition indices of the balanced conv kernel that cover this layer shape (bs = input tile size), straight from
@@ -477,7 +481,7 @@ class HipBackend:
         N, _, GH, GW = grid_idx.shape
         B, C, bs, _ = data_exec.shape
         n_exec = mapping_exec.numel()
-        assert n_exec == B and wpk.numel() in (9 * C * cout, 25 * C * cout)     # (fp32: direct + Winograd streams)
+        assert n_exec == B and wpk.numel() in (9 * C * cout, 41 * C * cout)     # (fp32: direct + two Winograd streams)
         assert tuple(ring.shape) == (N * GH * GW, C, 4 * bs), (ring.shape, (N * GH * GW, C, 4 * bs))
         assert stride in (1, 2) and bs % stride == 0
         out = empty_like_layout((B, cout, bs // stride, bs // stride), data_exec)

@@ -153,7 +153,8 @@ ADAPTIVE_POOL = os.environ.get("BLOCKCOPY_ADAPTIVE_POOL", "1") != "0"   # adapti
 STEM_KERNEL = os.environ.get("BLOCKCOPY_STEM", "1") != "0"        # network input: window gather + 7x7 stem conv in one kernel
 HEAD_KERNEL = os.environ.get("BLOCKCOPY_HEAD", "1") != "0"        # network output: prologue + 1x1 conv to <= 32 channels + out-of-place combine in one kernel
 CONV_TUNE_LOG = []    # (key, {candidate: microseconds}, choice) of every measurement, for the bench report
-WINOGRAD_FLAG = 0x200  # decomposition codes with this bit run the Winograd F(2x2,3x3) form (csrc/conv3x3_wino.inc)
+WINOGRAD_FLAG = 0x600  # decomposition codes with one of these bits run a Winograd F(2x2,3x3) form (0x200: csrc/conv3x3_wino.inc,
+WINOGRAD_WIDE = 0x400  # 0x400: the wide wave tile of csrc/conv3x3_wino32.inc)
 
 # Plan table persistence.  A plan decides which KERNEL FORM a layer runs in (library conv / direct MFMA form / Winograd form), and
 # the forms differ by fp32 rounding, so a run is only reproducible -- from run to run and from rank to rank -- with a fixed table.
@@ -247,17 +248,18 @@ def conv3x3_plan(n_exec: int, bs: int, cin: int, cout: int, n_total: int, dtype,
     """How to run one padded 3x3 conv layer (or, ``ks=1``, one pointwise conv): ``None`` = halo gather + library conv, ``int`` =
     the fused halo+conv kernel with that decomposition code (-1: the library's cost model; codes with WINOGRAD_FLAG: Winograd form).
 
-    ``BLOCKCOPY_CONV`` = ``library`` | ``native`` (direct MFMA form everywhere) | ``winograd`` (every layer that lists a Winograd
-    candidate runs its first one, the rest the direct form) | ``auto``: the plan table decides (see PLAN_FILE above); a shape it
+    ``BLOCKCOPY_CONV`` = ``library`` | ``native`` (direct MFMA form everywhere) | ``winograd`` / ``winograd-wide`` (every layer that
+    lists a Winograd candidate of the 16-channel / the wide wave tile runs its first one, the rest the direct form) | ``auto``: the plan table decides (see PLAN_FILE above); a shape it
     does not know is MEASURED once (``tuner()`` times the library route and every decomposition on the live tensors -- the conv
     library's own solver-search idea -- never during graph capture) or, untuned, follows a fixed rule."""
     if CONV_MODE == "library":
         return None
     if CONV_MODE == "native":
         return -1
-    if CONV_MODE == "winograd":
+    if CONV_MODE in ("winograd", "winograd-wide"):
         if ks == 3 and stride == 1 and dtype == torch.float32 and candidates is not None:
-            wino = [c for c in candidates() if c >= 0 and (c & WINOGRAD_FLAG)]
+            flag = WINOGRAD_WIDE if CONV_MODE == "winograd-wide" else 0x200
+            wino = [c for c in candidates() if c >= 0 and (c & flag)]
             if wino:
                 return wino[0]
         return -1

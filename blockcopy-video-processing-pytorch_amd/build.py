@@ -9,13 +9,14 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = [os.path.join(HERE, "csrc", "blockcopy_hip.hip")]
 HDR = [os.path.join(os.path.dirname(HERE), "include", "blockcopy_hip.h")] + [os.path.join(HERE, "csrc", f) for f in
-                                                                             ("conv3x3_mfma.inc", "conv3x3_v2.inc", "conv3x3_wino.inc", "stem7x7.inc")]
+                                                                             ("conv3x3_mfma.inc", "conv3x3_v2.inc", "conv3x3_wino.inc", "conv3x3_wino32.inc", "stem7x7.inc", "head1x1.inc")]
 OUT = os.path.join(HERE, "lib", "libblockcopy_hip.so")
 OBJ_DIR = os.path.join(HERE, "lib", "obj")
 ARCH = "gfx950"
 # the one source is compiled as 7 translation units (-DBC_PART=n, see ConvV2Args in csrc/blockcopy_hip.hip): part 0 = everything
-# but the decompositions of the fused conv kernel, parts 1..6 = one (dtype, kernel size) slice of them each, part 7 = its Winograd form
-PARTS = list(range(8))
+# but the decompositions of the fused conv kernel, parts 1..6 = one (dtype, kernel size) slice of them each, part 7 = its Winograd form,
+# part 8 = the wide-tile Winograd form
+PARTS = list(range(9))
 
 
 def hipcc() -> str:

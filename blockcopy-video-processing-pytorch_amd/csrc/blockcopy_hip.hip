@@ -2104,6 +2104,7 @@ int check_halo(const void *out, const void *features, const int32_t *grid_idx, c
 #include "conv3x3_mfma.inc"
 #include "conv3x3_v2.inc"
 #include "conv3x3_wino.inc"
+#include "conv3x3_wino32.inc"
 #include "stem7x7.inc"
 #include "head1x1.inc"
 
@@ -2174,7 +2175,7 @@ struct ConvV2Args {
 };
 struct LaunchProf { bool on; struct { hipEvent_t a, b; } rec; };   // what BC_LAUNCH needs of a ProfScope
 
-#if defined(BC_MONO) || (BC_PART != 0 && BC_PART != 7)
+#if defined(BC_MONO) || (BC_PART != 0 && BC_PART != 7 && BC_PART != 8)
 template <int DT, int RM, int RN, int WMW, int WNW, int WKW, int SC, int PW, int S, int KS>
 static void launch_conv3x3_v2_cfg(LaunchProf &ps, dim3 grid, size_t lds_bytes, const ConvV2Args &a, const ConvGeom2 &g)
 {
@@ -2359,7 +2360,73 @@ static int conv_wino_run(ConvV2Args &a)
 extern "C" int bc_part_conv_wino(void *p) { return conv_wino_run(*static_cast<ConvV2Args *>(p)); }
 #endif
 
-#if BC_PART != 0 && BC_PART != 7
+// ---- host side of conv3x3_wino32.inc (wide wave tile, one wave per SIMD): decompositions (WMW, WNW, WKW) of 4 waves; code 0x400 | index
+struct Wino32Cfg { int WMW, WNW, WKW; };
+static const Wino32Cfg WINO32_CFGS[] = {{2, 2, 1}, {1, 4, 1}, {1, 2, 2}, {2, 1, 2}, {1, 1, 4}};
+constexpr int WINO32_N = (int)(sizeof(WINO32_CFGS) / sizeof(WINO32_CFGS[0]));
+
+struct Wino32Plan { long long wgs; size_t lds_bytes; uint32_t n_slots; };
+static bool wino32_plan(const Wino32Cfg &k, int n_exec, int Cin, int Cout, int bs, Wino32Plan &p)
+{
+    if (bs % 8 != 0 || bs > 248 || Cin % 32 != 0 || Cout % (32 * k.WNW) != 0) return false;
+    const size_t img = (size_t)k.WMW * 2 * 100 * 9 * 16;                                   // one staged image: 2 * WMW patches
+    const size_t per_wave = 64 * 64 * sizeof(float);                                        // transposition / K-group partial area of a wave
+    const size_t tail = k.WKW > 1 ? (size_t)k.WMW * k.WNW * (k.WKW - 1) * per_wave : 4 * per_wave;
+    p.lds_bytes = 2 * img > tail ? 2 * img : tail;
+    if (p.lds_bytes > 160 * 1024 - 2048 - 1024) return false;
+    p.n_slots = (uint32_t)n_exec * (uint32_t)((bs / 8) * (bs / 8));
+    const long long rows = (p.n_slots + 2 * k.WMW - 1) / (2 * k.WMW);
+    p.wgs = rows * (Cout / (32 * k.WNW));
+    return true;
+}
+
+#if defined(BC_MONO) || BC_PART == 8
+template <int WMW, int WNW, int WKW>
+static void launch_wino32_cfg(LaunchProf &ps, dim3 grid, size_t lds_bytes, const ConvV2Args &a, const ConvGeom2 &g)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_wino32<WMW, WNW, WKW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+        attr_set = true;
+    }
+    // the wide-tile Winograd stream follows the direct and the 16-channel Winograd streams (pack_conv3x3_weights: 9 + 16 + 16 values per pair)
+    const float4 *w32 = reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(a.wpk) + (size_t)25 * a.Cin * a.Cout);
+    BC_LAUNCH(ps, (k_conv3x3_wino32<WMW, WNW, WKW>), grid, dim3(256), lds_bytes, a.st, (float *)a.out, (const uint4 *)a.features,
+              (long long)(((const char *)a.ring - (const char *)a.features) / 16), (uint4 *)a.ring, w32, a.grid_idx, a.mapping_exec, g, a.pr, a.ep);
+}
+
+static int conv_wino32_run(ConvV2Args &a)
+{
+    const int c = a.force_cfg & 0xff;
+    if (c >= WINO32_N) return BC_ERR_SHAPE;
+    const Wino32Cfg &k = WINO32_CFGS[c];
+    Wino32Plan plan;
+    if (!wino32_plan(k, a.n_exec, a.Cin, a.Cout, a.bs, plan)) return BC_ERR_SHAPE;
+    LaunchProf ps{a.prof_on != 0, {a.ev_a, a.ev_b}};
+    ConvGeom2 g;
+    g.Cin = a.Cin; g.Cout = a.Cout; g.bs = a.bs; g.GH = a.GH; g.GW = a.GW; g.n_exec = a.n_exec;
+    g.patches_x = a.bs / 8;
+    g.patches_per_tile = (a.bs / 8) * (a.bs / 8);
+    g.n_rows = plan.n_slots;
+    g.cin_chunks = a.Cin / 32;
+    const dim3 grid((plan.n_slots + 2 * k.WMW - 1) / (2 * k.WMW), (unsigned)a.Cout / (32 * k.WNW));
+    switch (c) {
+    case 0: launch_wino32_cfg<2, 2, 1>(ps, grid, plan.lds_bytes, a, g); break;
+    case 1: launch_wino32_cfg<1, 4, 1>(ps, grid, plan.lds_bytes, a, g); break;
+    case 2: launch_wino32_cfg<1, 2, 2>(ps, grid, plan.lds_bytes, a, g); break;
+    case 3: launch_wino32_cfg<2, 1, 2>(ps, grid, plan.lds_bytes, a, g); break;
+    default: launch_wino32_cfg<1, 1, 4>(ps, grid, plan.lds_bytes, a, g); break;
+    }
+    a.chosen = a.force_cfg & 0x7ff;
+    return launch_status();
+}
+#endif
+
+#if BC_PART == 8
+extern "C" int bc_part_conv_wino32(void *p) { return conv_wino32_run(*static_cast<ConvV2Args *>(p)); }
+#endif
+
+#if BC_PART != 0 && BC_PART != 7 && BC_PART != 8
 // this slice: dtype (BC_PART - 1) / 2, kernel size 3 (odd parts) or 1 (even parts), both strides
 #define BC_PART_NAME2(n_) bc_part_conv_v2_##n_
 #define BC_PART_NAME(n_) BC_PART_NAME2(n_)
@@ -2388,6 +2455,7 @@ extern "C" {
 int bc_part_conv_v2_1(void *); int bc_part_conv_v2_2(void *); int bc_part_conv_v2_3(void *);
 int bc_part_conv_v2_4(void *); int bc_part_conv_v2_5(void *); int bc_part_conv_v2_6(void *);
 int bc_part_conv_wino(void *);
+int bc_part_conv_wino32(void *);
 }
 #endif
 
@@ -2399,12 +2467,12 @@ static int launch_conv3x3_v2(ProfScope &ps, void *out, const void *features, voi
     ConvV2Args a{out, features, ring, wpk, grid_idx, mapping_exec, n_exec, Cin, Cout, GH, GW, bs, S, pr, ep, st,
                  ps.on ? 1 : 0, ps.rec.a, ps.rec.b, g_tune.conv2_cfg, g_tune.conv2_min_lds, g_tune.conv_stamps, -2};
     const double direct_flops = 2.0 * n_exec * (double)(bs / S) * (bs / S) * (KS * KS) * (double)Cin * Cout;
-    if (DT == BC_F32 && S == 1 && KS == 3 && a.force_cfg >= 0 && (a.force_cfg & 0x200)) {       // Winograd form (conv3x3_wino.inc)
+    if (DT == BC_F32 && S == 1 && KS == 3 && a.force_cfg >= 0 && (a.force_cfg & 0x600)) {       // Winograd forms (conv3x3_wino.inc, conv3x3_wino32.inc)
         ps.add_aux(direct_flops * 16.0 / 36.0);     // F(2x2,3x3): 16 multiplications per 2x2 outputs instead of 36
 #if defined(BC_MONO)
-        const int rcw = conv_wino_run(a);
+        const int rcw = (a.force_cfg & 0x400) ? conv_wino32_run(a) : conv_wino_run(a);
 #else
-        const int rcw = bc_part_conv_wino(&a);
+        const int rcw = (a.force_cfg & 0x400) ? bc_part_conv_wino32(&a) : bc_part_conv_wino(&a);
 #endif
         if (a.chosen >= 0) g_tune.conv_last_cfg = a.chosen;
         return rcw;
@@ -2818,6 +2886,10 @@ static int conv_candidates(int dtype, int stride, int ks, int n_exec, int Cin, i
                 // (no 0x100 variant: at 208-255 VGPRs per lane a second 8-wave workgroup cannot join the CU whatever the LDS size.
                 //  Four-wave workgroups -- two independent ones per CU -- were tried and lost 5-20 %: profiles/r02 README)
             }
+        // the wide-tile Winograd form (one wave per SIMD, conv3x3_wino32.inc)
+        Wino32Plan wp32;
+        for (int c = 0; c < WINO32_N && n < max_out; ++c)
+            if (wino32_plan(WINO32_CFGS[c], n_exec, Cin, Cout, bs, wp32)) out[n++] = c | 0x400;
     }
     return n;
 }

@@ -637,13 +637,13 @@ def test_fused_conv3x3_stride2(be, dtype, tol):
         be.tune("conv2_cfg", -1)
 
 
-@pytest.mark.parametrize("cfg", list(range(20)) + [0x200 | w for w in range(11)])
+@pytest.mark.parametrize("cfg", list(range(20)) + [0x200 | w for w in range(11)] + [0x400 | w for w in range(5)])
 def test_fused_conv3x3_every_decomposition(be, cfg):
     """The CU-balanced conv kernel (csrc/conv3x3_v2.inc) picks one of 20 decompositions per launch (register blocking
     RM x RN, wave grid, in-workgroup split-K); here each one is FORCED in turn on shapes it covers -- incl. ragged wave
     rows, 4x4 tiles, prologue, epilogue with residual, ring cache from a previous frame -- against halo gather + fp64 conv
     (2e-5 relative: fp32 summation order), with the ring cache left bit-identical.  Codes 0x200 | w: the Winograd F(2x2,3x3)
-    form of the same layer (csrc/conv3x3_wino.inc), same bar."""
+    form of the same layer (csrc/conv3x3_wino.inc), codes 0x400 | w its wide wave tile (csrc/conv3x3_wino32.inc), same bar."""
     import torch.nn.functional as F
 
     rng = np.random.default_rng(500 + cfg)
@@ -744,7 +744,7 @@ def test_fused_conv3x3_random_geometries(be, form):
                     want = torch.relu(want)
             cfg = None
             if form == "winograd":
-                wino = [c for c in be.conv3x3_candidates(len(m), Cin, Cout, bs, 4, 1) if c & 0x200]
+                wino = [c for c in be.conv3x3_candidates(len(m), Cin, Cout, bs, 4, 1) if c & 0x600]
                 if wino:
                     cfg = int(rng.choice(wino))
                     forced += 1

@@ -24,6 +24,8 @@ for name, n, Cin, Cout, bs in [("layer1", 64, 64, 64, 32), ("layer2", 64, 128, 1
     for cfg in be.conv3x3_candidates(n, Cin, Cout, bs, 4, 1):
         f = lambda: be.conv3x3_ring(feats, ring, wpk, Cout, gi, m, (sc, sc, True), None, cfg=cfg)
         res[cfg] = timeit(f, 10)
-    v2 = sorted((t, c) for c, t in res.items() if not c & 0x200)[:3]
-    wn = sorted((t, c) for c, t in res.items() if c & 0x200)[:4]
-    print(f"{name:14s} direct best: " + ", ".join(f"{c}={t:.1f}" for t, c in v2) + " | winograd best: " + ", ".join(f"{c}={t:.1f}" for t, c in wn), flush=True)
+    v2 = sorted((t, c) for c, t in res.items() if not c & 0x600)[:3]
+    wn = sorted((t, c) for c, t in res.items() if c & 0x200)[:3]
+    ww = sorted((t, c) for c, t in res.items() if c & 0x400)[:5]
+    print(f"{name:14s} direct best: " + ", ".join(f"{c}={t:.1f}" for t, c in v2) + " | winograd best: " + ", ".join(f"{c}={t:.1f}" for t, c in wn)
+          + " | wide winograd: " + ", ".join(f"{c & 0xff}={t:.1f}" for t, c in ww), flush=True)
