@@ -60,13 +60,15 @@ def iou_matrix(a: np.ndarray, b: np.ndarray) -> np.ndarray:
     return np.where(valid, iou, 0.0)
 
 
-def paint_boxes_max(H: int, W: int, boxes: np.ndarray, values: np.ndarray, device="cpu", chunk: int = 64) -> torch.Tensor:
+def paint_boxes_max(H: int, W: int, boxes: np.ndarray, values: np.ndarray, device="cpu", chunk: int = 0) -> torch.Tensor:
     """(H,W) float32 map = max over boxes k of values[k] inside [y1,y2) x [x1,x2), 0 elsewhere: the order-free form of the
     reference's sequence of ``mask[y1:y2, x1:x2] = max(mask[...], v)`` slices (values are >= 0), evaluated as a few batched
     tensor ops on ``device`` instead of one tiny launch per box."""
     out = torch.zeros((H, W), dtype=torch.float32, device=device)
     if len(boxes) == 0:
         return out
+    if chunk <= 0:      # bound the transient (chunk, H, W) product to ~64 MB: 8 boxes at a time on a 1024x2048 map, 64 on small ones
+        chunk = int(max(1, min(64, (16 << 20) // max(1, H * W))))
     assert (boxes >= 0).all(), "boxes must be clipped to the image"
     bt = torch.from_numpy(np.ascontiguousarray(boxes, dtype=np.int64)).to(device)
     vt = torch.from_numpy(np.ascontiguousarray(values, dtype=np.float64).astype(np.float32)).to(device)

@@ -231,12 +231,11 @@ class PolicyTrainRL(Policy, metaclass=abc.ABCMeta):
         # graph; their policy-net trunk runs as a captured hipGraph over a static input (same logits, ~40 fewer launches)
         self.graph_forward = graph_forward
         self._fwd_graphs = {}
-        # MI355X-first: the REINFORCE step itself (policy-net forward with autograd, log-probabilities of the executed grid, loss,
-        # backward, RMSprop) as ONE captured hipGraph over static inputs, replayed on training frames: ~250 launches issued from
-        # Python (C3 was host-bound: 1.8 ms of enqueue work per 1.8 ms frame) become one replay.  See _train_graph_step.
-        self.graph_train = graph_forward and os.environ.get("BLOCKCOPY_GRAPH_TRAIN", "1") != "0"
-        self._train_graphs = {}
-        self._train_x = None
+        # (Training frames keep the eager autograd forward / backward.  Round 3 measured both graph forms of the REINFORCE step on C3
+        #  -- the whole step recomputed inside one captured graph, and torch.cuda.make_graphed_callables' forward / backward graph
+        #  pair -- at 514 and 491 fps against 535 eager: the frame is bound by the GPU time of the fp32 policy net and by the
+        #  host's wait for the executed-tile count, not by launch cost, and replaying 100-300 small kernels from a hipGraph is no
+        #  cheaper on this runtime than launching them.  DESIGN.md section 6.)
         # MI355X-first: sampling + count quantisation + index tables in ONE device kernel (bc_policy_step) on GPU frames;
         # the host only waits for the executed-tile count (it selects the captured graph).  False = the reference's host route.
         self.device_step = os.environ.get("BLOCKCOPY_DEVICE_POLICY", "1") != "0"
@@ -264,10 +263,8 @@ class PolicyTrainRL(Policy, metaclass=abc.ABCMeta):
                 with timings.env("policy/net", 3):
                     assert self.net.training
                     on_gpu = policy_meta["inputs"].is_cuda
-                    if self.graph_forward and on_gpu and (not will_train or self.graph_train):
-                        # (with the captured training step, training frames decide from the same no-grad graph: the step recomputes
-                        #  the forward inside its own graph from the features kept here)
-                        grid_logits = self._forward_nograd_graph(policy_meta, keep_features=will_train and self.graph_train)
+                    if self.graph_forward and on_gpu and not will_train:
+                        grid_logits = self._forward_nograd_graph(policy_meta)
                     else:
                         grid_logits = self.net(policy_meta)
                 if self.device_step and grid_logits.is_cuda and hasattr(_backend(), "policy_step"):
@@ -325,12 +322,11 @@ class PolicyTrainRL(Policy, metaclass=abc.ABCMeta):
         policy_meta["grid_probs"] = m.probs
 
     @torch.no_grad()
-    def _forward_nograd_graph(self, policy_meta: dict, keep_features: bool = False) -> torch.Tensor:
+    def _forward_nograd_graph(self, policy_meta: dict) -> torch.Tensor:
         """Policy logits for a frame that will not be trained on: feature build (a few small ops) eagerly, the
         resnet8 trunk + head as a captured graph over a static input.  BatchNorm stays in training mode (batch
         statistics, running-stat updates), exactly as in the autograd path."""
         x = self.net.build_features(policy_meta)
-        self._train_x = x if keep_features else None
         key = (tuple(x.shape), x.dtype, x.device)
         st = self._fwd_graphs.get(key)
         if st is None:
@@ -347,89 +343,6 @@ class PolicyTrainRL(Policy, metaclass=abc.ABCMeta):
             st["graph"] = g
         st["graph"].replay()
         return st["logits"]
-
-    def _train_graph_step(self, policy_meta: dict, grid: torch.Tensor, reward: torch.Tensor) -> None:
-        """One REINFORCE update (reference policy/policy.py:319-349: loss = mean(-log pi(grid) * reward), backward, RMSprop step) as a
-        replay of ONE captured graph over static inputs: the decision-time policy features, the executed grid and the signed reward
-        map.  The graph recomputes the policy-net forward with autograd (the decision itself came from the no-grad graph); its
-        BatchNorms use batch statistics like every forward of this net but leave the running statistics alone -- the decision
-        forward has already updated them for this frame, exactly once as in the reference.
-
-        Capture follows PyTorch's whole-step recipe (warm-up iterations on a side stream, grads set to None before capture,
-        capturable optimizer); the warm-up iterations are REAL steps, so parameters, buffers and optimizer state are snapshotted
-        before and restored afterwards -- the first replay is then the first and only update of this frame."""
-        x = self._train_x
-        self._train_x = None
-        key = (tuple(x.shape), x.dtype, x.device, tuple(grid.shape))
-        st = self._train_graphs.get(key)
-        if st is None:
-            st = self._train_graphs[key] = self._capture_train_graph(x, grid, reward)
-        st["x"].copy_(x)
-        st["grid"].copy_(grid)
-        st["reward"].copy_(reward)
-        st["graph"].replay()
-        policy_meta["loss_policy"] = st["loss"]             # (static tensors of the graph: valid until the next training step)
-        policy_meta["grid_log_probs"] = st["log_probs"]
-
-    def _capture_train_graph(self, x: torch.Tensor, grid: torch.Tensor, reward: torch.Tensor) -> dict:
-        dev = x.device
-        net, opt = self.net, self.optimizer
-        st = {"x": x.clone(), "grid": grid.to(torch.float32).clone(), "reward": reward.detach().to(torch.float32).clone()}
-        bns = [m for m in net.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
-        tracked = [m.track_running_stats for m in bns]
-
-        def step():
-            logits = net.layers(net.backbone(st["x"]))
-            log_probs = Bernoulli(logits=logits).log_prob(st["grid"])
-            loss = (-log_probs * st["reward"]).mean()
-            loss.backward()
-            opt.step()
-            return loss.detach(), log_probs.detach()
-
-        # --- snapshot (the warm-up iterations below are real optimiser steps)
-        with torch.no_grad():
-            saved_p = [p.detach().clone() for p in net.parameters()]
-            saved_b = [b.detach().clone() for b in net.buffers()]
-            had_state = {p: {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in s.items()} for p, s in opt.state.items()}
-        for g in opt.param_groups:
-            g["capturable"] = True
-        for s in opt.state.values():                         # steps taken eagerly before: their counters live on the host
-            if torch.is_tensor(s.get("step")) and s["step"].device != dev:
-                s["step"] = s["step"].to(dev)
-        try:
-            for m in bns:
-                m.track_running_stats = False                # batch statistics, running statistics untouched (see _train_graph_step)
-            side = torch.cuda.Stream(dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side), torch.enable_grad():
-                for _ in range(3):
-                    opt.zero_grad(set_to_none=True)
-                    step()
-            torch.cuda.current_stream(dev).wait_stream(side)
-            torch.cuda.synchronize(dev)
-            opt.zero_grad(set_to_none=True)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g), torch.enable_grad():
-                st["loss"], st["log_probs"] = step()
-            st["graph"] = g
-        finally:
-            for m, t in zip(bns, tracked):
-                m.track_running_stats = t
-        # --- restore: in place, the graph holds these addresses
-        with torch.no_grad():
-            for p, v in zip(net.parameters(), saved_p):
-                p.copy_(v)
-            for b, v in zip(net.buffers(), saved_b):
-                b.copy_(v)
-            for p, s in opt.state.items():
-                old = had_state.get(p)
-                for k, v in s.items():
-                    if torch.is_tensor(v):
-                        if old is not None and torch.is_tensor(old.get(k)):
-                            v.copy_(old[k].to(v.device))
-                        else:
-                            v.zero_()                        # state created by the warm-up steps: back to a fresh optimiser
-        return st
 
     def _get_information_gain(self, policy_meta: dict) -> torch.Tensor:
         with timings.env("policy/information_gain", 3):
@@ -457,14 +370,6 @@ class PolicyTrainRL(Policy, metaclass=abc.ABCMeta):
                 reward_complexity_weighted = self._get_reward_complexity(policy_meta) * self.complexity_weight_gamma
                 reward = ig + reward_complexity_weighted
                 assert reward.dim() == 4
-                if self._train_x is not None and policy_meta.get("grid_log_probs") is None:
-                    # captured training step: same reward, same loss, same update -- one graph replay
-                    with torch.no_grad():
-                        reward = F.adaptive_max_pool2d(reward, output_size=grid.shape[2:])
-                        reward = torch.where(grid, reward, -reward)
-                    with timings.env("policy/optimizer_graph", 3):
-                        self._train_graph_step(policy_meta, grid, reward)
-                    return policy_meta
                 log_probs = policy_meta["grid_log_probs"]
                 reward = F.adaptive_max_pool2d(reward, output_size=log_probs.shape[2:])
                 reward = torch.where(grid, reward, -reward)   # skipped tiles are rewarded for LOW gain

@@ -461,6 +461,53 @@ def gen_swiftnet_rn18_c2(ref):
     gen_swiftnet(ref, "rn18_c2", "resnet18", 1, 1024, 2048, 128, 4, 8, False, subsample=(8, (0, 7)))
 
 
+def gen_detgain(ref):
+    """The detector-side reward functions of the REFERENCE (blockcopy/blockcopy/policy/information_gain.py:43-108:
+    InformationGainObjectDetection.get_output_repr / .forward = build_instance_mask / build_instance_mask_iou_gain) on seeded
+    detections.  ``build_instance_mask_iou_gain`` allocates its mask with a hard-coded ``device='cuda'`` (:70); the LOADER (not the
+    reference) maps that request to the CPU for the duration of the call.  Boxes are at least 4 pixels wide and high so that none
+    collapses at SUBSAMPLE = 2 (the reference asserts there, :137-140).  One class, as in the shipped pedestrian configs (the
+    reference's per-class loop rebinds its own arguments, :76-77, so it only runs with one)."""
+    import blockcopy.policy.information_gain as ref_ig
+
+    assert ref_ig.__file__.startswith(ref_loader.REF_ROOT)
+    rng = np.random.default_rng(17)
+    H, W = 96, 160
+
+    def dets(n):
+        x1, y1 = rng.integers(0, W - 12, n), rng.integers(0, H - 12, n)
+        w, h = rng.integers(4, 48, n), rng.integers(4, 64, n)
+        return np.stack([x1, y1, np.minimum(x1 + w, W - 1), np.minimum(y1 + h, H - 1), rng.random(n) * 0.9 + 0.1], 1).astype(np.float32)
+
+    a = dets(12)
+    shifted = a.copy(); shifted[:, [0, 2]] += 2
+    cases = [(dets(30), dets(25)), (dets(1), dets(0)), (dets(0), dets(7)), (dets(0), dets(0)), (dets(60), dets(75)),
+             (a, a.copy()), (a, shifted), (np.repeat(a[:3], 3, 0), a[:3])]
+    real_zeros = torch.zeros
+
+    def zeros_on_cpu(*args, **kw):
+        if str(kw.get("device", "cpu")).startswith("cuda"):
+            kw["device"] = "cpu"
+        return real_zeros(*args, **kw)
+
+    ig = ref_ig.InformationGainObjectDetection(num_classes=1)
+    out = {"cfg": np.frombuffer(json.dumps(dict(H=H, W=W, n_cases=len(cases), num_classes=1)).encode(), dtype=np.uint8)}
+    frame = torch.zeros(1, 3, H, W)
+    for k, (cur, prev) in enumerate(cases):
+        pm = {"inputs": frame, "outputs": [[cur]], "outputs_prev": [[prev]]}
+        torch.zeros = zeros_on_cpu
+        try:
+            gain = ig(pm)
+            rep = ig.get_output_repr(pm)
+        finally:
+            torch.zeros = real_zeros
+        out[f"cur{k}"], out[f"prev{k}"] = cur, prev
+        out[f"gain{k}"], out[f"repr{k}"] = gain.numpy().copy(), rep.numpy().copy()
+    np.savez_compressed(os.path.join(GOLD, "detgain.npz"), **out)
+    print("detgain.npz", len(cases), "cases; gain range", float(min(out[f"gain{k}"].min() for k in range(len(cases)))),
+          float(max(out[f"gain{k}"].max() for k in range(len(cases)))))
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     ref = ref_loader.load_reference()
@@ -482,6 +529,7 @@ def main():
     gen_swiftnet(ref, "rn50_a", "resnet50", 1, 128, 256, 32, 3, 4, False)
     gen_swiftnet_rn18_c(ref)
     gen_swiftnet_rn18_c2(ref)
+    gen_detgain(ref)
 
 
 if __name__ == "__main__":

@@ -131,3 +131,27 @@ def scenario_grids(N, GH, GW, seed):
             seeded.fixed_fraction_grid(seed + 3, N, GH, GW, total - 1),
             torch.zeros(N, 1, GH, GW, dtype=torch.bool),
             seeded.fixed_fraction_grid(seed + 5, N, GH, GW, total // 4)]
+
+
+def nms_known_answers():
+    """Hand-derived known answers for greedy NMS as Pedestron/mmdet/ops/nms/src/nms_kernel.cu defines it: IoU with the +1 pixel
+    convention (devIoU, :12-21: width = right - left + 1), a box is suppressed by an earlier KEPT box when IoU > threshold
+    (strict, :61), candidates in descending score order (:73-75).  Integer boxes, so every IoU below is an exact ratio.
+    Each case: (dets (n,5) float32 [x1,y1,x2,y2,score], threshold, kept original indices ascending)."""
+    f = lambda rows: np.array(rows, dtype=np.float32)
+    A, B = [0, 0, 9, 9], [0, 0, 9, 4]          # areas 100 and 50 (+1 convention), intersection 50: IoU = 50 / 100 = 0.5 exactly
+    C, D = [0, 0, 9, 9], [5, 0, 14, 9]         # +1: inter 5 x 10 = 50, union 150: IoU = 1/3.   Without +1 it would be 36 / 126 = 0.2857
+    E, F_ = [0, 0, 9, 9], [9, 0, 18, 9]        # share only the column x = 9: +1 convention gives inter 1 x 10 = 10, IoU = 10 / 190
+    # chain: P suppresses Q (7 x 10 = 70 / 130 = 0.538 > 0.5); R overlaps Q the same way but P only 40 / 160 = 0.25 -> R survives
+    P, Q, R = [0, 0, 9, 9], [3, 0, 12, 9], [6, 0, 15, 9]
+    return [
+        (f([A + [0.9], B + [0.8]]), 0.5, [0, 1]),               # IoU == threshold: NOT suppressed (strict >)
+        (f([A + [0.9], B + [0.8]]), 0.4999, [0]),
+        (f([C + [0.9], D + [0.8]]), 0.3, [0]),                  # suppressed only under the +1 convention
+        (f([C + [0.9], D + [0.8]]), 1.0 / 3.0 + 1e-3, [0, 1]),
+        (f([E + [0.9], F_ + [0.8]]), 0.05, [0]),                # 10 / 190 = 0.0526 > 0.05
+        (f([E + [0.9], F_ + [0.8]]), 0.06, [0, 1]),
+        (f([P + [0.9], Q + [0.8], R + [0.7]]), 0.5, [0, 2]),    # greedy: Q is gone before it could suppress R
+        (f([R + [0.7], Q + [0.8], P + [0.9]]), 0.5, [0, 2]),    # same boxes, input order reversed: indices refer to the input
+        (f([P + [0.5], P + [0.6], P + [0.7]]), 0.99, [2]),      # identical boxes: IoU = 1, only the best score stays
+    ]

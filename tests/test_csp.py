@@ -1,5 +1,8 @@
 """CSP detector workload (BASELINE config C5) on CPU with the oracle-backed checker: mmcv/mmdet cannot be installed
 here, so the model is pinned by reference-independent properties instead of reference outputs."""
+import json
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -209,3 +212,25 @@ def test_vectorised_detection_rewards_equal_the_loop_restatement():
     c2, p2 = [[dets(9), dets(11)]], [[dets(10), dets(4)]]
     assert torch.equal(V.build_instance_mask_iou_gain(c2, p2, size2), L.build_instance_mask_iou_gain(c2, p2, size2))
     assert torch.equal(V.build_instance_mask(c2, size2), L.build_instance_mask(c2, size2))
+
+
+def test_detection_rewards_match_the_reference(golden_dir):
+    """tests/golden/detgain.npz: InformationGainObjectDetection of the REFERENCE (policy/information_gain.py:43-108) run in the build
+    container on seeded detections -- random sets, empty frames, exact matches (gain 0), heavy overlaps, duplicates / ties.  Both the
+    box-by-box restatement (tests/policy_oracle.py) and the product's vectorised form must reproduce its maps bit for bit."""
+    import policy_oracle as L
+    from blockcopy.policy import information_gain as V
+
+    G = np.load(os.path.join(golden_dir, "detgain.npz"))
+    cfg = json.loads(bytes(G["cfg"]).decode())
+    size = (1, cfg["num_classes"], cfg["H"], cfg["W"])
+    ig = V.InformationGainObjectDetection(num_classes=cfg["num_classes"])
+    frame = torch.zeros(1, 3, cfg["H"], cfg["W"])
+    for k in range(cfg["n_cases"]):
+        cur, prev = G[f"cur{k}"], G[f"prev{k}"]
+        want_gain, want_repr = torch.from_numpy(G[f"gain{k}"]), torch.from_numpy(G[f"repr{k}"])
+        assert torch.equal(L.build_instance_mask_iou_gain([[cur]], [[prev]], size), want_gain), k
+        assert torch.equal(L.build_instance_mask([[cur]], size), want_repr), k
+        pm = {"inputs": frame, "outputs": [[cur]], "outputs_prev": [[prev]]}
+        assert torch.equal(ig(pm), want_gain), k
+        assert torch.equal(ig.get_output_repr(pm), want_repr), k

@@ -468,6 +468,22 @@ def test_nms_matches_oracle(be):
             kept, inds = be.nms(torch.from_numpy(dets).cuda(), thr)
             assert np.array_equal(inds.cpu().numpy(), want), (n, thr)
             assert kept.shape == (len(inds), 5) and torch.equal(kept.cpu(), torch.from_numpy(dets)[inds.cpu()])
+    # hand-derived known answers of nms_kernel.cu's rules: +1 pixel convention, strict threshold at IoU == thr, greedy chains
+    from common import nms_known_answers
+
+    for dets, thr, want in nms_known_answers():
+        _, inds = be.nms(torch.from_numpy(dets).cuda(), thr)
+        assert inds.cpu().tolist() == want, (dets.tolist(), thr)
+    # the kernel's maximum (4096 boxes: 64 x 64 mask words per box row) on integer boxes in dense clusters: many exact-ratio IoUs,
+    # many of them equal to the threshold
+    n = 4096
+    xy = rng.integers(0, 48, (n, 2)).astype(np.float32) * 5
+    wh = rng.integers(1, 5, (n, 2)).astype(np.float32) * 5 - 1          # widths 4, 9, 14, 19 (+1 convention: 5, 10, 15, 20)
+    score = ((rng.permutation(n)[:, None] + 1.0) / (n + 1.0)).astype(np.float32)
+    dets = np.concatenate([xy, xy + wh, score], 1).astype(np.float32)
+    for thr in (0.5, 0.25, 1.0 / 3.0):
+        _, inds = be.nms(torch.from_numpy(dets).cuda(), thr)
+        assert np.array_equal(inds.cpu().numpy(), O.c_nms(dets, thr)), thr
 
 
 def test_plain_c_consumer_runs():
