@@ -2601,7 +2601,7 @@ static int launch_head1x1(ProfScope &ps, void *out, const void *features, const 
 {
     typedef typename CvType<DT>::T T;
     constexpr int PXV_ = CIN * CvType<DT>::E / 16;
-    constexpr size_t lds_bytes = ((size_t)4 * 32 * ((PXV_ < 16 ? PXV_ : 16) + 1) + (size_t)(CIN / (2 * CvType<DT>::EPV)) * 64) * 16;
+    constexpr size_t lds_bytes = (size_t)4 * 32 * ((PXV_ < 16 ? PXV_ : 16) + 1) * 16;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_head1x1<DT, CIN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
