@@ -193,14 +193,14 @@ def pmc_traffic():
     (tools/pmc_traffic.py writes profiles/traffic_latest.json); None when no such measurement is committed."""
     path = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if not os.path.exists(path):
-        return None, None, {}
+        return (None, None), None, {}
     with open(path) as f:
         t = json.load(f)
     per_kernel = {label: {"kernel": v.get("kernel"), "hbm_MB": round(v["hbm_bytes_per_launch"] / 1e6, 2),
                           "algorithmic_MB": round(v["algorithmic_bytes_per_launch"] / 1e6, 2),
                           "traffic_over_algorithmic": round(v["traffic_over_algorithmic"], 3)}
                   for label, v in t.get("kernels", {}).items() if "traffic_over_algorithmic" in v}
-    return t.get("k_combine_copy_bytes_per_launch"), t.get("source"), per_kernel
+    return (t.get("k_combine_copy_bytes_per_launch"), t.get("k_head1x1_bytes_per_launch")), t.get("source"), per_kernel
 
 
 def _free_port():
@@ -611,7 +611,7 @@ def main(argv=None):
                        "exec_fraction": exec_frac, "warmup_s": warm_s},
             "roofline": {"kernel": cc.get("kernel") or ("k_combine_copy_ind (fused scatter+copy of the logits map, a node of the frame's hipGraph)" if stamp_us
                                                         else "k_combine_copy (fused scatter+copy of the logits map)"), "bound": "hbm", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None if cc.get("kernel") else traffic,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[1] if cc.get("kernel") else traffic[0],
                          "traffic_source": traffic_src,
                          "launches": cc["launches"], "avg_launch_us": (1e3 * cc["total_ms"] / cc["launches"]) if cc["launches"] else None,
                          "p50_us": cc.get("p50_us"), "min_us": cc.get("min_us"), "max_us": cc.get("max_us"),

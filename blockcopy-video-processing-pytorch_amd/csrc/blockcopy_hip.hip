@@ -2647,7 +2647,10 @@ BC_EXPORT int bc_head1x1_scatter_nhwc(void *out, const void *features, const voi
     g.runs = 32 / g.run_px;
     Prologue pr{in_scale, in_shift, in_relu};
     const double px = (double)n_exec * bs * bs;
-    ProfScope ps(BC_OP_HEAD, px * Cin * E + (scatter ? 2.0 * N * GH * GW * (double)bs * bs * Cout * E : px * Cout * E));
+    // algorithmic bytes: packed features read; scatter: every skipped tile read once from the previous map + the whole map written
+    // (the packed logits of the executed tiles never exist in memory), else the packed result written
+    const double map_px = (double)N * GH * GW * bs * bs;
+    ProfScope ps(BC_OP_HEAD, px * Cin * E + (scatter ? (map_px - px) * Cout * E + map_px * Cout * E : px * Cout * E));
     ps.add_aux(2.0 * px * Cin * 32.0);
     hipStream_t st = (hipStream_t)stream;
 #define BC_HD(DT_, CIN_) return launch_head1x1<DT_, CIN_>(ps, out, features, weights_packed, prev, slots, grid_idx, mapping_exec, g, pr, out_shift, st)

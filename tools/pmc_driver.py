@@ -50,6 +50,21 @@ def main():
         prev = cl(torch.randn((1, C, H, W), device="cuda"))
         out = torch.empty_like(prev)
         run(name, 2.0 * C * H * W * 4, lambda: be.combine_copy(blocks, prev, out, gi))
+    # the network's output stage in one launch (round 3): BN/ReLU + 1x1 conv 128 -> 19 + bias + out-of-place combine of the C2 logits map.
+    # algorithmic bytes = packed features read + skipped tiles read from the previous map + the whole map written + weights (the packed
+    # logits of the executed tiles never exist in memory, so SURVEY 8(d)'s 2*N*C*H*W*E of the stand-alone scatter+copy shrinks by them)
+    C, H, W, bs, cin = 19, 256, 512, 32, 128
+    feats = cl(torch.randn((n, cin, bs, bs), device="cuda"))
+    w = torch.randn((C, cin, 1, 1), device="cuda") * 0.1
+    wpk = be.pack_head1x1_weights(w)
+    sc, bias = torch.rand(cin, device="cuda") + 0.5, torch.randn(C, device="cuda")
+    prev = cl(torch.randn((1, C, H, W), device="cuda"))
+    out = torch.empty_like(prev)
+    run("head1x1_scatter C2 logits (64,128,32,32) -> (1,19,256,512)", 4.0 * (n * cin * bs * bs + (128 - n) * C * bs * bs + C * H * W + 32 * cin),
+        lambda: be.head1x1_scatter(feats, wpk, C, (sc, sc, True), bias, gi, m, prev=prev, out=out))
+    blocks = cl(torch.randn((n, C, bs, bs), device="cuda"))
+    slots = torch.tensor([prev.data_ptr(), out.data_ptr(), 0], dtype=torch.int64).cuda()
+    run("combine_copy_indirect C2 logits (1,19,256,512)", 2.0 * C * H * W * 4, lambda: be.combine_copy_indirect(blocks, slots, gi, (1, C, H, W)))
     # gather / in-place scatter of the network input (NCHW frame)
     img = torch.randn((1, 3, 1024, 2048), device="cuda")
     blocks = torch.empty((n, 3, 128, 128), device="cuda")
@@ -81,6 +96,13 @@ def main():
     # as for the direct form: the 16/9 larger transformed weight stream shows up as extra reads
     for (Cin, Cout, bs, code, name) in [(64, 64, 32, 0x204, "winograd layer1"), (128, 128, 16, 0x204, "winograd layer2"), (256, 256, 8, 0x207, "winograd layer3"),
                                         (512, 512, 4, 0x208, "winograd layer4"), (128, 128, 32, 0x204, "winograd up 1/4")]:
+        feats = cl(torch.randn((n, Cin, bs, bs), device="cuda"))
+        ring = torch.randn((128, Cin, 4 * bs), device="cuda")
+        wpk = be.pack_conv3x3_weights(torch.randn((Cout, Cin, 3, 3), device="cuda") * 0.05)
+        alg = 4.0 * (n * Cin * ((bs + 2) ** 2 + 4 * bs) + n * Cout * bs * bs + 9 * Cin * Cout)
+        run(f"{name} ({n},{Cin}->{Cout},{bs}x{bs})", alg, lambda: be.conv3x3_ring(feats, ring, wpk, Cout, gi, m, None, None, cfg=code))
+    # the wide wave tile of the Winograd form (round 3, codes 0x400 | w), where the plan table picks it
+    for (Cin, Cout, bs, code, name) in [(128, 128, 32, 0x401, "wide winograd up 1/4"), (128, 128, 16, 0x402, "wide winograd layer2"), (64, 64, 32, 0x400, "wide winograd layer1")]:
         feats = cl(torch.randn((n, Cin, bs, bs), device="cuda"))
         ring = torch.randn((128, Cin, 4 * bs), device="cuda")
         wpk = be.pack_conv3x3_weights(torch.randn((Cout, Cin, 3, 3), device="cuda") * 0.05)

@@ -43,7 +43,9 @@ def main():
     if len(sys.argv) > 4:
         cc = out.get("combine_copy C2 logits (1,19,256,512)")
         with open(sys.argv[4], "w") as fjson:
+            hd = out.get("head1x1_scatter C2 logits (64,128,32,32) -> (1,19,256,512)")
             json.dump({"k_combine_copy_bytes_per_launch": cc["hbm_bytes_per_launch"] if cc else None,
+                       "k_head1x1_bytes_per_launch": hd["hbm_bytes_per_launch"] if hd else None,
                        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of tools/pmc_driver.py (same kernels and shapes as bench.py's default path); FETCH_SIZE x2 (gfx950), KiB units",
                        "kernels": out}, fjson, indent=1)
 
