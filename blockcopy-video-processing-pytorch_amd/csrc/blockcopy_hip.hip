@@ -2172,6 +2172,7 @@ struct ConvV2Args {
     int force_cfg, min_lds;                        // tuning knobs of the caller (g_tune)
     unsigned long long *stamps;
     int chosen;                                    // out: the decomposition that was launched
+    int xcd_remap;                                 // 1: XCD-aware workgroup order (xcd_remap() in conv3x3_v2.inc)
 };
 struct LaunchProf { bool on; struct { hipEvent_t a, b; } rec; };   // what BC_LAUNCH needs of a ProfScope
 
@@ -2229,6 +2230,7 @@ static int conv_v2_run(ConvV2Args &a)
     g.patches_per_tile = best_plan.patches_per_tile;
     g.n_rows = best_plan.n_rows;
     g.cin_chunks = Cin / CV_CH;
+    g.xcd = (uint32_t)a.xcd_remap;
     size_t lds_bytes = best_plan.lds_bytes;
     if (lds_bytes < (size_t)min_lds) lds_bytes = min_lds;      // one workgroup per CU: two waves on every SIMD, no more
     const dim3 grid((g.n_rows + k.WMW - 1) / k.WMW, (unsigned)Cout / (32 * k.RN * k.WNW));
@@ -2335,6 +2337,7 @@ static int conv_wino_run(ConvV2Args &a)
     g.patches_per_tile = a.bs == 4 ? 1 : (a.bs / 8) * (a.bs / 8);
     g.n_rows = plan.n_rows;
     g.cin_chunks = a.Cin / 32;
+    g.xcd = (uint32_t)a.xcd_remap;
     size_t lds_bytes = plan.lds_bytes;
     if (!(a.force_cfg & 0x100) && lds_bytes < (size_t)a.min_lds) lds_bytes = a.min_lds;
     const dim3 grid((plan.n_rows + k.WMW - 1) / k.WMW, (unsigned)a.Cout / (16 * k.WNW));
@@ -2409,6 +2412,7 @@ static int conv_wino32_run(ConvV2Args &a)
     g.patches_per_tile = (a.bs / 8) * (a.bs / 8);
     g.n_rows = plan.n_slots;
     g.cin_chunks = a.Cin / 32;
+    g.xcd = (uint32_t)a.xcd_remap;
     const dim3 grid((plan.n_slots + 2 * k.WMW - 1) / (2 * k.WMW), (unsigned)a.Cout / (32 * k.WNW));
     switch (c) {
     case 0: launch_wino32_cfg<2, 2, 1>(ps, grid, plan.lds_bytes, a, g); break;
@@ -2447,6 +2451,9 @@ struct TuneState {
     int conv_last_cfg = -2;   // decomposition of the most recent bc_conv3x3_ring_nhwc launch (-1: first-generation kernel)
     int stem_min_lds = [] { const char *e = getenv("BC_STEM_MINLDS"); return e ? atoi(e) : 84 * 1024; }();
     int conv2_min_lds = [] { const char *e = getenv("BC_CONV2_MINLDS"); return e ? atoi(e) : 84 * 1024; }();   // bytes; > 80 KB = one workgroup per CU
+    // XCD-aware workgroup order of the conv kernels (xcd_remap in conv3x3_v2.inc).  Measured neutral on every layer shape of the configs
+    // (profiles/r03/11: +-2 %, the weights of a layer are served by the Infinity Cache either way), so the launch order stays the default
+    int xcd_remap = [] { const char *e = getenv("BC_XCD_REMAP"); return e ? atoi(e) : 0; }();
 } g_tune;
 
 
@@ -2465,7 +2472,7 @@ static int launch_conv3x3_v2(ProfScope &ps, void *out, const void *features, voi
                              const Prologue &pr, const EpilogueT &ep, hipStream_t st)
 {
     ConvV2Args a{out, features, ring, wpk, grid_idx, mapping_exec, n_exec, Cin, Cout, GH, GW, bs, S, pr, ep, st,
-                 ps.on ? 1 : 0, ps.rec.a, ps.rec.b, g_tune.conv2_cfg, g_tune.conv2_min_lds, g_tune.conv_stamps, -2};
+                 ps.on ? 1 : 0, ps.rec.a, ps.rec.b, g_tune.conv2_cfg, g_tune.conv2_min_lds, g_tune.conv_stamps, -2, g_tune.xcd_remap};
     const double direct_flops = 2.0 * n_exec * (double)(bs / S) * (bs / S) * (KS * KS) * (double)Cin * Cout;
     if (DT == BC_F32 && S == 1 && KS == 3 && a.force_cfg >= 0 && (a.force_cfg & 0x600)) {       // Winograd forms (conv3x3_wino.inc, conv3x3_wino32.inc)
         ps.add_aux(direct_flops * 16.0 / 36.0);     // F(2x2,3x3): 16 multiplications per 2x2 outputs instead of 36
@@ -2941,6 +2948,7 @@ BC_EXPORT int bc_tune_set(const char *key, int value)
     if (!strcmp(key, "conv_impl")) g_tune.conv_impl = value;
     else if (!strcmp(key, "conv2_cfg")) g_tune.conv2_cfg = value;
     else if (!strcmp(key, "conv2_min_lds")) g_tune.conv2_min_lds = value;
+    else if (!strcmp(key, "xcd_remap")) g_tune.xcd_remap = value;
     else if (!strcmp(key, "stem_min_lds")) g_tune.stem_min_lds = value;
     else return BC_ERR_SHAPE;
     return BC_OK;
@@ -2960,6 +2968,7 @@ BC_EXPORT int bc_tune_get(const char *key, int *value)
     if (!strcmp(key, "conv_impl")) *value = g_tune.conv_impl;
     else if (!strcmp(key, "conv2_cfg")) *value = g_tune.conv2_cfg;
     else if (!strcmp(key, "conv2_min_lds")) *value = g_tune.conv2_min_lds;
+    else if (!strcmp(key, "xcd_remap")) *value = g_tune.xcd_remap;
     else if (!strcmp(key, "conv_last_cfg")) *value = g_tune.conv_last_cfg;
     else return BC_ERR_SHAPE;
     return BC_OK;

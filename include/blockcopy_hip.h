@@ -335,6 +335,8 @@ int bc_policy_features(float *out, int N, int h, int w, const void *const *ptrs,
 /* tuning / A-B knob (measurement infrastructure; defaults are the shipped behaviour): key in
  *   "conv_impl"      1 = first-generation fused conv kernel, 2 = CU-balanced kernel (default)
  *   "conv2_cfg"      -1 = choose the decomposition per launch (default), 0..15 = force one (BC_ERR_SHAPE at launch if it does not fit)
+ *   "xcd_remap"      1 = XCD-aware workgroup order in the fused conv kernels (workgroups that share an XCD take a contiguous,
+ *                    output-channel-group-major run of logical ids); 0 (default) = launch order.  Speed only, results identical
  *   "conv2_min_lds"  dynamic LDS floor in bytes (default 84 KiB: one 8-wave workgroup per CU)
  * Not part of the reference's boundary. */
 int bc_tune_set(const char *key, int value);
