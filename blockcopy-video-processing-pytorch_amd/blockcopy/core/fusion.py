@@ -152,6 +152,9 @@ GROUP_NORM = os.environ.get("BLOCKCOPY_GROUP_NORM", "1") != "0"   # group_norm o
 ADAPTIVE_POOL = os.environ.get("BLOCKCOPY_ADAPTIVE_POOL", "1") != "0"   # adaptive_avg_pool2d of dense channels-last maps (pyramid pooling) in the library's kernel
 STEM_KERNEL = os.environ.get("BLOCKCOPY_STEM", "1") != "0"        # network input: window gather + 7x7 stem conv in one kernel
 HEAD_KERNEL = os.environ.get("BLOCKCOPY_HEAD", "1") != "0"        # network output: prologue + 1x1 conv to <= 32 channels + out-of-place combine in one kernel
+# tuner: charge the library route the elementwise pass that follows a conv in a CNN (bias / folded BN, residual add, ReLU: it rides in the
+# fused kernels' epilogue but costs the library route one more pass over the result).  Measured on C4: 204 -> 212 fps (profiles/r03)
+TUNE_EPILOGUE_COST = os.environ.get("BLOCKCOPY_TUNE_EPILOGUE_COST", "1") != "0"
 CONV_TUNE_LOG = []    # (key, {candidate: microseconds}, choice) of every measurement, for the bench report
 WINOGRAD_FLAG = 0x600  # decomposition codes with one of these bits run a Winograd F(2x2,3x3) form (0x200: csrc/conv3x3_wino.inc,
 WINOGRAD_WIDE = 0x400  # 0x400: the wide wave tile of csrc/conv3x3_wino32.inc)

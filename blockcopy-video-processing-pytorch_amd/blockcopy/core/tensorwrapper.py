@@ -904,7 +904,12 @@ class TensorWrapper(torch.Tensor):
             w_plain = weight.as_subclass(torch.Tensor) if isinstance(weight, TensorWrapper) else weight
             wpk = fusion.packed_conv3x3_weight(weight, be.pack_conv3x3_weights)
             scratch = torch.zeros((n_total, cin, 4 * bs), dtype=data.dtype, device=data.device)   # a ring nobody else reads
-            routes = {"library": lambda: torch.nn.functional.conv2d(be.pad_ring(data, scratch, grid_idx, mapping_exec, 1, None), w_plain.detach(), stride=stride)}
+            lib0 = lambda: torch.nn.functional.conv2d(be.pad_ring(data, scratch, grid_idx, mapping_exec, 1, None), w_plain.detach(), stride=stride)
+            lib = lib0
+            if fusion.TUNE_EPILOGUE_COST:      # (see fusion.TUNE_EPILOGUE_COST: the elementwise pass the library route needs after the conv)
+                zero = torch.zeros(cout, dtype=torch.float32, device=data.device)
+                lib = lambda: be.affine_act(lib0(), None, zero, None, True)
+            routes = {"library": lib}
             for c in be.conv3x3_candidates(n_exec, cin, cout, bs, data.element_size(), stride):
                 routes[str(c)] = (lambda c_: lambda: be.conv3x3_ring(data, scratch, wpk, cout, grid_idx, mapping_exec, None, None, cfg=c_, stride=stride))(c)
             return be.time_routes(routes)
@@ -976,8 +981,14 @@ class TensorWrapper(torch.Tensor):
             wpk = fusion.packed_conv3x3_weight(weight, be.pack_conv3x3_weights)
             src = dense_layout(raw)
             pro = (P.scale, P.shift, P.relu) if foldable else None
-            lib = (lambda: torch.nn.functional.conv2d(be.affine_act(src, pro[0], pro[1], None, pro[2]), w_plain.detach(), stride=stride)) if pro is not None \
+            lib0 = (lambda: torch.nn.functional.conv2d(be.affine_act(src, pro[0], pro[1], None, pro[2]), w_plain.detach(), stride=stride)) if pro is not None \
                 else (lambda: torch.nn.functional.conv2d(src, w_plain.detach(), stride=stride))
+            lib = lib0
+            if fusion.TUNE_EPILOGUE_COST:
+                # what follows a conv in a CNN (bias / folded BN, residual add, ReLU) rides in the fused kernel's epilogue but costs
+                # the library route one more elementwise pass over the result: price that pass in
+                zero = torch.zeros(cout, dtype=torch.float32, device=src.device)
+                lib = lambda: be.affine_act(lib0(), None, zero, None, True)
             routes = {"library": lib}
             for c in be.conv1x1_candidates(src, cout, stride):
                 routes[str(c)] = (lambda c_: lambda: be.conv1x1(src, wpk, cout, pro, None, cfg=c_, stride=stride))(c)
