@@ -488,7 +488,7 @@ def main(argv=None):
             if r["launches"]:
                 extra[op] = {"launches_per_frame": r["launches"] / CLIP_LEN, "avg_us": 1e3 * r["total_ms"] / r["launches"],
                              "GBps": r["total_bytes"] / (r["total_ms"] * 1e-3) / 1e9, "MB_per_frame": r["total_bytes"] / CLIP_LEN / 1e6,
-                             "mode": "eager launches (in-library events per launch); the timed region replays hipGraphs"}
+                             }
         hd = be.prof_read("head1x1")
         if hd["launches"]:
             # the network's output stage: BN/ReLU + 1x1 conv to the class logits + bias + out-of-place combine (scatter of the executed
@@ -497,8 +497,7 @@ def main(argv=None):
             gb = hd["total_bytes"] / (hd["total_ms"] * 1e-3) / 1e9
             extra["head1x1"] = {"kernel": "k_head1x1 (logits conv with the scatter+copy as its epilogue)", "launches_per_frame": hd["launches"] / CLIP_LEN,
                                 "avg_us": 1e3 * hd["total_ms"] / hd["launches"], "algorithmic_MB_per_launch": hd["total_bytes"] / hd["launches"] / 1e6,
-                                "achieved": gb, "frac": gb / HBM_PEAK_GBS,
-                                "mode": "eager launches (events attached to each dispatch); the timed region replays the same kernel as a hipGraph node"}
+                                "achieved": gb, "frac": gb / HBM_PEAK_GBS}
         r = be.prof_read("conv3x3")
         if r["launches"]:
             # the fused conv kernel (3x3 halo form, its stride-2 and one-tap forms): FLOPs of all its launches of one clip over their
@@ -506,15 +505,14 @@ def main(argv=None):
             peak = 157.3 if dtype == torch.float32 else 2516.0
             tf = r["total_aux"] / (r["total_ms"] * 1e-3) / 1e12          # matrix FLOPs actually issued
             tf_alg = r["total_bytes"] / (r["total_ms"] * 1e-3) / 1e12    # FLOPs of the direct definition 2*px*k*k*Cin*Cout
-            extra["roofline_conv"] = {"kernel": "k_conv3x3_wino (Winograd F(2x2,3x3): 16/36 of the direct multiplications) + k_conv3x3_v2 (direct: "
-                                                "3x3, 3x3 stride 2, 1x1 forms) + k_stem7x7; per-layer form: details file",
+            extra["roofline_conv"] = {"kernel": "k_conv3x3_wino / k_conv3x3_wino32 (Winograd: 16/36 of the direct multiplications) + k_conv3x3_v2 (direct, "
+                                                "stride 2, 1x1) + k_stem7x7; per-layer form: details file",
                                       "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "issued_frac": tf / peak,
                                       "effective_TFLOPs": tf_alg, "effective_frac": tf_alg / peak, "traffic": None,
                                       "launches_per_frame": r["launches"] / CLIP_LEN, "ms_per_frame": r["total_ms"] / CLIP_LEN,
                                       "GFLOP_issued_per_frame": r["total_aux"] / CLIP_LEN / 1e9, "GFLOP_algorithmic_per_frame": r["total_bytes"] / CLIP_LEN / 1e9,
-                                      "note": "achieved / frac = ISSUED matrix FLOPs over the summed kernel time; effective_* = FLOPs of the direct "
-                                              "definition over the same time (what the layer is worth, not what the matrix cores did)",
-                                      "mode": "eager launches (events attached to each dispatch); the timed region replays the same kernels from hipGraphs"}
+                                      "note": "achieved / frac = ISSUED matrix FLOPs over the summed kernel time of an eager clip (dispatch-attached events); "
+                                              "effective_* = FLOPs of the direct definition over the same time"}
         # host-side enqueue cost of one clip (no sync inside): tells whether the frame is CPU- or GPU-bound
         torch.cuda.synchronize(device)
         th = time.perf_counter()
@@ -539,8 +537,7 @@ def main(argv=None):
                 ufps, _, _ = harness.measure_fps_with_upload(model, hclips, n_clips=max(1, min(args.steps, 3)), warmup_clips=1, device=device,
                                                              dtype=dtype, prefetch=pf)
                 up[name] = ufps
-            up["note"] = ("frames start in pinned host memory and are uploaded inside the timed region; last frame of each clip: bilinear "
-                          "upsample to input size + argmax + .cpu() (reference test_swiftnet.py:190-197). PCIe-inclusive: never `value`")
+            up["note"] = "per-frame H->D upload + last-frame upsample / argmax / .cpu() inside the timed region (reference test_swiftnet.py:181-197); never `value`"
             extra["upload_inclusive"] = up
         from blockcopy.core import fusion
         # route per padded 3x3 / pointwise layer shape (fusion.conv3x3_plan): null = halo gather + MIOpen, code = fused kernel decomposition
@@ -569,7 +566,7 @@ def main(argv=None):
                 hd = build_workload(args, "static", h, device, rank)
                 hdfps, _, _ = harness.measure_fps(hd, hclips, n_clips=max(1, min(args.steps, 3)), warmup_clips=1, device=device)
                 extra["fp16"] = {"fps": hfps, "dense_gpu_fps": hdfps, "speedup_vs_dense_gpu": hfps / hdfps,
-                                 "note": "same workload, weights and masks in float16 (not parity-gated; the headline value is fp32)"}
+                                 "note": "same workload in float16; the headline value is fp32"}
                 del hm, hd
                 if args.batch == 1 and not is_csp:
                     # secondary measurement: two clips side by side (the reference's speed configs use --batch-size 2)
@@ -584,7 +581,7 @@ def main(argv=None):
                     bd = harness.build_model(args.backbone, block_policy="static", device=device, dtype=dtype, channels_last=bool(args.channels_last))
                     bdfps, _, _ = harness.measure_fps(bd, bclips, n_clips=max(1, min(args.steps, 3)), warmup_clips=1, device=device)
                     extra["batch2"] = {"fps": bfps, "dense_gpu_fps": bdfps, "speedup_vs_dense_gpu": bfps / bdfps,
-                                       "note": "same workload with 2 clips per step (batch 2), fp32; the headline value is batch 1"}
+                                       "note": "2 clips per step, fp32; the headline value is batch 1"}
                     del bm, bd
 
     if rank == 0:
@@ -593,8 +590,8 @@ def main(argv=None):
             h = extra["head1x1"]
             cc = {"launches": int(round(h["launches_per_frame"] * CLIP_LEN)), "total_ms": h["avg_us"] * 1e-3 * h["launches_per_frame"] * CLIP_LEN,
                   "total_bytes": h["algorithmic_MB_per_launch"] * 1e6 * h["launches_per_frame"] * CLIP_LEN, "kernel": h["kernel"],
-                  "method": "HIP events attached to each dispatch (hipExtLaunchKernelGGL) over one eager clip of the same workload run inside bench.py right "
-                            "after the timed region (graph kernel nodes cannot carry events); profiles/ holds the rocprofv3 trace of the graph replays"}
+                  "method": "dispatch-attached HIP events (hipExtLaunchKernelGGL) over one eager clip run inside bench.py right after the timed region "
+                            "(graph kernel nodes cannot carry events); rocprofv3 trace of the graph replays: profiles/"}
         achieved = (cc["total_bytes"] / (cc["total_ms"] * 1e-3) / 1e9) if cc["total_ms"] > 0 else 0.0
         traffic, traffic_src, traffic_kernels = pmc_traffic()
         if traffic_kernels:
@@ -604,20 +601,19 @@ def main(argv=None):
             "metric": METRIC, "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16" if args.half else "f32", "data": "synthetic",
-            "config": {"workload": f"{config_name(args)}: {'CSP-ResNet50 pedestrian detector (backbone + neck + head + decode + NMS)' if is_csp else 'SwiftNet-' + args.backbone} {shape[0]}x3x{args.height}x{args.width} synthetic clips of {CLIP_LEN} frames, "
-                                   f"block {args.block_size}, policy {args.policy} target {args.target:.0%} (frame 0 of each clip all-active), "
-                                   f"{args.engine} engine{' + hipGraph replay' if args.graph else ''}{', channels-last' if args.channels_last else ''}, name-seeded weights, BN folded; step = 1 clip",
+            "config": {"workload": f"{config_name(args)}: {'CSP-ResNet50 detector (backbone + neck + head + decode + NMS)' if is_csp else 'SwiftNet-' + args.backbone} {shape[0]}x3x{args.height}x{args.width} synthetic clips of {CLIP_LEN} frames, "
+                                   f"block {args.block_size}, policy {args.policy} target {args.target:.0%} (frame 0 all-active), "
+                                   f"{args.engine} engine{' + hipGraph' if args.graph else ''}{', channels-last' if args.channels_last else ''}, seeded weights, BN folded; step = 1 clip",
                        "clips_per_rank": args.steps, "parallelism": f"{world} independent replica(s), no collective",
                        "exec_fraction": exec_frac, "warmup_s": warm_s},
             "roofline": {"kernel": cc.get("kernel") or ("k_combine_copy_ind (fused scatter+copy of the logits map, a node of the frame's hipGraph)" if stamp_us
                                                         else "k_combine_copy (fused scatter+copy of the logits map)"), "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[1] if cc.get("kernel") else traffic[0],
-                         "traffic_source": traffic_src,
                          "launches": cc["launches"], "avg_launch_us": (1e3 * cc["total_ms"] / cc["launches"]) if cc["launches"] else None,
-                         "p50_us": cc.get("p50_us"), "min_us": cc.get("min_us"), "max_us": cc.get("max_us"),
+                         **({"p50_us": cc["p50_us"], "min_us": cc["min_us"], "max_us": cc["max_us"]} if "p50_us" in cc else {}),
                          "algorithmic_bytes_per_launch": (cc["total_bytes"] / cc["launches"]) if cc["launches"] else None,
                          "method": cc["method"]},
-            "per_rank_fps": {"min": min(per_rank), "max": max(per_rank), "all": [round(v, 1) for v in per_rank]},
+            **({"per_rank_fps": {"min": min(per_rank), "max": max(per_rank), "all": [round(v, 1) for v in per_rank]}} if world > 1 else {}),
             "kernels": extra,
         }
         if "roofline_conv" in extra:
@@ -626,12 +622,23 @@ def main(argv=None):
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_dense_baseline(args, args.cpu_frames)
         details["rank_env"] = rank_env
+        details["traffic_source"] = traffic_src
         dpath = details_path(args)
         out["details_file"] = os.path.relpath(dpath, ROOT)
+        def compact(o, top=True):      # six significant digits inside the nested objects (the line must stay small); top-level scalars stay exact
+            if isinstance(o, dict):
+                return {k: (v if top and not isinstance(v, (dict, list)) else compact(v, False)) for k, v in o.items()}
+            if isinstance(o, list):
+                return [compact(v, False) for v in o]
+            if isinstance(o, float):
+                return float(f"{o:.6g}")
+            return o
+
+        out = compact(out)
         line = json.dumps(out)
         with open(dpath, "w") as f:
             json.dump({"bench_line": out, **details}, f, indent=1)
-        assert len(line) < 6000, f"bench line grew to {len(line)} bytes: move tables to the details file"
+        assert len(line) < 4096, f"bench line grew to {len(line)} bytes: move tables to the details file"
         print(line, flush=True)
     if args.save_plan and rank == 0:
         from blockcopy.core import fusion

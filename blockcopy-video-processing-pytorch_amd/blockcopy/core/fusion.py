@@ -168,6 +168,7 @@ WINOGRAD_WIDE = 0x400  # 0x400: the wide wave tile of csrc/conv3x3_wino32.inc)
 DEFAULT_PLAN_FILE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "plans", "gfx950.json")
 PLAN_FILE = os.environ.get("BLOCKCOPY_CONV_PLAN", DEFAULT_PLAN_FILE)
 PLAN_STATS = {"from_table": 0, "tuned_live": 0, "fixed_rule": 0}
+PLAN_KEYS_SEEN = {}    # layer-shape key -> lookups in this process (tools/refine_plans.py: which entries a workload actually uses)
 _DTYPE_NAMES = {torch.float32: "f32", torch.float16: "f16", torch.bfloat16: "bf16"}
 _DTYPE_BY_NAME = {v: k for k, v in _DTYPE_NAMES.items()}
 _loaded_keys = set()
@@ -267,6 +268,7 @@ def conv3x3_plan(n_exec: int, bs: int, cin: int, cout: int, n_total: int, dtype,
                 return wino[0]
         return -1
     key = (n_exec, bs, cin, cout, n_total, dtype, stride, ks)
+    PLAN_KEYS_SEEN[key] = PLAN_KEYS_SEEN.get(key, 0) + 1
     if key in _conv_plans:
         if key in _loaded_keys:
             PLAN_STATS["from_table"] += 1
