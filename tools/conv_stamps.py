@@ -21,14 +21,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=64)
     ap.add_argument("--cfg", type=int, default=-1)
+    ap.add_argument("--half", action="store_true", help="fp16 tensors (16-bit matrix instructions)")
     a = ap.parse_args()
+    dt = torch.float16 if a.half else torch.float32
     be = bk.get_backend()
     be.tune("conv2_cfg", a.cfg)
     for name, Cin, Cout, bs in CASES:
         gi, m = grid_tables(1, 8, 16, a.n)
-        feats = torch.randn((a.n, Cin, bs, bs), device="cuda").contiguous(memory_format=torch.channels_last)
-        ring = torch.randn((128, Cin, 4 * bs), device="cuda")
-        w = (torch.randn((Cout, Cin, 3, 3), device="cuda") * 0.05).contiguous(memory_format=torch.channels_last)
+        feats = torch.randn((a.n, Cin, bs, bs), device="cuda").to(dt).contiguous(memory_format=torch.channels_last)
+        ring = torch.randn((128, Cin, 4 * bs), device="cuda").to(dt)
+        w = (torch.randn((Cout, Cin, 3, 3), device="cuda") * 0.05).to(dt).contiguous(memory_format=torch.channels_last)
         wpk = be.pack_conv3x3_weights(w)
         stamps = torch.zeros(8 * 4096, dtype=torch.int64, device="cuda")
         for _ in range(3):
