@@ -125,6 +125,8 @@ def load_library(path: str = None) -> ctypes.CDLL:
         "bc_conv3x3_ring_nhwc": [p, p, p, p, p, p] + [i] * 8 + [p, p, i, p, p, p, i, p],
         "bc_conv3x3s2_ring_nhwc": [p, p, p, p, p, p] + [i] * 8 + [p, p, i, p, p, p, i, p],
         "bc_conv3x3_candidates": [i, i, i, i, i, i, ctypes.POINTER(i), i],
+        "bc_conv3x3_dil_ring_nhwc": [p, p, p, p, p, p] + [i] * 9 + [p, p, i, p, p, p, i, p],
+        "bc_conv3x3_dil_candidates": [i, i, i, i, i, i, ctypes.POINTER(i), i],
         "bc_stem7x7s2_nhwc": [p, p, p, p] + [i] * 7 + [p, p, p, i, p],
         "bc_conv1x1_nhwc": [p, p, p] + [i] * 6 + [p, p, i, p, p, p, i, p],
         "bc_conv1x1_candidates": [i, i, i, i, i, i, ctypes.POINTER(i), i],
@@ -403,8 +405,13 @@ class HipBackend:
             return False
         bs = data_exec.shape[2] // st                                 # output tile size
         cin_unit = 32 if data_exec.dtype == torch.float32 else 64     # 16-bit: two 32-channel units are staged per K iteration
+        dil = _one(dilation)
+        if dil == 2:        # the dilated stage of a detector backbone: padding = dilation = 2, stride 1, tiles of a multiple of 8 pixels
+            return (data_exec.dtype in _DTYPE_CODE and weight.dtype == data_exec.dtype and is_nhwc(data_exec) and tuple(weight.shape[2:]) == (3, 3)
+                    and _one(padding) == 2 and st == 1 and groups == 1 and weight.shape[1] % cin_unit == 0 and weight.shape[0] % 64 == 0
+                    and data_exec.shape[2] == data_exec.shape[3] and bs % 8 == 0 and bs <= 248)
         return (data_exec.dtype in _DTYPE_CODE and weight.dtype == data_exec.dtype and is_nhwc(data_exec)
-                and tuple(weight.shape[2:]) == (3, 3) and _one(padding) == 1 and _one(dilation) == 1
+                and tuple(weight.shape[2:]) == (3, 3) and _one(padding) == 1 and dil == 1
                 and groups == 1 and weight.shape[1] % cin_unit == 0 and weight.shape[0] % 64 == 0
                 and data_exec.shape[2] == data_exec.shape[3] and (bs == 4 or (bs % 8 == 0 and bs * st <= 248)))
 
@@ -434,12 +441,15 @@ class HipBackend:
         V = V.permute(6, 2, 3, 0, 4, 7, 1, 5)                                                               # nb, chunk, ss, q, h, n, f%2, t
         return torch.cat([direct, U16.contiguous().view(-1), V.contiguous().view(-1)])
 
-    def conv3x3_candidates(self, n_exec, cin, cout, bs, elem_size=4, stride=1):
+    def conv3x3_candidates(self, n_exec, cin, cout, bs, elem_size=4, stride=1, dilation=1):
         """Decomposition indices of the balanced conv kernel that cover this layer shape (bs = input tile size), straight from
-        the library's launcher rules (bc_conv3x3_candidates)."""
+        the library's launcher rules (bc_conv3x3_candidates / bc_conv3x3_dil_candidates)."""
         buf = (ctypes.c_int * 64)()
         dt = 0 if elem_size == 4 else 1
-        n = self.lib.bc_conv3x3_candidates(dt, int(stride), int(n_exec), int(cin), int(cout), int(bs), buf, 64)
+        if dilation != 1:
+            n = self.lib.bc_conv3x3_dil_candidates(dt, int(dilation), int(n_exec), int(cin), int(cout), int(bs), buf, 64)
+        else:
+            n = self.lib.bc_conv3x3_candidates(dt, int(stride), int(n_exec), int(cin), int(cout), int(bs), buf, 64)
         if n < 0:
             return []
         return [int(buf[k]) for k in range(n)]
@@ -472,7 +482,7 @@ class HipBackend:
             out[name] = sorted(ts)[len(ts) // 2]
         return out
 
-    def conv3x3_ring(self, data_exec, ring, wpk, cout, grid_idx, mapping_exec, prologue=None, epilogue=None, cfg=None, stride=1):
+    def conv3x3_ring(self, data_exec, ring, wpk, cout, grid_idx, mapping_exec, prologue=None, epilogue=None, cfg=None, stride=1, dilation=1):
         """Fused halo gather + 3x3/s1/p1 conv (+ optional epilogue) of a channels-last packed batch on the fp32 matrix
         cores.  prologue = (scale, shift, relu) per input channel, epilogue = (scale, shift, add, relu) per output channel."""
         dt = data_exec.dtype
@@ -482,7 +492,8 @@ class HipBackend:
         B, C, bs, _ = data_exec.shape
         n_exec = mapping_exec.numel()
         assert n_exec == B and wpk.numel() in (9 * C * cout, 41 * C * cout)     # (fp32: direct + two Winograd streams)
-        assert tuple(ring.shape) == (N * GH * GW, C, 4 * bs), (ring.shape, (N * GH * GW, C, 4 * bs))
+        assert dilation in (1, 2) and (dilation == 1 or stride == 1)
+        assert tuple(ring.shape) == (N * GH * GW, C, 4 * dilation * bs), (ring.shape, (N * GH * GW, C, 4 * dilation * bs))
         assert stride in (1, 2) and bs % stride == 0
         out = empty_like_layout((B, cout, bs // stride, bs // stride), data_exec)
         isc, ish, irelu = prologue if prologue is not None else (None, None, False)
@@ -497,6 +508,13 @@ class HipBackend:
                 if want != self._conv_cfg:
                     self._check(self.lib.bc_tune_set(b"conv2_cfg", want), "tune_set")
                     self._conv_cfg = want
+                if dilation == 2:
+                    self._check(self.lib.bc_conv3x3_dil_ring_nhwc(out.data_ptr(), data_exec.data_ptr(), ring.data_ptr(), wpk.data_ptr(),
+                                                                  grid_idx.data_ptr(), mapping_exec.data_ptr(), n_exec, N, C, cout, GH, GW, bs, 2,
+                                                                  _DTYPE_CODE[data_exec.dtype], ptr(isc), ptr(ish), int(bool(irelu)),
+                                                                  ptr(osc), ptr(osh), ptr(oadd), int(bool(orelu)), self._stream()),
+                                "conv3x3_dil_ring_nhwc")
+                    return out
                 fn = self.lib.bc_conv3x3_ring_nhwc if stride == 1 else self.lib.bc_conv3x3s2_ring_nhwc
                 self._check(fn(out.data_ptr(), data_exec.data_ptr(), ring.data_ptr(), wpk.data_ptr(),
                                grid_idx.data_ptr(), mapping_exec.data_ptr(), n_exec, N, C, cout, GH, GW,

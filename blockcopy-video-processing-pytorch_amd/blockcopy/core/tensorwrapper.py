@@ -815,29 +815,30 @@ class TensorWrapper(torch.Tensor):
         if feats.engine != "fused" and is_nhwc(data):
             data = data.contiguous()    # the reference decomposition is NCHW only
         grid_idx, mapping_exec = feats._grid_idx, feats._mapping_exec
-        if feats.engine == "fused" and fuse and op == "conv2d" and padding == 1:
-            # 3x3 / stride 1 convs: ONE hand-written MFMA kernel gathers the halo and convolves (no padded tensor, no
+        if feats.engine == "fused" and fuse and op == "conv2d" and padding in (1, 2):
+            # 3x3 convs (stride 1 / 2, or dilation 2 with padding 2): ONE hand-written MFMA kernel gathers the halo and convolves (no padded tensor, no
             # library conv) wherever it is the faster route for this layer shape; else halo gather + library conv
             be = get_backend()
-            plan = self._conv3x3_plan(be, data, args, kwargs, grid_idx, mapping_exec, func)
+            plan = self._conv3x3_plan(be, data, args, kwargs, grid_idx, mapping_exec, func, padding)
             if plan is not None:
                 weight = args[1] if len(args) > 1 else kwargs["weight"]
                 wpk = fusion.packed_conv3x3_weight(weight, be.pack_conv3x3_weights)   # cached per parameter object
                 ring = feats.next_ring(data, padding)
                 feats._pad_memo = None
                 stride = self._conv_stride(args, kwargs)
+                dil = {} if padding == 1 else {"dilation": padding}        # (padding 2 reaches here only as padding = dilation = 2)
                 if fusion.DEFER_CONV and data.dtype in getattr(be, "supports_fusion_dtypes", ()):
                     # deferred: the launch happens when the value is needed, carrying the elementwise work recorded by then (bias,
                     # residual add, ReLU) as its epilogue.  The placeholder is never read or written; `data` is held by the record.
                     placeholder = empty_like_layout((data.shape[0], weight.shape[0], data.shape[2] // stride, data.shape[3] // stride), data)
                     P = pend_out if pend_out is not None else fusion.Pending()
                     P.defer_conv(be.conv3x3_ring, dict(data_exec=data, ring=ring, wpk=wpk, cout=weight.shape[0], grid_idx=grid_idx,
-                                                       mapping_exec=mapping_exec, prologue=prologue, cfg=plan, stride=stride), data,
+                                                       mapping_exec=mapping_exec, prologue=prologue, cfg=plan, stride=stride, **dil), data,
                                  registry=feats._deferred)
                     return placeholder, P
                 with timings.env("tensorwrapper/conv3x3_fused", 10):
                     return be.conv3x3_ring(data, ring, wpk, weight.shape[0], grid_idx, mapping_exec, prologue, None, cfg=plan,
-                                           stride=stride), pend_out
+                                           stride=stride, **dil), pend_out
         if feats.engine == "fused" and fuse and op == "max_pool2d" and padding == 1:
             # the ResNet stem pool (3x3, stride 2): halo gather + max in one kernel, no padded tensor
             be = get_backend()
@@ -887,13 +888,14 @@ class TensorWrapper(torch.Tensor):
         st = kwargs.get("stride", args[3] if len(args) > 3 else 1)
         return st if isinstance(st, int) else st[0]
 
-    def _conv3x3_plan(self, be, data, args, kwargs, grid_idx, mapping_exec, func):
+    def _conv3x3_plan(self, be, data, args, kwargs, grid_idx, mapping_exec, func, padding=1):
         """None = halo gather + library conv; int = fused halo+conv kernel with that decomposition (fusion.conv3x3_plan)."""
         weight = args[1] if len(args) > 1 else kwargs.get("weight")
         cv = {k: kwargs.get(k, args[i] if len(args) > i else d) for k, i, d in (("stride", 3, 1), ("dilation", 5, 1), ("groups", 6, 1))}
         if not (isinstance(weight, torch.Tensor) and hasattr(be, "conv3x3_ring")
-                and be.conv3x3_supported(data, weight, cv["stride"], 1, cv["dilation"], cv["groups"])):
+                and be.conv3x3_supported(data, weight, cv["stride"], padding, cv["dilation"], cv["groups"])):
             return None
+        dil = 1 if padding == 1 else 2
         n_exec, cin, bs = data.shape[0], data.shape[1], data.shape[2]
         cout, n_total = weight.shape[0], grid_idx.numel()
         stride = self._conv_stride(args, kwargs)
@@ -903,21 +905,25 @@ class TensorWrapper(torch.Tensor):
                 return None
             w_plain = weight.as_subclass(torch.Tensor) if isinstance(weight, TensorWrapper) else weight
             wpk = fusion.packed_conv3x3_weight(weight, be.pack_conv3x3_weights)
-            scratch = torch.zeros((n_total, cin, 4 * bs), dtype=data.dtype, device=data.device)   # a ring nobody else reads
-            lib0 = lambda: torch.nn.functional.conv2d(be.pad_ring(data, scratch, grid_idx, mapping_exec, 1, None), w_plain.detach(), stride=stride)
+            scratch = torch.zeros((n_total, cin, 4 * dil * bs), dtype=data.dtype, device=data.device)   # a ring nobody else reads
+            dkw = {} if dil == 1 else {"dilation": dil}
+            lib0 = lambda: torch.nn.functional.conv2d(be.pad_ring(data, scratch, grid_idx, mapping_exec, dil, None), w_plain.detach(), stride=stride, dilation=dil)
             lib = lib0
             if fusion.TUNE_EPILOGUE_COST:      # (see fusion.TUNE_EPILOGUE_COST: the elementwise pass the library route needs after the conv)
                 zero = torch.zeros(cout, dtype=torch.float32, device=data.device)
                 lib = lambda: be.affine_act(lib0(), None, zero, None, True)
             routes = {"library": lib}
-            for c in be.conv3x3_candidates(n_exec, cin, cout, bs, data.element_size(), stride):
-                routes[str(c)] = (lambda c_: lambda: be.conv3x3_ring(data, scratch, wpk, cout, grid_idx, mapping_exec, None, None, cfg=c_, stride=stride))(c)
+            for c in be.conv3x3_candidates(n_exec, cin, cout, bs, data.element_size(), stride, **dkw):
+                routes[str(c)] = (lambda c_: lambda: be.conv3x3_ring(data, scratch, wpk, cout, grid_idx, mapping_exec, None, None, cfg=c_, stride=stride, **dkw))(c)
             return be.time_routes(routes)
 
         def candidates():
-            return be.conv3x3_candidates(n_exec, cin, cout, bs, data.element_size(), stride) if hasattr(be, "conv3x3_candidates") else []
+            if not hasattr(be, "conv3x3_candidates"):
+                return []
+            return be.conv3x3_candidates(n_exec, cin, cout, bs, data.element_size(), stride, **({} if dil == 1 else {"dilation": dil}))
 
-        return fusion.conv3x3_plan(n_exec, bs, cin, cout, n_total, data.dtype, tuner, stride, candidates=candidates)
+        # (plan-table key: kernel-size field 3 for the plain form, 13 for dilation 2)
+        return fusion.conv3x3_plan(n_exec, bs, cin, cout, n_total, data.dtype, tuner, stride, ks=3 if dil == 1 else 13, candidates=candidates)
 
     def _dense_pointwise_conv(self, args, kwargs):
         """conv2d on a dense (non-packed) TensorWrapper: 1x1 convs take the fused one-tap kernel; returns (result, pending) or None."""
@@ -1025,10 +1031,10 @@ class TensorWrapper(torch.Tensor):
         raw = x._raw()
         if not (is_nhwc(raw) and be.pad_ring_add_supported(dense_layout(raw), dense_layout(P.add))):
             return False
-        if op == "conv2d" and padding == 1:
+        if op == "conv2d" and padding in (1, 2):
             # layers that go to the fused MFMA conv keep the plain route (materialise, then conv without prologue)
             feats = self._features
-            if self._conv3x3_plan(be, dense_layout(raw), args, kwargs, feats._grid_idx, feats._mapping_exec, None) is not None:
+            if self._conv3x3_plan(be, dense_layout(raw), args, kwargs, feats._grid_idx, feats._mapping_exec, None, padding) is not None:
                 return False
         return True
 

@@ -15,8 +15,8 @@ OBJ_DIR = os.path.join(HERE, "lib", "obj")
 ARCH = "gfx950"
 # the one source is compiled as 7 translation units (-DBC_PART=n, see ConvV2Args in csrc/blockcopy_hip.hip): part 0 = everything
 # but the decompositions of the fused conv kernel, parts 1..6 = one (dtype, kernel size) slice of them each, part 7 = its Winograd form,
-# part 8 = the wide-tile Winograd form
-PARTS = list(range(9))
+# part 8 = the wide-tile Winograd form, part 9 = the dilation-2 form of the direct kernel
+PARTS = list(range(10))
 
 
 def hipcc() -> str:

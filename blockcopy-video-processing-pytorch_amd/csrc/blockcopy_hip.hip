@@ -2134,7 +2134,7 @@ static const Conv2Cfg CONV2_CFGS[] = {{2, 2, 4, 2, 1}, {2, 1, 4, 2, 1}, {1, 2, 4
 // geometry of one decomposition for a layer (bs = OUTPUT tile size); false if the decomposition does not cover the layer
 struct Conv2Plan { long long wgs; size_t lds_bytes; uint32_t n_rows, patches_per_tile, patches_x; };
 
-static bool conv2_plan(const Conv2Cfg &k, int E, int S, int n_exec, int Cin, int Cout, int bs, Conv2Plan &p, int KS = 3)
+static bool conv2_plan(const Conv2Cfg &k, int E, int S, int n_exec, int Cin, int Cout, int bs, Conv2Plan &p, int KS = 3, int D = 1)
 {
     const int pw = bs == 4 ? 4 : 8;
     const int uv = E == 4 ? 8 : 4, sc_lo = E == 4 ? 1 : 2;
@@ -2144,7 +2144,7 @@ static bool conv2_plan(const Conv2Cfg &k, int E, int S, int n_exec, int Cin, int
     if (pw == 8 && bs % (4 * k.RM) != 0) return false;
     if (Cout % (32 * k.RN * k.WNW) != 0 || Cin % (32 * sc) != 0) return false;
     const uint32_t ph = pw == 8 ? 4u * k.RM : 4u, tpr = pw == 8 ? 1u : 2u * k.RM;
-    const uint32_t slot_px = (uint32_t)(S * (pw - 1) + KS) * (S * (ph - 1) + KS);
+    const uint32_t slot_px = (uint32_t)(S * (pw - 1) + D * (KS - 1) + 1) * (S * (ph - 1) + D * (KS - 1) + 1);
     const size_t img = (size_t)k.WMW * tpr * slot_px * (uv * sc + 1) * 16;
     const size_t red = (size_t)k.WMW * k.WNW * (k.WKW - 1) * k.RM * k.RN * 16 * 64 * sizeof(float);
     p.lds_bytes = 2 * img > red ? 2 * img : red;
@@ -2173,20 +2173,21 @@ struct ConvV2Args {
     unsigned long long *stamps;
     int chosen;                                    // out: the decomposition that was launched
     int xcd_remap;                                 // 1: XCD-aware workgroup order (xcd_remap() in conv3x3_v2.inc)
+    int dilation;                                  // 1, or 2 (bc_conv3x3_dil_ring_nhwc: part 9)
 };
 struct LaunchProf { bool on; struct { hipEvent_t a, b; } rec; };   // what BC_LAUNCH needs of a ProfScope
 
 #if defined(BC_MONO) || (BC_PART != 0 && BC_PART != 7 && BC_PART != 8)
-template <int DT, int RM, int RN, int WMW, int WNW, int WKW, int SC, int PW, int S, int KS>
+template <int DT, int RM, int RN, int WMW, int WNW, int WKW, int SC, int PW, int S, int KS, int D = 1>
 static void launch_conv3x3_v2_cfg(LaunchProf &ps, dim3 grid, size_t lds_bytes, const ConvV2Args &a, const ConvGeom2 &g)
 {
     static bool attr_set = false;   // > 64 KB of dynamic LDS needs the opt-in once per kernel
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_v2<DT, RM, RN, WMW, WNW, WKW, SC, PW, S, KS>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_v2<DT, RM, RN, WMW, WNW, WKW, SC, PW, S, KS, D>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
         attr_set = true;
     }
-    BC_LAUNCH(ps, (k_conv3x3_v2<DT, RM, RN, WMW, WNW, WKW, SC, PW, S, KS>), grid, dim3(512), lds_bytes, a.st, (typename CvType<DT>::T *)a.out,
+    BC_LAUNCH(ps, (k_conv3x3_v2<DT, RM, RN, WMW, WNW, WKW, SC, PW, S, KS, D>), grid, dim3(512), lds_bytes, a.st, (typename CvType<DT>::T *)a.out,
               (const uint4 *)a.features, (long long)(((const char *)a.ring - (const char *)a.features) / 16), (uint4 *)a.ring, (const uint4 *)a.wpk,
               a.grid_idx, a.mapping_exec, g, a.pr, a.ep, a.stamps);
 }
@@ -2275,6 +2276,68 @@ static int conv_v2_run(ConvV2Args &a)
     return launch_status();
 }
 
+#endif
+
+// ---- dilation 2 (3x3, stride 1, tiles of a multiple of 8 pixels): the decompositions of CONV2_CFGS with one 32-channel column per wave
+static const int CONV2_DIL_CFGS[] = {3, 5, 6, 7, 11, 15};
+constexpr int CONV2_DIL_N = (int)(sizeof(CONV2_DIL_CFGS) / sizeof(CONV2_DIL_CFGS[0]));
+
+#if defined(BC_MONO) || BC_PART == 9
+template <int DT>
+static int conv_v2_dil_run(ConvV2Args &a)
+{
+    constexpr int E = CvType<DT>::E;
+    LaunchProf ps{a.prof_on != 0, {a.ev_a, a.ev_b}};
+    constexpr int SC_LO = DT == BC_F32 ? 1 : 2, SC_HI = 2 * SC_LO;
+    const int force = a.force_cfg < 0 ? -1 : (a.force_cfg & 0xff);
+    const int min_lds = (a.force_cfg >= 0 && (a.force_cfg & 0x100)) ? 0 : a.min_lds;
+    if (a.bs % 8 != 0) return BC_ERR_SHAPE;
+    const int cus = device_cu_count();
+    int best = -1;
+    double best_t = 0;
+    Conv2Plan plan, best_plan{};
+    for (int i = 0; i < CONV2_DIL_N; ++i) {
+        const int c = CONV2_DIL_CFGS[i];
+        const Conv2Cfg &k = CONV2_CFGS[c];
+        if (force >= 0 && c != force) continue;
+        if (!conv2_plan(k, E, 1, a.n_exec, a.Cin, a.Cout, a.bs, plan, 3, 2)) continue;
+        const long long rounds = (plan.wgs + cus - 1) / cus;
+        const double mf = (double)k.RM * k.RN * 9.0 * (a.Cin / 8) * 4.0 / k.WKW;
+        const double t = rounds * (mf / (k.RM == 2 ? 0.79 : 0.70) + 70.0 + 12.0 * (k.WKW - 1) * k.RM * k.RN);
+        if (best < 0 || t < best_t) { best = c; best_t = t; best_plan = plan; }
+    }
+    if (best < 0) return BC_ERR_SHAPE;
+    a.chosen = best;
+    const Conv2Cfg &k = CONV2_CFGS[best];
+    ConvGeom2 g;
+    g.Cin = a.Cin; g.Cout = a.Cout; g.bs = a.bs; g.GH = a.GH; g.GW = a.GW; g.n_exec = a.n_exec;
+    g.patches_x = best_plan.patches_x;
+    g.patches_per_tile = best_plan.patches_per_tile;
+    g.n_rows = best_plan.n_rows;
+    g.cin_chunks = a.Cin / CV_CH;
+    g.xcd = (uint32_t)a.xcd_remap;
+    size_t lds_bytes = best_plan.lds_bytes;
+    if (lds_bytes < (size_t)min_lds) lds_bytes = min_lds;
+    const dim3 grid((g.n_rows + k.WMW - 1) / k.WMW, (unsigned)a.Cout / (32 * k.RN * k.WNW));
+    switch (best) {
+    case 3: launch_conv3x3_v2_cfg<DT, 1, 1, 4, 2, 1, SC_LO, 8, 1, 3, 2>(ps, grid, lds_bytes, a, g); break;
+    case 5: launch_conv3x3_v2_cfg<DT, 1, 1, 2, 2, 2, SC_LO, 8, 1, 3, 2>(ps, grid, lds_bytes, a, g); break;
+    case 6: launch_conv3x3_v2_cfg<DT, 1, 1, 1, 4, 2, SC_LO, 8, 1, 3, 2>(ps, grid, lds_bytes, a, g); break;
+    case 7: launch_conv3x3_v2_cfg<DT, 1, 1, 1, 2, 4, SC_LO, 8, 1, 3, 2>(ps, grid, lds_bytes, a, g); break;
+    case 11: launch_conv3x3_v2_cfg<DT, 2, 1, 1, 4, 2, SC_LO, 8, 1, 3, 2>(ps, grid, lds_bytes, a, g); break;
+    default: launch_conv3x3_v2_cfg<DT, 1, 1, 1, 1, 8, SC_HI, 8, 1, 3, 2>(ps, grid, lds_bytes, a, g); break;
+    }
+    return launch_status();
+}
+#endif
+
+#if BC_PART == 9
+extern "C" int bc_part_conv_v2_dil(void *p)
+{
+    ConvV2Args &a = *static_cast<ConvV2Args *>(p);
+    // dtype travels in `stride` for this part (the stride of a dilated launch is always 1)
+    return a.stride == BC_F32 ? conv_v2_dil_run<BC_F32>(a) : (a.stride == BC_F16 ? conv_v2_dil_run<BC_F16>(a) : conv_v2_dil_run<BC_BF16>(a));
+}
 #endif
 
 // ---- host side of conv3x3_wino.inc (Winograd F(2x2,3x3), fp32 / stride 1): decompositions (MB, WMW, WNW, WKW); code 0x200 | index
@@ -2430,7 +2493,7 @@ static int conv_wino32_run(ConvV2Args &a)
 extern "C" int bc_part_conv_wino32(void *p) { return conv_wino32_run(*static_cast<ConvV2Args *>(p)); }
 #endif
 
-#if BC_PART != 0 && BC_PART != 7 && BC_PART != 8
+#if BC_PART != 0 && BC_PART != 7 && BC_PART != 8 && BC_PART != 9
 // this slice: dtype (BC_PART - 1) / 2, kernel size 3 (odd parts) or 1 (even parts), both strides
 #define BC_PART_NAME2(n_) bc_part_conv_v2_##n_
 #define BC_PART_NAME(n_) BC_PART_NAME2(n_)
@@ -2463,6 +2526,7 @@ int bc_part_conv_v2_1(void *); int bc_part_conv_v2_2(void *); int bc_part_conv_v
 int bc_part_conv_v2_4(void *); int bc_part_conv_v2_5(void *); int bc_part_conv_v2_6(void *);
 int bc_part_conv_wino(void *);
 int bc_part_conv_wino32(void *);
+int bc_part_conv_v2_dil(void *);
 }
 #endif
 
@@ -2472,7 +2536,7 @@ static int launch_conv3x3_v2(ProfScope &ps, void *out, const void *features, voi
                              const Prologue &pr, const EpilogueT &ep, hipStream_t st)
 {
     ConvV2Args a{out, features, ring, wpk, grid_idx, mapping_exec, n_exec, Cin, Cout, GH, GW, bs, S, pr, ep, st,
-                 ps.on ? 1 : 0, ps.rec.a, ps.rec.b, g_tune.conv2_cfg, g_tune.conv2_min_lds, g_tune.conv_stamps, -2, g_tune.xcd_remap};
+                 ps.on ? 1 : 0, ps.rec.a, ps.rec.b, g_tune.conv2_cfg, g_tune.conv2_min_lds, g_tune.conv_stamps, -2, g_tune.xcd_remap, 1};
     const double direct_flops = 2.0 * n_exec * (double)(bs / S) * (bs / S) * (KS * KS) * (double)Cin * Cout;
     if (DT == BC_F32 && S == 1 && KS == 3 && a.force_cfg >= 0 && (a.force_cfg & 0x600)) {       // Winograd forms (conv3x3_wino.inc, conv3x3_wino32.inc)
         ps.add_aux(direct_flops * 16.0 / 36.0);     // F(2x2,3x3): 16 multiplications per 2x2 outputs instead of 36
@@ -3033,6 +3097,53 @@ BC_EXPORT int bc_conv3x3_ring_nhwc(void *out, const void *features, void *ring, 
     else { if (WM_ == 2) BC_CV(4, 2); else BC_CV(4, 1); }
 #undef BC_CV
     return launch_status();
+}
+
+BC_EXPORT int bc_conv3x3_dil_ring_nhwc(void *out, const void *features, void *ring, const void *weights_packed,
+                                       const int32_t *grid_idx, const int32_t *mapping_exec, int n_exec, int N, int Cin, int Cout,
+                                       int GH, int GW, int bs, int dilation, int dtype, const float *in_scale, const float *in_shift, int in_relu,
+                                       const float *out_scale, const float *out_shift, const void *out_add, int out_relu, void *stream)
+{
+    if (dilation == 1)
+        return bc_conv3x3_ring_nhwc(out, features, ring, weights_packed, grid_idx, mapping_exec, n_exec, N, Cin, Cout, GH, GW, bs, dtype,
+                                    in_scale, in_shift, in_relu, out_scale, out_shift, out_add, out_relu, stream);
+    if (dtype < BC_F32 || dtype > BC_BF16) return BC_ERR_ELEM;
+    if (dilation != 2 || n_exec < 0 || N <= 0 || Cin <= 0 || Cout <= 0 || GH <= 0 || GW <= 0 || bs <= 0) return BC_ERR_SHAPE;
+    if (Cin % CV_CH != 0 || Cout % 32 != 0 || bs % 8 != 0 || bs > 248) return BC_ERR_SHAPE;
+    if (n_exec == 0) return BC_OK;
+    if (!out || !features || !ring || !weights_packed || !grid_idx || !mapping_exec) return BC_ERR_NULL;
+    if ((uint64_t)n_exec * bs * bs * (uint64_t)(Cin > Cout ? Cin : Cout) >= (1ull << 31) ||
+        (uint64_t)N * GH * GW * 8 * bs * Cin >= (1ull << 31)) return BC_ERR_RANGE;
+    if (!aligned(out, 16) || !aligned(features, 16) || !aligned(ring, 16) || !aligned(weights_packed, 16) || !aligned(out_add, 2))
+        return BC_ERR_ALIGN;
+    Prologue pr{in_scale, in_shift, in_relu};
+    EpilogueT ept{out_scale, out_shift, out_add, out_relu};
+    const double flops = 2.0 * n_exec * bs * bs * 9.0 * Cin * Cout;
+    ProfScope ps(BC_OP_CONV3X3, flops);
+    ps.add_aux(flops);
+    // (this part's dispatcher reads the dtype from the `stride` field: the stride of a dilated launch is always 1)
+    ConvV2Args a{out, features, ring, weights_packed, grid_idx, mapping_exec, n_exec, Cin, Cout, GH, GW, bs, dtype, pr, ept, (hipStream_t)stream,
+                 ps.on ? 1 : 0, ps.rec.a, ps.rec.b, g_tune.conv2_cfg, g_tune.conv2_min_lds, g_tune.conv_stamps, -2, g_tune.xcd_remap, 2};
+#if defined(BC_MONO)
+    const int rc = dtype == BC_F32 ? conv_v2_dil_run<BC_F32>(a) : (dtype == BC_F16 ? conv_v2_dil_run<BC_F16>(a) : conv_v2_dil_run<BC_BF16>(a));
+#else
+    const int rc = bc_part_conv_v2_dil(&a);
+#endif
+    if (a.chosen >= 0) g_tune.conv_last_cfg = a.chosen;
+    return rc;
+}
+
+BC_EXPORT int bc_conv3x3_dil_candidates(int dtype, int dilation, int n_exec, int Cin, int Cout, int bs, int *out, int max_out)
+{
+    if (dilation == 1) return bc_conv3x3_candidates(dtype, 1, n_exec, Cin, Cout, bs, out, max_out);
+    if (dtype < BC_F32 || dtype > BC_BF16 || dilation != 2 || !out) return BC_ERR_SHAPE;
+    if (bs % 8 != 0 || bs > 248) return 0;
+    const int E = dtype == BC_F32 ? 4 : 2;
+    int n = 0;
+    Conv2Plan plan;
+    for (int i = 0; i < CONV2_DIL_N && n < max_out; ++i)
+        if (conv2_plan(CONV2_CFGS[CONV2_DIL_CFGS[i]], E, 1, n_exec, Cin, Cout, bs, plan, 3, 2)) out[n++] = CONV2_DIL_CFGS[i];
+    return n;
 }
 
 BC_EXPORT int bc_stem7x7s2_nhwc(void *out, const void *frame_state, const void *weights_packed, const int32_t *mapping_exec, int n_exec,

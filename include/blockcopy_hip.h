@@ -281,6 +281,17 @@ int bc_adaptive_avg_pool_nhwc(void *out, const void *in, int N, int C, int H, in
  * The Winograd form reads a second weight stream placed behind the direct one in weights_packed (fp32 3x3 only):
  *   wino[nb16][chunk][step < 4][q < 8][lane = 16*kq + n][e < 4] = (G g Gt)[f][cin = 32*chunk + 8*step + 2*kq + t][cout = 16*nb16 + n],
  *   2*f + t = 4*q + e, f = 4*xi + nu, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]  (16 * Cin * Cout floats after the 9 * Cin * Cout). */
+/* The same fused halo + 3x3 conv with DILATION 2 (padding = dilation = 2, stride 1): the dilated last stage of a detector backbone
+ * (Pedestron/mmdet/models/backbones/resnet.py:155-162; reference path: BlockPadFunction with pad 2 + F.conv2d(dilation=2),
+ * core/tensorwrapper.py:529-575).  Everything as bc_conv3x3_ring_nhwc except: taps 2 pixels apart, halo / zero border 2 pixels
+ * wide, `ring` = (N*GH*GW, 8*bs, Cin) records of the pad-2 layout of bc_pad_ring_nhwc (bit-identical refresh), bs a multiple of 8,
+ * Cout a multiple of 32.  dilation = 1 forwards to bc_conv3x3_ring_nhwc.  bc_conv3x3_dil_candidates lists the decompositions
+ * (indices into the direct form's table) that cover a layer. */
+int bc_conv3x3_dil_ring_nhwc(void *out, const void *features, void *ring, const void *weights_packed,
+                             const int32_t *grid_idx, const int32_t *mapping_exec, int n_exec, int N, int Cin, int Cout,
+                             int GH, int GW, int bs, int dilation, int dtype, const float *in_scale, const float *in_shift, int in_relu,
+                             const float *out_scale, const float *out_shift, const void *out_add, int out_relu, void *stream);
+int bc_conv3x3_dil_candidates(int dtype, int dilation, int n_exec, int Cin, int Cout, int bs, int *out, int max_out);
 int bc_conv3x3_candidates(int dtype, int stride, int n_exec, int Cin, int Cout, int bs_in, int *out, int max_out);
 
 /* halo gather with a residual-add prologue and a by-product: v = relu?(features*scale[c] + shift[c] + add) is computed while

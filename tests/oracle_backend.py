@@ -141,17 +141,17 @@ class OracleBackend:
     @staticmethod
     def conv3x3_supported(data_exec, weight, stride=1, padding=1, dilation=1, groups=1):
         one = lambda v: v if isinstance(v, int) else (v[0] if len(set(v)) == 1 else None)
-        return (_nhwc(data_exec) and tuple(weight.shape[2:]) == (3, 3) and one(stride) in (1, 2) and one(padding) == 1 and one(dilation) == 1
-                and groups == 1 and data_exec.shape[2] % one(stride) == 0 and data_exec.dtype == torch.float32)
+        return (_nhwc(data_exec) and tuple(weight.shape[2:]) == (3, 3) and one(stride) in (1, 2) and one(padding) == one(dilation) and one(dilation) in (1, 2)
+                and (one(dilation) == 1 or one(stride) == 1) and groups == 1 and data_exec.shape[2] % one(stride) == 0 and data_exec.dtype == torch.float32)
 
     @staticmethod
     def pack_conv3x3_weights(weight):
         return weight.detach().contiguous().reshape(-1)        # the checker keeps the plain (Cout, Cin, 3, 3) order
 
-    def conv3x3_ring(self, data_exec, ring, wpk, cout, grid_idx, mapping_exec, prologue=None, epilogue=None, cfg=None, stride=1):
-        padded = self.pad_ring(data_exec, ring, grid_idx, mapping_exec, 1, prologue)
+    def conv3x3_ring(self, data_exec, ring, wpk, cout, grid_idx, mapping_exec, prologue=None, epilogue=None, cfg=None, stride=1, dilation=1):
+        padded = self.pad_ring(data_exec, ring, grid_idx, mapping_exec, dilation, prologue)
         w = wpk.reshape(cout, data_exec.shape[1], 3, 3)
-        y = torch.nn.functional.conv2d(padded.contiguous(), w, stride=stride)
+        y = torch.nn.functional.conv2d(padded.contiguous(), w, stride=stride, dilation=dilation)
         if epilogue is not None:
             scale, shift, add, relu = epilogue
             y = self.affine_act(y, scale, shift, add.contiguous() if add is not None else None, relu)

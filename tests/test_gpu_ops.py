@@ -653,6 +653,56 @@ def test_fused_conv3x3_stride2(be, dtype, tol):
         be.tune("conv2_cfg", -1)
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
+def test_fused_conv3x3_dilation2(be, dtype, tol):
+    """bc_conv3x3_dil_ring_nhwc (the dilated stage of a detector backbone: 3x3, dilation 2, padding 2, stride 1) == 2-pixel halo
+    gather (bit-exact against the oracle elsewhere) + fp64 dilated conv, for every decomposition the library lists for the layer
+    (bc_conv3x3_dil_candidates) and its own choice, with prologue / epilogue / residual; ring caches (4 * 2 * bs records per
+    tile) bit-identical."""
+    import torch.nn.functional as F
+
+    rng = np.random.default_rng(53)
+    gen = torch.Generator().manual_seed(53)
+    try:
+        for case, (Cin, Cout, bs, N, GH, GW) in enumerate([(64, 64, 8, 1, 3, 4), (128, 128, 16, 1, 2, 3), (512, 512, 8, 2, 2, 3), (64, 128, 24, 1, 2, 2),
+                                                            (128, 64, 32, 1, 1, 2), (256, 256, 8, 1, 1, 1)]):
+            T = N * GH * GW
+            w = (torch.randn((Cout, Cin, 3, 3), generator=gen) * (2.0 / (9 * Cin)) ** 0.5).cuda().to(dtype)
+            assert be.conv3x3_supported(_cl(torch.zeros((1, Cin, bs, bs), dtype=dtype).cuda()), w, 1, 2, 2, 1)
+            assert not be.conv3x3_supported(_cl(torch.zeros((1, Cin, bs, bs), dtype=dtype).cuda()), w, 2, 2, 2, 1)
+            assert not be.conv3x3_supported(_cl(torch.zeros((1, Cin, bs, bs), dtype=dtype).cuda()), w, 1, 1, 2, 1)
+            wpk = be.pack_conv3x3_weights(w)
+            cands = be.conv3x3_candidates(T, Cin, Cout, bs, w.element_size(), 1, dilation=2)
+            assert cands, (case, "no decomposition covers this dilated layer")
+            for cfg in [-1] + cands:
+                be.tune("conv2_cfg", cfg)
+                ring_a, ring_b = torch.zeros((T, Cin, 8 * bs), dtype=dtype).cuda(), torch.zeros((T, Cin, 8 * bs), dtype=dtype).cuda()
+                for t in range(4):
+                    g = np.ones(T, bool) if t == 0 else rng.random(T) < (0.3, 0.5, 0.8, 0.4)[t]
+                    if not g.any():
+                        g[int(rng.integers(T))] = True
+                    gi, m = O.c_grid_mappings(g.reshape(N, 1, GH, GW))
+                    gi_d, m_d = _dev(gi), _dev(m)
+                    feats = _cl(torch.randn((len(m), Cin, bs, bs), generator=gen).cuda().to(dtype))
+                    pro = None if t == 0 else ((torch.rand(Cin, generator=gen) + 0.5).cuda(), (torch.randn(Cin, generator=gen) * 0.1).cuda(), t >= 2)
+                    add = _cl(torch.randn((len(m), Cout, bs, bs), generator=gen).cuda().to(dtype)) if t == 1 else None
+                    epi = None if t == 0 else ((torch.rand(Cout, generator=gen) + 0.5).cuda(), (torch.randn(Cout, generator=gen) * 0.1).cuda(), add, t != 2)
+                    want = F.conv2d(be.pad_ring(feats, ring_a, gi_d, m_d, 2, pro).double(), w.double(), dilation=2)
+                    if epi is not None:
+                        want = want * epi[0].view(1, -1, 1, 1) + epi[1].view(1, -1, 1, 1)
+                        if epi[2] is not None:
+                            want = want + epi[2].double()
+                        if epi[3]:
+                            want = torch.relu(want)
+                    got = be.conv3x3_ring(feats, ring_b, wpk, Cout, gi_d, m_d, pro, epi, dilation=2)
+                    assert tuple(got.shape) == (len(m), Cout, bs, bs) and got.dtype == dtype and (cfg < 0 or be.tune_get("conv_last_cfg") == cfg)
+                    err = (got.double() - want).abs().max().item()
+                    assert err <= tol * max(1.0, want.abs().max().item()), (case, cfg, t, err)
+                    assert torch.equal(ring_a, ring_b), (case, cfg, t)
+    finally:
+        be.tune("conv2_cfg", -1)
+
+
 @pytest.mark.parametrize("cfg", list(range(20)) + [0x200 | w for w in range(11)] + [0x400 | w for w in range(5)])
 def test_fused_conv3x3_every_decomposition(be, cfg):
     """The CU-balanced conv kernel (csrc/conv3x3_v2.inc) picks one of 20 decompositions per launch (register blocking
