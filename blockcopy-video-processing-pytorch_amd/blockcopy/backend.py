@@ -20,7 +20,7 @@ _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("BLOCKCOPY_HIP_LIB", os.path.join(_PKG_ROOT, "lib", "libblockcopy_hip.so"))
 
 OP_SPLIT, OP_COMBINE, OP_TRANSFER, OP_PAD, OP_COMBINE_COPY, OP_PAD_RING, OP_GRID_TABLES, OP_INTERP, OP_AFFINE = range(9)
-OP_NAMES = ("split", "combine", "transfer", "pad", "combine_copy", "pad_ring", "grid_tables", "interp", "affine", "nms", "conv3x3", "head1x1")
+OP_NAMES = ("split", "combine", "transfer", "pad", "combine_copy", "pad_ring", "grid_tables", "interp", "affine", "nms", "conv3x3", "head1x1", "pred3x3")
 _DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 ABI_VERSION = 2
 
@@ -127,6 +127,7 @@ def load_library(path: str = None) -> ctypes.CDLL:
         "bc_conv3x3_candidates": [i, i, i, i, i, i, ctypes.POINTER(i), i],
         "bc_conv3x3_dil_ring_nhwc": [p, p, p, p, p, p] + [i] * 9 + [p, p, i, p, p, p, i, p],
         "bc_conv3x3_dil_candidates": [i, i, i, i, i, i, ctypes.POINTER(i), i],
+        "bc_pred3x3_nhwc": [p, p, p, p, i, i, i, i, i, i, p],
         "bc_stem7x7s2_nhwc": [p, p, p, p] + [i] * 7 + [p, p, p, i, p],
         "bc_conv1x1_nhwc": [p, p, p] + [i] * 6 + [p, p, i, p, p, p, i, p],
         "bc_conv1x1_candidates": [i, i, i, i, i, i, ctypes.POINTER(i), i],
@@ -440,6 +441,32 @@ class HipBackend:
         V = torch.einsum("xi,ocij,yj->xyco", G, w0.double(), G).reshape(8, 2, Cin // 32, 8, 2, 2, Cout // 32, 32).float()   # q, f%2, chunk, ss, h, t, nb, n
         V = V.permute(6, 2, 3, 0, 4, 7, 1, 5)                                                               # nb, chunk, ss, q, h, n, f%2, t
         return torch.cat([direct, U16.contiguous().view(-1), V.contiguous().view(-1)])
+
+    # ---- dense 3x3 conv to <= 4 output channels (detector prediction convs on the combined map): bc_pred3x3_nhwc
+    @staticmethod
+    def pred3x3_supported(x, weight, stride=1, padding=1, dilation=1, groups=1):
+        def _one(v):
+            return v if isinstance(v, (int, str)) else (v[0] if len(set(v)) == 1 else None)
+
+        return (x.dim() == 4 and x.dtype in _DTYPE_CODE and x.is_contiguous(memory_format=torch.channels_last) and weight.dim() == 4
+                and tuple(weight.shape[2:]) == (3, 3) and _one(stride) == 1 and _one(padding) == 1 and _one(dilation) == 1 and groups == 1
+                and weight.shape[1] == x.shape[1] and x.shape[1] % 32 == 0 and 1 <= weight.shape[0] <= 4
+                and x.numel() < 2 ** 31 and x.shape[0] <= 65535)
+
+    @staticmethod
+    def pack_pred3x3_weights(weight):
+        """(Cout, Cin, 3, 3) -> fp32 [Cin][3][3][Cout] (the scalar operand order of k_pred3x3, include/blockcopy_hip.h)."""
+        return weight.detach().float().permute(1, 2, 3, 0).contiguous()
+
+    def pred3x3(self, x, wpk, bias, cout):
+        """y = conv2d(x, w, bias, stride 1, padding 1) for a dense channels-last map and cout <= 4; returns (N, cout, H, W) channels-last."""
+        N, C, H, W = x.shape
+        assert x.is_contiguous(memory_format=torch.channels_last) and tuple(wpk.shape) == (C, 3, 3, cout) and wpk.dtype == torch.float32 and wpk.is_contiguous()
+        assert bias is None or (bias.dtype == torch.float32 and bias.numel() == cout and bias.is_contiguous())
+        out = torch.empty((N, H, W, cout), dtype=x.dtype, device=x.device).permute(0, 3, 1, 2)
+        self._check(self.lib.bc_pred3x3_nhwc(out.data_ptr(), x.data_ptr(), wpk.data_ptr(), 0 if bias is None else bias.data_ptr(),
+                                             N, H, W, C, cout, _DTYPE_CODE[x.dtype], self._stream()), "pred3x3_nhwc")
+        return out
 
     def conv3x3_candidates(self, n_exec, cin, cout, bs, elem_size=4, stride=1, dilation=1):
         """Decomposition indices of the balanced conv kernel that cover this layer shape (bs = input tile size), straight from

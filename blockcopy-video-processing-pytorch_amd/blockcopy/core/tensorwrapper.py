@@ -71,6 +71,45 @@ def to_tensorwrapper(x: torch.Tensor) -> "TensorWrapper":
         return x.as_subclass(TensorWrapper)
 
 
+_CONV2D = torch.nn.functional.conv2d
+
+
+class DenseMap(torch.Tensor):
+    """What ``to_tensor`` hands out for a wide channels-last map under the fused engine: an ordinary dense tensor in every respect
+    but one -- a 3x3 / stride 1 / padding 1 conv to at most 4 output channels on it (the prediction convs a detector head applies
+    right after ``blockcopy.to_tensor``, reference Pedestron/mmdet/models/anchor_heads/csp_head.py:139-151) runs in the bandwidth
+    kernel ``bc_pred3x3_nhwc`` instead of the conv library (200-410 us -> 20-35 us per (1,256,256,512) map).  Every other op
+    sees, and returns, plain tensors."""
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func is _CONV2D and fusion.PRED_KERNEL:
+            got = _dense_pred_conv(args, kwargs)
+            if got is not None:
+                return got
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*args, **kwargs)
+
+
+def _dense_pred_conv(args, kwargs):
+    """conv2d(DenseMap, weight (<= 4, Cin, 3, 3), bias, stride 1, padding 1) through bc_pred3x3_nhwc, or None."""
+    cv = {k: kwargs.get(k, args[i] if len(args) > i else d) for k, i, d in
+          (("input", 0, None), ("weight", 1, None), ("bias", 2, None), ("stride", 3, 1), ("padding", 4, 0), ("dilation", 5, 1), ("groups", 6, 1))}
+    x, weight, bias = cv["input"], cv["weight"], cv["bias"]
+    if not (isinstance(x, DenseMap) and isinstance(weight, torch.Tensor) and not isinstance(weight, DenseMap)) or torch.is_grad_enabled() and (
+            x.requires_grad or weight.requires_grad):
+        return None
+    be = get_backend()
+    with torch._C.DisableTorchFunctionSubclass():
+        xt = x.as_subclass(torch.Tensor)
+        if not (hasattr(be, "pred3x3") and be.pred3x3_supported(xt, weight, cv["stride"], cv["padding"], cv["dilation"], cv["groups"])):
+            return None
+        wpk = fusion.packed_conv3x3_weight(weight, be.pack_pred3x3_weights)        # cached per parameter object
+        b32 = None if bias is None else fusion.packed_conv3x3_weight(bias, lambda b: b.detach().float().contiguous())
+        return be.pred3x3(xt, wpk, b32, weight.shape[0])
+
+
 def to_tensor(x):
     """TensorWrapper (or list / tuple / dict of them) -> torch.Tensor; packed tensors are combined first."""
     if isinstance(x, TensorWrapper):
@@ -484,7 +523,12 @@ class TensorWrapper(torch.Tensor):
     def to_tensor(self) -> torch.Tensor:
         """Plain torch.Tensor view; packed tensors are combined (out of place) first."""
         out = self.combine() if self.is_blocks else self
-        return out._plain()
+        plain = out._plain()
+        if (fusion.PRED_KERNEL and self.fuses_dense_ops and plain.dim() == 4 and plain.shape[1] % 32 == 0 and plain.shape[1] >= 32
+                and is_nhwc(plain) and get_backend().name == "hip"):
+            with _NoDispatch():
+                return plain.as_subclass(DenseMap)       # (see DenseMap: a plain tensor whose small-Cout 3x3 convs skip the conv library)
+        return plain
 
     def combine_(self) -> "TensorWrapper":
         """In-place ``combine``: scatters into (and returns) the previous frame's dense map of this call site."""

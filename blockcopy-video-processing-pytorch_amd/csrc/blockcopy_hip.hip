@@ -26,6 +26,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/blockcopy_hip.h"
@@ -2107,6 +2108,7 @@ int check_halo(const void *out, const void *features, const int32_t *grid_idx, c
 #include "conv3x3_wino32.inc"
 #include "stem7x7.inc"
 #include "head1x1.inc"
+#include "pred3x3.inc"
 
 }  // namespace
 
@@ -2578,7 +2580,7 @@ BC_EXPORT const char *bc_error_string(int code)
 
 BC_EXPORT const char *bc_op_name(int op)
 {
-    static const char *names[BC_OP_COUNT] = {"split", "combine", "transfer", "pad", "combine_copy", "pad_ring", "grid_tables", "interp", "affine", "nms", "conv3x3", "head1x1"};
+    static const char *names[BC_OP_COUNT] = {"split", "combine", "transfer", "pad", "combine_copy", "pad_ring", "grid_tables", "interp", "affine", "nms", "conv3x3", "head1x1", "pred3x3"};
     return (op >= 0 && op < BC_OP_COUNT) ? names[op] : "?";
 }
 
@@ -2731,6 +2733,50 @@ BC_EXPORT int bc_head1x1_scatter_nhwc(void *out, const void *features, const voi
     if (Cin == 128) BC_HD(BC_BF16, 128);
     BC_HD(BC_BF16, 256);
 #undef BC_HD
+}
+
+template <int DT, int COUT, int R>
+static int launch_pred3x3(ProfScope &ps, void *out, const void *x, const float *wpk, const float *bias, PredGeom g, hipStream_t st)
+{
+    typedef typename CvType<DT>::T T;
+    constexpr int NPX = PRED_PW * 8 * R;
+    constexpr size_t stage = (size_t)NPX * PRED_PS * 4, sums = (size_t)9 * COUT * NPX * 4;
+    constexpr size_t lds_bytes = stage > sums ? stage : sums;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pred3x3<DT, COUT, R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        attr_set = true;
+    }
+    g.tiles_x = (g.W + (PRED_PW - 2) - 1) / (PRED_PW - 2);
+    g.tiles_y = (g.H + (8 * R - 2) - 1) / (8 * R - 2);
+    const dim3 grid(g.tiles_x * g.tiles_y, g.N);
+    BC_LAUNCH(ps, (k_pred3x3<DT, COUT, R>), grid, dim3(256), lds_bytes, st, (T *)out, (const uint4 *)x, wpk, bias, g);
+    return launch_status();
+}
+
+BC_EXPORT int bc_pred3x3_nhwc(void *out, const void *x, const float *weights_packed, const float *bias, int N, int H, int W, int Cin, int Cout,
+                              int dtype, void *stream)
+{
+    if (dtype < BC_F32 || dtype > BC_BF16) return BC_ERR_ELEM;
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin % PRED_CK != 0 || Cout < 1 || Cout > 4) return BC_ERR_SHAPE;
+    if (!out || !x || !weights_packed) return BC_ERR_NULL;
+    if ((uint64_t)N * H * W * (uint64_t)Cin >= (1ull << 31) || N > 65535) return BC_ERR_RANGE;
+    const int E = dtype == BC_F32 ? 4 : 2;
+    if (!aligned(out, E) || !aligned(x, 16) || !aligned(weights_packed, 4) || !aligned(bias, 4)) return BC_ERR_ALIGN;
+    PredGeom g;
+    g.N = N; g.H = H; g.W = W; g.C = Cin; g.tiles_x = g.tiles_y = 0;
+    ProfScope ps(BC_OP_PRED, (double)N * H * W * ((double)Cin + Cout) * E);
+    ps.add_aux(2.0 * N * H * W * 9.0 * Cin * Cout);
+    hipStream_t st = (hipStream_t)stream;
+    // (8-row patches, one pixel per lane.  16-row patches -- 14 % halo rows instead of 25 % -- measured the same or slower: the halo
+    //  re-reads are L2 hits, and two pixels per lane with two chunks in flight leave one wave per SIMD)
+#define BC_PR3(DT_, CO_) return launch_pred3x3<DT_, CO_, 1>(ps, out, x, weights_packed, bias, g, st)
+#define BC_PR2(DT_) switch (Cout) { case 1: BC_PR3(DT_, 1); case 2: BC_PR3(DT_, 2); case 3: BC_PR3(DT_, 3); default: BC_PR3(DT_, 4); }
+    if (dtype == BC_F32) BC_PR2(BC_F32)
+    if (dtype == BC_F16) BC_PR2(BC_F16)
+    BC_PR2(BC_BF16)
+#undef BC_PR2
+#undef BC_PR3
 }
 
 BC_EXPORT int bc_combine_copy_cells(const void *blocks, int N, int C, int H, int W, int bs, int E, int align)

@@ -111,6 +111,16 @@ int bc_head1x1_scatter_nhwc(void *out, const void *features, const void *weights
                             const int32_t *grid_idx, const int32_t *mapping_exec, int n_exec, int N, int Cin, int Cout,
                             int GH, int GW, int bs, int dtype, const float *in_scale, const float *in_shift, int in_relu,
                             const float *out_shift, int scatter, void *stream);
+/* Dense 3x3 conv (stride 1, zero padding 1) from Cin channels to 1..4 output channels on a channels-last map (N, H, W, Cin) ->
+ * (N, H, W, Cout): the prediction convs a detector head applies to the combined map right after blockcopy.to_tensor (reference
+ * Pedestron/mmdet/models/anchor_heads/csp_head.py:103-108 csp_cls / csp_reg / csp_offset, applied at :139,146,151; in the
+ * reference that is nn.Conv2d -> cuDNN on the dense tensor).  A bandwidth op (the map is read once: (Cin + Cout) * E bytes per pixel).
+ *   weights_packed  fp32 [Cin][3][3][Cout] (= weight.permute(1, 2, 3, 0), fp32 whatever the map's dtype)
+ *   bias            fp32 [Cout] or NULL
+ * Cin: multiple of 32.  fp32 accumulation per pixel in channel order within a tap, taps added in (ky, kx) order, bias first;
+ * one rounding to the map's dtype. */
+int bc_pred3x3_nhwc(void *out, const void *x, const float *weights_packed, const float *bias, int N, int H, int W, int Cin, int Cout,
+                    int dtype, void *stream);
 /* number of timing cells (= workgroups) such a launch writes, or a negative error code */
 int bc_combine_copy_cells(const void *blocks, int N, int C, int H, int W, int bs, int elem_size, int align);
 
@@ -362,7 +372,7 @@ int bc_tune_get(const char *key, int *value);
  * ------------------------------------------------------------------------------------------- */
 
 enum { BC_OP_SPLIT = 0, BC_OP_COMBINE = 1, BC_OP_TRANSFER = 2, BC_OP_PAD = 3,
-       BC_OP_COMBINE_COPY = 4, BC_OP_PAD_RING = 5, BC_OP_GRID_TABLES = 6, BC_OP_INTERP = 7, BC_OP_AFFINE = 8, BC_OP_NMS = 9, BC_OP_CONV3X3 = 10, BC_OP_HEAD = 11, BC_OP_COUNT = 12 };
+       BC_OP_COMBINE_COPY = 4, BC_OP_PAD_RING = 5, BC_OP_GRID_TABLES = 6, BC_OP_INTERP = 7, BC_OP_AFFINE = 8, BC_OP_NMS = 9, BC_OP_CONV3X3 = 10, BC_OP_HEAD = 11, BC_OP_PRED = 12, BC_OP_COUNT = 13 };
 
 int bc_abi_version(void);
 const char *bc_error_string(int code);

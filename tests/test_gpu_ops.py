@@ -654,6 +654,62 @@ def test_fused_conv3x3_stride2(be, dtype, tol):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
+def test_pred3x3_dense_prediction_conv(be, dtype, tol):
+    """bc_pred3x3_nhwc (dense 3x3 conv, padding 1, to 1..4 channels on a channels-last map: the detector head's prediction convs,
+    reference csp_head.py:103-108) == fp64 conv2d of the same values, for map sizes that do and do not divide into the 30 x 6
+    output patches, batch > 1, with and without bias."""
+    import torch.nn.functional as F
+
+    gen = torch.Generator().manual_seed(77)
+    if True:
+        for case, (N, C, H, W, Cout, with_bias) in enumerate([(1, 32, 5, 7, 1, True), (2, 64, 30, 61, 2, True), (1, 256, 28, 60, 1, False), (1, 96, 17, 33, 3, True),
+                                                               (3, 32, 14, 30, 4, True), (1, 256, 64, 128, 2, True), (1, 128, 1, 1, 1, True), (1, 64, 2, 95, 4, False)]):
+            x = _cl((torch.randn((N, C, H, W), generator=gen)).cuda().to(dtype))
+            w = (torch.randn((Cout, C, 3, 3), generator=gen) * (1.0 / (9 * C)) ** 0.5).cuda().to(dtype)
+            b = (torch.randn(Cout, generator=gen)).cuda().to(dtype) if with_bias else None
+            assert be.pred3x3_supported(x, w, 1, 1, 1, 1) and not be.pred3x3_supported(x, w, 2, 1, 1, 1) and not be.pred3x3_supported(x, w, 1, 0, 1, 1)
+            assert not be.pred3x3_supported(x.contiguous(), w, 1, 1, 1, 1) or H * W == 1
+            got = be.pred3x3(x, be.pack_pred3x3_weights(w), None if b is None else b.float().contiguous(), Cout)
+            want = F.conv2d(x.double(), w.double(), None if b is None else b.double(), padding=1)
+            assert tuple(got.shape) == (N, Cout, H, W) and got.dtype == dtype
+            assert got.permute(0, 2, 3, 1).is_contiguous()
+            err = (got.double() - want).abs().max().item()
+            assert err <= tol * max(1.0, want.abs().max().item()), (case, err)
+
+
+def test_dense_map_routes_prediction_convs_only(be):
+    """to_tensor's DenseMap: conv2d to <= 4 channels goes through bc_pred3x3_nhwc (spy), everything else behaves like -- and
+    returns -- a plain tensor; the result equals the library conv within fp32 summation order."""
+    import torch.nn.functional as F
+    from blockcopy.core import tensorwrapper as tw
+
+    gen = torch.Generator().manual_seed(5)
+    x = _cl(torch.randn((1, 64, 24, 40), generator=gen).cuda())
+    dm = x.as_subclass(tw.DenseMap)
+    w, b = (torch.randn((2, 64, 3, 3), generator=gen) * 0.05).cuda(), torch.randn(2, generator=gen).cuda()
+    calls = []
+    orig = be.pred3x3
+    be.pred3x3 = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        y = F.conv2d(dm, w, b, padding=1)
+        conv = torch.nn.Conv2d(64, 2, 3, padding=1).cuda()
+        assert type(conv(dm)) is torch.Tensor and len(calls) == 1        # (parameters that want gradients: the conv library)
+        with torch.no_grad():
+            y2 = conv(dm)
+        assert len(calls) == 2 and type(y) is torch.Tensor and type(y2) is torch.Tensor
+        assert (y - F.conv2d(x, w, b, padding=1)).abs().max().item() <= 2e-5 * max(1.0, y.abs().max().item())
+        assert (y2 - conv(x).detach()).abs().max().item() <= 2e-5 * max(1.0, y2.abs().max().item())
+        wide = F.conv2d(dm, torch.randn((8, 64, 3, 3), generator=gen).cuda(), padding=1)        # 8 channels: the conv library
+        strided = F.conv2d(dm, w, b, padding=1, stride=2)
+        assert len(calls) == 2 and type(wide) is torch.Tensor and type(strided) is torch.Tensor
+        z = dm * 2 + 1
+        assert type(z) is torch.Tensor and torch.equal(z, x * 2 + 1) and type(dm[0]) is torch.Tensor and type(dm.float()) in (torch.Tensor, tw.DenseMap)
+        assert torch.equal(torch.relu(dm), torch.relu(x)) and dm.sum().item() == x.sum().item()
+    finally:
+        be.pred3x3 = orig
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
 def test_fused_conv3x3_dilation2(be, dtype, tol):
     """bc_conv3x3_dil_ring_nhwc (the dilated stage of a detector backbone: 3x3, dilation 2, padding 2, stride 1) == 2-pixel halo
     gather (bit-exact against the oracle elsewhere) + fp64 dilated conv, for every decomposition the library lists for the layer
