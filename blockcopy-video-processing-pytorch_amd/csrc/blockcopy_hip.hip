@@ -2343,9 +2343,10 @@ extern "C" int bc_part_conv_v2_dil(void *p)
 #endif
 
 // ---- host side of conv3x3_wino.inc (Winograd F(2x2,3x3), fp32 / stride 1): decompositions (MB, WMW, WNW, WKW); code 0x200 | index
-struct WinoCfg { int MB, WMW, WNW, WKW; };
-static const WinoCfg WINO_CFGS[] = {{2, 2, 4, 1}, {2, 2, 2, 2}, {2, 1, 4, 2}, {2, 1, 2, 4}, {1, 2, 4, 1}, {1, 4, 2, 1}, {1, 2, 2, 2}, {1, 1, 4, 2}, {1, 1, 2, 4},
-                                    {1, 1, 8, 1}, {2, 1, 8, 1}};     // 9, 10: 128 output channels per workgroup (the patches of a 128-channel layer are staged once)
+struct WinoCfg { int MB, WMW, WNW, WKW, SH; };
+static const WinoCfg WINO_CFGS[] = {{2, 2, 4, 1, 0}, {2, 2, 2, 2, 0}, {2, 1, 4, 2, 0}, {2, 1, 2, 4, 0}, {1, 2, 4, 1, 0}, {1, 4, 2, 1, 0}, {1, 2, 2, 2, 0}, {1, 1, 4, 2, 0}, {1, 1, 2, 4, 0},
+                                    {1, 1, 8, 1, 0}, {2, 1, 8, 1, 0},     // 9, 10: 128 output channels per workgroup (the patches of a 128-channel layer are staged once)
+                                    {1, 1, 8, 1, 1}, {1, 1, 4, 2, 1}, {1, 1, 2, 4, 1}};     // 11-13: input transform shared by the workgroup (SH in conv3x3_wino.inc)
 constexpr int WINO_N = (int)(sizeof(WINO_CFGS) / sizeof(WINO_CFGS[0]));
 
 struct WinoPlan { long long wgs; size_t lds_bytes; uint32_t n_rows; };
@@ -2356,6 +2357,7 @@ static bool wino_plan(const WinoCfg &k, int n_exec, int Cin, int Cout, int bs, W
     const size_t img = (size_t)k.WMW * k.MB * (bs == 4 ? 4 * 36 : 100) * 9 * 16;
     const size_t red = (size_t)k.WMW * k.WNW * (k.WKW - 1) * k.MB * 16 * 64 * sizeof(float);
     p.lds_bytes = 2 * img > red ? 2 * img : red;
+    if (k.SH) p.lds_bytes = 2 * img + 2 * (size_t)16 * 16 * 36 * sizeof(float);      // + two transformed images
     if (p.lds_bytes > 160 * 1024 - 2048 - 1024) return false;
     const long long slots = bs == 4 ? ((long long)n_exec + 3) / 4 : (long long)n_exec * (bs / 8) * (bs / 8);     // M-blocks
     p.n_rows = (uint32_t)((slots + k.MB - 1) / k.MB);
@@ -2364,27 +2366,27 @@ static bool wino_plan(const WinoCfg &k, int n_exec, int Cin, int Cout, int bs, W
 }
 
 #if defined(BC_MONO) || BC_PART == 7
-template <int MB, int WMW, int WNW, int WKW, int TS>
+template <int MB, int WMW, int WNW, int WKW, int TS, bool SH = false>
 static void launch_wino_ts(LaunchProf &ps, dim3 grid, size_t lds_bytes, const ConvV2Args &a, const ConvGeom2 &g)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_wino<MB, WMW, WNW, WKW, TS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_wino<MB, WMW, WNW, WKW, TS, SH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
         attr_set = true;
     }
     // the Winograd weight stream follows the direct one in the packed buffer (pack_conv3x3_weights: 9 + 16 values per (cin, cout))
     const float4 *wino_w = reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(a.wpk) + (size_t)9 * a.Cin * a.Cout);
-    BC_LAUNCH(ps, (k_conv3x3_wino<MB, WMW, WNW, WKW, TS>), grid, dim3(512), lds_bytes, a.st, (float *)a.out, (const uint4 *)a.features,
+    BC_LAUNCH(ps, (k_conv3x3_wino<MB, WMW, WNW, WKW, TS, SH>), grid, dim3(512), lds_bytes, a.st, (float *)a.out, (const uint4 *)a.features,
               (long long)(((const char *)a.ring - (const char *)a.features) / 16), (uint4 *)a.ring, wino_w, a.grid_idx, a.mapping_exec, g, a.pr, a.ep, a.stamps);
 }
 
-template <int MB, int WMW, int WNW, int WKW>
+template <int MB, int WMW, int WNW, int WKW, bool SH = false>
 static void launch_wino_cfg(LaunchProf &ps, dim3 grid, size_t lds_bytes, const ConvV2Args &a, const ConvGeom2 &g)
 {
     if (a.bs == 4) {
-        if constexpr (MB * WMW <= 2) launch_wino_ts<MB, WMW, WNW, WKW, 4>(ps, grid, lds_bytes, a, g);     // (4 tile slots per M-block: LDS)
+        if constexpr (MB * WMW <= 2) launch_wino_ts<MB, WMW, WNW, WKW, 4, SH>(ps, grid, lds_bytes, a, g);     // (4 tile slots per M-block: LDS)
     } else {
-        launch_wino_ts<MB, WMW, WNW, WKW, 8>(ps, grid, lds_bytes, a, g);
+        launch_wino_ts<MB, WMW, WNW, WKW, 8, SH>(ps, grid, lds_bytes, a, g);
     }
 }
 
@@ -2417,7 +2419,10 @@ static int conv_wino_run(ConvV2Args &a)
     case 7: launch_wino_cfg<1, 1, 4, 2>(ps, grid, lds_bytes, a, g); break;
     case 8: launch_wino_cfg<1, 1, 2, 4>(ps, grid, lds_bytes, a, g); break;
     case 9: launch_wino_cfg<1, 1, 8, 1>(ps, grid, lds_bytes, a, g); break;
-    default: launch_wino_cfg<2, 1, 8, 1>(ps, grid, lds_bytes, a, g); break;
+    case 10: launch_wino_cfg<2, 1, 8, 1>(ps, grid, lds_bytes, a, g); break;
+    case 11: launch_wino_cfg<1, 1, 8, 1, true>(ps, grid, lds_bytes, a, g); break;
+    case 12: launch_wino_cfg<1, 1, 4, 2, true>(ps, grid, lds_bytes, a, g); break;
+    default: launch_wino_cfg<1, 1, 2, 4, true>(ps, grid, lds_bytes, a, g); break;
     }
     a.chosen = a.force_cfg & 0x3ff;
     return launch_status();

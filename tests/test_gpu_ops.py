@@ -759,7 +759,7 @@ def test_fused_conv3x3_dilation2(be, dtype, tol):
         be.tune("conv2_cfg", -1)
 
 
-@pytest.mark.parametrize("cfg", list(range(20)) + [0x200 | w for w in range(11)] + [0x400 | w for w in range(5)])
+@pytest.mark.parametrize("cfg", list(range(20)) + [0x200 | w for w in range(14)] + [0x400 | w for w in range(5)])
 def test_fused_conv3x3_every_decomposition(be, cfg):
     """The CU-balanced conv kernel (csrc/conv3x3_v2.inc) picks one of 20 decompositions per launch (register blocking
     RM x RN, wave grid, in-workgroup split-K); here each one is FORCED in turn on shapes it covers -- incl. ragged wave

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Direct (conv3x3_v2.inc) vs Winograd F(2x2,3x3) (conv3x3_wino.inc) form of the fused halo + 3x3 conv at the layer shapes of the
 benchmark configs: every candidate decomposition of both forms is timed (hipGraph replay, prologue on, post-ReLU-like inputs) and
-the best three / four of each are printed.  usage: python tools/kbench_wino.py"""
+the best three / four of each are printed (Winograd codes 0x200 | 11..13: the shared-transform variant).  usage: python tools/kbench_wino.py"""
 import os
 import sys
 
@@ -25,7 +25,8 @@ for name, n, Cin, Cout, bs in [("layer1", 64, 64, 64, 32), ("layer2", 64, 128, 1
         f = lambda: be.conv3x3_ring(feats, ring, wpk, Cout, gi, m, (sc, sc, True), None, cfg=cfg)
         res[cfg] = timeit(f, 10)
     v2 = sorted((t, c) for c, t in res.items() if not c & 0x600)[:3]
-    wn = sorted((t, c) for c, t in res.items() if c & 0x200)[:3]
+    wn = sorted((t, c) for c, t in res.items() if c & 0x200 and (c & 0xff) < 11)[:3]
+    sh = sorted((t, c) for c, t in res.items() if c & 0x200 and (c & 0xff) >= 11)[:3]
     ww = sorted((t, c) for c, t in res.items() if c & 0x400)[:5]
     print(f"{name:14s} direct best: " + ", ".join(f"{c}={t:.1f}" for t, c in v2) + " | winograd best: " + ", ".join(f"{c}={t:.1f}" for t, c in wn)
-          + " | wide winograd: " + ", ".join(f"{c & 0xff}={t:.1f}" for t, c in ww), flush=True)
+          + " | shared transform: " + ", ".join(f"{c}={t:.1f}" for t, c in sh) + " | wide winograd: " + ", ".join(f"{c & 0xff}={t:.1f}" for t, c in ww), flush=True)

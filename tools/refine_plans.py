@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--margin", type=float, default=0.006)
     ap.add_argument("--clips", type=int, default=3)
+    ap.add_argument("--codes", type=int, nargs="*", default=None, help="try only these decomposition codes (e.g. the ones a new kernel form added)")
     a = ap.parse_args()
 
     import torch
@@ -84,7 +85,8 @@ def main():
             n = be.lib.bc_conv1x1_candidates(code, 1, n_exec, cin, cout, 8, buf, 64)
         else:
             return []
-        return [None] + [int(buf[i]) for i in range(max(n, 0))]
+        cands = [None] + [int(buf[i]) for i in range(max(n, 0))]
+        return [c for c in cands if c in a.codes] if a.codes else cands
 
     changed = []
     t0 = time.time()
