@@ -108,6 +108,28 @@ def main():
         wpk = be.pack_conv3x3_weights(torch.randn((Cout, Cin, 3, 3), device="cuda") * 0.05)
         alg = 4.0 * (n * Cin * ((bs + 2) ** 2 + 4 * bs) + n * Cout * bs * bs + 9 * Cin * Cout)
         run(f"{name} ({n},{Cin}->{Cout},{bs}x{bs})", alg, lambda: be.conv3x3_ring(feats, ring, wpk, Cout, gi, m, None, None, cfg=code))
+    # shared-transform Winograd form (round 3, codes 0x200 | 11..13) at the shapes the refined plan table runs it, and the CSP head conv
+    for (nn, Cin, Cout, bs, code, name) in [(64, 128, 128, 16, 0x20b, "shared-transform winograd layer2"), (64, 128, 128, 32, 0x20b, "shared-transform winograd up 1/4"),
+                                            (64, 256, 256, 8, 0x20c, "shared-transform winograd layer3"), (38, 768, 256, 32, 0x20b, "shared-transform winograd CSP head"),
+                                            (38, 768, 256, 32, 0x209, "winograd CSP head")]:
+        gi2, m2 = grid_tables(1, 8, 16, nn)
+        feats = cl(torch.randn((nn, Cin, bs, bs), device="cuda"))
+        ring = torch.randn((128, Cin, 4 * bs), device="cuda")
+        wpk = be.pack_conv3x3_weights(torch.randn((Cout, Cin, 3, 3), device="cuda") * 0.05)
+        alg = 4.0 * (nn * Cin * ((bs + 2) ** 2 + 4 * bs) + nn * Cout * bs * bs + 9 * Cin * Cout)
+        run(f"{name} ({nn},{Cin}->{Cout},{bs}x{bs})", alg, lambda: be.conv3x3_ring(feats, ring, wpk, Cout, gi2, m2, None, None, cfg=code))
+    # dilation-2 form of the direct kernel (C5 backbone stage 4) and the dense prediction convs of the CSP head
+    gi2, m2 = grid_tables(1, 8, 16, 38)
+    feats = cl(torch.randn((38, 512, 8, 8), device="cuda"))
+    ring = torch.randn((128, 512, 8 * 8), device="cuda")
+    wpk = be.pack_conv3x3_weights(torch.randn((512, 512, 3, 3), device="cuda") * 0.05)
+    run("conv3x3 dilation 2 (38,512->512,8x8)", 4.0 * (38 * 512 * ((8 + 4) ** 2 + 8 * 8) + 38 * 512 * 64 + 9 * 512 * 512),
+        lambda: be.conv3x3_ring(feats, ring, wpk, 512, gi2, m2, None, None, dilation=2))
+    xmap = cl(torch.randn((1, 256, 256, 512), device="cuda"))
+    for cout in (1, 2):
+        wp = be.pack_pred3x3_weights(torch.randn((cout, 256, 3, 3), device="cuda") * 0.05)
+        bp = torch.randn(cout, device="cuda")
+        run(f"pred3x3 (1,256,256,512) -> {cout}", 4.0 * 256 * 512 * (256 + cout), (lambda c_, w_, b_: lambda: be.pred3x3(xmap, w_, b_, c_))(cout, wp, bp))
     # network-input stage (window gather + 7x7 stem conv): frame-state windows in, packed stem output out
     state = torch.randn((1, 3, 1024, 2048), device="cuda")
     wst = be.pack_stem7x7_weights(cl(torch.randn((64, 3, 7, 7), device="cuda") * 0.05))
