@@ -2109,6 +2109,7 @@ int check_halo(const void *out, const void *features, const int32_t *grid_idx, c
 #include "stem7x7.inc"
 #include "head1x1.inc"
 #include "pred3x3.inc"
+#include "gemm1x1.inc"
 
 }  // namespace
 
@@ -3016,7 +3017,27 @@ static int conv_candidates(int dtype, int stride, int ks, int n_exec, int Cin, i
         for (int c = 0; c < WINO32_N && n < max_out; ++c)
             if (wino32_plan(WINO32_CFGS[c], n_exec, Cin, Cout, bs, wp32)) out[n++] = c | 0x400;
     }
+    // the plain-GEMM form of a pointwise conv (fp32, stride 1; gemm1x1.inc): workgroup tiles 128x128, 128x64, 64x128, 64x64
+    if (dtype == BC_F32 && stride == 1 && ks == 1 && Cin % 32 == 0) {
+        for (int c = 0; c < 4 && n < max_out; ++c)
+            if (Cout % (64 * (2 - (c & 1))) == 0) out[n++] = c | 0x800;
+    }
     return n;
+}
+
+// host side of gemm1x1.inc: code 0x800 | c, c = 0..3 -> (TM, TN) = (2,2), (2,1), (1,2), (1,1)
+template <int TM, int TN>
+static int launch_gemm1x1(ProfScope &ps, void *out, const void *x, const void *wpk, const GemmGeom &g, const Prologue &pr, const EpilogueT &ep, hipStream_t st)
+{
+    constexpr size_t lds_bytes = (size_t)2 * (64 * TM * 9 + 2 * TN * 256) * 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm1x1<TM, TN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        attr_set = true;
+    }
+    const dim3 grid((g.M + 64 * TM - 1) / (64 * TM), g.N / (64 * TN));
+    BC_LAUNCH(ps, (k_gemm1x1<TM, TN>), grid, dim3(256), lds_bytes, st, (float *)out, (const uint4 *)x, (const uint4 *)wpk, g, pr, ep);
+    return launch_status();
 }
 
 BC_EXPORT int bc_conv3x3_candidates(int dtype, int stride, int n_exec, int Cin, int Cout, int bs_in, int *out, int max_out)
@@ -3048,6 +3069,20 @@ BC_EXPORT int bc_conv1x1_nhwc(void *out, const void *features, const void *weigh
     ProfScope ps(BC_OP_CONV3X3, 2.0 * n_tiles * bso * bso * (double)Cin * Cout);
     void *ring = const_cast<void *>(features);      // (unused by the one-tap form)
     hipStream_t st = (hipStream_t)stream;
+    if (g_tune.conv2_cfg >= 0 && (g_tune.conv2_cfg & 0x800)) {
+        const int c = g_tune.conv2_cfg & 3;
+        if (dtype != BC_F32 || stride != 1 || Cout % (64 * (2 - (c & 1))) != 0) return BC_ERR_SHAPE;
+        if (!aligned(out_add, 16)) return BC_ERR_ALIGN;
+        GemmGeom g{(uint32_t)n_tiles * (uint32_t)bs * (uint32_t)bs, (uint32_t)Cin, (uint32_t)Cout, (uint32_t)Cin / 32};
+        ps.add_aux(2.0 * g.M * (double)Cin * Cout);
+        g_tune.conv_last_cfg = 0x800 | c;
+        switch (c) {
+        case 0: return launch_gemm1x1<2, 2>(ps, out, features, weights_packed, g, pr, ept, st);
+        case 1: return launch_gemm1x1<2, 1>(ps, out, features, weights_packed, g, pr, ept, st);
+        case 2: return launch_gemm1x1<1, 2>(ps, out, features, weights_packed, g, pr, ept, st);
+        default: return launch_gemm1x1<1, 1>(ps, out, features, weights_packed, g, pr, ept, st);
+        }
+    }
 #define BC_C1(DT_)                                                                                                         \
     (stride == 1 ? launch_conv3x3_v2<DT_, 1, 1>(ps, out, features, ring, weights_packed, nullptr, nullptr, n_tiles, Cin, Cout, 1, 1, bso, pr, ept, st) \
                  : launch_conv3x3_v2<DT_, 2, 1>(ps, out, features, ring, weights_packed, nullptr, nullptr, n_tiles, Cin, Cout, 1, 1, bso, pr, ept, st))

@@ -1008,7 +1008,7 @@ def test_stem7x7_window_conv(be, dtype, tol):
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
 def test_pointwise_conv(be, dtype, tol):
-    """bc_conv1x1_nhwc (the fused kernel's one-tap form) vs an fp64 1x1 conv: packed tiles and dense maps, stride 1 (any 8x8
+    """bc_conv1x1_nhwc (the fused kernel's one-tap form and, fp32 stride 1, the plain-GEMM form) vs an fp64 1x1 conv: packed tiles and dense maps, stride 1 (any 8x8
     re-tiling of the pixels) and stride 2 (ResNet downsample on real tiles, incl. 8x8 -> 4x4), prologue (BN + ReLU recorded before the
     conv), epilogue (bias + residual + ReLU), every decomposition the library lists and its own choice."""
     import torch.nn.functional as F
@@ -1022,6 +1022,8 @@ def test_pointwise_conv(be, dtype, tol):
         wpk = be.pack_conv3x3_weights(w)
         cands = be.conv1x1_candidates(x, Cout, stride)
         assert cands, (B, Cin, Cout, H, stride)
+        # (fp32 stride 1: the plain-GEMM form csrc/gemm1x1.inc, codes 0x800 | c, is among them -- incl. a ragged last row block)
+        assert any(c & 0x800 for c in cands) == (dtype == torch.float32 and stride == 1), cands
         isc, ish = (torch.rand(Cin, generator=gen) + 0.5).cuda(), (torch.randn(Cin, generator=gen) * 0.1).cuda()
         osc, osh = (torch.rand(Cout, generator=gen) + 0.5).cuda(), (torch.randn(Cout, generator=gen) * 0.1).cuda()
         add = _cl(torch.randn((B, Cout, H // stride, W // stride), generator=gen).cuda().to(dtype))

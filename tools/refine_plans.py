@@ -81,6 +81,8 @@ def main():
         code = bk._DTYPE_CODE[dt]
         if ks == 3:
             n = be.lib.bc_conv3x3_candidates(code, stride, n_exec, cin, cout, bs, buf, 64)
+        elif ks == 13:          # (the dilation-2 form's key)
+            n = be.lib.bc_conv3x3_dil_candidates(code, 2, n_exec, cin, cout, bs, buf, 64)
         elif stride == 1:
             n = be.lib.bc_conv1x1_candidates(code, 1, n_exec, cin, cout, 8, buf, 64)
         else:
