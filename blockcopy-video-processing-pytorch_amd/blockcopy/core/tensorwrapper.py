@@ -525,7 +525,7 @@ class TensorWrapper(torch.Tensor):
         out = self.combine() if self.is_blocks else self
         plain = out._plain()
         if (fusion.PRED_KERNEL and self.fuses_dense_ops and plain.dim() == 4 and plain.shape[1] % 32 == 0 and plain.shape[1] >= 32
-                and is_nhwc(plain) and get_backend().name == "hip"):
+                and is_nhwc(plain) and hasattr(get_backend(), "pred3x3")):
             with _NoDispatch():
                 return plain.as_subclass(DenseMap)       # (see DenseMap: a plain tensor whose small-Cout 3x3 convs skip the conv library)
         return plain

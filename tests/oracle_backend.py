@@ -172,6 +172,23 @@ class OracleBackend:
             y = self.affine_act(y, scale, shift, add.contiguous() if add is not None else None, relu)
         return y.contiguous(memory_format=torch.channels_last)
 
+    # dense 3x3 conv to <= 4 channels on a map handed out by to_tensor (checker form of bc_pred3x3_nhwc: the library conv)
+    @staticmethod
+    def pred3x3_supported(x, weight, stride=1, padding=1, dilation=1, groups=1):
+        one = lambda v: v if isinstance(v, (int, str)) else (v[0] if len(set(v)) == 1 else None)
+        return (x.dim() == 4 and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last) and tuple(weight.shape[2:]) == (3, 3)
+                and one(stride) == 1 and one(padding) == 1 and one(dilation) == 1 and groups == 1 and weight.shape[1] == x.shape[1]
+                and x.shape[1] % 32 == 0 and 1 <= weight.shape[0] <= 4)
+
+    @staticmethod
+    def pack_pred3x3_weights(weight):
+        return weight.detach().float().permute(1, 2, 3, 0).contiguous()
+
+    def pred3x3(self, x, wpk, bias, cout):
+        self.calls.append("pred3x3") if hasattr(self, "calls") else None
+        w = wpk.permute(3, 0, 1, 2).contiguous()
+        return torch.nn.functional.conv2d(x, w, bias, padding=1).contiguous(memory_format=torch.channels_last)
+
     @staticmethod
     def head1x1_supported(data, weight, stride=1, padding=0, dilation=1, groups=1):
         one = lambda v: v if isinstance(v, int) else (v[0] if len(set(v)) == 1 else None)

@@ -225,6 +225,35 @@ def test_policies(oracle_backend):
         pol(dict(meta, inputs=torch.randn(1, 3, 60, 128)))
 
 
+def test_dense_map_routes_small_cout_convs_through_the_backend(oracle_backend):
+    """to_tensor's DenseMap (core/tensorwrapper.py): a 3x3 / padding 1 conv to <= 4 channels goes to the backend's pred3x3 (here the
+    checker's library conv, spied), anything else -- wider convs, strided ones, parameters under autograd, elementwise ops -- takes the
+    stock path, and every result is a plain tensor."""
+    import torch.nn.functional as F
+    import blockcopy.backend as bk
+    from blockcopy.core import tensorwrapper as tw
+
+    be = bk.get_backend()
+    calls = []
+    orig = be.pred3x3
+    be.pred3x3 = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((1, 64, 12, 20), generator=g).contiguous(memory_format=torch.channels_last)
+    dm = x.as_subclass(tw.DenseMap)
+    w, b = torch.randn((2, 64, 3, 3), generator=g) * 0.05, torch.randn(2, generator=g)
+    y = F.conv2d(dm, w, b, padding=1)
+    assert calls == [1] and type(y) is torch.Tensor and torch.allclose(y, F.conv2d(x, w, b, padding=1), atol=1e-5)
+    conv = torch.nn.Conv2d(64, 1, 3, padding=1)
+    assert type(conv(dm)) is torch.Tensor and calls == [1]                     # parameters that want gradients: stock conv
+    with torch.no_grad():
+        y2 = conv(dm)
+    assert calls == [1, 1] and type(y2) is torch.Tensor and torch.allclose(y2, conv(x).detach(), atol=1e-5)
+    for other in (F.conv2d(dm, torch.randn((8, 64, 3, 3), generator=g), padding=1), F.conv2d(dm, w, b, padding=1, stride=2),
+                  F.conv2d(dm, torch.randn((2, 64, 1, 1), generator=g)), dm * 2 + 1, torch.relu(dm), dm[0], dm.mean()):
+        assert type(other) is torch.Tensor
+    assert calls == [1, 1] and torch.equal(dm * 2 + 1, x * 2 + 1)
+
+
 def test_no_cpu_fallback():
     """Without an injected checker the package's only backend is the HIP library, which refuses CPU tensors."""
     import blockcopy.backend as bk
