@@ -287,7 +287,10 @@ int bc_adaptive_avg_pool_nhwc(void *out, const void *in, int N, int C, int H, in
  * count returned.  What bc_tune_set("conv2_cfg", code) may force; the engine times exactly these when it measures a layer shape.
  * code = decomposition index (bits 0-7) | 0x100 if the launch runs without the one-workgroup-per-CU LDS floor (two workgroups
  * may then share a CU; listed only for multi-round launches whose workgroups need <= 78 KB) | 0x200 for the Winograd F(2x2,3x3)
- * form (fp32, stride 1, 3x3: csrc/conv3x3_wino.inc; index = its own decomposition table).  At most 64 codes.
+ * form (fp32, stride 1, 3x3: csrc/conv3x3_wino.inc; index = its own decomposition table, 11..13 = the variants whose input
+ * transform is computed once per workgroup) | 0x400 for its wide wave tile (csrc/conv3x3_wino32.inc) | 0x800 (pointwise convs,
+ * fp32, stride 1: bc_conv1x1_candidates) for the plain-GEMM form csrc/gemm1x1.inc (index 0..3 = workgroup tile 128x128, 128x64,
+ * 64x128, 64x64; reads the same packed one-tap weight stream).  At most 64 codes.
  * The Winograd form reads a second weight stream placed behind the direct one in weights_packed (fp32 3x3 only):
  *   wino[nb16][chunk][step < 4][q < 8][lane = 16*kq + n][e < 4] = (G g Gt)[f][cin = 32*chunk + 8*step + 2*kq + t][cout = 16*nb16 + n],
  *   2*f + t = 4*q + e, f = 4*xi + nu, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]  (16 * Cin * Cout floats after the 9 * Cin * Cout). */
