@@ -128,7 +128,6 @@ def load_library(path: str = None) -> ctypes.CDLL:
         "bc_conv3x3_dil_ring_nhwc": [p, p, p, p, p, p] + [i] * 9 + [p, p, i, p, p, p, i, p],
         "bc_conv3x3_dil_candidates": [i, i, i, i, i, i, ctypes.POINTER(i), i],
         "bc_pred3x3_nhwc": [p, p, p, p, i, i, i, i, i, i, p],
-        "bc_dense_pw_nhwc": [p, p, p, p, ctypes.c_longlong, i, i, i, p, p, i, p],
         "bc_stem7x7s2_nhwc": [p, p, p, p] + [i] * 7 + [p, p, p, i, p],
         "bc_conv1x1_nhwc": [p, p, p] + [i] * 6 + [p, p, i, p, p, p, i, p],
         "bc_conv1x1_candidates": [i, i, i, i, i, i, ctypes.POINTER(i), i],
@@ -442,36 +441,6 @@ class HipBackend:
         V = torch.einsum("xi,ocij,yj->xyco", G, w0.double(), G).reshape(8, 2, Cin // 32, 8, 2, 2, Cout // 32, 32).float()   # q, f%2, chunk, ss, h, t, nb, n
         V = V.permute(6, 2, 3, 0, 4, 7, 1, 5)                                                               # nb, chunk, ss, q, h, n, f%2, t
         return torch.cat([direct, U16.contiguous().view(-1), V.contiguous().view(-1)])
-
-    # ---- pointwise conv of a small dense map with any channel counts (pyramid-pooling blocks): bc_dense_pw_nhwc
-    @staticmethod
-    def dense_pw_supported(x, weight, stride=1, padding=0, dilation=1, groups=1):
-        def _one(v):
-            return v if isinstance(v, (int, str)) else (v[0] if len(set(v)) == 1 else None)
-
-        n_px = x.shape[0] * x.shape[2] * x.shape[3] if x.dim() == 4 else 0
-        return (x.dim() == 4 and x.dtype in _DTYPE_CODE and x.is_contiguous(memory_format=torch.channels_last) and weight.dim() == 4
-                and tuple(weight.shape[2:]) == (1, 1) and _one(stride) == 1 and _one(padding) == 0 and _one(dilation) == 1 and groups == 1
-                and weight.shape[1] == x.shape[1] and x.shape[1] <= 2048 and weight.shape[0] <= 256 and 0 < n_px <= 4096)
-
-    @staticmethod
-    def pack_dense_pw_weights(weight):
-        """(Cout, Cin, 1, 1) -> fp32 [Cin][Cout] (include/blockcopy_hip.h bc_dense_pw_nhwc)."""
-        return weight.detach().float().reshape(weight.shape[0], weight.shape[1]).t().contiguous()
-
-    def dense_pw(self, x, wpk, bias, cout, prologue=None):
-        """y = conv1x1(relu?(x * scale + shift), w) + bias for a small dense channels-last map, one launch."""
-        N, C, H, W = x.shape
-        assert x.is_contiguous(memory_format=torch.channels_last) and tuple(wpk.shape) == (C, cout) and wpk.dtype == torch.float32 and wpk.is_contiguous()
-        sc, sh, relu = prologue if prologue is not None else (None, None, False)
-        for v, n in ((sc, C), (sh, C), (bias, cout)):
-            assert v is None or (_ok(v, torch.float32) and v.numel() == n)
-        out = torch.empty((N, H, W, cout), dtype=x.dtype, device=x.device).permute(0, 3, 1, 2)
-        ptr = lambda t: t.data_ptr() if t is not None else None
-        with torch.cuda.device_of(x):
-            self._check(self.lib.bc_dense_pw_nhwc(out.data_ptr(), x.data_ptr(), wpk.data_ptr(), ptr(bias), N * H * W, C, cout, _DTYPE_CODE[x.dtype],
-                                                  ptr(sc), ptr(sh), int(bool(relu)), self._stream()), "dense_pw_nhwc")
-        return out
 
     # ---- dense 3x3 conv to <= 4 output channels (detector prediction convs on the combined map): bc_pred3x3_nhwc
     @staticmethod

@@ -135,7 +135,7 @@ def channel_vector(t: torch.Tensor) -> torch.Tensor:
 
 def packed_conv3x3_weight(weight: torch.Tensor, pack) -> torch.Tensor:
     """MFMA operand stream of a (Cout, Cin, 3, 3) weight for the fused halo+conv kernel, derived once per parameter."""
-    k = ("wpk", getattr(pack, "__name__", "")) + _key(weight)      # (per packing: one parameter may feed two kernel forms)
+    k = ("wpk",) + _key(weight)
     v = _lookup(k, (weight,))
     if v is None:
         with torch.no_grad():
@@ -151,7 +151,6 @@ POINTWISE = os.environ.get("BLOCKCOPY_POINTWISE", "1") != "0"     # 1x1 convs th
 GROUP_NORM = os.environ.get("BLOCKCOPY_GROUP_NORM", "1") != "0"   # group_norm on packed tiles as a recorded per-channel affine map (one stats pass)
 ADAPTIVE_POOL = os.environ.get("BLOCKCOPY_ADAPTIVE_POOL", "1") != "0"   # adaptive_avg_pool2d of dense channels-last maps (pyramid pooling) in the library's kernel
 STEM_KERNEL = os.environ.get("BLOCKCOPY_STEM", "1") != "0"        # network input: window gather + 7x7 stem conv in one kernel
-DENSE_PW = os.environ.get("BLOCKCOPY_DENSE_PW", "1") != "0"        # BN -> ReLU -> 1x1 conv of small dense maps with odd channel counts (pyramid pooling) in one launch
 PRED_KERNEL = os.environ.get("BLOCKCOPY_PRED", "1") != "0"        # dense 3x3 convs to <= 4 channels on a map handed out by to_tensor (detector prediction convs)
 HEAD_KERNEL = os.environ.get("BLOCKCOPY_HEAD", "1") != "0"        # network output: prologue + 1x1 conv to <= 32 channels + out-of-place combine in one kernel
 # tuner: charge the library route the elementwise pass that follows a conv in a CNN (bias / folded BN, residual add, ReLU: it rides in the

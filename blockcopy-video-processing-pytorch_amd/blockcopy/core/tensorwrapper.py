@@ -983,32 +983,7 @@ class TensorWrapper(torch.Tensor):
         pend_out = None
         bias = kwargs["bias"] if "bias" in kwargs else (args[2] if len(args) > 2 else None)
         got = self._pointwise_conv(args[0], args, kwargs, None, bias=bias)
-        if got is None:
-            got = self._small_dense_pointwise_conv(args[0], args, kwargs, bias)
         return got
-
-    def _small_dense_pointwise_conv(self, x, args, kwargs, bias):
-        """BN -> ReLU -> conv1x1 of a small dense map whose channel counts no matrix kernel covers (pyramid-pooling blocks: 128 -> 42,
-        254 -> 128): recorded BN / ReLU, conv and bias in ONE launch (bc_dense_pw_nhwc) instead of an elementwise pass + a library conv."""
-        be = get_backend()
-        weight = args[1] if len(args) > 1 else kwargs.get("weight")
-        if (not fusion.DENSE_PW or not hasattr(be, "dense_pw") or not isinstance(x, TensorWrapper) or x._is_blocks or not isinstance(weight, torch.Tensor)
-                or torch.is_grad_enabled() and (weight.requires_grad or (bias is not None and bias.requires_grad))):
-            return None
-        cv = {k: kwargs.get(k, args[i] if len(args) > i else d) for k, i, d in (("stride", 3, 1), ("dilation", 5, 1), ("groups", 6, 1))}
-        raw = x._raw()
-        if raw.dim() != 4 or raw.dtype not in getattr(be, "supports_fusion_dtypes", ()) or not be.dense_pw_supported(raw, weight, cv["stride"], 0, cv["dilation"], cv["groups"]):
-            return None
-        P = x._pending
-        prologue = None
-        if P is not None and P.add is None and not P.deferred:
-            prologue = (P.scale, P.shift, P.relu)
-            data = raw
-        else:
-            data = x._plain()
-        wpk = fusion.packed_conv3x3_weight(weight, be.pack_dense_pw_weights)
-        b32 = None if bias is None else fusion.channel_vector(bias)
-        return be.dense_pw(dense_layout(data), wpk, b32, weight.shape[0], prologue), None
 
     def _pointwise_conv(self, x, args, kwargs, pend_out, bias=None):
         """1x1 / pad 0 conv through bc_conv1x1_nhwc where that is the faster route: the pending BN / ReLU of ``x`` becomes the

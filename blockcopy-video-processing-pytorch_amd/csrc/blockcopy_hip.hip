@@ -2110,7 +2110,6 @@ int check_halo(const void *out, const void *features, const int32_t *grid_idx, c
 #include "head1x1.inc"
 #include "pred3x3.inc"
 #include "gemm1x1.inc"
-#include "dense_pw.inc"
 
 }  // namespace
 
@@ -2784,43 +2783,6 @@ BC_EXPORT int bc_pred3x3_nhwc(void *out, const void *x, const float *weights_pac
     BC_PR2(BC_BF16)
 #undef BC_PR2
 #undef BC_PR3
-}
-
-template <int DT, int CT>
-static int launch_dense_pw(ProfScope &ps, void *out, const void *x, const float *w, const float *bias, const DensePwGeom &g, const Prologue &pr, hipStream_t st)
-{
-    typedef typename CvType<DT>::T T;
-    const size_t lds_bytes = (size_t)DPW_PX * ((g.Cin + 3u) & ~3u) * sizeof(float);
-    static size_t attr_set = 0;
-    if (lds_bytes > attr_set && lds_bytes > 48 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dense_pw<DT, CT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        attr_set = lds_bytes;
-    }
-    BC_LAUNCH(ps, (k_dense_pw<DT, CT>), dim3((g.n_px + DPW_PX - 1) / DPW_PX), dim3(256), lds_bytes, st, (T *)out, (const T *)x, w, bias, g, pr);
-    return launch_status();
-}
-
-BC_EXPORT int bc_dense_pw_nhwc(void *out, const void *x, const float *weights_packed, const float *bias, long long n_px, int Cin, int Cout, int dtype,
-                               const float *in_scale, const float *in_shift, int in_relu, void *stream)
-{
-    if (dtype < BC_F32 || dtype > BC_BF16) return BC_ERR_ELEM;
-    if (n_px < 0 || Cin <= 0 || Cin > 2048 || Cout <= 0 || Cout > 256) return BC_ERR_SHAPE;
-    if (n_px == 0) return BC_OK;
-    if (n_px > (1 << 20)) return BC_ERR_RANGE;
-    if (!out || !x || !weights_packed) return BC_ERR_NULL;
-    const int E = dtype == BC_F32 ? 4 : 2;
-    if (!aligned(out, E) || !aligned(x, E) || !aligned(weights_packed, 4) || !aligned(bias, 4)) return BC_ERR_ALIGN;
-    DensePwGeom g{(uint32_t)n_px, (uint32_t)Cin, (uint32_t)Cout};
-    Prologue pr{in_scale, in_shift, in_relu};
-    ProfScope ps(BC_OP_AFFINE, (double)n_px * ((double)Cin + Cout) * E + 4.0 * Cin * Cout);
-    hipStream_t st = (hipStream_t)stream;
-#define BC_DP(DT_) return Cout <= 64 ? launch_dense_pw<DT_, 64>(ps, out, x, weights_packed, bias, g, pr, st) \
-                        : (Cout <= 128 ? launch_dense_pw<DT_, 128>(ps, out, x, weights_packed, bias, g, pr, st) \
-                                       : launch_dense_pw<DT_, 256>(ps, out, x, weights_packed, bias, g, pr, st))
-    if (dtype == BC_F32) BC_DP(BC_F32);
-    if (dtype == BC_F16) BC_DP(BC_F16);
-    BC_DP(BC_BF16);
-#undef BC_DP
 }
 
 BC_EXPORT int bc_combine_copy_cells(const void *blocks, int N, int C, int H, int W, int bs, int E, int align)

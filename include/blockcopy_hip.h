@@ -121,15 +121,6 @@ int bc_head1x1_scatter_nhwc(void *out, const void *features, const void *weights
  * one rounding to the map's dtype. */
 int bc_pred3x3_nhwc(void *out, const void *x, const float *weights_packed, const float *bias, int N, int H, int W, int Cin, int Cout,
                     int dtype, void *stream);
-/* Pointwise (1x1, stride 1) conv of a SMALL dense channels-last map (n_px pixels) with any channel counts (Cin <= 2048, Cout <= 256),
- * the preceding BN -> ReLU as prologue and the bias in the same launch: the BN -> ReLU -> conv1x1 blocks of a pyramid-pooling module
- * that runs dense inside blockcopy_noblocks (reference core/blockcopy.py:104-139; semantic_segmentation lib/models/swiftnet/util.py
- * _BNReluConv in SpatialPyramidPooling: 128 -> 42 on 8x16 / 4x8 / 2x4 maps, 254 -> 128 on the 32x64 map), which no matrix kernel
- * covers.  out (n_px, Cout), x (n_px, Cin) in the map's dtype; weights_packed fp32 [Cin][Cout] (= weight[:, :, 0, 0].t());
- * in_scale / in_shift fp32 [Cin] or NULL, bias fp32 [Cout] or NULL.  fp32 FMAs in input-channel order, bias last, one rounding
- * (16-bit maps: the prologue result is rounded to the map's dtype first, like the stand-alone elementwise pass). */
-int bc_dense_pw_nhwc(void *out, const void *x, const float *weights_packed, const float *bias, long long n_px, int Cin, int Cout, int dtype,
-                     const float *in_scale, const float *in_shift, int in_relu, void *stream);
 /* number of timing cells (= workgroups) such a launch writes, or a negative error code */
 int bc_combine_copy_cells(const void *blocks, int N, int C, int H, int W, int bs, int elem_size, int align);
 

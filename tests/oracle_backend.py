@@ -172,25 +172,6 @@ class OracleBackend:
             y = self.affine_act(y, scale, shift, add.contiguous() if add is not None else None, relu)
         return y.contiguous(memory_format=torch.channels_last)
 
-    # small dense pointwise conv with odd channel counts (checker form of bc_dense_pw_nhwc: elementwise pass + library conv)
-    @staticmethod
-    def dense_pw_supported(x, weight, stride=1, padding=0, dilation=1, groups=1):
-        one = lambda v: v if isinstance(v, (int, str)) else (v[0] if len(set(v)) == 1 else None)
-        n_px = x.shape[0] * x.shape[2] * x.shape[3] if x.dim() == 4 else 0
-        return (x.dim() == 4 and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last) and tuple(weight.shape[2:]) == (1, 1)
-                and one(stride) == 1 and one(padding) == 0 and one(dilation) == 1 and groups == 1 and weight.shape[1] == x.shape[1]
-                and x.shape[1] <= 2048 and weight.shape[0] <= 256 and 0 < n_px <= 4096)
-
-    @staticmethod
-    def pack_dense_pw_weights(weight):
-        return weight.detach().float().reshape(weight.shape[0], weight.shape[1]).t().contiguous()
-
-    def dense_pw(self, x, wpk, bias, cout, prologue=None):
-        if prologue is not None:
-            x = self.affine_act(x, prologue[0], prologue[1], None, prologue[2])
-        w = wpk.t().contiguous().view(cout, x.shape[1], 1, 1)
-        return torch.nn.functional.conv2d(x, w, bias).contiguous(memory_format=torch.channels_last)
-
     # dense 3x3 conv to <= 4 channels on a map handed out by to_tensor (checker form of bc_pred3x3_nhwc: the library conv)
     @staticmethod
     def pred3x3_supported(x, weight, stride=1, padding=1, dilation=1, groups=1):

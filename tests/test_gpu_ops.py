@@ -677,31 +677,6 @@ def test_pred3x3_dense_prediction_conv(be, dtype, tol):
             assert err <= tol * max(1.0, want.abs().max().item()), (case, err)
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
-def test_dense_pw_small_map_pointwise_conv(be, dtype, tol):
-    """bc_dense_pw_nhwc (BN -> ReLU -> conv1x1 + bias of a small dense map, any channel counts: the pyramid-pooling blocks 128 -> 42 and
-    254 -> 128) == elementwise pass (same rounding) + fp64 conv, incl. pixel counts that do not fill the last workgroup, channel counts
-    that are not multiples of 4, every output-channel band (<= 64, <= 128, <= 256), with and without prologue / bias."""
-    import torch.nn.functional as F
-
-    gen = torch.Generator().manual_seed(91)
-    for case, (N, Cin, Cout, H, W) in enumerate([(1, 128, 42, 8, 16), (1, 128, 42, 2, 4), (1, 254, 128, 32, 64), (2, 37, 5, 3, 3), (1, 512, 200, 4, 7),
-                                                 (1, 64, 64, 1, 1), (1, 2048, 256, 2, 2)]):
-        x = _cl(torch.randn((N, Cin, H, W), generator=gen).cuda().to(dtype))
-        w = (torch.randn((Cout, Cin, 1, 1), generator=gen) * (2.0 / Cin) ** 0.5).cuda().to(dtype)
-        assert be.dense_pw_supported(x, w) and not be.dense_pw_supported(x, w, 2) and not be.dense_pw_supported(x, w, 1, 1)
-        wpk = be.pack_dense_pw_weights(w)
-        sc, sh = (torch.rand(Cin, generator=gen) + 0.5).cuda(), (torch.randn(Cin, generator=gen) * 0.2).cuda()
-        b = torch.randn(Cout, generator=gen).cuda()
-        for pro, bias in (((sc, sh, True), b), (None, None), ((None, sh, False), b)):
-            xin = x if pro is None else be.affine_act(x, pro[0], pro[1], None, pro[2])
-            want = F.conv2d(xin.double(), w.double(), None if bias is None else bias.double())
-            got = be.dense_pw(x, wpk, bias, Cout, pro)
-            assert tuple(got.shape) == (N, Cout, H, W) and got.dtype == dtype and got.permute(0, 2, 3, 1).is_contiguous()
-            err = (got.double() - want).abs().max().item()
-            assert err <= tol * max(1.0, want.abs().max().item()), (case, pro is not None, err)
-
-
 def test_dense_map_routes_prediction_convs_only(be):
     """to_tensor's DenseMap: conv2d to <= 4 channels goes through bc_pred3x3_nhwc (spy), everything else behaves like -- and
     returns -- a plain tensor; the result equals the library conv within fp32 summation order."""
