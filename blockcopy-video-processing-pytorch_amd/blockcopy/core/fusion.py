@@ -135,7 +135,7 @@ def channel_vector(t: torch.Tensor) -> torch.Tensor:
 
 def packed_conv3x3_weight(weight: torch.Tensor, pack) -> torch.Tensor:
     """MFMA operand stream of a (Cout, Cin, 3, 3) weight for the fused halo+conv kernel, derived once per parameter."""
-    k = ("wpk",) + _key(weight)
+    k = ("wpk", getattr(pack, "__name__", "")) + _key(weight)      # (per packing: one parameter may feed two kernel forms)
     v = _lookup(k, (weight,))
     if v is None:
         with torch.no_grad():
