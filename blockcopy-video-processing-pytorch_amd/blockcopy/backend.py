@@ -128,6 +128,8 @@ def load_library(path: str = None) -> ctypes.CDLL:
         "bc_conv3x3_dil_ring_nhwc": [p, p, p, p, p, p] + [i] * 9 + [p, p, i, p, p, p, i, p],
         "bc_conv3x3_dil_candidates": [i, i, i, i, i, i, ctypes.POINTER(i), i],
         "bc_pred3x3_nhwc": [p, p, p, p, i, i, i, i, i, i, p],
+        "bc_spp_levels_nhwc": [p, p, p, p, p, i, i, i, i, i, ctypes.POINTER(i), i, p],
+        "bc_spp_fuse_nhwc": [p, p, p, p, p, p, i, i, i, i, i, ctypes.POINTER(i), i, i, p],
         "bc_stem7x7s2_nhwc": [p, p, p, p] + [i] * 7 + [p, p, p, i, p],
         "bc_conv1x1_nhwc": [p, p, p] + [i] * 6 + [p, p, i, p, p, p, i, p],
         "bc_conv1x1_candidates": [i, i, i, i, i, i, ctypes.POINTER(i), i],
@@ -441,6 +443,59 @@ class HipBackend:
         V = torch.einsum("xi,ocij,yj->xyco", G, w0.double(), G).reshape(8, 2, Cin // 32, 8, 2, 2, Cout // 32, 32).float()   # q, f%2, chunk, ss, h, t, nb, n
         V = V.permute(6, 2, 3, 0, 4, 7, 1, 5)                                                               # nb, chunk, ss, q, h, n, f%2, t
         return torch.cat([direct, U16.contiguous().view(-1), V.contiguous().view(-1)])
+
+    # ---- pyramid pooling of a dense map in two launches (csrc/spp.inc): bc_spp_levels_nhwc + bc_spp_fuse_nhwc
+    @staticmethod
+    def spp_supported(x, co, n_levels, cout):
+        """x: ONE dense channels-last image (1, C, H, W)."""
+        C = x.shape[1]
+        return (x.dim() == 4 and x.shape[0] == 1 and x.dtype in _DTYPE_CODE and x.is_contiguous(memory_format=torch.channels_last) and C % 4 == 0 and C <= 1024
+                and 256 % (C // 4) == 0 and 1 <= n_levels <= 4 and 0 < co <= 1024 and cout % 64 == 0 and x.shape[2] * x.shape[3] * (C + n_levels * co) < 2 ** 31)
+
+    @staticmethod
+    def pack_spp_level_weights(weights):
+        """L weights (CO, C, 1, 1) -> fp32 [L][C][CO] (include/blockcopy_hip.h bc_spp_levels_nhwc)."""
+        return torch.stack([w.detach().float().reshape(w.shape[0], w.shape[1]).t() for w in weights]).contiguous()
+
+    def pack_spp_fuse_weights(self, weight):
+        """(N, K, 1, 1) -> the fp32 one-tap stream of the weight zero-padded to a multiple of 32 input channels (bc_spp_fuse_nhwc)."""
+        N, K = weight.shape[0], weight.shape[1]
+        Kp = (K + 31) // 32 * 32
+        w = torch.zeros((N, Kp, 1, 1), dtype=torch.float32, device=weight.device)
+        w[:, :K] = weight.detach().float()
+        return self.pack_conv3x3_weights(w)
+
+    def spp_levels(self, x, scale, shift, w, grids):
+        """lv[bin][CO] of every level: conv1x1_l(relu(bn_l(adaptive_avg_pool2d(x, grid_l)))); bins of level l start at sum of the earlier grids."""
+        _, C, H, W = x.shape
+        L, CO = w.shape[0], w.shape[2]
+        assert tuple(w.shape) == (L, C, CO) and w.dtype == torch.float32 and w.is_contiguous() and len(grids) == L
+        for v in (scale, shift):
+            assert v is None or (_ok(v, torch.float32) and tuple(v.shape) == (L, C) and v.is_contiguous())
+        n_bins = sum(gh * gw for gh, gw in grids)
+        lv = torch.empty((n_bins, CO), dtype=x.dtype, device=x.device)
+        garr = (ctypes.c_int * (2 * L))(*[int(v) for g in grids for v in g])
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        with torch.cuda.device_of(x):
+            self._check(self.lib.bc_spp_levels_nhwc(lv.data_ptr(), x.data_ptr(), ptr(scale), ptr(shift), w.data_ptr(), H, W, C, CO, L, garr,
+                                                    _DTYPE_CODE[x.dtype], self._stream()), "spp_levels_nhwc")
+        return lv
+
+    def spp_fuse(self, x, lv, scale, shift, wpk, grids, cout):
+        """conv1x1_f(relu(bn_f(cat[x, upsampled levels]))) without the upsampled maps or the concatenation; returns (1, cout, H, W) channels-last."""
+        _, C, H, W = x.shape
+        L, CO = len(grids), lv.shape[1]
+        K = C + L * CO
+        for v in (scale, shift):
+            assert v is None or (_ok(v, torch.float32) and v.numel() == K and v.is_contiguous())
+        assert lv.dtype == x.dtype and lv.is_contiguous() and wpk.dtype == torch.float32 and wpk.numel() == cout * ((K + 31) // 32 * 32)
+        out = torch.empty((1, H, W, cout), dtype=x.dtype, device=x.device).permute(0, 3, 1, 2)
+        garr = (ctypes.c_int * (2 * L))(*[int(v) for g in grids for v in g])
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        with torch.cuda.device_of(x):
+            self._check(self.lib.bc_spp_fuse_nhwc(out.data_ptr(), x.data_ptr(), lv.data_ptr(), ptr(scale), ptr(shift), wpk.data_ptr(), H, W, C, CO, L, garr,
+                                                  cout, _DTYPE_CODE[x.dtype], self._stream()), "spp_fuse_nhwc")
+        return out
 
     # ---- dense 3x3 conv to <= 4 output channels (detector prediction convs on the combined map): bc_pred3x3_nhwc
     @staticmethod

@@ -151,6 +151,7 @@ POINTWISE = os.environ.get("BLOCKCOPY_POINTWISE", "1") != "0"     # 1x1 convs th
 GROUP_NORM = os.environ.get("BLOCKCOPY_GROUP_NORM", "1") != "0"   # group_norm on packed tiles as a recorded per-channel affine map (one stats pass)
 ADAPTIVE_POOL = os.environ.get("BLOCKCOPY_ADAPTIVE_POOL", "1") != "0"   # adaptive_avg_pool2d of dense channels-last maps (pyramid pooling) in the library's kernel
 STEM_KERNEL = os.environ.get("BLOCKCOPY_STEM", "1") != "0"        # network input: window gather + 7x7 stem conv in one kernel
+SPP_FUSED = os.environ.get("BLOCKCOPY_SPP", "1") != "0"            # SwiftNet's pyramid pooling (after its first block) as two launches instead of 15
 PRED_KERNEL = os.environ.get("BLOCKCOPY_PRED", "1") != "0"        # dense 3x3 convs to <= 4 channels on a map handed out by to_tensor (detector prediction convs)
 HEAD_KERNEL = os.environ.get("BLOCKCOPY_HEAD", "1") != "0"        # network output: prologue + 1x1 conv to <= 32 channels + out-of-place combine in one kernel
 # tuner: charge the library route the elementwise pass that follows a conv in a CNN (bias / folded BN, residual add, ReLU: it rides in the

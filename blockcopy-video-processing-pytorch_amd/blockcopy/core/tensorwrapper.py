@@ -72,6 +72,7 @@ def to_tensorwrapper(x: torch.Tensor) -> "TensorWrapper":
 
 
 _CONV2D = torch.nn.functional.conv2d
+_S2_PLAN_OK = {}      # (plan, pixels, tile size, cin, cout, dtype) -> does this stride-2 pointwise decomposition cover that geometry
 
 
 class DenseMap(torch.Tensor):
@@ -1047,6 +1048,16 @@ class TensorWrapper(torch.Tensor):
         plan = fusion.conv3x3_plan(n_px // 64, 8, cin, cout, int(foldable), raw.dtype, tuner, stride, ks=1)
         if plan is None:
             return None
+        if stride != 1 and plan >= 0:
+            # the plan key of a pointwise conv carries the pixel count, not the tile size -- enough for stride 1 (any 8x8 re-tiling), but
+            # a stride-2 launch works on the REAL tiles: a decomposition measured on 16-pixel tiles need not cover 8-pixel ones with the
+            # same pixel count (found by the differential fuzz: plans measured live in one geometry met another one).  Checked once per shape.
+            vkey = (plan, n_px, raw.shape[2], cin, cout, raw.dtype)
+            ok = _S2_PLAN_OK.get(vkey)
+            if ok is None:
+                ok = _S2_PLAN_OK[vkey] = plan in be.conv1x1_candidates(dense_layout(raw), cout, stride)
+            if not ok:
+                plan = -1
         if pend_out is None and bias is not None:
             if raw.dtype not in getattr(be, "supports_fusion_dtypes", ()):
                 return None

@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = [os.path.join(HERE, "csrc", "blockcopy_hip.hip")]
 HDR = [os.path.join(os.path.dirname(HERE), "include", "blockcopy_hip.h")] + [os.path.join(HERE, "csrc", f) for f in
-                                                                             ("conv3x3_mfma.inc", "conv3x3_v2.inc", "conv3x3_wino.inc", "conv3x3_wino32.inc", "stem7x7.inc", "head1x1.inc", "pred3x3.inc", "gemm1x1.inc")]
+                                                                             ("conv3x3_mfma.inc", "conv3x3_v2.inc", "conv3x3_wino.inc", "conv3x3_wino32.inc", "stem7x7.inc", "head1x1.inc", "pred3x3.inc", "gemm1x1.inc", "spp.inc")]
 OUT = os.path.join(HERE, "lib", "libblockcopy_hip.so")
 OBJ_DIR = os.path.join(HERE, "lib", "obj")
 ARCH = "gfx950"

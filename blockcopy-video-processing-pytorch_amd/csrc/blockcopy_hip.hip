@@ -2110,6 +2110,7 @@ int check_halo(const void *out, const void *features, const int32_t *grid_idx, c
 #include "head1x1.inc"
 #include "pred3x3.inc"
 #include "gemm1x1.inc"
+#include "spp.inc"
 
 }  // namespace
 
@@ -2783,6 +2784,65 @@ BC_EXPORT int bc_pred3x3_nhwc(void *out, const void *x, const float *weights_pac
     BC_PR2(BC_BF16)
 #undef BC_PR2
 #undef BC_PR3
+}
+
+static int spp_geom(SppGeom &g, int H, int W, int C, int CO, int L, const int32_t *grids, int N)
+{
+    if (H <= 0 || W <= 0 || C <= 0 || CO <= 0 || L <= 0 || L > SPP_MAX_LEVELS || !grids) return BC_ERR_SHAPE;
+    if (C % 4 != 0 || C > 1024 || 256 % (C / 4) != 0 || CO > 1024) return BC_ERR_SHAPE;
+    if ((uint64_t)H * W * (uint64_t)(C + L * CO) >= (1ull << 31)) return BC_ERR_RANGE;
+    g.H = H; g.W = W; g.C = C; g.CO = CO; g.L = L;
+    uint32_t nb = 0;
+    for (int l = 0; l < L; ++l) {
+        if (grids[2 * l] <= 0 || grids[2 * l + 1] <= 0 || grids[2 * l] > 4096 || grids[2 * l + 1] > 4096) return BC_ERR_SHAPE;     // (a grid finer than the map is fine: ATen's bins overlap then)
+        g.gh[l] = grids[2 * l]; g.gw[l] = grids[2 * l + 1]; g.bin0[l] = nb;
+        nb += g.gh[l] * g.gw[l];
+    }
+    for (int l = L; l < SPP_MAX_LEVELS; ++l) { g.gh[l] = g.gw[l] = 1; g.bin0[l] = nb; }
+    g.n_bins = nb; g.K = C + L * CO; g.N = N;
+    return BC_OK;
+}
+
+BC_EXPORT int bc_spp_levels_nhwc(void *lv, const void *x, const float *scale, const float *shift, const float *weights, int H, int W, int C, int CO,
+                                 int L, const int32_t *grids, int dtype, void *stream)
+{
+    if (dtype < BC_F32 || dtype > BC_BF16) return BC_ERR_ELEM;
+    SppGeom g;
+    const int rc = spp_geom(g, H, W, C, CO, L, grids, 0);
+    if (rc != BC_OK) return rc;
+    if (!lv || !x || !weights) return BC_ERR_NULL;
+    const int E = dtype == BC_F32 ? 4 : 2;
+    if (!aligned(lv, E) || !aligned(x, 16) || !aligned(scale, 4) || !aligned(shift, 4) || !aligned(weights, 4)) return BC_ERR_ALIGN;
+    ProfScope ps(BC_OP_AFFINE, (double)L * H * W * C * E);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds_bytes = (size_t)(256 / (C / 4) + 1) * C * sizeof(float);
+#define BC_SL(DT_) BC_LAUNCH(ps, (k_spp_levels<DT_>), dim3(g.n_bins), dim3(256), lds_bytes, st, (CvType<DT_>::T *)lv, (const CvType<DT_>::T *)x, scale, shift, weights, g)
+    if (dtype == BC_F32) BC_SL(BC_F32); else if (dtype == BC_F16) BC_SL(BC_F16); else BC_SL(BC_BF16);
+#undef BC_SL
+    return launch_status();
+}
+
+BC_EXPORT int bc_spp_fuse_nhwc(void *out, const void *x, const void *lv, const float *scale, const float *shift, const void *weights_packed, int H, int W,
+                               int C, int CO, int L, const int32_t *grids, int N, int dtype, void *stream)
+{
+    if (dtype < BC_F32 || dtype > BC_BF16) return BC_ERR_ELEM;
+    SppGeom g;
+    const int rc = spp_geom(g, H, W, C, CO, L, grids, N);
+    if (rc != BC_OK) return rc;
+    if (N <= 0 || N % 64 != 0) return BC_ERR_SHAPE;
+    if (!out || !x || !lv || !weights_packed) return BC_ERR_NULL;
+    const int E = dtype == BC_F32 ? 4 : 2;
+    if (!aligned(out, E) || !aligned(x, E) || !aligned(lv, E) || !aligned(weights_packed, 16) || !aligned(scale, 4) || !aligned(shift, 4)) return BC_ERR_ALIGN;
+    ProfScope ps(BC_OP_CONV3X3, 2.0 * H * W * (double)g.K * N);
+    ps.add_aux(2.0 * H * W * (double)(((g.K + 31) / 32) * 32) * N);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds_bytes = (size_t)2 * (64 * 9 + 2 * 256) * 16;
+    const dim3 grid((H * W + 63) / 64, N / 64);
+#define BC_SF(DT_) BC_LAUNCH(ps, (k_spp_fuse<DT_>), grid, dim3(256), lds_bytes, st, (CvType<DT_>::T *)out, (const CvType<DT_>::T *)x, (const CvType<DT_>::T *)lv, \
+                             scale, shift, (const uint4 *)weights_packed, g)
+    if (dtype == BC_F32) BC_SF(BC_F32); else if (dtype == BC_F16) BC_SF(BC_F16); else BC_SF(BC_BF16);
+#undef BC_SF
+    return launch_status();
 }
 
 BC_EXPORT int bc_combine_copy_cells(const void *blocks, int N, int C, int H, int W, int bs, int E, int align)

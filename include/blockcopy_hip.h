@@ -121,6 +121,22 @@ int bc_head1x1_scatter_nhwc(void *out, const void *features, const void *weights
  * one rounding to the map's dtype. */
 int bc_pred3x3_nhwc(void *out, const void *x, const float *weights_packed, const float *bias, int N, int H, int W, int Cin, int Cout,
                     int dtype, void *stream);
+/* Pyramid pooling of a dense channels-last map x (H, W, C) in two launches (reference semantic_segmentation/lib/models/swiftnet/util.py
+ * SpatialPyramidPooling.forward after its first block, run dense inside blockcopy_noblocks, core/blockcopy.py:104-139):
+ *   bc_spp_levels_nhwc   lv[bin0[l] + by * gw_l + bx][CO] = conv1x1_l(relu(bn_l(adaptive_avg_pool2d(x, (gh_l, gw_l)))))  for every level l
+ *                        grids = {gh_0, gw_0, gh_1, gw_1, ...} (L <= 4 levels); scale / shift fp32 [L][C] (the levels' folded BN, NULL =
+ *                        identity); weights fp32 [L][C][CO].  ATen's bin limits; the pooled value and the BN -> ReLU result are rounded
+ *                        to the map's dtype like the stock passes, the conv accumulates in fp32 in channel order.
+ *   bc_spp_fuse_nhwc     out (H, W, N) = conv1x1_f(relu(bn_f(cat[x, upsample_bilinear(lv_0), ..., upsample_bilinear(lv_{L-1})])))
+ *                        without materialising the upsampled maps or the concatenation (align_corners = False, ATen's source index;
+ *                        sampled value and BN -> ReLU result rounded to the map's dtype); scale / shift fp32 [C + L * CO];
+ *                        weights_packed = the one-tap stream (pack layout of bc_conv1x1_nhwc, fp32 whatever the map's dtype) of
+ *                        the (N, K', 1, 1) weight zero-padded to K' = roundup(C + L * CO, 32) input channels; N a multiple of 64.
+ * C a multiple of 4 with 256 % (C / 4) == 0. */
+int bc_spp_levels_nhwc(void *lv, const void *x, const float *scale, const float *shift, const float *weights, int H, int W, int C, int CO,
+                       int L, const int32_t *grids, int dtype, void *stream);
+int bc_spp_fuse_nhwc(void *out, const void *x, const void *lv, const float *scale, const float *shift, const void *weights_packed, int H, int W,
+                     int C, int CO, int L, const int32_t *grids, int N, int dtype, void *stream);
 /* number of timing cells (= workgroups) such a launch writes, or a negative error code */
 int bc_combine_copy_cells(const void *blocks, int N, int C, int H, int W, int bs, int elem_size, int align);
 

@@ -172,6 +172,47 @@ class OracleBackend:
             y = self.affine_act(y, scale, shift, add.contiguous() if add is not None else None, relu)
         return y.contiguous(memory_format=torch.channels_last)
 
+    # pyramid pooling in two steps (checker form of bc_spp_levels_nhwc / bc_spp_fuse_nhwc: the stock ops, composed)
+    @staticmethod
+    def spp_supported(x, co, n_levels, cout):
+        return x.dim() == 4 and x.shape[0] == 1 and x.dtype == torch.float32 and x.shape[1] % 4 == 0 and 1 <= n_levels <= 4 and cout % 64 == 0
+
+    @staticmethod
+    def pack_spp_level_weights(weights):
+        return torch.stack([w.detach().float().reshape(w.shape[0], w.shape[1]).t() for w in weights]).contiguous()
+
+    @staticmethod
+    def pack_spp_fuse_weights(weight):
+        return weight.detach().float().clone()
+
+    def spp_levels(self, x, scale, shift, w, grids):
+        F = torch.nn.functional
+        out = []
+        for l, (gh, gw) in enumerate(grids):
+            p = F.adaptive_avg_pool2d(x.contiguous(), (gh, gw))
+            if scale is not None:
+                p = p * scale[l].view(1, -1, 1, 1)
+            if shift is not None:
+                p = p + shift[l].view(1, -1, 1, 1)
+            p = torch.relu(p)
+            out.append(p.permute(0, 2, 3, 1).reshape(gh * gw, -1) @ w[l])
+        return torch.cat(out, 0).contiguous()
+
+    def spp_fuse(self, x, lv, scale, shift, wpk, grids, cout):
+        F = torch.nn.functional
+        H, W = x.shape[2:]
+        parts, b0 = [x.contiguous()], 0
+        for gh, gw in grids:
+            m = lv[b0:b0 + gh * gw].reshape(1, gh, gw, -1).permute(0, 3, 1, 2).contiguous()
+            parts.append(F.interpolate(m, (H, W), mode="bilinear", align_corners=False))
+            b0 += gh * gw
+        cat = torch.cat(parts, 1)
+        if scale is not None:
+            cat = cat * scale.view(1, -1, 1, 1)
+        if shift is not None:
+            cat = cat + shift.view(1, -1, 1, 1)
+        return F.conv2d(torch.relu(cat), wpk).contiguous(memory_format=torch.channels_last)
+
     # dense 3x3 conv to <= 4 channels on a map handed out by to_tensor (checker form of bc_pred3x3_nhwc: the library conv)
     @staticmethod
     def pred3x3_supported(x, weight, stride=1, padding=1, dilation=1, groups=1):

@@ -677,6 +677,46 @@ def test_pred3x3_dense_prediction_conv(be, dtype, tol):
             assert err <= tol * max(1.0, want.abs().max().item()), (case, err)
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.float16, 4e-3), (torch.bfloat16, 3e-2)])
+def test_spp_levels_and_fuse_match_the_stock_ops(be, dtype, tol):
+    """bc_spp_levels_nhwc + bc_spp_fuse_nhwc (csrc/spp.inc) == adaptive_avg_pool2d -> BN/ReLU -> conv1x1 per level, bilinear upsample,
+    concat, BN/ReLU, conv1x1 composed from the stock ops (fp64 convs on the same rounded intermediates), for SwiftNet's shapes and for
+    awkward ones: grids that do not divide the map, a grid finer than the map, 1-4 levels, K not a multiple of 32, a ragged last row tile."""
+    import torch.nn.functional as F
+
+    gen = torch.Generator().manual_seed(17)
+    for case, (C, CO, N, H, W, grids) in enumerate([(128, 42, 128, 32, 64, [(8, 16), (4, 8), (2, 4)]), (64, 10, 64, 7, 13, [(3, 5), (2, 2)]),
+                                                    (128, 42, 128, 4, 8, [(8, 16), (4, 8), (2, 4)]), (32, 7, 192, 9, 9, [(6, 6), (3, 3), (2, 2), (1, 1)]),
+                                                    (256, 16, 64, 5, 6, [(1, 1)])]):
+        L = len(grids)
+        x = _cl(torch.randn((1, C, H, W), generator=gen).cuda().to(dtype))
+        lws = [(torch.randn((CO, C, 1, 1), generator=gen) * (2.0 / C) ** 0.5).cuda().to(dtype) for _ in range(L)]
+        K = C + L * CO
+        fw = (torch.randn((N, K, 1, 1), generator=gen) * (2.0 / K) ** 0.5).cuda().to(dtype)
+        lsc, lsh = (torch.rand((L, C), generator=gen) + 0.5).cuda(), (torch.randn((L, C), generator=gen) * 0.2).cuda()
+        fsc, fsh = (torch.rand(K, generator=gen) + 0.5).cuda(), (torch.randn(K, generator=gen) * 0.2).cuda()
+        assert be.spp_supported(x, CO, L, N)
+        lv = be.spp_levels(x, lsc, lsh, be.pack_spp_level_weights(lws), grids)
+        got = be.spp_fuse(x, lv, fsc, fsh, be.pack_spp_fuse_weights(fw), grids, N)
+        # the stock route, every intermediate in the map's dtype
+        parts, lv_want = [x], []
+        for l, (gh, gw) in enumerate(grids):
+            p = F.adaptive_avg_pool2d(x.float().contiguous(), (gh, gw)).to(dtype)          # (fp32 accumulation, one rounding: what the stock kernel does)
+            a = be.affine_act(_cl(p) if gh * gw > 1 else p, lsc[l], lsh[l], None, True)
+            y = F.conv2d(a.double(), lws[l].double()).to(dtype)
+            lv_want.append(y.permute(0, 2, 3, 1).reshape(gh * gw, CO))
+            parts.append(F.interpolate(y.float(), (H, W), mode="bilinear", align_corners=False).to(dtype))
+        lv_want = torch.cat(lv_want, 0)
+        err_lv = (lv.double() - lv_want.double()).abs().max().item()
+        assert err_lv <= tol * max(1.0, lv_want.abs().max().item()), (case, "levels", err_lv)
+        cat = _cl(torch.cat(parts, 1))
+        a = be.affine_act(cat, fsc, fsh, None, True)
+        want = F.conv2d(a.double(), fw.double())
+        assert tuple(got.shape) == (1, N, H, W) and got.dtype == dtype and got.permute(0, 2, 3, 1).is_contiguous()
+        err = (got.double() - want).abs().max().item()
+        assert err <= tol * max(1.0, want.abs().max().item()), (case, "fuse", err)
+
+
 def test_dense_map_routes_prediction_convs_only(be):
     """to_tensor's DenseMap: conv2d to <= 4 channels goes through bc_pred3x3_nhwc (spy), everything else behaves like -- and
     returns -- a plain tensor; the result equals the library conv within fp32 summation order."""

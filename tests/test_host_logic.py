@@ -440,6 +440,64 @@ def test_fusion_switch_off_gives_the_same_logits(golden_dir, oracle_backend):
     assert max(errs) <= 2e-5, errs
 
 
+def test_pyramid_pooling_fast_path_is_taken_and_changes_nothing(golden_dir, oracle_backend):
+    """core/spp_fused.py: inside blockcopy_noblocks the reference-shaped SpatialPyramidPooling runs as spp_levels + spp_fuse (one
+    call each per frame, spied on the checker backend), the golden logits hold, and with the switch off (generic op-by-op route)
+    they hold too; a module that does not match (another class name, a level grid option) takes the generic route."""
+    import blockcopy.backend as bk
+    from blockcopy.core import fusion, spp_fused
+    from bc_workloads.swiftnet import SpatialPyramidPooling
+
+    be = bk.get_backend()
+    calls = []
+    o_lv, o_fu = be.spp_levels, be.spp_fuse
+    be.spp_levels = lambda *a, **k: (calls.append("levels"), o_lv(*a, **k))[1]
+    be.spp_fuse = lambda *a, **k: (calls.append("fuse"), o_fu(*a, **k))[1]
+    import blockcopy
+    from blockcopy.core.argparser import default_settings
+    from bc_workloads import seeded
+    from bc_workloads.bn_fold import fold_batchnorm
+    from bc_workloads.swiftnet import build_swiftnet
+
+    G, cfg = load_golden(golden_dir, "swiftnet_rn18_a.npz")
+
+    def clip_errors(channels_last):
+        net = build_swiftnet(cfg["backbone"])
+        net.load_state_dict(seeded.name_seeded_state_dict(net.state_dict()), strict=True)
+        model = blockcopy.BlockCopyModel(net.eval(), default_settings(block_policy="all", block_size=cfg["block_size"]))
+        model.policy = make_forced_policy(cfg["block_size"], [torch.from_numpy(G[f"grid{t}"]) for t in range(cfg["n_frames"])])
+        model = fold_batchnorm(model)
+        if channels_last:
+            model = model.to(memory_format=torch.channels_last)
+        model.reset_temporal()
+        with torch.no_grad():
+            return [float((model(seeded.synthetic_frame(cfg["frame_seed0"] + t, (cfg["N"], 3, cfg["H"], cfg["W"]))) - torch.from_numpy(G[f"logits{t}"])).abs().max())
+                    for t in range(cfg["n_frames"])]
+
+    try:
+        errs = clip_errors(True)
+        n_frames = len(errs)
+        # (one frame of this clip executes no tile at all and returns the cached output: no network pass)
+        assert max(errs) <= 1e-4 and calls.count("levels") == calls.count("fuse") and n_frames - 1 <= calls.count("fuse") <= n_frames, (errs, calls)
+        del calls[:]
+        assert max(clip_errors(False)) <= 1e-4 and not calls            # an NCHW model keeps NCHW maps: generic route
+        fusion.SPP_FUSED = False
+        assert max(clip_errors(True)) <= 1e-4 and not calls
+    finally:
+        fusion.SPP_FUSED = True
+        be.spp_levels, be.spp_fuse = o_lv, o_fu
+    spp = SpatialPyramidPooling(64, 3, bt_size=32, level_size=8, out_size=64, grids=(4, 2, 1)).eval()
+    assert spp_fused.match(spp) is not None
+    spp.square_grid = True
+    assert spp_fused.match(spp) is None
+    spp.square_grid = False
+    spp.train()
+    assert spp_fused.match(spp) is None
+    spp.eval()
+    spp.upsampling_method = lambda x, size: torch.nn.functional.interpolate(x, size, mode="nearest")
+    assert spp_fused.match(spp) is None
+
+
 def test_c1_cpu_plumbing_4x512x1024_block128_all_active(oracle_backend):
     """BASELINE config C1 at its stated shape: SwiftNet-RN18 on 4 synthetic 512x1024 frames, block 128 (4x8 tiles),
     policy forced 100 %-active, no GPU (the block ops are served by the checker backend).  Both engines agree, every
