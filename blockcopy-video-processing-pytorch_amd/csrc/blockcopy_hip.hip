@@ -2815,9 +2815,16 @@ BC_EXPORT int bc_spp_levels_nhwc(void *lv, const void *x, const float *scale, co
     if (!aligned(lv, E) || !aligned(x, 16) || !aligned(scale, 4) || !aligned(shift, 4) || !aligned(weights, 4)) return BC_ERR_ALIGN;
     ProfScope ps(BC_OP_AFFINE, (double)L * H * W * C * E);
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds_bytes = (size_t)(256 / (C / 4) + 1) * C * sizeof(float);
-#define BC_SL(DT_) BC_LAUNCH(ps, (k_spp_levels<DT_>), dim3(g.n_bins), dim3(256), lds_bytes, st, (CvType<DT_>::T *)lv, (const CvType<DT_>::T *)x, scale, shift, weights, g)
-    if (dtype == BC_F32) BC_SL(BC_F32); else if (dtype == BC_F16) BC_SL(BC_F16); else BC_SL(BC_BF16);
+    const size_t lds_bytes = ((size_t)(256 / (C / 4) + 1) * C + (size_t)C * CO) * sizeof(float);       // partial sums, activated means, the level's weights
+    if (lds_bytes > 150 * 1024) return BC_ERR_SHAPE;
+    static size_t lv_attr[3] = {0, 0, 0};
+#define BC_SL(DT_)                                                                                                                                   \
+    if (lds_bytes > lv_attr[DT_] && lds_bytes > 48 * 1024) {                                                                                           \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spp_levels<DT_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);   \
+        lv_attr[DT_] = lds_bytes;                                                                                                                      \
+    }                                                                                                                                                  \
+    BC_LAUNCH(ps, (k_spp_levels<DT_>), dim3(g.n_bins), dim3(256), lds_bytes, st, (CvType<DT_>::T *)lv, (const CvType<DT_>::T *)x, scale, shift, weights, g)
+    if (dtype == BC_F32) { BC_SL(BC_F32); } else if (dtype == BC_F16) { BC_SL(BC_F16); } else { BC_SL(BC_BF16); }
 #undef BC_SL
     return launch_status();
 }
@@ -2836,11 +2843,20 @@ BC_EXPORT int bc_spp_fuse_nhwc(void *out, const void *x, const void *lv, const f
     ProfScope ps(BC_OP_CONV3X3, 2.0 * H * W * (double)g.K * N);
     ps.add_aux(2.0 * H * W * (double)(((g.K + 31) / 32) * 32) * N);
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds_bytes = (size_t)2 * (64 * 9 + 2 * 256) * 16;
+    const size_t kp = (size_t)((g.K + 31) / 32) * 32;
+    // two stages + the level maps (fp32) + the block's folded BN + per (row, level) bilinear taps and weights
+    const size_t lds_bytes = (size_t)2 * (64 * 9 + 2 * 256) * 16 + ((size_t)g.n_bins * CO + 2 * kp + 64 * SPP_MAX_LEVELS * 6) * 4;
+    if (lds_bytes > 150 * 1024) return BC_ERR_SHAPE;
+    static size_t attr_set[3] = {0, 0, 0};
     const dim3 grid((H * W + 63) / 64, N / 64);
-#define BC_SF(DT_) BC_LAUNCH(ps, (k_spp_fuse<DT_>), grid, dim3(256), lds_bytes, st, (CvType<DT_>::T *)out, (const CvType<DT_>::T *)x, (const CvType<DT_>::T *)lv, \
+#define BC_SF(DT_)                                                                                                                                   \
+    if (lds_bytes > attr_set[DT_] && lds_bytes > 48 * 1024) {                                                                                          \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spp_fuse<DT_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);     \
+        attr_set[DT_] = lds_bytes;                                                                                                                     \
+    }                                                                                                                                                  \
+    BC_LAUNCH(ps, (k_spp_fuse<DT_>), grid, dim3(256), lds_bytes, st, (CvType<DT_>::T *)out, (const CvType<DT_>::T *)x, (const CvType<DT_>::T *)lv, \
                              scale, shift, (const uint4 *)weights_packed, g)
-    if (dtype == BC_F32) BC_SF(BC_F32); else if (dtype == BC_F16) BC_SF(BC_F16); else BC_SF(BC_BF16);
+    if (dtype == BC_F32) { BC_SF(BC_F32); } else if (dtype == BC_F16) { BC_SF(BC_F16); } else { BC_SF(BC_BF16); }
 #undef BC_SF
     return launch_status();
 }
