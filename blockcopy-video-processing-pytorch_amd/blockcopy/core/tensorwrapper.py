@@ -1055,7 +1055,7 @@ class TensorWrapper(torch.Tensor):
             vkey = (plan, n_px, raw.shape[2], cin, cout, raw.dtype)
             ok = _S2_PLAN_OK.get(vkey)
             if ok is None:
-                ok = _S2_PLAN_OK[vkey] = plan in be.conv1x1_candidates(dense_layout(raw), cout, stride)
+                ok = _S2_PLAN_OK[vkey] = (not hasattr(be, "conv1x1_candidates")) or plan in be.conv1x1_candidates(dense_layout(raw), cout, stride)
             if not ok:
                 plan = -1
         if pend_out is None and bias is not None:
