@@ -95,7 +95,8 @@ def _params(module, blocks, be):
         fscale, fshift = (a.contiguous() for a in _affine(fbn)) if fbn is not None else (None, None)
         fw = be.pack_spp_fuse_weights(fconv.weight)
     out = (lscale, lshift, lw, fscale, fshift, fw)
-    module._bc_spp_params = (key, out)
+    if not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
+        module._bc_spp_params = (key, out)      # (memory of a graph's private pool must not outlive the capture as a cached constant)
     return out
 
 
