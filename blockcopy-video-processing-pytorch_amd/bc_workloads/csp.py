@@ -5,9 +5,12 @@ Own restatement of the architecture the reference evaluates (Pedestron/mmdet/mod
 necks/csp_neck.py, anchor_heads/csp_head.py, detectors/csp_blockcopy.py} with
 configs/elephant/cityperson/csp_r50_clip_blockcopy_030.py): same parameter names (backbone.*, neck.p3/p4/p5(+_l2),
 bbox_head.{cls,reg,offset}_convs.0.{conv,gn}, bbox_head.csp_{cls,reg,offset}, *_scales), same op order, same per-frame
-state machine.  mmcv/mmdet are not installable here, so unlike SwiftNet this model cannot be checked against the
-reference's own outputs; tests pin it with the reference-independent properties (all-active == dense, static-clip
-invariance) and its NMS against the oracle restatement of nms_kernel.cu.
+state machine, same decode (get_bboxes_single csp_head.py:230-284, csp_height2bbox core/bbox/transforms.py:182-212,
+multiclass_nms core/post_processing/bbox_nms.py:6-64).  Pinned against the reference's OWN modules: oracle/ref_loader.py
+``load_reference_csp`` imports those mmdet files by path (mmcv / compiled extensions stubbed) and
+tests/golden/csp_ref_modules.npz holds what the reference detector built from the C5 config produced -- state_dict key set,
+packed neck output, head maps and post-NMS boxes per frame, plus the dense detector -- for name-seeded weights
+(tests/test_csp.py, tests/test_gpu_e2e.py: maps <= 1e-4, boxes equal).
 
 What it exercises in the engine beyond SwiftNet: dilation-2 convs (halo width 2), transposed convs (run per tile
 WITHOUT halo, as in the reference), L2Norm over the channel axis, GroupNorm over all executed tiles (batched trick),
@@ -304,8 +307,9 @@ class CSPBlockCopy(CSP):
 
 
 def build_csp(block_policy="fixed", block_size=128, block_target=0.3, device="cuda", dtype=torch.float32, fold_bn=True,
-              channels_last=False, results="device", seed=0, **settings_overrides):
-    """CSP detector with name-seeded weights; ``block_policy='static'`` returns the dense detector."""
+              channels_last=False, results="device", seed=0, weights=None, **settings_overrides):
+    """CSP detector with name-seeded weights (``weights``: callable state_dict template -> values, default
+    ``seeded.name_seeded_state_dict``); ``block_policy='static'`` returns the dense detector."""
     from blockcopy.core.argparser import default_settings
 
     from . import seeded
@@ -318,7 +322,7 @@ def build_csp(block_policy="fixed", block_size=128, block_target=0.3, device="cu
                                     block_num_classes=1, **settings_overrides)
         model = CSPBlockCopy(settings, results=results)
     core = {k: v for k, v in model.state_dict().items() if not k.startswith("policy.")}
-    model.load_state_dict(seeded.name_seeded_state_dict(core), strict=False)
+    model.load_state_dict((weights or seeded.name_seeded_state_dict)(core), strict=False)
     with torch.no_grad():
         for m in model.modules():
             if isinstance(m, Scale):

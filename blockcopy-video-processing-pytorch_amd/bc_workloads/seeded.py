@@ -68,3 +68,22 @@ def fixed_fraction_grid(seed: int, N: int, GH: int, GW: int, n_exec: int) -> tor
     grid = torch.zeros(total, dtype=torch.bool)
     grid[torch.randperm(total, generator=g)[:n_exec]] = True
     return grid.view(N, 1, GH, GW)
+
+
+# (weight gain, bias shift) of the CSP head's three prediction convs for the reference-pinned detector fixture
+# (tests/golden/csp_ref_modules.npz): the name-seeded fill scales by fan_OUT, which for a 256 -> 1 conv gives logits of +-100
+# (saturated scores, e^12-pixel boxes); with these the scores spread around the 0.1 threshold and boxes are ~30 px tall, so the
+# top-k cut, the score threshold, NMS and the per-image cap of the decode all have work to do.
+CSP_REF_OVERRIDES = {"csp_cls": (0.15, -4.5), "csp_reg": (0.03, 2.0), "csp_offset": (0.03, 0.0)}
+
+
+def csp_reference_weights(template: dict) -> dict:
+    """Name-seeded values over a CSP detector's state_dict keys + CSP_REF_OVERRIDES (shared by oracle/gen_golden.py, where the
+    keys are the REFERENCE detector's, and by the parity tests, where they are this repo's: same names, same tensors)."""
+    vals = name_seeded_state_dict(template)
+    for k, (gain, bias) in CSP_REF_OVERRIDES.items():
+        vals[f"bbox_head.{k}.weight"] = vals[f"bbox_head.{k}.weight"] * gain
+        vals[f"bbox_head.{k}.bias"] = vals[f"bbox_head.{k}.bias"] + bias
+    vals["bbox_head.reg_scales.0.scale"] = torch.tensor(1.0)
+    vals["bbox_head.offset_scales.0.scale"] = torch.tensor(1.0)
+    return vals

@@ -352,6 +352,80 @@ def gen_csp_r50(ref):
                       extra=dict(weights="name-seeded over CSP().state_dict() keys, BN not folded (Pedestron does not fold)"))
 
 
+csp_ref_weights = seeded.csp_reference_weights
+CSP_REF_OVERRIDES = seeded.CSP_REF_OVERRIDES
+
+
+def gen_csp_ref_modules(ref):
+    """The reference's OWN detector -- mmdet CSPBlockCopy / CSP (detectors/csp_blockcopy.py:46-95), ResNet (backbones/resnet.py),
+    CSPNeck (necks/csp_neck.py:68-83), CSPHead.forward_single (anchor_heads/csp_head.py:130-152) and get_bboxes_single (:230-284:
+    sigmoid / exp decode, top-1000, csp_height2bbox core/bbox/transforms.py:182-212, multiclass_nms) -- built from the C5 config
+    (csp_r50_clip_blockcopy_030.py) and run through the reference TensorWrapper with forced grids.  See ref_loader.load_reference_csp
+    for what is a stand-in (mmcv initialisers, the compiled NMS extension -> oracle restatement of nms_kernel.cu).
+    Clip a: 128x256, block 32 (tiles down to 2x2 with dilation 2: the reference's padding == tile size regime), 4 frames + the dense
+    detector on frame 0; clip b: 256x512, block 128 (the tile sizes of C5 itself: 128 -> 64 -> 32 -> 16 -> 8), 3 frames."""
+    import warnings
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import tinycsp
+
+    ped = ref_loader.load_reference_csp(ref)
+    out = {}
+    clips = {"a": dict(N=1, H=128, W=256, block_size=32, n_frames=4, frame_seed0=77000, grid_seed=29),
+             "b": dict(N=1, H=256, W=512, block_size=128, n_frames=3, frame_seed0=78000, grid_seed=31)}
+    for tag, cfg in clips.items():
+        model_cfg, test_cfg = ref_loader.csp_r50_config(cfg["block_size"])
+        with quiet():
+            det = ped.det.CSPBlockCopy(train_cfg=None, test_cfg=test_cfg, **model_cfg)
+        sd = det.state_dict()
+        if tag == "a":
+            out["state_dict_keys"] = np.frombuffer(json.dumps({k: list(v.shape) for k, v in sd.items()}).encode(), dtype=np.uint8)
+        det.load_state_dict(csp_ref_weights(sd), strict=True)
+        det.eval()
+        grids = tinycsp.tinycsp_grids(cfg)
+        det.policy = ref_loader.make_forced_policy(ref, cfg["block_size"], grids)
+        rec = {}
+        h1 = det.neck.register_forward_hook(lambda m, i, o: rec.__setitem__("neck", o[0].as_subclass(torch.Tensor).detach().clone()))
+        h2 = det.bbox_head.register_forward_hook(lambda m, i, o: rec.__setitem__("maps", [x[0].detach().clone() for x in o]))
+        meta = [dict(img_shape=(cfg["H"], cfg["W"], 3), scale_factor=1.0)]
+        det.reset_temporal()
+        kept = []
+        for t in range(cfg["n_frames"]):
+            img = seeded.synthetic_frame(cfg["frame_seed0"] + t, (cfg["N"], 3, cfg["H"], cfg["W"]))
+            with torch.no_grad(), warnings.catch_warnings(), quiet():
+                warnings.simplefilter("ignore")
+                res = det.simple_test(img, meta, rescale=False)
+            assert isinstance(res, list) and len(res) == 1 and res[0].shape[1] == 5
+            out[f"{tag}_grid{t}"] = grids[t].numpy()
+            for k, m in zip(("cls", "reg", "offset"), rec["maps"]):
+                out[f"{tag}_{k}{t}"] = m.numpy().copy()
+            out[f"{tag}_neck{t}"] = rec["neck"][:, ::16, ::4, ::4].numpy().copy()      # packed tiles (n_exec, 768, bs/4, bs/4), strided sample
+            out[f"{tag}_boxes{t}"] = res[0].copy()                                       # bbox2result(...)[class 0]: (k, 5) after NMS, top max_per_img
+            kept.append(res[0].shape[0])
+            scores = torch.from_numpy(out[f"{tag}_cls{t}"]).sigmoid().reshape(-1)
+            print(f"csp_ref_modules {tag} frame {t}: n_exec {int(grids[t].sum())}, scores > thr among top-1000: {int((scores.topk(min(1000, scores.numel()))[0] > 0.1).sum())}, kept {kept[-1]}")
+        h1.remove(), h2.remove()
+        if tag == "a":
+            # the dense detector (detectors/csp.py + single_stage.py:61-70) on frame 0: pins the model without the block path
+            with quiet():
+                dense = ped.csp.CSP(model_cfg["backbone"], model_cfg["neck"], model_cfg["bbox_head"], train_cfg=None, test_cfg=test_cfg, pretrained=None)
+            dense.load_state_dict(csp_ref_weights(dense.state_dict()), strict=True)
+            dense.eval()
+            h2 = dense.bbox_head.register_forward_hook(lambda m, i, o: rec.__setitem__("maps", [x[0].detach().clone() for x in o]))
+            img = seeded.synthetic_frame(cfg["frame_seed0"], (cfg["N"], 3, cfg["H"], cfg["W"]))
+            with torch.no_grad(), quiet():
+                res = dense.simple_test(img, meta, rescale=False)
+            h2.remove()
+            for k, m in zip(("cls", "reg", "offset"), rec["maps"]):
+                out[f"dense_{k}"] = m.numpy().copy()
+            out["dense_boxes"] = res[0].copy()
+        out[f"{tag}_cfg"] = np.frombuffer(json.dumps(dict(cfg, weights="csp_ref_weights: name-seeded over the reference state_dict keys, prediction convs rescaled by overrides, "
+                                                          "scales = 1; BN not folded (Pedestron does not fold)", overrides=CSP_REF_OVERRIDES,
+                                                          test_cfg=dict(nms_pre=1000, score_thr=0.1, iou_thr=0.5, max_per_img=100))).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(GOLD, "csp_ref_modules.npz"), **out)
+    print("csp_ref_modules.npz", os.path.getsize(os.path.join(GOLD, "csp_ref_modules.npz")), "bytes")
+
+
 # ----------------------------------------------------------------------------- G. I/O format, quality metrics, GMACs counter
 def gen_io_metrics(ref):
     """Fixtures for the components either side of the hot path, from the reference's own
@@ -518,6 +592,7 @@ def main():
         return
     gen_tinycsp(ref)
     gen_csp_r50(ref)
+    gen_csp_ref_modules(ref)
     gen_keys(ref)
     gen_rl(ref)
     gen_index_tables(ref)

@@ -155,3 +155,76 @@ def nms_known_answers():
         (f([R + [0.7], Q + [0.8], P + [0.9]]), 0.5, [0, 2]),    # same boxes, input order reversed: indices refer to the input
         (f([P + [0.5], P + [0.6], P + [0.7]]), 0.99, [2]),      # identical boxes: IoU = 1, only the best score stays
     ]
+
+
+def run_csp_ref_clip(G, tag, device, engine="fused", graph=0, channels_last=False, fold_bn=False, repeats=1):
+    """Replays clip ``tag`` of tests/golden/csp_ref_modules.npz -- what the REFERENCE's own mmdet detector (CSPBlockCopy built from
+    the C5 config; oracle/gen_golden.py gen_csp_ref_modules) produced -- through this repo's CSP-ResNet50 + CSPBlockCopy manager.
+    Returns a dict of worst-case figures over the frames: ``maps`` (head maps, relative to max(1, |golden|max)), ``neck`` (strided
+    sample of the packed 768-channel neck output, same scale), ``decode`` (boxes decoded by THIS repo from the FIXTURE's maps vs the
+    fixture's boxes, absolute; -1 if the counts differ), ``e2e_match`` (fraction of fixture boxes the end-to-end boxes reproduce
+    within 1e-3)."""
+    import json
+
+    from blockcopy.core import tensorwrapper as tw
+    from blockcopy.core.argparser import default_settings
+    from bc_workloads import seeded
+    from bc_workloads.bn_fold import fold_batchnorm
+    from bc_workloads.csp import CSP, CSPBlockCopy
+
+    cfg = json.loads(bytes(G[f"{tag}_cfg"]).decode())
+    tw.set_engine(engine)
+    grids = [torch.from_numpy(G[f"{tag}_grid{t}"]) for t in range(cfg["n_frames"])]
+    base = CSP()
+    base.load_state_dict(seeded.csp_reference_weights(dict(base.state_dict())), strict=True)
+    det = CSPBlockCopy(default_settings(block_policy="all", block_size=cfg["block_size"], block_graph=graph), results="device",
+                       arch=(base.backbone, base.neck, base.bbox_head))
+    det.policy = make_forced_policy(cfg["block_size"], grids * repeats)
+    det.eval()
+    det = det.to(device)
+    if fold_bn:
+        det = fold_batchnorm(det)
+    if channels_last:
+        det = det.to(memory_format=torch.channels_last)
+    rec = {}
+
+    def neck_hook(mod, inp, out):
+        o = out[0]
+        rec["neck"] = (o._plain() if hasattr(o, "_plain") else o)[:, ::16, ::4, ::4].float().cpu().clone()
+
+    hook = det.neck.register_forward_hook(neck_hook)
+    worst = dict(maps=0.0, neck=0.0, decode=0.0, e2e_match=1.0)
+    tc = cfg["test_cfg"]
+    kw = dict(nms_pre=tc["nms_pre"], score_thr=tc["score_thr"], iou_thr=tc["iou_thr"], max_per_img=tc["max_per_img"])
+    try:
+        for rep in range(repeats):
+            det.reset_temporal()
+            for t in range(cfg["n_frames"]):
+                x = seeded.synthetic_frame(cfg["frame_seed0"] + t, (cfg["N"], 3, cfg["H"], cfg["W"])).to(device)
+                with torch.no_grad():
+                    dets, labels = det.simple_test(x)
+                for k, m in zip(("cls", "reg", "offset"), det.head_out):
+                    want = torch.from_numpy(G[f"{tag}_{k}{t}"])
+                    assert tuple(m.shape) == tuple(want.shape), (k, t, m.shape, want.shape)
+                    worst["maps"] = max(worst["maps"], float((m.float().cpu() - want).abs().max()) / max(1.0, float(want.abs().max())))
+                if not graph:    # (a captured body does not run Python hooks on replay)
+                    want = torch.from_numpy(G[f"{tag}_neck{t}"])
+                    assert rec["neck"].shape == want.shape, (rec["neck"].shape, want.shape)
+                    worst["neck"] = max(worst["neck"], float((rec["neck"] - want).abs().max()) / max(1.0, float(want.abs().max())))
+                boxes = torch.from_numpy(G[f"{tag}_boxes{t}"])
+                # decode + NMS of the FIXTURE's maps: every decision (top-k, threshold, suppression, cap) has the reference's inputs
+                fm = [torch.from_numpy(G[f"{tag}_{k}{t}"]).to(device) for k in ("cls", "reg", "offset")]
+                got, lab = det.bbox_head.get_bboxes(*fm, img_shape=(cfg["H"], cfg["W"]), **kw)
+                if tuple(got.shape) != tuple(boxes.shape) or int(lab.abs().sum()) != 0:
+                    worst["decode"] = -1.0
+                elif worst["decode"] >= 0 and boxes.numel():
+                    worst["decode"] = max(worst["decode"], float((got.float().cpu() - boxes).abs().max()))
+                # end to end: own maps differ by rounding, so a borderline decision may flip -- count the boxes reproduced
+                e2e = dets.float().cpu()
+                if boxes.shape[0]:
+                    d = (boxes[:, None, :] - e2e[None, :, :]).abs().amax(dim=2) if e2e.shape[0] else torch.full((boxes.shape[0], 1), 1e9)
+                    worst["e2e_match"] = min(worst["e2e_match"], float((d.amin(dim=1) <= 1e-3).float().mean()))
+    finally:
+        hook.remove()
+        tw.set_engine("fused")
+    return worst

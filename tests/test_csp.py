@@ -234,3 +234,55 @@ def test_detection_rewards_match_the_reference(golden_dir):
         pm = {"inputs": frame, "outputs": [[cur]], "outputs_prev": [[prev]]}
         assert torch.equal(ig(pm), want_gain), k
         assert torch.equal(ig.get_output_repr(pm), want_repr), k
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The model, its decode and NMS against the REFERENCE'S OWN mmdet modules (tests/golden/csp_ref_modules.npz, generated by
+# oracle/gen_golden.py gen_csp_ref_modules from detectors/csp_blockcopy.py, backbones/resnet.py, necks/csp_neck.py,
+# anchor_heads/csp_head.py, core/bbox/transforms.py, core/post_processing/bbox_nms.py loaded by path).
+def _csp_ref(golden_dir):
+    return np.load(os.path.join(golden_dir, "csp_ref_modules.npz"))
+
+
+def test_state_dict_keys_equal_the_reference_detector(golden_dir):
+    """Key set AND shapes of the reference's CSPBlockCopy (C5 config, policy parameters aside) == this repo's CSP: a Pedestron
+    checkpoint loads with strict=True."""
+    from bc_workloads.csp import CSP
+
+    want = json.loads(bytes(_csp_ref(golden_dir)["state_dict_keys"]).decode())
+    have = {k: list(v.shape) for k, v in CSP().state_dict().items()}
+    assert len(want) == 344 and have == want, sorted(set(want) ^ set(have))[:10]
+    assert list(have) == list(want), "registration order differs (matters for BN folding and name-seeded fills)"
+
+
+@pytest.mark.parametrize("tag,engine,graph,fold", [("a", "fused", 0, False), ("a", "fused", 1, True), ("a", "reference", 0, False), ("b", "fused", 0, True)])
+def test_csp_matches_reference_modules(oracle_backend, golden_dir, tag, engine, graph, fold):
+    """Own CSP-ResNet50 + manager + decode on the checker backend vs the reference detector's head maps (<= 5e-5), packed neck output,
+    and boxes: decoding the fixture's maps reproduces the reference's post-NMS boxes (count, order, <= 1e-4 px / score)."""
+    from common import run_csp_ref_clip
+
+    w = run_csp_ref_clip(_csp_ref(golden_dir), tag, "cpu", engine, graph, fold_bn=fold, repeats=2 if graph else 1)
+    assert w["maps"] <= 5e-5 and w["neck"] <= 5e-5, w
+    assert 0 <= w["decode"] <= 1e-4, w
+    assert w["e2e_match"] >= 0.9, w
+
+
+def test_dense_csp_matches_the_reference_dense_detector(oracle_backend, golden_dir):
+    """detectors/csp.py + single_stage.py:61-70 (no block path) on frame 0 of clip a: maps and boxes of this repo's dense CSP."""
+    from bc_workloads import seeded
+    from bc_workloads.csp import CSP
+
+    G = _csp_ref(golden_dir)
+    cfg = json.loads(bytes(G["a_cfg"]).decode())
+    det = CSP()
+    det.load_state_dict(seeded.csp_reference_weights(dict(det.state_dict())), strict=True)
+    det.eval()
+    x = seeded.synthetic_frame(cfg["frame_seed0"], (cfg["N"], 3, cfg["H"], cfg["W"]))
+    with torch.no_grad():
+        maps = det.head_maps(x)
+        dets, _ = det.bbox_head.get_bboxes(*[torch.from_numpy(G[f"dense_{k}"]) for k in ("cls", "reg", "offset")], img_shape=(cfg["H"], cfg["W"]))
+    for k, m in zip(("cls", "reg", "offset"), maps):
+        want = torch.from_numpy(G[f"dense_{k}"])
+        assert float((m - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max())), k
+    want = torch.from_numpy(G["dense_boxes"])
+    assert dets.shape == want.shape and float((dets - want).abs().max()) <= 1e-4
