@@ -10,7 +10,10 @@ buffers with fixed addresses:
     persistent ring caches, MIOpen convs, per-tile resampling, dense SPP ...] -> packed output tiles
 
 Per frame the host then does: policy -> index tables (C loop, pinned) -> one H->D copy into the static table buffer ->
-one D->D copy of the frame -> ``graph.replay()``.  No Python runs per layer and nothing synchronises.
+``graph.replay()``.  No Python runs per layer and nothing synchronises.  The caller's frame is NOT staged: its address rides in a slot
+word behind the index tables and the graph's first node copies the executed tiles from it straight into the persistent frame-state map
+(``bc_tile_copy_indirect``; rounds 1-3 copied the whole frame into a static buffer, gathered the executed tiles from it and scattered
+them into the map: three launches and ~100 MB of traffic per C2 frame for the same 12.6 MB of new pixels).
 
 The final out-of-place combine (fused scatter+copy of the output map) is a node of the same graph although its output must
 be a FRESH tensor every frame (callers may keep every frame's result, as with the reference) and its ``prev`` operand is
@@ -32,7 +35,8 @@ from .tensorwrapper import BlockFeatures, PersistentState, TensorWrapper, _NoDis
 
 WARM_RUNS = 1   # eager runs of a new executed-tile count before it is captured (MIOpen solver search, lazy module loads)
 GRAPH_COMBINE = os.environ.get("BLOCKCOPY_GRAPH_COMBINE", "1") != "0"   # final scatter+copy as a graph node (0: the eager launch of rounds 1-2)
-SLOT_WORDS = 3  # uint64 words behind the index tables: prev address, out address, timing record (bc_combine_copy_indirect)
+GRAPH_INPUT = os.environ.get("BLOCKCOPY_GRAPH_INPUT", "1") != "0"       # input stage = one tile copy from the caller's frame (0: staging copy + gather + scatter)
+SLOT_WORDS = 4  # uint64 words behind the index tables: prev address, out address, timing record (bc_combine_copy_indirect), input frame address
 
 
 class _Bucket:
@@ -55,7 +59,9 @@ class GraphedFrame:
         self.grid_shape = (N, 1, H // block_size, W // block_size)
         self.n_total = N * (H // block_size) * (W // block_size)
         self.device = inputs.device
-        self.static_in = torch.empty_like(inputs, memory_format=torch.contiguous_format)
+        self.in_meta = (tuple(inputs.shape), inputs.dtype)
+        self.static_in = None     # staging copy of the frame: only when the input-slot stage is off / unavailable
+        self.cur_in = None        # the caller's frame of the current replay (kept alive until the next one)
         # [grid_idx | mapping_exec | slot words of the in-graph scatter+copy]: ONE buffer, one H->D copy per frame
         self.tables = torch.zeros(2 * self.n_total + 2 * SLOT_WORDS, dtype=torch.int32, device=self.device)
         self.grid_idx = self.tables[:self.n_total].view(self.grid_shape)
@@ -80,29 +86,40 @@ class GraphedFrame:
         staging = ring.next()
         st = staging.numpy()
         n_exec = get_backend().grid_tables_host(g8, st[:self.n_total], st[self.n_total:2 * self.n_total], None, None)
-        words = self._next_out()
-        st[2 * self.n_total:].view(np.int64)[:] = words if words is not None else 0
+        st[2 * self.n_total:].view(np.int64)[:] = self._slot_words(inputs)
         self.tables.copy_(staging, non_blocking=True)
         ring.uploaded()
-        if inputs.data_ptr() != self.static_in.data_ptr():
-            self.static_in.copy_(inputs, non_blocking=True)
         return n_exec
 
     def upload_tables(self, inputs: torch.Tensor, tables: torch.Tensor, n_exec: int) -> int:
-        """Per-frame work when the policy already built the index tables on the device (bc_policy_step): two D->D copies (+ the
-        24-byte slot words of the in-graph scatter+copy)."""
+        """Per-frame work when the policy already built the index tables on the device (bc_policy_step): one D->D copy of the tables
+        + the 32 bytes of slot words."""
         assert tables.numel() == 2 * self.n_total and tables.dtype == torch.int32
         self.tables[:2 * self.n_total].copy_(tables, non_blocking=True)
-        words = self._next_out()
-        if words is not None:
-            ring = pinned_ring(SLOT_WORDS, torch.int64, self.device.type == "cuda")
-            staging = ring.next()
-            staging.numpy()[:] = words
-            self.slots.copy_(staging, non_blocking=True)
-            ring.uploaded()
-        if inputs.data_ptr() != self.static_in.data_ptr():
-            self.static_in.copy_(inputs, non_blocking=True)
+        ring = pinned_ring(SLOT_WORDS, torch.int64, self.device.type == "cuda")
+        staging = ring.next()
+        staging.numpy()[:] = self._slot_words(inputs)
+        self.slots.copy_(staging, non_blocking=True)
+        ring.uploaded()
         return int(n_exec)
+
+    def uses_input_slot(self) -> bool:
+        return GRAPH_INPUT and hasattr(get_backend(), "tile_copy_indirect")
+
+    def _slot_words(self, inputs: torch.Tensor):
+        """This frame's slot words [prev, out, timing record, input frame]; also stages the frame when the input-slot stage is off."""
+        assert (tuple(inputs.shape), inputs.dtype) == self.in_meta, "input geometry changed under a captured frame pipeline"
+        if self.uses_input_slot():
+            self.cur_in = inputs if inputs.is_contiguous() else inputs.contiguous()
+            in_word = self.cur_in.data_ptr()
+        else:
+            if self.static_in is None:
+                self.static_in = torch.empty_like(inputs, memory_format=torch.contiguous_format)
+            if inputs.data_ptr() != self.static_in.data_ptr():
+                self.static_in.copy_(inputs, non_blocking=True)
+            self.cur_in, in_word = self.static_in, self.static_in.data_ptr()
+        words = self._next_out()
+        return (words if words is not None else (0, 0, 0)) + (in_word,)
 
     def _next_out(self):
         """Allocate this frame's output map and return the slot words that point the in-graph scatter+copy at it (None until the
@@ -150,12 +167,20 @@ class GraphedFrame:
         feats._grid_idx = self.grid_idx
         feats._mapping_exec = self.tables[self.n_total:self.n_total + n_exec]
         feats.n_exec, feats.n_total = n_exec, self.n_total
-        with _NoDispatch():
-            x = self.static_in.as_subclass(TensorWrapper)
-        x._init_metadata()
-        x._features = feats
-        blocks = x._split(self.block_size)
-        frame_state = blocks.combine_()._plain()
+        if self.uses_input_slot():
+            # input stage: ONE masked tile copy from the caller's frame (address in slot word 3) into the persistent frame-state map;
+            # the packed input tiles exist only if something other than the fused stem asks for them (deferred gather from the map)
+            shape, dtype = self.in_meta
+            frame_state = self.state.next_map(shape, dtype, self.device, False)
+            get_backend().tile_copy_indirect(frame_state, self.slots[3:4], feats._mapping_exec, self.block_size, target=self.cur_in)
+            blocks = TensorWrapper._deferred_split(frame_state, self.block_size, feats)
+        else:
+            with _NoDispatch():
+                x = self.static_in.as_subclass(TensorWrapper)
+            x._init_metadata()
+            x._features = feats
+            blocks = x._split(self.block_size)
+            frame_state = blocks.combine_()._plain()
         out = base_model(blocks, **kwargs)
         if isinstance(out, TensorWrapper) and out.is_blocks:
             head = out._head_record()      # network output stage still deferred: prologue + 1x1 conv + bias + combine in one launch

@@ -121,10 +121,10 @@ def forward(module, x):
     B, C, H, W = x0.shape
     # an NCHW model keeps NCHW maps (the kernels read and write channels-last ones, and what follows expects the layout the generic
     # route would have produced): the first block's output tells which kind of model this is
-    if not x0.is_contiguous(memory_format=torch.channels_last) or not be.spp_supported(x0[:1], CO, L, N):
-        return _generic_tail(module, x0, x)
     ar = W / H
     grids = [(g, max(1, round(ar * g))) for g in grids_cfg]              # (reference: grid_size = (g, max(1, round(ar * g))))
+    if not x0.is_contiguous(memory_format=torch.channels_last) or not be.spp_supported(x0[:1], CO, L, N, grids):
+        return _generic_tail(module, x0, x)
     lscale, lshift, lw, fscale, fshift, fw = _params(module, blocks, be)
     outs = []
     for b in range(B):

@@ -520,6 +520,37 @@ class TensorWrapper(torch.Tensor):
             out = SplitFunction.apply(out, dense, mapping_exec, grid_idx)
             return self._wrap_like(out, self, True)
 
+    @staticmethod
+    def _deferred_split(dense_map: torch.Tensor, block_size: int, feats: "BlockFeatures") -> "TensorWrapper":
+        """The packed tiles of ``dense_map`` at the executed grid positions as a DEFERRED gather: the map already holds them in place
+        (graph body: bc_tile_copy_indirect has just written this frame's tiles into the frame-state map), and the usual first consumer
+        -- the fused stem conv -- reads its windows from the map, so the packed tensor is only materialised (bc_split from the map) if
+        something else asks for its value.  The placeholder is never read or written otherwise."""
+        N, C, H, W = dense_map.shape
+        n_exec = feats._mapping_exec.numel()
+        placeholder = empty_like_layout((n_exec, C, block_size, block_size), dense_map)
+        be = get_backend()
+
+        def launch(epilogue=None, **kw):
+            out = be.split(empty_like_layout((n_exec, C, block_size, block_size), dense_map), dense_map, feats._mapping_exec, feats._grid_idx)
+            return out if epilogue is None else be.affine_act(out, *epilogue)
+
+        with _NoDispatch():
+            blocks = placeholder.as_subclass(TensorWrapper)
+        blocks._init_metadata()
+        blocks._features = feats
+        blocks._is_blocks = True
+        blocks._pending = fusion.Pending().defer_conv(launch, {}, dense_map)
+        blocks._pending.conv[2]["split"] = True
+        blocks._dense_map = dense_map
+        return blocks
+
+    def _is_plain_split(self) -> bool:
+        """True for a packed tensor that is nothing but the not-yet-launched gather of its ``_dense_map`` (see _deferred_split)."""
+        P = self._pending
+        return (P is not None and P.conv is not None and bool(P.conv[2].get("split")) and P.scale is None and P.shift is None and P.add is None
+                and not P.relu and P.interp is None and getattr(self, "_dense_map", None) is not None)
+
     # ------------------------------------------------------------------ packed -> dense
     def to_tensor(self) -> torch.Tensor:
         """Plain torch.Tensor view; packed tensors are combined (out of place) first."""
@@ -813,7 +844,7 @@ class TensorWrapper(torch.Tensor):
                 return func(*args, **kwargs), pend_out
 
         feats = self._features
-        if fuse and op == "conv2d" and padding == 3 and fusion.STEM_KERNEL and isinstance(x, TensorWrapper) and x._pending is None:
+        if fuse and op == "conv2d" and padding == 3 and fusion.STEM_KERNEL and isinstance(x, TensorWrapper) and (x._pending is None or x._is_plain_split()):
             # network input: the padded tiles are windows of the frame-state map this packed tensor was just scattered into
             # (combine_), so window gather + 7x7 stem conv run as ONE kernel -- no halo gather, no ring cache, no layout copy
             be = get_backend()

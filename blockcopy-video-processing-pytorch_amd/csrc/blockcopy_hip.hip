@@ -226,6 +226,36 @@ __global__ __launch_bounds__(WG) void k_combine_copy_ind(const typename VecOf<VB
     }
 }
 
+// The network-input stage of a graph-replayed frame: dst[tile] = src[tile] for every executed tile of two dense maps of ONE geometry
+// (src = the caller's frame, dst = the persistent frame-state map), i.e. the reference's split + combine_ of the input
+// (core/blockcopy.py:62-68: to_blocks -> combine_ -> frame_state) without the packed tensor in between and without a staging copy of
+// the frame: the source ADDRESS is read from a device word at run time (`src_slot`, refreshed by the host with the frame's index
+// tables), so the captured node serves whatever tensor the caller passes each frame.  2 * n_exec*C*bs^2*E bytes instead of the
+// 2 * (N*C*H*W + 2 * n_exec*C*bs^2) * E of copy-in + gather + in-place scatter.  `n_exec_dev` (optional): executed-tile count read from
+// device memory (<= the count the grid was sized for), for frames whose count the host does not know at launch time.
+template <int VB>
+__global__ __launch_bounds__(WG) void k_tile_copy_ind(typename VecOf<VB>::type *__restrict__ dst, const unsigned long long *__restrict__ src_slot,
+                                                      const int32_t *__restrict__ mapping_exec, const int32_t *__restrict__ n_exec_dev,
+                                                      uint32_t per_tile /* vectors per packed tile: C*bs*vpr */, TileGeom g)
+{
+    typedef typename VecOf<VB>::type V;
+    uint32_t total = g.total;
+    if (n_exec_dev) total = min(total, (uint32_t)*n_exec_dev * per_tile);
+    if (total == 0) return;
+    // (address formed as `dst + offset`: a pointer cast from an integer would be a generic pointer and the loads flat_*)
+    const V *__restrict__ src = dst + (long long)(src_slot[0] - reinterpret_cast<unsigned long long>(dst)) / (long long)sizeof(V);
+    const uint32_t v = min(blockIdx.x * WG + threadIdx.x, total - 1);      // tail lanes redo the last vector (same value)
+    uint32_t r, xv, r2, h, c, b, t, gw, n, gh;
+    fd_divmod(v, g.vpr, r, xv);
+    fd_divmod(r, g.bs, r2, h);
+    fd_divmod(r2, g.C, b, c);
+    const uint32_t ig = (uint32_t)mapping_exec[b];
+    fd_divmod(ig, g.GW, t, gw);
+    fd_divmod(t, g.GH, n, gh);
+    const uint32_t di = (c * g.H + h) * g.vprW + xv + (n * g.C.d * g.H + gh * g.bsz) * g.vprW + gw * g.vpr.d;
+    dst[di] = nt_load(src + di);        // (the frame is read once; the state map is re-read by the stem conv right behind)
+}
+
 // ------------------------------------------------------------------------------------------ border-ring transfer
 struct TransferGeom {
     FastDiv vpr, bs, C;
@@ -2693,6 +2723,36 @@ static int launch_head1x1(ProfScope &ps, void *out, const void *features, const 
     return launch_status();
 }
 
+BC_EXPORT int bc_tile_copy_indirect(void *dst, const void *src_slot, const int32_t *mapping_exec, const int32_t *n_exec_dev, int n_exec,
+                                    int N, int C, int H, int W, int bs, int E, int align, void *stream)
+{
+    int rc = check_dense(N, C, H, W, bs, E);
+    if (rc != BC_OK) return rc;
+    if (n_exec < 0 || n_exec > N * (H / bs) * (W / bs)) return BC_ERR_SHAPE;
+    if (n_exec == 0) return BC_OK;
+    if (!dst || !src_slot || !mapping_exec) return BC_ERR_NULL;
+    if (align <= 0 || (align & (align - 1))) return BC_ERR_ALIGN;
+    if (!aligned(dst, E) || !aligned(src_slot, 8) || !aligned(n_exec_dev, 4)) return BC_ERR_ALIGN;
+    // the source address is not known here: `align` is the caller's promise about it (any future frame)
+    const int vb = pick_vb((size_t)bs * E, {dst, reinterpret_cast<const void *>((uintptr_t)(align > 16 ? 16 : align))});
+    TileGeom g;
+    const uint32_t vpr = (uint32_t)((size_t)bs * E / vb);
+    g.vpr = make_fd(vpr); g.bs = make_fd(bs); g.C = make_fd(C); g.GW = make_fd(W / bs); g.GH = make_fd(H / bs);
+    g.H = H; g.bsz = bs; g.vprW = (uint32_t)((size_t)W * E / vb);
+    g.total = (uint32_t)((uint64_t)n_exec * C * bs * vpr);
+    const int grid = grid_exact(g.total, 1);
+    ProfScope ps(BC_OP_SPLIT, 2.0 * n_exec * C * bs * bs * E);
+    hipStream_t st = (hipStream_t)stream;
+#define BC_TC(VB_)                                                                                                          \
+    case VB_:                                                                                                               \
+        BC_LAUNCH(ps, (k_tile_copy_ind<VB_>), dim3(grid), dim3(WG), 0, st, (VecOf<VB_>::type *)dst,                         \
+                  (const unsigned long long *)src_slot, mapping_exec, n_exec_dev, (uint32_t)C * bs * vpr, g);               \
+        break;
+    switch (vb) { BC_TC(16) BC_TC(8) BC_TC(4) BC_TC(2) BC_TC(1) }
+#undef BC_TC
+    return launch_status();
+}
+
 BC_EXPORT int bc_head1x1_scatter_nhwc(void *out, const void *features, const void *weights_packed, const void *prev, const void *slots,
                                       const int32_t *grid_idx, const int32_t *mapping_exec, int n_exec, int N, int Cin, int Cout,
                                       int GH, int GW, int bs, int dtype, const float *in_scale, const float *in_shift, int in_relu,
@@ -2700,7 +2760,9 @@ BC_EXPORT int bc_head1x1_scatter_nhwc(void *out, const void *features, const voi
 {
     if (dtype < BC_F32 || dtype > BC_BF16) return BC_ERR_ELEM;
     if (n_exec < 0 || N <= 0 || Cin <= 0 || Cout <= 0 || Cout > 32 || GH <= 0 || GW <= 0 || bs <= 0) return BC_ERR_SHAPE;
-    if (bs % 8 != 0 || (bs > 32 && bs % 32 != 0) || ((long long)bs * bs) % 32 != 0) return BC_ERR_SHAPE;
+    // a 32-pixel M-block is stored as 32 / run_px row segments of run_px = min(bs, 32) pixels: bs must divide 32 or be a multiple of it
+    // (bs = 24 would leave 8 of every 32 pixels unwritten and start segments mid-row)
+    if (bs % 8 != 0 || !((bs >= 32 && bs % 32 == 0) || 32 % bs == 0)) return BC_ERR_SHAPE;
     const bool cin_ok = dtype == BC_F32 ? (Cin == 64 || Cin == 128) : (Cin == 64 || Cin == 128 || Cin == 256);
     if (!cin_ok) return BC_ERR_SHAPE;
     if (scatter && n_exec > N * GH * GW) return BC_ERR_SHAPE;

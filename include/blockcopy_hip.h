@@ -92,6 +92,15 @@ int bc_combine_copy(const void *blocks, const void *prev, void *out, const int32
  * (s_memrealtime) in cell i -- graph kernel nodes cannot carry start / stop events; launch time = max(exit) - min(entry). */
 int bc_combine_copy_indirect(const void *blocks, const void *slots, const int32_t *grid_idx,
                              int N, int C, int H, int W, int bs, int elem_size, int align, void *stream);
+/* The network-INPUT stage of a graph-replayed frame: dst[tile] = src[tile] for every executed tile (mapping_exec) of two dense maps of
+ * one geometry (N,C,H,W) -- src = the caller's frame, dst = the persistent frame-state map.  Equals the reference's
+ * to_blocks(split) + combine_ of the network input (core/blockcopy.py:62-68, frame_state = "latest executed frame per block") without
+ * the packed tensor and without a staging copy of the frame: the source address is read at run time from the device word
+ * `src_slot` (uint64, refreshed by the host with the frame's index tables), as in bc_combine_copy_indirect.
+ * `align` = power of two every future source address is a multiple of.  n_exec_dev: NULL, or a device int32 holding the executed-tile
+ * count of THIS replay (<= n_exec, which sizes the launch): frames whose count the host does not know when it launches. */
+int bc_tile_copy_indirect(void *dst, const void *src_slot, const int32_t *mapping_exec, const int32_t *n_exec_dev, int n_exec,
+                          int N, int C, int H, int W, int bs, int elem_size, int align, void *stream);
 /* The network's last stage in one launch (csrc/head1x1.inc): activation prologue + pointwise conv to Cout <= 32 channels + the
  * out-of-place combine.  Replaces, for a model whose head is BN -> ReLU -> 1x1 conv on packed tiles followed by
  * `out.combine()` (SwiftNet logits: semantic_segmentation/lib/models/swiftnet/swiftnet.py via util.py:40-55, then

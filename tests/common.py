@@ -192,7 +192,7 @@ def run_csp_ref_clip(G, tag, device, engine="fused", graph=0, channels_last=Fals
         o = out[0]
         rec["neck"] = (o._plain() if hasattr(o, "_plain") else o)[:, ::16, ::4, ::4].float().cpu().clone()
 
-    hook = det.neck.register_forward_hook(neck_hook)
+    hook = det.neck.register_forward_hook(neck_hook) if not graph else None     # (no host reads inside a graph capture)
     worst = dict(maps=0.0, neck=0.0, decode=0.0, e2e_match=1.0)
     tc = cfg["test_cfg"]
     kw = dict(nms_pre=tc["nms_pre"], score_thr=tc["score_thr"], iou_thr=tc["iou_thr"], max_per_img=tc["max_per_img"])
@@ -225,6 +225,7 @@ def run_csp_ref_clip(G, tag, device, engine="fused", graph=0, channels_last=Fals
                     d = (boxes[:, None, :] - e2e[None, :, :]).abs().amax(dim=2) if e2e.shape[0] else torch.full((boxes.shape[0], 1), 1e9)
                     worst["e2e_match"] = min(worst["e2e_match"], float((d.amin(dim=1) <= 1e-3).float().mean()))
     finally:
-        hook.remove()
+        if hook is not None:
+            hook.remove()
         tw.set_engine("fused")
     return worst

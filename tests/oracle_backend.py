@@ -88,6 +88,18 @@ class OracleBackend:
             prev = torch.zeros_like(out)
         return self.combine_copy(blocks, prev, out, grid_idx)
 
+    def tile_copy_indirect(self, dst, src_slot, mapping_exec, bs, n_exec_dev=None, target=None):
+        """Checker form of the in-graph input stage: the slot word must hold the address of ``target`` (what the HIP kernel would
+        dereference); the arithmetic is the oracle's split followed by its in-place combine."""
+        assert int(src_slot[0]) == target.data_ptr() and target.shape == dst.shape and target.is_contiguous()
+        n = mapping_exec.numel() if n_exec_dev is None else min(mapping_exec.numel(), int(n_exec_dev[0]))
+        if n:
+            m = mapping_exec[:n].contiguous()
+            blocks = torch.empty((n, dst.shape[1], bs, bs), dtype=dst.dtype)
+            O.c_split(blocks, target, m)
+            O.c_combine(blocks, dst, m)
+        return dst
+
     def pad_ring(self, data_exec, ring, grid_idx, mapping_exec, pad, prologue=None):
         if _nhwc(data_exec):   # ring records are opaque to the host: the checker keeps its own (NCHW-style) convention
             return _like(self.pad_ring(data_exec.contiguous(), ring, grid_idx, mapping_exec, pad, prologue), data_exec)
@@ -174,7 +186,7 @@ class OracleBackend:
 
     # pyramid pooling in two steps (checker form of bc_spp_levels_nhwc / bc_spp_fuse_nhwc: the stock ops, composed)
     @staticmethod
-    def spp_supported(x, co, n_levels, cout):
+    def spp_supported(x, co, n_levels, cout, grids=None):
         return x.dim() == 4 and x.shape[0] == 1 and x.dtype == torch.float32 and x.shape[1] % 4 == 0 and 1 <= n_levels <= 4 and cout % 64 == 0
 
     @staticmethod

@@ -1228,3 +1228,61 @@ def test_head1x1_prologue_conv_bias_scatter_copy(be, geo, dtype, tol):
     got = be.head1x1(x, wpk, cout, None, (osc, bias, add, True))
     want = torch.relu(torch.nn.functional.conv2d(x.double(), w.double()) * osc.double().view(1, -1, 1, 1) + bias.double().view(1, -1, 1, 1) + add.double())
     assert float((got.double() - want).abs().max()) / max(1.0, float(want.abs().max())) <= 2 * tol
+
+
+def test_head1x1_refuses_tile_sizes_it_cannot_store(be):
+    """bs = 24 (block 96 at the stride-4 head): 24 % 8 == 0 and 576 % 32 == 0, but a 32-pixel M-block is stored as runs of min(bs, 32)
+    pixels, which needs bs | 32 or 32 | bs.  Both the binding's check and the launcher refuse it (round-3 advisor: it used to be accepted
+    and wrote garbage), so such a model takes the generic route -- checked end to end: a packed 1x1 conv to 19 channels on 24-pixel
+    tiles followed by an out-of-place combine equals the definition."""
+    import blockcopy
+    import blockcopy.backend as bk
+
+    x = torch.randn((3, 128, 24, 24), device="cuda").contiguous(memory_format=torch.channels_last)
+    w = (torch.randn((19, 128, 1, 1), device="cuda") / 128 ** 0.5)
+    assert not be.head1x1_supported(x, w)
+    for bs, ok in ((8, True), (16, True), (32, True), (64, True), (96, True), (24, False), (40, False), (48, False)):
+        assert be.head1x1_supported(torch.empty((1, 128, bs, bs), device="cuda").contiguous(memory_format=torch.channels_last), w) == ok, bs
+    with pytest.raises(bk.BlockCopyBackendError) as ei:
+        be._head_launch(torch.empty((3, 19, 24, 24), device="cuda").contiguous(memory_format=torch.channels_last), x, be.pack_head1x1_weights(w), 19, None, None, False)
+    assert ei.value.code == bk.BC_ERR_SHAPE
+    # end to end on 24-pixel tiles (frame 48 x 72 -> grid 2 x 3)
+    frame = torch.randn((1, 128, 48, 72), device="cuda").contiguous(memory_format=torch.channels_last)
+    xw = blockcopy.to_tensorwrapper(frame)
+    xw.process_temporal_features(None)
+    grid = torch.ones(1, 1, 2, 3, dtype=torch.bool)
+    with torch.no_grad():
+        blocks = xw.to_blocks(grid.cuda(), grid)
+        got = torch.nn.functional.conv2d(torch.relu(blocks), w).combine().to_tensor()
+        want = torch.nn.functional.conv2d(torch.relu(frame), w)
+    assert got.shape == want.shape and float((got - want).abs().max()) <= 1e-4 * max(1.0, float(want.abs().max()))
+
+
+def test_pyramid_pooling_with_the_reference_default_widths_takes_the_generic_route(be):
+    """SpatialPyramidPooling with the reference's own defaults (bt_size 512, level_size 128; lib/models/swiftnet/util.py:97-111) needs
+    268 KB of LDS in bc_spp_levels_nhwc: spp_supported must say no and the module must run op by op with the same result as the
+    stock module on the dense map (round-3 advisor: the launcher's BC_ERR_SHAPE used to surface in the middle of the frame)."""
+    import blockcopy
+    from blockcopy.core import spp_fused
+    from bc_workloads import seeded
+    from bc_workloads.swiftnet import SpatialPyramidPooling
+
+    spp = SpatialPyramidPooling(256, 3, bt_size=512, level_size=128, out_size=128, grids=(8, 4, 2, 1)).eval()
+    spp.load_state_dict(seeded.name_seeded_state_dict(spp.state_dict()), strict=True)
+    spp = spp.cuda().to(memory_format=torch.channels_last)
+    assert spp_fused.match(spp) is not None
+    frame = torch.randn((1, 256, 16, 32), device="cuda").contiguous(memory_format=torch.channels_last)
+    calls = []
+    o_lv = be.spp_levels
+    be.spp_levels = lambda *a, **k: (calls.append("levels"), o_lv(*a, **k))[1]
+    try:
+        xw = blockcopy.to_tensorwrapper(frame)
+        xw.process_temporal_features(None)
+        grid = torch.ones(1, 1, 2, 4, dtype=torch.bool)
+        with torch.no_grad():
+            got = spp(xw.to_blocks(grid.cuda(), grid)).combine().to_tensor()
+            want = spp(frame)        # a plain tensor: blockcopy_noblocks calls the stock forward
+    finally:
+        be.spp_levels = o_lv
+    assert not calls, "the two-launch route must not be taken above the LDS budget"
+    assert got.shape == (1, 128, 16, 32) and float((got - want).abs().max()) <= 1e-4 * max(1.0, float(want.abs().max()))

@@ -498,6 +498,21 @@ def test_pyramid_pooling_fast_path_is_taken_and_changes_nothing(golden_dir, orac
     assert spp_fused.match(spp) is None
 
 
+def test_spp_support_check_mirrors_the_launchers_lds_budget():
+    """HipBackend.spp_supported (pure shape logic, no library needed) refuses what bc_spp_levels_nhwc / bc_spp_fuse_nhwc refuse: the
+    reference's own SpatialPyramidPooling defaults (bt_size 512, level_size 128 -> 268 KB of LDS) must take the generic route, not raise
+    BC_ERR_SHAPE in the middle of a frame (round-3 advisor)."""
+    from blockcopy.backend import HipBackend
+
+    x128 = torch.empty((1, 32, 64, 128), dtype=torch.float32).permute(0, 3, 1, 2)        # SwiftNet-RN18: 128 channels, level size 42
+    assert HipBackend.spp_supported(x128, 42, 3, 128, [(8, 16), (4, 8), (2, 4)])
+    x512 = torch.empty((1, 32, 64, 512), dtype=torch.float32).permute(0, 3, 1, 2)
+    assert not HipBackend.spp_supported(x512, 128, 3, 128, [(8, 16), (4, 8), (2, 4)])      # levels: (3 * 512 + 512 * 128) * 4 = 268 KB
+    assert HipBackend.spp_supported(x128, 42, 3, 128)                                     # without grids: the levels budget only
+    fine = [(32, 64), (16, 32), (8, 16)]                                                   # 2688 bins x 42 channels of level maps: 451 KB
+    assert not HipBackend.spp_supported(x128, 42, 3, 128, fine)
+
+
 def test_c1_cpu_plumbing_4x512x1024_block128_all_active(oracle_backend):
     """BASELINE config C1 at its stated shape: SwiftNet-RN18 on 4 synthetic 512x1024 frames, block 128 (4x8 tiles),
     policy forced 100 %-active, no GPU (the block ops are served by the checker backend).  Both engines agree, every
