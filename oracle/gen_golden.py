@@ -158,10 +158,10 @@ def scenario_grids(N, GH, GW, seed):
     return gs
 
 
-def gen_swiftnet(ref, tag, backbone, N, H, W, bs, n_frames, seed, store_frame_state, subsample=None):
+def gen_swiftnet(ref, tag, backbone, N, H, W, bs, n_frames, seed, store_frame_state, subsample=None, grids=None):
     """``subsample=(step, offsets)``: store ``logits[..., o::step, o::step]`` for every offset instead of the full map (full-size
     clips: the lattices are chosen so that both border pixels of every logits tile are among the samples)."""
-    grids = scenario_grids(N, H // bs, W // bs, seed)[:n_frames]
+    grids = scenario_grids(N, H // bs, W // bs, seed)[:n_frames] if grids is None else grids
     model, _ = build_ref_swiftnet(ref, backbone, bs, grids)
     model.reset_temporal()
     cfg = dict(backbone=backbone, N=N, H=H, W=W, block_size=bs, n_frames=n_frames, frame_seed0=seed * 1000)
@@ -255,20 +255,25 @@ def gen_keys(ref):
 
 
 # ----------------------------------------------------------------------------- E. one online-RL policy run (config C3)
-def gen_rl(ref):
-    """4 frames of SwiftNet-RN18 under the reference's rl_semseg policy (PolicyTrainRL + PolicyNet +
-    InformationGainSemSeg + RMSprop), train_interval 2.  Seeds: torch/random = 0 right before the first frame; the
+def gen_rl_c3(ref):
+    """BASELINE config C3 at its FULL size through the reference: SwiftNet-RN18 1x3x1024x2048, block 128, rl_semseg at target 0.3,
+    train_interval 3 (bench.py --config C3), 5 frames; logits as two 8-strided lattices."""
+    gen_rl(ref, name="rl_semseg_c3.npz", N=1, H=1024, W=2048, bs=128, target=0.3, interval=3, n_frames=5, frame_seed0=9100, subsample=(8, (0, 7)))
+
+
+def gen_rl(ref, name="rl_semseg_run.npz", N=1, H=128, W=256, bs=32, target=0.4, interval=2, n_frames=4, frame_seed0=4242, subsample=None):
+    """``n_frames`` frames of SwiftNet-RN18 under the reference's rl_semseg policy (PolicyTrainRL + PolicyNet +
+    InformationGainSemSeg + RMSprop).  Seeds: torch/random = 0 right before the first frame; the
     policy net gets name-seeded weights so the fixture does not depend on constructor RNG order."""
     import random
     import warnings
 
-    N, H, W, bs = 1, 128, 256, 32
     with quiet():
         bb = ref.resnet.resnet18(pretrained=False)
         model = ref.swiftnet.SwiftNet(backbone=bb, num_classes=19, num_features=128, use_spp=True)
         model.load_state_dict(seeded.name_seeded_state_dict(model.state_dict()), strict=True)
         model.eval()
-        st = dict(SETTINGS, block_policy="rl_semseg", block_size=bs, block_target=0.4, block_train_interval=2)
+        st = dict(SETTINGS, block_policy="rl_semseg", block_size=bs, block_target=target, block_train_interval=interval)
         wrapped = ref.bc.BlockCopyModel(model, st)
         wrapped.policy.net.load_state_dict(seeded.name_seeded_state_dict(wrapped.policy.net.state_dict()))
         wrapped = ref.bn_fusion.fuse_bn_recursively(wrapped)
@@ -276,26 +281,34 @@ def gen_rl(ref):
     torch.manual_seed(0)
     random.seed(0)
     wrapped.reset_temporal()
-    out = {"cfg": np.frombuffer(json.dumps(dict(N=N, H=H, W=W, block_size=bs, n_frames=4, block_target=0.4, train_interval=2,
-                                                frame_seed0=4242)).encode(), dtype=np.uint8)}
+    cfg = dict(N=N, H=H, W=W, block_size=bs, n_frames=n_frames, block_target=target, train_interval=interval, frame_seed0=frame_seed0)
+    if subsample is not None:
+        cfg["subsample"] = dict(step=subsample[0], offsets=list(subsample[1]))
+    out = {"cfg": np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8)}
     with torch.no_grad(), warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        for t in range(4):
-            x = seeded.synthetic_frame(4242 + t, (N, 3, H, W))
+        for t in range(n_frames):
+            x = seeded.synthetic_frame(frame_seed0 + t, (N, 3, H, W))
             y = wrapped(x)
             pm = wrapped.policy_meta
             out[f"grid{t}"] = pm["grid"].numpy().copy()
-            out[f"logits{t}"] = y.detach().numpy().copy()
+            if subsample is None:
+                out[f"logits{t}"] = y.detach().numpy().copy()
+            else:
+                for o in subsample[1]:
+                    out[f"logits{t}_o{o}"] = y.detach()[:, :, o::subsample[0], o::subsample[0]].numpy().copy()
+                out[f"logits{t}_absmax"] = np.float32(y.detach().abs().max())
+                out[f"logits{t}_chansum"] = y.detach().double().sum(dim=(0, 2, 3)).numpy()
             if t > 0:
                 out[f"grid_probs{t}"] = pm["grid_probs"].detach().numpy().copy()
-            if "information_gain" in pm and wrapped.clip_length % 2 == 0:
+            if "information_gain" in pm and wrapped.clip_length % interval == 0:
                 out[f"information_gain{t}"] = pm["information_gain"].detach().numpy().copy()
             out[f"running_cost{t}"] = np.float64(wrapped.policy.running_cost)
     sd = wrapped.policy.net.state_dict()
     out["policy_abs_sum_after"] = np.float64(sum(float(v.double().abs().sum()) for k, v in sd.items() if v.dtype.is_floating_point))
     out["policy_conv1_after"] = sd["backbone.conv1.weight"].numpy().copy()
-    np.savez_compressed(os.path.join(GOLD, "rl_semseg_run.npz"), **out)
-    print("rl_semseg_run.npz exec per frame:", [int(out[f"grid{t}"].sum()) for t in range(4)], "running_cost", float(out["running_cost3"]))
+    np.savez_compressed(os.path.join(GOLD, name), **out)
+    print(name, "exec per frame:", [int(out[f"grid{t}"].sum()) for t in range(n_frames)], "running_cost", float(out[f"running_cost{n_frames - 1}"]))
 
 
 # ----------------------------------------------------------------------------- F. detector op classes (Pedestron CSP path)
@@ -535,6 +548,23 @@ def gen_swiftnet_rn18_c2(ref):
     gen_swiftnet(ref, "rn18_c2", "resnet18", 1, 1024, 2048, 128, 4, 8, False, subsample=(8, (0, 7)))
 
 
+def gen_swiftnet_rn18_c1(ref):
+    """BASELINE config C1 at its stated shape through the reference: SwiftNet-RN18, 4 frames torch.randn(1,3,512,1024) with seeds 0..3,
+    block 128 (grid 4x8), every tile executed on every frame.  Logits stored as two 8-strided lattices (see rn18_c2)."""
+    grids = [torch.ones(1, 1, 4, 8, dtype=torch.bool) for _ in range(4)]
+    gen_swiftnet(ref, "rn18_c1", "resnet18", 1, 512, 1024, 128, 4, 0, False, subsample=(8, (0, 7)), grids=grids)
+
+
+def gen_swiftnet_rn50_c4(ref):
+    """BASELINE config C4 at its FULL size through the reference: SwiftNet-RN50, 1x3x2048x4096, block 64 (grid 32x64 = 2048 tiles:
+    tiles 64 -> 32 -> 16 -> 8 -> 4 -> 2, the regime where packed element offsets approach 2^31), frame 0 all-active, frames 1-2 with
+    512 of 2048 tiles (25 %).  The 40 MB logits map of a frame is stored as two 16-strided lattices (offsets 0 and 15: rows / columns
+    0 and 15 of every 16x16 logits tile) plus its absolute maximum and per-class sums."""
+    N, GH, GW = 1, 32, 64
+    grids = [torch.ones(N, 1, GH, GW, dtype=torch.bool), seeded.fixed_fraction_grid(4001, N, GH, GW, 512), seeded.fixed_fraction_grid(4002, N, GH, GW, 512)]
+    gen_swiftnet(ref, "rn50_c4", "resnet50", 1, 2048, 4096, 64, 3, 12, False, subsample=(16, (0, 15)), grids=grids)
+
+
 def gen_detgain(ref):
     """The detector-side reward functions of the REFERENCE (blockcopy/blockcopy/policy/information_gain.py:43-108:
     InformationGainObjectDetection.get_output_repr / .forward = build_instance_mask / build_instance_mask_iou_gain) on seeded
@@ -604,6 +634,9 @@ def main():
     gen_swiftnet(ref, "rn50_a", "resnet50", 1, 128, 256, 32, 3, 4, False)
     gen_swiftnet_rn18_c(ref)
     gen_swiftnet_rn18_c2(ref)
+    gen_swiftnet_rn18_c1(ref)
+    gen_swiftnet_rn50_c4(ref)
+    gen_rl_c3(ref)
     gen_detgain(ref)
 
 

@@ -1286,3 +1286,42 @@ def test_pyramid_pooling_with_the_reference_default_widths_takes_the_generic_rou
         be.spp_levels = o_lv
     assert not calls, "the two-launch route must not be taken above the LDS budget"
     assert got.shape == (1, 128, 16, 32) and float((got - want).abs().max()) <= 1e-4 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CASES)
+def test_tile_copy_indirect_equals_split_then_combine(be, case, dtype):
+    """bc_tile_copy_indirect (the graph's input stage): the frame-state map after the launch == the oracle's split of the frame
+    followed by its in-place combine into the map (reference core/blockcopy.py:62-68), bit for bit; the source address is read from
+    the slot word at run time (two different source tensors through ONE slot buffer), and with ``n_exec_dev`` only the first
+    *n_exec_dev rows of the tables are honoured (the launch is sized for more)."""
+    N, C, GH, GW, bs, _ = case
+    g = torch.Generator().manual_seed(sum(case))
+    total = N * GH * GW
+    state = torch.randn((N, C, GH * bs, GW * bs), generator=g).to(dtype)
+    dst = state.cuda()
+    want = state.clone()
+    slot = torch.zeros(1, dtype=torch.int64, device="cuda")
+    for t, grid in enumerate(_grids(N, GH, GW, 4, 3)):
+        gi, m = O.c_grid_mappings(grid)
+        frame = torch.randn(state.shape, generator=g).to(dtype)
+        src = frame.cuda()
+        slot.fill_(src.data_ptr())
+        be.tile_copy_indirect(dst, slot, _dev(m), bs)
+        blocks = torch.empty((len(m), C, bs, bs), dtype=dtype)
+        O.c_split(blocks, frame, m)
+        O.c_combine(blocks, want, m)
+        assert torch.equal(dst.cpu(), want), (case, t)
+    # device-side count: tables sized for every tile, only the first k rows valid
+    full = np.random.default_rng(5).permutation(total).astype(np.int32)
+    for k in (0, 1, total // 2, total):
+        frame = torch.randn(state.shape, generator=g).to(dtype)
+        src = frame.cuda()
+        slot.fill_(src.data_ptr())
+        be.tile_copy_indirect(dst, slot, _dev(full), bs, n_exec_dev=torch.tensor([k], dtype=torch.int32, device="cuda"))
+        if k:
+            m = np.ascontiguousarray(full[:k])
+            blocks = torch.empty((k, C, bs, bs), dtype=dtype)
+            O.c_split(blocks, frame, m)
+            O.c_combine(blocks, want, m)
+        assert torch.equal(dst.cpu(), want), (case, "dynamic", k)

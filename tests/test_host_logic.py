@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from common import load_golden, make_forced_policy, run_golden_clip
+from common import golden_logit_error, load_golden, make_forced_policy, run_golden_clip
 
 
 class TinyNet(torch.nn.Module):
@@ -299,9 +299,11 @@ def _rl_model(cfg, device, graph=0):
     return model
 
 
-def test_rl_policy_loop_matches_reference(golden_dir, oracle_backend):
-    """Config C3 plumbing: PolicyTrainRL + PolicyNet + InformationGainSemSeg + RMSprop for 4 frames with the reference's
-    seeds reproduce its sampled grids, probabilities, information gain, running cost and weight update.
+@pytest.mark.parametrize("fixture", ["rl_semseg_run.npz", "rl_semseg_c3.npz"])
+def test_rl_policy_loop_matches_reference(golden_dir, oracle_backend, fixture):
+    """Config C3 plumbing: PolicyTrainRL + PolicyNet + InformationGainSemSeg + RMSprop with the reference's seeds reproduce its
+    sampled grids, probabilities, information gain, running cost and weight update (rl_semseg_run.npz: 4 frames at 128x256;
+    rl_semseg_c3.npz: C3 at its FULL size -- 1024x2048, block 128, target 0.3, train_interval 3, 5 frames).
 
     RMSprop's first steps are sign-like (step ~ lr / sqrt(1 - alpha) whatever the gradient magnitude), so weights whose
     gradient is ~0 may step the other way under 1e-6 input noise: after the first update the comparison is on the
@@ -310,20 +312,28 @@ def test_rl_policy_loop_matches_reference(golden_dir, oracle_backend):
 
     from bc_workloads import seeded
 
-    G, cfg = load_golden(golden_dir, "rl_semseg_run.npz")
+    G, cfg = load_golden(golden_dir, fixture)
     model = _rl_model(cfg, "cpu")
     w0 = model.policy.net.state_dict()["backbone.conv1.weight"].clone()
     torch.manual_seed(0)
     random.seed(0)
     model.reset_temporal()
+    # Frames decided BEFORE the first optimiser step must reproduce the reference's samples exactly (same RNG stream, same
+    # probabilities).  After a step the probabilities agree only loosely (see above), so a borderline tile may be sampled the other
+    # way: from then on the full-size clip is teacher-forced with the fixture's grid (the small clip happens to stay exact).
+    frame = {"t": 0}
+    quantize = model.policy.quantize_number_exec_grid
+    forced_from = cfg["train_interval"] if fixture == "rl_semseg_c3.npz" else cfg["n_frames"]
+    model.policy.quantize_number_exec_grid = lambda g: torch.from_numpy(G[f"grid{frame['t']}"]).clone() if frame["t"] >= forced_from else quantize(g)
     with torch.no_grad():
         for t in range(cfg["n_frames"]):
+            frame["t"] = t
             y = model(seeded.synthetic_frame(cfg["frame_seed0"] + t, (cfg["N"], 3, cfg["H"], cfg["W"])))
             pm = model.policy_meta
             assert np.array_equal(pm["grid"].numpy(), G[f"grid{t}"]), t          # same Bernoulli samples + quantisation
-            assert float((y - torch.from_numpy(G[f"logits{t}"])).abs().max()) <= 2e-5
+            assert golden_logit_error(G, cfg, t, y) <= 2e-5 * max(1.0, float(G[f"logits{t}_absmax"]) if f"logits{t}_absmax" in G.files else 1.0)
             if t > 0:
-                tight = t == 1   # no optimiser step has happened yet
+                tight = t < cfg["train_interval"]   # no optimiser step has happened yet
                 assert np.allclose(pm["grid_probs"].detach().numpy(), G[f"grid_probs{t}"], rtol=2e-3 if tight else 0, atol=1e-6 if tight else 0.05)
             if f"information_gain{t}" in G.files:
                 assert np.allclose(pm["information_gain"].detach().numpy(), G[f"information_gain{t}"], rtol=1e-3, atol=1e-6)
@@ -513,10 +523,11 @@ def test_spp_support_check_mirrors_the_launchers_lds_budget():
     assert not HipBackend.spp_supported(x128, 42, 3, 128, fine)
 
 
-def test_c1_cpu_plumbing_4x512x1024_block128_all_active(oracle_backend):
+def test_c1_cpu_plumbing_4x512x1024_block128_all_active(oracle_backend, golden_dir):
     """BASELINE config C1 at its stated shape: SwiftNet-RN18 on 4 synthetic 512x1024 frames, block 128 (4x8 tiles),
-    policy forced 100 %-active, no GPU (the block ops are served by the checker backend).  Both engines agree, every
-    tile is executed on every frame, the packed encoder equals the dense one (P1) and frame_state is the input."""
+    policy forced 100 %-active, no GPU (the block ops are served by the checker backend).  The logits equal the REFERENCE's for
+    the same clip (tests/golden/swiftnet_rn18_c1.npz, <= 2e-5), both engines agree, every tile is executed on every frame, the
+    packed encoder equals the dense one (P1) and frame_state is the input."""
     import blockcopy
     from blockcopy.core import tensorwrapper as tw
     from bc_workloads import harness, seeded
@@ -540,6 +551,10 @@ def test_c1_cpu_plumbing_4x512x1024_block128_all_active(oracle_backend):
         tw.set_engine("fused")
     for a, b in zip(outs["fused"], outs["reference"]):
         assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
+    G, cfg = load_golden(golden_dir, "swiftnet_rn18_c1.npz")
+    assert (cfg["H"], cfg["W"], cfg["block_size"], cfg["frame_seed0"], cfg["n_frames"]) == (512, 1024, 128, 0, 4)
+    for t, y in enumerate(outs["fused"]):
+        assert golden_logit_error(G, cfg, t, y) <= 2e-5 * max(1.0, float(G[f"logits{t}_absmax"])), t
     dense = harness.build_model("resnet18", block_policy="static", device="cpu")
     model = harness.build_model("resnet18", block_policy="all", block_size=128, device="cpu")
     with torch.no_grad():
