@@ -527,7 +527,22 @@ def main(argv=None):
         harness.run_clip(model, clips[0])
         host_s = time.perf_counter() - th
         torch.cuda.synchronize(device)
-        extra["host_enqueue_ms_per_frame"] = 1e3 * host_s / CLIP_LEN
+        extra["host_enqueue_ms_per_frame"] = 1e3 * host_s / CLIP_LEN      # (back to back: includes blocking on a full queue)
+        # what a frame costs the HOST: the stream is idle before every frame (no back-pressure in the figure), wall time of the enqueue
+        # and CPU time of this thread -- the number that decides whether N pinned replicas per host stay GPU-bound
+        if hasattr(model, "reset_temporal"):
+            model.reset_temporal()
+        wall = cpu = 0.0
+        with torch.no_grad():
+            for f in clips[0]:
+                torch.cuda.synchronize(device)
+                w0, c0 = time.perf_counter(), time.thread_time()
+                model(f)
+                wall += time.perf_counter() - w0
+                cpu += time.thread_time() - c0
+        torch.cuda.synchronize(device)
+        extra["host_ms_per_frame_idle_stream"] = {"wall": 1e3 * wall / CLIP_LEN, "cpu_thread": 1e3 * cpu / CLIP_LEN,
+                                                  "note": "device idle before each frame: enqueue cost without queue back-pressure"}
         extra["roofline_large"] = scatter_copy_large(be, device)
         if world == 1 and args.upload_variant and not is_csp:
             # the reference driver's complete loop: per-frame upload from pinned host memory + last-frame upsample / argmax / .cpu()
@@ -612,6 +627,10 @@ def main(argv=None):
                                    f"{args.engine} engine{' + hipGraph' if args.graph else ''}{', channels-last' if args.channels_last else ''}, seeded weights, BN folded; step = 1 clip",
                        "clips_per_rank": args.steps, "parallelism": f"{world} independent replica(s), no collective",
                        "exec_fraction": exec_frac, "warmup_s": warm_s},
+            **({"value_reference_loop": extra["upload_inclusive"]["double_buffered_upload"],
+                "value_reference_loop_note": "frames/s of the reference driver's complete loop (test_swiftnet.py:181-197: per-frame H->D upload from pinned "
+                                             "memory, last-frame upsample + argmax + .cpu()) with the upload double-buffered on a copy stream; PCIe-inclusive, never `value`"}
+               if "upload_inclusive" in extra else {}),
             "roofline": {"kernel": cc.get("kernel") or ("k_combine_copy_ind (fused scatter+copy of the logits map, a node of the frame's hipGraph)" if stamp_us
                                                         else "k_combine_copy (fused scatter+copy of the logits map)"), "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
