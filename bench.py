@@ -66,10 +66,15 @@ def parse_args(argv=None):
     ap.add_argument("--no-dense", action="store_true", help="skip the dense-GPU comparison run")
     ap.add_argument("--miopen-find", type=int, default=1, help="torch.backends.cudnn.benchmark during warm-up")
     ap.add_argument("--cpu-frames", type=int, default=8)
-    ap.add_argument("--graph", type=int, default=1, help="hipGraph replay of the packed pipeline (0 = eager launches)")
-    ap.add_argument("--config", default=None, choices=["C2", "C3", "C4", "C5"],
-                    help="BASELINE.json config preset: C2 (default workload), C3 = --policy rl_semseg --target 0.3, C4 = SwiftNet-RN50 "
-                         "2048x4096 block 64 target 0.25, C5 = CSP-ResNet50 pedestrian detector 1024x2048 block 128 target 0.3 (one stream per GPU)")
+    ap.add_argument("--graph", type=int, default=None,
+                    help="hipGraph replay of the packed pipeline: 0 = eager launches, 1 = one graph per executed-tile count, 2 = ONE graph for "
+                         "every count (launches sized for all tiles, count read from the device; no wait for a device-side policy decision). "
+                         "Default: 2 for the online-RL policies, 1 otherwise")
+    ap.add_argument("--config", default=None, choices=["C2", "C3", "C3h", "C4", "C5"],
+                    help="BASELINE.json config preset: C2 (default workload), C3 = --policy rl_semseg --target 0.3, C3h = the reference's own speed "
+                         "scenario (configs/swiftnet_rn18/swiftnet_rn18_rl05_speed.sh: rl_semseg, target 0.5, --half, batch 2, train-interval 3), "
+                         "C4 = SwiftNet-RN50 2048x4096 block 64 target 0.25, C5 = CSP-ResNet50 pedestrian detector 1024x2048 block 128 target 0.3 "
+                         "(one stream per GPU)")
     ap.add_argument("--upload-variant", type=int, default=1, help="1 (default, N=1): also report the PCIe-inclusive fps of the reference's full loop")
     ap.add_argument("--stub-cpu", action="store_true",
                     help="(tests only) replace the GPU workload by a tiny CPU stand-in so that the launcher, the per-rank "
@@ -84,10 +89,14 @@ def parse_args(argv=None):
     args.workload = "swiftnet"
     if args.config == "C3":
         args.policy, args.target = "rl_semseg", 0.3
+    elif args.config == "C3h":
+        args.policy, args.target, args.half, args.batch, args.train_interval = "rl_semseg", 0.5, True, 2, 3
     elif args.config == "C4":
         args.backbone, args.height, args.width, args.block_size, args.target = "resnet50", 2048, 4096, 64, 0.25
     elif args.config == "C5":
         args.workload, args.target, args.backbone = "csp", 0.3, "csp_resnet50"
+    if args.graph is None:
+        args.graph = 2 if (args.policy.startswith("rl_") and args.workload != "csp" and args.channels_last) else 1
     return args
 
 
@@ -152,6 +161,8 @@ def config_name(args):
     """Which BASELINE.json config the arguments correspond to."""
     if args.workload == "csp":
         return "C5"
+    if (args.backbone, args.height, args.width, args.block_size, args.policy, args.target, args.batch, bool(args.half)) == ("resnet18", 1024, 2048, 128, "rl_semseg", 0.5, 2, True):
+        return "C3h (reference speed scenario: rl_semseg target 0.5, fp16, batch 2, train-interval 3)"
     if args.batch != 1:
         return f"custom(batch {args.batch})"
     base = (args.backbone, args.height, args.width, args.block_size)
@@ -624,7 +635,7 @@ def main(argv=None):
             "dtype": "f16" if args.half else "f32", "data": "synthetic",
             "config": {"workload": f"{config_name(args)}: {'CSP-ResNet50 detector (backbone + neck + head + decode + NMS)' if is_csp else 'SwiftNet-' + args.backbone} {shape[0]}x3x{args.height}x{args.width} synthetic clips of {CLIP_LEN} frames, "
                                    f"block {args.block_size}, policy {args.policy} target {args.target:.0%} (frame 0 all-active), "
-                                   f"{args.engine} engine{' + hipGraph' if args.graph else ''}{', channels-last' if args.channels_last else ''}, seeded weights, BN folded; step = 1 clip",
+                                   f"{args.engine} engine{(' + hipGraph' if args.graph == 1 else ' + ONE dynamic hipGraph (device-side tile count, no wait)') if args.graph else ''}{', channels-last' if args.channels_last else ''}, seeded weights, BN folded; step = 1 clip",
                        "clips_per_rank": args.steps, "parallelism": f"{world} independent replica(s), no collective",
                        "exec_fraction": exec_frac, "warmup_s": warm_s},
             **({"value_reference_loop": extra["upload_inclusive"]["double_buffered_upload"],

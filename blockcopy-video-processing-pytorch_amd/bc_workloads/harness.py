@@ -90,8 +90,11 @@ def measure_fps_with_upload(model, host_clips, n_clips: int, warmup_clips: int =
     the input resolution, arg-maxed and copied back to the host (``preds = out.max(dim=1)[1].cpu()``).
 
     ``prefetch=False`` is the reference's own form: ``inputs.to(device, non_blocking=True)`` on the compute stream, i.e. the
-    25 MB upload of frame t sits between the models of frames t-1 and t.  ``prefetch=True`` is the MI355X-first form: frame
-    t+1 travels on a copy stream into the other half of a double buffer while frame t is computed (PCIe and compute overlap)."""
+    25 MB upload of frame t sits between the models of frames t-1 and t, and ``.cpu()`` of the predictions blocks the host at the
+    end of every clip.  ``prefetch=True`` is the MI355X-first form of the same loop: frame t+1 travels on a copy stream into the
+    other half of a double buffer while frame t is computed (PCIe and compute overlap), and the predictions of a clip travel back
+    into pinned host memory on a second copy stream while the next clip is already being enqueued -- every clip's predictions still end
+    up on the host (checked one clip later), the host just does not stall for them."""
     dev = torch.device(device)
     host_clips = [[f.pin_memory() if not f.is_pinned() else f for f in clip] for clip in host_clips]
     compute = torch.cuda.current_stream(dev)
@@ -100,6 +103,9 @@ def measure_fps_with_upload(model, host_clips, n_clips: int, warmup_clips: int =
     bufs = [torch.empty(shape, dtype=dtype, device=dev) for _ in range(2)]
     staged = [torch.cuda.Event() for _ in range(2)]      # upload into bufs[i] finished
     consumed = [torch.cuda.Event() for _ in range(2)]    # model finished reading bufs[i]
+
+    # double-buffered download of the per-clip predictions, on a stream of its own (behind the uploads it would delay the next clip's first frame)
+    down = {"n": 0, "host": [None, None], "ev": [None, None], "stream": torch.cuda.Stream(dev) if prefetch else None}
 
     def upload(frame, i):
         with torch.cuda.stream(copy):
@@ -126,7 +132,25 @@ def measure_fps_with_upload(model, host_clips, n_clips: int, warmup_clips: int =
                 consumed[t % 2].record(compute)
             if t == len(clip) - 1:
                 out = torch.nn.functional.interpolate(out, size=inputs.shape[2:], mode="bilinear")
-                preds = out.detach().max(dim=1)[1].cpu()
+                preds = out.detach().max(dim=1)[1]
+                if prefetch:
+                    k = down["n"] % 2
+                    down["n"] += 1
+                    if down["ev"][k] is not None:
+                        down["ev"][k].synchronize()              # the predictions of two clips ago have long arrived
+                    if down["host"][k] is None:
+                        down["host"][k] = torch.empty(preds.shape, dtype=preds.dtype, pin_memory=True)
+                    ready = torch.cuda.Event()
+                    ready.record(compute)
+                    with torch.cuda.stream(down["stream"]):
+                        down["stream"].wait_event(ready)
+                        down["host"][k].copy_(preds, non_blocking=True)
+                        preds.record_stream(down["stream"])
+                        down["ev"][k] = torch.cuda.Event()
+                        down["ev"][k].record(down["stream"])
+                    preds = down["host"][k]
+                else:
+                    preds = preds.cpu()
         return preds
 
     for i in range(2):

@@ -144,6 +144,7 @@ def load_library(path: str = None) -> ctypes.CDLL:
         "bc_nms_sorted": [p, i, ctypes.c_float, p, p, p, p],
         "bc_policy_step": [p, i, ctypes.c_ulonglong, ctypes.c_ulonglong, i, i, p, p, p, p, p, p],
         "bc_policy_features": [p, i, i, i, p, p, p, p, p],
+        "bc_dyn_set": [p, i],
         "bc_tune_set": [ctypes.c_char_p, i],
         "bc_tune_get": [ctypes.c_char_p, ctypes.POINTER(i)],
         "bc_tune_set_ptr": [ctypes.c_char_p, p],
@@ -187,8 +188,16 @@ class HipBackend:
     def _stream() -> int:
         return torch.cuda.current_stream().cuda_stream
 
+    def _arm(self, dyn):
+        """``dyn`` = (n_exec_dev: device int32[1], ceiling) or None: make the NEXT launch read its executed-tile count from the
+        device (include/blockcopy_hip.h bc_dyn_set; the launcher consumes the arming at entry, whatever it then does)."""
+        if dyn is not None:
+            ptr, ceiling = dyn
+            assert _ok(ptr, torch.int32) and ptr.numel() >= 1
+            self._check(self.lib.bc_dyn_set(ptr.data_ptr(), int(ceiling)), "dyn_set")
+
     # -- A. reference operator boundary ---------------------------------------------------------------
-    def split(self, blocks, image, mapping_exec, grid_idx):
+    def split(self, blocks, image, mapping_exec, grid_idx, dyn=None):
         """blocks <- executed tiles of image.  reference: SplitFunction.forward, utils/block_funcs.py:12-49."""
         assert _ok(blocks) and _ok(image, blocks.dtype) and _ok(mapping_exec, torch.int32) and _ok(grid_idx, torch.int32)
         assert blocks.dim() == 4 and image.dim() == 4 and blocks.shape[2] == blocks.shape[3]
@@ -202,11 +211,12 @@ class HipBackend:
         Ck, Ek = (1, C * blocks.element_size()) if is_nhwc(image) else (C, blocks.element_size())   # channels-last: fat elements
         if n_exec > 0:
             with torch.cuda.device_of(blocks):
+                self._arm(dyn)
                 self._check(self.lib.bc_split(blocks.data_ptr(), image.data_ptr(), mapping_exec.data_ptr(), n_exec,
                                               N, Ck, H, W, bs, Ek, self._stream()), "split")
         return blocks
 
-    def combine(self, blocks, out, grid_idx, mapping_exec):
+    def combine(self, blocks, out, grid_idx, mapping_exec, dyn=None):
         """out[executed tiles] <- blocks, in place.  reference: CombineFunction.forward, utils/block_funcs.py:87-124."""
         assert _ok(blocks) and _ok(out, blocks.dtype) and _ok(mapping_exec, torch.int32) and _ok(grid_idx, torch.int32)
         N, C, H, W = out.shape
@@ -219,6 +229,7 @@ class HipBackend:
         Ck, Ek = (1, C * blocks.element_size()) if is_nhwc(out) else (C, blocks.element_size())
         if n_exec > 0:
             with torch.cuda.device_of(blocks):
+                self._arm(dyn)
                 self._check(self.lib.bc_combine(blocks.data_ptr(), out.data_ptr(), mapping_exec.data_ptr(), n_exec,
                                                 N, Ck, H, W, bs, Ek, self._stream()), "combine")
         return out
@@ -324,7 +335,7 @@ class HipBackend:
                                                            N, C, H, W, int(bs), dst.element_size(), 16, self._stream()), "tile_copy_indirect")
         return dst
 
-    def pad_ring(self, data_exec, ring, grid_idx, mapping_exec, pad, prologue=None):
+    def pad_ring(self, data_exec, ring, grid_idx, mapping_exec, pad, prologue=None, dyn=None):
         """halo gather over the persistent ring cache (+ refresh of the executed tiles' rings).
         prologue = (scale, shift, relu): per-channel fp32 affine + ReLU fused into the gather (applied to
         values read from packed tiles; the ring keeps the ACTIVATED values, so records do not depend on the route that wrote them)."""
@@ -340,6 +351,7 @@ class HipBackend:
             for v in (scale, shift):
                 assert v is None or (_ok(v, torch.float32) and v.numel() == C)
             with torch.cuda.device_of(data_exec):
+                self._arm(dyn)
                 self._check(self.lib.bc_pad_ring_nhwc(out.data_ptr(), data_exec.data_ptr(), ring.data_ptr(), grid_idx.data_ptr(),
                                                       mapping_exec.data_ptr(), n_exec, N, C, GH, GW, bs, int(pad),
                                                       data_exec.element_size(), _DTYPE_CODE.get(data_exec.dtype, -1),
@@ -348,6 +360,7 @@ class HipBackend:
                                                       self._stream()), "pad_ring_nhwc")
         elif n_exec > 0:
             with torch.cuda.device_of(data_exec):
+                self._arm(dyn)
                 if prologue is None:
                     self._check(self.lib.bc_pad_ring(out.data_ptr(), data_exec.data_ptr(), ring.data_ptr(), grid_idx.data_ptr(),
                                                      mapping_exec.data_ptr(), n_exec, N, C, GH, GW, bs, int(pad),
@@ -369,7 +382,7 @@ class HipBackend:
         return (is_nhwc(data_exec) and data_exec.dtype in _DTYPE_CODE and (data_exec.shape[1] * data_exec.element_size()) % 16 == 0
                 and add.shape == data_exec.shape and add.dtype == data_exec.dtype and is_nhwc(add) and add.is_contiguous(memory_format=torch.channels_last))
 
-    def pad_ring_add(self, data_exec, add, ring, grid_idx, mapping_exec, pad, prologue):
+    def pad_ring_add(self, data_exec, add, ring, grid_idx, mapping_exec, pad, prologue, dyn=None):
         """Halo gather of v = relu?(data*scale + shift + add) plus the plain v as a by-product: returns (padded, v).
         The ring cache of this op holds activated values (see include/blockcopy_hip.h)."""
         assert _ok(data_exec, *_DTYPE_CODE) and is_nhwc(data_exec) and _ok(add, data_exec.dtype) and _ok(ring, data_exec.dtype)
@@ -384,6 +397,7 @@ class HipBackend:
             assert v is None or (_ok(v, torch.float32) and v.numel() == C)
         if B > 0:
             with torch.cuda.device_of(data_exec):
+                self._arm(dyn)
                 self._check(self.lib.bc_pad_ring_add_nhwc(out.data_ptr(), act.data_ptr(), data_exec.data_ptr(), add.data_ptr(), ring.data_ptr(),
                                                           grid_idx.data_ptr(), mapping_exec.data_ptr(), B, N, C, GH, GW, bs, int(pad),
                                                           _DTYPE_CODE[data_exec.dtype], scale.data_ptr() if scale is not None else None,
@@ -397,7 +411,7 @@ class HipBackend:
         return (is_nhwc(data_exec) and data_exec.dtype in _DTYPE_CODE and bs == data_exec.shape[3] and bs >= 2 and bs % 2 == 0
                 and (data_exec.shape[1] * data_exec.element_size()) % 16 == 0)
 
-    def maxpool3x3s2_ring(self, data_exec, ring, grid_idx, mapping_exec, prologue=None):
+    def maxpool3x3s2_ring(self, data_exec, ring, grid_idx, mapping_exec, prologue=None, dyn=None):
         """Fused halo gather + max_pool2d(3, stride 2, padding 1) on a channels-last packed batch (ring as for pad_ring, pad 1)."""
         assert _ok(data_exec, *_DTYPE_CODE) and is_nhwc(data_exec) and _ok(ring, data_exec.dtype)
         assert _ok(mapping_exec, torch.int32) and _ok(grid_idx, torch.int32)
@@ -410,6 +424,7 @@ class HipBackend:
             assert v is None or (_ok(v, torch.float32) and v.numel() == C)
         if B > 0:
             with torch.cuda.device_of(data_exec):
+                self._arm(dyn)
                 self._check(self.lib.bc_maxpool3x3s2_ring_nhwc(out.data_ptr(), data_exec.data_ptr(), ring.data_ptr(), grid_idx.data_ptr(),
                                                                mapping_exec.data_ptr(), B, N, C, GH, GW, bs, _DTYPE_CODE[data_exec.dtype],
                                                                scale.data_ptr() if scale is not None else None,
@@ -602,7 +617,7 @@ class HipBackend:
             out[name] = sorted(ts)[len(ts) // 2]
         return out
 
-    def conv3x3_ring(self, data_exec, ring, wpk, cout, grid_idx, mapping_exec, prologue=None, epilogue=None, cfg=None, stride=1, dilation=1):
+    def conv3x3_ring(self, data_exec, ring, wpk, cout, grid_idx, mapping_exec, prologue=None, epilogue=None, cfg=None, stride=1, dilation=1, dyn=None):
         """Fused halo gather + 3x3/s1/p1 conv (+ optional epilogue) of a channels-last packed batch on the fp32 matrix
         cores.  prologue = (scale, shift, relu) per input channel, epilogue = (scale, shift, add, relu) per output channel."""
         dt = data_exec.dtype
@@ -628,6 +643,7 @@ class HipBackend:
                 if want != self._conv_cfg:
                     self._check(self.lib.bc_tune_set(b"conv2_cfg", want), "tune_set")
                     self._conv_cfg = want
+                self._arm(dyn)
                 if dilation == 2:
                     self._check(self.lib.bc_conv3x3_dil_ring_nhwc(out.data_ptr(), data_exec.data_ptr(), ring.data_ptr(), wpk.data_ptr(),
                                                                   grid_idx.data_ptr(), mapping_exec.data_ptr(), n_exec, N, C, cout, GH, GW, bs, 2,
@@ -674,7 +690,7 @@ class HipBackend:
         n = self.lib.bc_conv1x1_candidates(_DTYPE_CODE[data.dtype], int(stride), geo[0], data.shape[1], int(cout), geo[1], buf, 64)
         return [int(buf[k]) for k in range(max(n, 0))]
 
-    def conv1x1(self, data, wpk, cout, prologue=None, epilogue=None, cfg=None, stride=1):
+    def conv1x1(self, data, wpk, cout, prologue=None, epilogue=None, cfg=None, stride=1, dyn=None):
         """relu?(conv1x1(prologue(data)) * scale + shift + add) of a channels-last tensor in one launch (bc_conv1x1_nhwc)."""
         assert _ok(data, *_DTYPE_CODE) and _ok(wpk, data.dtype)
         B, C, H, W = data.shape
@@ -694,6 +710,7 @@ class HipBackend:
                 if want != self._conv_cfg:
                     self._check(self.lib.bc_tune_set(b"conv2_cfg", want), "tune_set")
                     self._conv_cfg = want
+                self._arm(dyn)
                 self._check(self.lib.bc_conv1x1_nhwc(out.data_ptr(), data.data_ptr(), wpk.data_ptr(), n_tiles, C, cout, bs, int(stride),
                                                      _DTYPE_CODE[data.dtype], ptr(isc), ptr(ish), int(bool(irelu)), ptr(osc), ptr(osh),
                                                      ptr(oadd), int(bool(orelu)), self._stream()), "conv1x1_nhwc")
@@ -719,7 +736,7 @@ class HipBackend:
         full[:w.shape[0]] = w
         return self.pack_conv3x3_weights(full)
 
-    def _head_launch(self, out, data, wpk, cout, prologue, bias, scatter, grid_idx=None, mapping_exec=None, prev=None, slots=None):
+    def _head_launch(self, out, data, wpk, cout, prologue, bias, scatter, grid_idx=None, mapping_exec=None, prev=None, slots=None, dyn=None):
         B, C, bs, _ = data.shape
         isc, ish, irelu = prologue if prologue is not None else (None, None, False)
         for v, n in ((isc, C), (ish, C), (bias, cout)):
@@ -730,11 +747,12 @@ class HipBackend:
         else:
             N, GH, GW = 1, 1, max(B, 1)
         with torch.cuda.device_of(data):
+            self._arm(dyn)
             self._check(self.lib.bc_head1x1_scatter_nhwc(ptr(out), data.data_ptr() if B else None, wpk.data_ptr(), ptr(prev), ptr(slots), ptr(grid_idx),
                                                          ptr(mapping_exec), B, N, C, cout, GH, GW, bs, _DTYPE_CODE[data.dtype], ptr(isc), ptr(ish),
                                                          int(bool(irelu)), ptr(bias), int(bool(scatter)), self._stream()), "head1x1_scatter_nhwc")
 
-    def head1x1(self, data, wpk, cout, prologue=None, epilogue=None, cfg=None, stride=1):
+    def head1x1(self, data, wpk, cout, prologue=None, epilogue=None, cfg=None, stride=1, dyn=None):
         """Packed tiles (B, cout, bs, bs) channels-last = conv1x1(prologue(data)) [+ epilogue]; a per-channel shift (the conv bias) runs
         inside the kernel, anything else recorded after the conv as one bc_affine_act pass on the small result."""
         assert _ok(data, *_DTYPE_CODE) and is_nhwc(data) and _ok(wpk, data.dtype) and stride == 1
@@ -743,12 +761,12 @@ class HipBackend:
         osc, osh, oadd, orelu = epilogue if epilogue is not None else (None, None, None, False)
         bias_only = osc is None and oadd is None and not orelu
         if B > 0:
-            self._head_launch(out, data, wpk, cout, prologue, osh if bias_only else None, False)
+            self._head_launch(out, data, wpk, cout, prologue, osh if bias_only else None, False, dyn=dyn)
         if not bias_only:
-            out = self.affine_act(out, osc, osh, oadd, orelu)
+            out = self.affine_act(out, osc, osh, oadd, orelu, dyn=dyn)
         return out
 
-    def head1x1_scatter(self, data, wpk, cout, prologue, bias, grid_idx, mapping_exec, prev=None, out=None, slots=None, targets=None):
+    def head1x1_scatter(self, data, wpk, cout, prologue, bias, grid_idx, mapping_exec, prev=None, out=None, slots=None, targets=None, dyn=None):
         """The fresh dense map (N, cout, H, W) channels-last <- executed tiles conv1x1(prologue(data)) + bias at their grid positions,
         skipped tiles from ``prev``.  Either ``out`` (+ ``prev`` unless every tile is executed) or ``slots`` (hipGraph node: device
         int64 words [prev address, out address, ...]; ``targets`` = the tensors behind them, for checker backends only)."""
@@ -762,7 +780,7 @@ class HipBackend:
             assert prev is not None or B == N * GH * GW, "skipped tiles need the previous frame's map"
         else:
             assert _ok(slots, torch.int64) and slots.numel() >= 2
-        self._head_launch(out if slots is None else None, data, wpk, cout, prologue, bias, True, grid_idx, mapping_exec, prev if slots is None else None, slots)
+        self._head_launch(out if slots is None else None, data, wpk, cout, prologue, bias, True, grid_idx, mapping_exec, prev if slots is None else None, slots, dyn=dyn)
         return out
 
     # -- adaptive average pooling of dense channels-last maps (pyramid pooling)
@@ -874,7 +892,7 @@ class HipBackend:
             v = seg.reshape(2, 32, 7, 2, 2, 8).permute(0, 2, 3, 4, 1, 5)            # nb, n, ky, s, h, j  -> nb, ky, s, h, n, j
         return v.contiguous().view(-1)
 
-    def stem7x7(self, frame_state, wpk, mapping_exec, bs, epilogue=None):
+    def stem7x7(self, frame_state, wpk, mapping_exec, bs, epilogue=None, dyn=None):
         """(n_exec, 64, bs/2, bs/2) channels-last = epilogue(conv7x7 s2 p3 of the (bs+6)^2 windows of ``frame_state``)."""
         assert _ok(frame_state, *_DTYPE_CODE) and frame_state.is_contiguous() and _ok(wpk, frame_state.dtype) and _ok(mapping_exec, torch.int32)
         N, C, H, W = frame_state.shape
@@ -887,12 +905,13 @@ class HipBackend:
         ptr = lambda t: t.data_ptr() if t is not None else None
         if n_exec > 0:
             with torch.cuda.device_of(frame_state):
+                self._arm(dyn)
                 self._check(self.lib.bc_stem7x7s2_nhwc(out.data_ptr(), frame_state.data_ptr(), wpk.data_ptr(), mapping_exec.data_ptr(), n_exec,
                                                        N, H, W, int(bs), 64, _DTYPE_CODE[frame_state.dtype], ptr(osc), ptr(osh), ptr(oadd),
                                                        int(bool(orelu)), self._stream()), "stem7x7s2_nhwc")
         return out
 
-    def affine_act(self, data, scale=None, shift=None, add=None, relu=False):
+    def affine_act(self, data, scale=None, shift=None, add=None, relu=False, dyn=None):
         """relu?(data*scale[c] + shift[c] + add) on a packed (B,C,h,w) tensor in one pass (fp32 arithmetic)."""
         assert _ok(data, *_DTYPE_CODE) and data.dim() == 4
         B, C, h, w = data.shape
@@ -904,6 +923,7 @@ class HipBackend:
             add = add.contiguous(memory_format=torch.channels_last if is_nhwc(data) else torch.contiguous_format)
         if data.numel() > 0 and is_nhwc(data):
             with torch.cuda.device_of(data):
+                self._arm(dyn)
                 self._check(self.lib.bc_affine_act_nhwc(out.data_ptr(), data.data_ptr(), add.data_ptr() if add is not None else None,
                                                         scale.data_ptr() if scale is not None else None,
                                                         shift.data_ptr() if shift is not None else None, int(bool(relu)),
@@ -923,7 +943,7 @@ class HipBackend:
         """Deferred interpolation (epilogue fused into the resampling launch) exists for channels-last tensors."""
         return data.dim() == 4 and is_nhwc(data) and data.dtype in _DTYPE_CODE
 
-    def interp_bilinear(self, data, out_h, out_w, align_corners, rh, rw, epilogue=None):
+    def interp_bilinear(self, data, out_h, out_w, align_corners, rh, rw, epilogue=None, dyn=None):
         """per-tile bilinear resampling (planes = all leading dims); arithmetic of torch's upsample_bilinear2d.
         epilogue = (scale, shift, add, relu) on the resampled value (channels-last only)."""
         assert _ok(data, *_DTYPE_CODE) and data.dim() == 4
@@ -937,6 +957,7 @@ class HipBackend:
             assert add is None or (_ok(add, data.dtype) and tuple(add.shape) == tuple(out.shape) and is_nhwc(add))
             if out.numel() > 0:
                 with torch.cuda.device_of(data):
+                    self._arm(dyn)
                     self._check(self.lib.bc_interp_bilinear_act_nhwc(out.data_ptr(), data.data_ptr(), B, C, h, w, out_h, out_w,
                                                                      int(bool(align_corners)), float(rh), float(rw), _DTYPE_CODE[data.dtype],
                                                                      scale.data_ptr() if scale is not None else None,
@@ -946,6 +967,7 @@ class HipBackend:
             return out
         if out.numel() > 0 and is_nhwc(data):
             with torch.cuda.device_of(data):
+                self._arm(dyn)
                 self._check(self.lib.bc_interp_bilinear_nhwc(out.data_ptr(), data.data_ptr(), B, C, h, w, out_h, out_w,
                                                              int(bool(align_corners)), float(rh), float(rw),
                                                              _DTYPE_CODE[data.dtype], self._stream()), "interp_bilinear_nhwc")

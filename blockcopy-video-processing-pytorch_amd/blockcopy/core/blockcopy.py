@@ -29,8 +29,9 @@ class BlockCopyModel(nn.Module):
         self.block_temporal_features = None
         self.train_interval = settings["block_train_interval"]
         self.block_size = settings["block_size"]
-        # MI355X-first: replay the packed pipeline as a hipGraph per executed-tile count (core/graphs.py)
-        self.use_graph = bool(settings.get("block_graph", int(os.environ.get("BLOCKCOPY_GRAPH", "0"))))
+        # MI355X-first: replay the packed pipeline as a hipGraph (core/graphs.py): 1 = one graph per executed-tile count, 2 = ONE graph
+        # for every count (launches sized for all tiles, the count read from the device: no wait for a device-side policy decision)
+        self.use_graph = int(settings.get("block_graph", int(os.environ.get("BLOCKCOPY_GRAPH", "0"))))
         self._graphed = {}
         self.reset_temporal()
 
@@ -60,13 +61,20 @@ class BlockCopyModel(nn.Module):
         self.policy_meta["inputs"] = inputs
         # tells a trainable policy whether this frame's decision will be trained on (it then needs an autograd graph)
         self.policy_meta["train_hint"] = self.clip_length % self.train_interval == 0
+        if hasattr(self.policy, "wait_free"):
+            # a policy that decides on the device need not tell the host its executed-tile count when the frame runs as the ONE
+            # dynamic graph (every launch reads the count from the device); any other execution mode needs the number
+            self.policy.wait_free = self.use_graph == 2 and blockcopy.core.tensorwrapper.ENGINE == "fused"
         with timings.env("blockcopy/policy_forward", 3):
             # the policy writes the execution grid into policy_meta['grid'] (+ optional CPU mirror 'grid_host')
             self.policy_meta = self.policy(self.policy_meta)
 
         with timings.env("blockcopy/model", 3):
             x = blockcopy.to_tensorwrapper(inputs)
-            if self.policy_meta["num_exec"] == 0:
+            num_exec = self.policy_meta["num_exec"]
+            # (a count that only the device knows -- policy.LazyCount, dynamic graph -- is not asked for here: that would be the wait
+            #  the mode exists to avoid; the graph copes with zero executed tiles, its output is then a copy of the previous map)
+            if not getattr(num_exec, "lazy", False) and num_exec == 0:
                 # nothing to execute: hand back the cached outputs
                 self.policy_meta = self.policy_meta.copy()
                 out = self.policy_meta["outputs"]
@@ -100,12 +108,14 @@ def prewarm(self, inputs, counts=None, **kwargs):
     for its shape/dtype/device; temporal state is reset afterwards (call it between clips)."""
     from .graphs import GraphedFrame, WARM_RUNS
 
-    assert self.use_graph, "prewarm() is for the hipGraph execution mode (settings['block_graph'] = 1)"
+    assert self.use_graph, "prewarm() is for the hipGraph execution mode (settings['block_graph'] = 1 or 2)"
     key = (tuple(inputs.shape), inputs.dtype, inputs.device)
     gf = self._graphed.get(key)
     if gf is None:
-        gf = self._graphed[key] = GraphedFrame(inputs, self.block_size)
+        gf = self._graphed[key] = GraphedFrame(inputs, self.block_size, dynamic=self.use_graph == 2)
     total = gf.n_total
+    if gf.dynamic:
+        counts = [total]        # one graph serves every count: warm and capture it on the all-active frame
     if counts is None:
         step = max(1, total // 16)
         counts = sorted(set(list(range(step, total + 1, step)) + [total]), reverse=True)
@@ -132,7 +142,7 @@ def _forward_graphed(self, inputs, **kwargs):
     key = (tuple(inputs.shape), inputs.dtype, inputs.device)
     gf = self._graphed.get(key)
     if gf is None:
-        gf = self._graphed[key] = GraphedFrame(inputs, self.block_size)
+        gf = self._graphed[key] = GraphedFrame(inputs, self.block_size, dynamic=self.use_graph == 2)
     grid = self.policy_meta["grid"]
     dev_tables = self.policy_meta.pop("grid_tables", None)
     if dev_tables is not None:

@@ -21,6 +21,14 @@ last frame's output: the kernel reads both addresses from three slot words that 
 (``bc_combine_copy_indirect``).  As the one eager launch of the frame it used to start cold behind the graph's end-of-launch
 release fence (5.7-6.1 us for the 19.9 MB logits map of C2 against 3.5 us back to back).
 
+**Dynamic mode** (``block_graph = 2`` / ``GraphedFrame(dynamic=True)``): ONE graph for every executed-tile count.  The body is captured
+with every launch sized for the ceiling -- all tiles executed -- and armed to read the frame's actual count from a device word that
+travels with the index tables (``bc_dyn_set``: surplus workgroups exit at once, rows of the tables beyond the count are never read).  A
+policy that decides on the device (``bc_policy_step``) then never has to tell the host how many tiles it switched on: no wait, no bucket
+selection, no ``prewarm`` over 16 counts.  Packed tensors have ``n_total`` rows (the memory of the dense model); ops without a
+device-side count (library convs on packed tensors) would run on all of them, so this mode wants every packed conv in the package's own
+kernels (channels-last models).
+
 Reference behaviour being reproduced: BlockCopyModel._forward_blockcopy, core/blockcopy.py:62-79.
 """
 from __future__ import annotations
@@ -37,6 +45,7 @@ WARM_RUNS = 1   # eager runs of a new executed-tile count before it is captured 
 GRAPH_COMBINE = os.environ.get("BLOCKCOPY_GRAPH_COMBINE", "1") != "0"   # final scatter+copy as a graph node (0: the eager launch of rounds 1-2)
 GRAPH_INPUT = os.environ.get("BLOCKCOPY_GRAPH_INPUT", "1") != "0"       # input stage = one tile copy from the caller's frame (0: staging copy + gather + scatter)
 SLOT_WORDS = 4  # uint64 words behind the index tables: prev address, out address, timing record (bc_combine_copy_indirect), input frame address
+COUNT_WORDS = 4  # int32 words between the tables and the slot words: [n_exec, skipped-before-rounding, NaN flag, -] (bc_policy_step's counts)
 
 
 class _Bucket:
@@ -52,7 +61,7 @@ class _Bucket:
 class GraphedFrame:
     """Static buffers + captured graphs for one (input shape, dtype)."""
 
-    def __init__(self, inputs: torch.Tensor, block_size: int):
+    def __init__(self, inputs: torch.Tensor, block_size: int, dynamic: bool = False):
         N, C, H, W = inputs.shape
         assert H % block_size == 0 and W % block_size == 0
         self.block_size = block_size
@@ -62,10 +71,12 @@ class GraphedFrame:
         self.in_meta = (tuple(inputs.shape), inputs.dtype)
         self.static_in = None     # staging copy of the frame: only when the input-slot stage is off / unavailable
         self.cur_in = None        # the caller's frame of the current replay (kept alive until the next one)
-        # [grid_idx | mapping_exec | slot words of the in-graph scatter+copy]: ONE buffer, one H->D copy per frame
-        self.tables = torch.zeros(2 * self.n_total + 2 * SLOT_WORDS, dtype=torch.int32, device=self.device)
+        # [grid_idx | mapping_exec | counts | slot words of the in-graph scatter+copy / input stage]: ONE buffer, one H->D copy per frame
+        self.tables = torch.zeros(2 * self.n_total + COUNT_WORDS + 2 * SLOT_WORDS, dtype=torch.int32, device=self.device)
         self.grid_idx = self.tables[:self.n_total].view(self.grid_shape)
-        self.slots = self.tables[2 * self.n_total:].view(torch.int64)
+        self.counts = self.tables[2 * self.n_total:2 * self.n_total + COUNT_WORDS]     # counts[0] = this frame's executed-tile count
+        self.slots = self.tables[2 * self.n_total + COUNT_WORDS:].view(torch.int64)
+        self.dynamic = bool(dynamic) and hasattr(get_backend(), "tile_copy_indirect") and GRAPH_INPUT
         self.state = PersistentState()
         self.buckets = {}
         self.pool = None
@@ -82,26 +93,30 @@ class GraphedFrame:
     def upload(self, inputs: torch.Tensor, grid_host: torch.Tensor) -> int:
         g8 = grid_host.to(torch.bool).contiguous().numpy().view(np.uint8).reshape(-1)
         assert g8.size == self.n_total
-        ring = pinned_ring(2 * self.n_total + 2 * SLOT_WORDS, torch.int32, self.device.type == "cuda")     # reused pinned staging (no per-frame page-locking)
+        ring = pinned_ring(2 * self.n_total + COUNT_WORDS + 2 * SLOT_WORDS, torch.int32, self.device.type == "cuda")     # reused pinned staging (no per-frame page-locking)
         staging = ring.next()
         st = staging.numpy()
         n_exec = get_backend().grid_tables_host(g8, st[:self.n_total], st[self.n_total:2 * self.n_total], None, None)
-        st[2 * self.n_total:].view(np.int64)[:] = self._slot_words(inputs)
+        st[2 * self.n_total:2 * self.n_total + COUNT_WORDS] = (n_exec, 0, 0, 0)
+        st[2 * self.n_total + COUNT_WORDS:].view(np.int64)[:] = self._slot_words(inputs)
         self.tables.copy_(staging, non_blocking=True)
         ring.uploaded()
         return n_exec
 
-    def upload_tables(self, inputs: torch.Tensor, tables: torch.Tensor, n_exec: int) -> int:
-        """Per-frame work when the policy already built the index tables on the device (bc_policy_step): one D->D copy of the tables
-        + the 32 bytes of slot words."""
-        assert tables.numel() == 2 * self.n_total and tables.dtype == torch.int32
-        self.tables[:2 * self.n_total].copy_(tables, non_blocking=True)
+    def upload_tables(self, inputs: torch.Tensor, tables: torch.Tensor, n_exec):
+        """Per-frame work when the policy already built the index tables on the device (bc_policy_step): one D->D copy of
+        [grid_idx | mapping_exec | counts] + the 32 bytes of slot words.  ``n_exec`` may be None in dynamic mode: the host does not
+        know the count (nobody waited for the policy step); the graph reads it from ``counts[0]``."""
+        n_words = 2 * self.n_total + COUNT_WORDS
+        assert tables.numel() == n_words and tables.dtype == torch.int32
+        assert n_exec is not None or self.dynamic, "an executed-tile count only the device knows needs the dynamic graph (block_graph=2)"
+        self.tables[:n_words].copy_(tables, non_blocking=True)
         ring = pinned_ring(SLOT_WORDS, torch.int64, self.device.type == "cuda")
         staging = ring.next()
         staging.numpy()[:] = self._slot_words(inputs)
         self.slots.copy_(staging, non_blocking=True)
         ring.uploaded()
-        return int(n_exec)
+        return None if n_exec is None else int(n_exec)
 
     def uses_input_slot(self) -> bool:
         return GRAPH_INPUT and hasattr(get_backend(), "tile_copy_indirect")
@@ -165,6 +180,11 @@ class GraphedFrame:
         self.state.rewind()
         feats._grid = grid
         feats._grid_idx = self.grid_idx
+        if self.dynamic:
+            # every launch on a packed tensor is sized for all tiles and reads the actual count from counts[0] (see module docstring)
+            n_exec = self.n_total
+            feats.dyn = (self.counts, self.n_total)
+        dkw = {} if feats.dyn is None else {"dyn": feats.dyn}
         feats._mapping_exec = self.tables[self.n_total:self.n_total + n_exec]
         feats.n_exec, feats.n_total = n_exec, self.n_total
         if self.uses_input_slot():
@@ -172,7 +192,8 @@ class GraphedFrame:
             # the packed input tiles exist only if something other than the fused stem asks for them (deferred gather from the map)
             shape, dtype = self.in_meta
             frame_state = self.state.next_map(shape, dtype, self.device, False)
-            get_backend().tile_copy_indirect(frame_state, self.slots[3:4], feats._mapping_exec, self.block_size, target=self.cur_in)
+            get_backend().tile_copy_indirect(frame_state, self.slots[3:4], feats._mapping_exec, self.block_size, target=self.cur_in,
+                                             **({} if feats.dyn is None else {"n_exec_dev": self.counts}))
             blocks = TensorWrapper._deferred_split(frame_state, self.block_size, feats)
         else:
             with _NoDispatch():
@@ -192,7 +213,7 @@ class GraphedFrame:
             if ready and head is not None:
                 kw, bias, state = head
                 get_backend().head1x1_scatter(kw["data"], kw["wpk"], kw["cout"], kw["prologue"], bias, self.grid_idx, feats._mapping_exec,
-                                              slots=self.slots, targets=(prev, self.cur_out))
+                                              slots=self.slots, targets=(prev, self.cur_out), **dkw)
                 state["launched"] = True
                 self.out_blocks_like = None
                 feats.flush_deferred()
@@ -215,8 +236,9 @@ class GraphedFrame:
         """Outputs of ``base_model(packed tiles)`` for this frame -- packed output tiles, or whatever dense structure
         the model returns -- eager while warming up, graph replay afterwards (``base_model`` may be any callable)."""
         if self.prev_out is None:
-            assert n_exec == self.n_total, "No previous features known, first run should execute all blocks!"
-        b = self.buckets.setdefault(n_exec, _Bucket())
+            assert n_exec is None or n_exec == self.n_total, "No previous features known, first run should execute all blocks!"
+        assert n_exec is not None or self.dynamic
+        b = self.buckets.setdefault("dyn" if self.dynamic else n_exec, _Bucket())
         if b.graph is None and (b.warm < WARM_RUNS or self.device.type != "cuda"):   # (no graphs off-GPU: test hook only)
             b.warm += 1
             out_blocks, self.frame_state, self._combined = self.body(base_model, n_exec, grid, **kwargs)

@@ -211,6 +211,9 @@ class BlockFeatures:
         self._pad_memo = None        # (source, padding, prologue key, padded): consecutive padded ops on the SAME tensor share one gather
         self._deferred = []          # deferred producers of this frame whose launch also refreshes a ring cache (fusion.Pending.defer_conv)
         self.persistent = None       # PersistentState when running as a graph-capturable body (core/graphs.py)
+        # (n_exec_dev: device int32[1], ceiling) when the body is sized for a ceiling and the executed-tile count is read from the
+        # device by every packed-tensor launch (core/graphs.py dynamic mode; include/blockcopy_hip.h bc_dyn_set); None = exact shapes
+        self.dyn = None
 
     # ------------------------------------------------------------------ grid -> index tables
     def _process_grid(self, grid: torch.Tensor, meta_prev: "BlockFeatures" = None, grid_host: torch.Tensor = None) -> None:
@@ -400,6 +403,17 @@ class TensorWrapper(torch.Tensor):
     def get_features(self) -> BlockFeatures:
         return self._features
 
+    def _dyn(self):
+        """Device-side executed-tile count for launches on THIS tensor: the frame's (n_exec_dev, ceiling) for a packed tensor, None
+        for dense maps (their size does not depend on the count) and for frames with exact shapes."""
+        f = self._features
+        return f.dyn if (f is not None and self._is_blocks) else None
+
+    def _dyn_kw(self) -> dict:
+        """``{"dyn": ...}`` for backend calls on this tensor, or ``{}`` (checker backends and exact-shape frames never see the keyword)."""
+        d = self._dyn()
+        return {} if d is None else {"dyn": d}
+
     def _plain(self) -> torch.Tensor:
         """Plain-tensor view of the VALUE (pending elementwise work is executed first)."""
         if self._pending is not None:
@@ -434,9 +448,9 @@ class TensorWrapper(torch.Tensor):
             elif P.interp is not None:    # deferred interpolation: resample now, the rest of the record is its epilogue
                 src, H, W, align, rh, rw = P.interp
                 plain = P.scale is None and P.shift is None and add is None and not P.relu
-                out = be.interp_bilinear(src, H, W, align, rh, rw, None if plain else (P.scale, P.shift, add, P.relu))
+                out = be.interp_bilinear(src, H, W, align, rh, rw, None if plain else (P.scale, P.shift, add, P.relu), **self._dyn_kw())
             elif raw.dtype in getattr(be, "supports_fusion_dtypes", ()):
-                out = be.affine_act(raw, P.scale, P.shift, add, P.relu)
+                out = be.affine_act(raw, P.scale, P.shift, add, P.relu, **self._dyn_kw())
             else:   # exotic dtype: the same arithmetic with stock ops
                 out = raw.float()
                 if P.scale is not None:
@@ -517,7 +531,8 @@ class TensorWrapper(torch.Tensor):
             n_exec = mapping_exec.numel()
             dense = dense_layout(self.as_subclass(torch.Tensor))
             out = empty_like_layout((n_exec, C, block_size, block_size), dense)   # packed tiles keep the dense map's layout
-            out = SplitFunction.apply(out, dense, mapping_exec, grid_idx)
+            dyn = self._features.dyn if self._features is not None else None
+            out = SplitFunction.apply(out, dense, mapping_exec, grid_idx) if dyn is None else SplitFunction.apply(out, dense, mapping_exec, grid_idx, dyn)
             return self._wrap_like(out, self, True)
 
     @staticmethod
@@ -531,9 +546,11 @@ class TensorWrapper(torch.Tensor):
         placeholder = empty_like_layout((n_exec, C, block_size, block_size), dense_map)
         be = get_backend()
 
+        dkw = {} if feats.dyn is None else {"dyn": feats.dyn}
+
         def launch(epilogue=None, **kw):
-            out = be.split(empty_like_layout((n_exec, C, block_size, block_size), dense_map), dense_map, feats._mapping_exec, feats._grid_idx)
-            return out if epilogue is None else be.affine_act(out, *epilogue)
+            out = be.split(empty_like_layout((n_exec, C, block_size, block_size), dense_map), dense_map, feats._mapping_exec, feats._grid_idx, **dkw)
+            return out if epilogue is None else be.affine_act(out, *epilogue, **dkw)
 
         with _NoDispatch():
             blocks = placeholder.as_subclass(TensorWrapper)
@@ -604,7 +621,8 @@ class TensorWrapper(torch.Tensor):
                 # (each call site owns its map; nothing else writes it until the next frame).  Only the executed
                 # tiles move: 2*n_exec*C*bs^2*E bytes instead of the 2*N*C*H*W*E of a full copy.
                 buf = ps.next_map(out_shape, blocks.dtype, blocks.device, is_nhwc(blocks))
-                out = CombineFunction.apply(blocks, buf, grid_idx, mapping_exec)
+                dyn = self._dyn()
+                out = CombineFunction.apply(blocks, buf, grid_idx, mapping_exec) if dyn is None else CombineFunction.apply(blocks, buf, grid_idx, mapping_exec, dyn)
                 self._dense_map = out     # the map now holds these packed tiles in place: a halo window of it IS their padded form
                 return self._wrap_like(out, self, False)
 
@@ -857,7 +875,7 @@ class TensorWrapper(torch.Tensor):
                 placeholder = torch.empty((x.shape[0], 64, x.shape[2] // 2, x.shape[3] // 2), dtype=dm.dtype, device=dm.device,
                                           memory_format=torch.channels_last)
                 P = pend_out if pend_out is not None else fusion.Pending()
-                P.defer_conv(be.stem7x7, dict(frame_state=dm, wpk=wpk, mapping_exec=feats._mapping_exec, bs=x.shape[2]), dm)
+                P.defer_conv(be.stem7x7, dict(frame_state=dm, wpk=wpk, mapping_exec=feats._mapping_exec, bs=x.shape[2], **x._dyn_kw()), dm)
                 return placeholder, P
         prologue = None
         residual = None      # pending residual add folded into the halo gather (with the activated tiles as a by-product)
@@ -877,7 +895,7 @@ class TensorWrapper(torch.Tensor):
             with timings.env("tensorwrapper/pad_residual", 10):
                 padded, act = get_backend().pad_ring_add(data, dense_layout(residual.checked_add()), feats.next_ring(data, padding),
                                                          feats._grid_idx, feats._mapping_exec, padding,
-                                                         (residual.scale, residual.shift, residual.relu))
+                                                         (residual.scale, residual.shift, residual.relu), **x._dyn_kw())
             x._pending = None
             x.data = act
             feats._pad_memo = None
@@ -909,12 +927,12 @@ class TensorWrapper(torch.Tensor):
                     placeholder = empty_like_layout((data.shape[0], weight.shape[0], data.shape[2] // stride, data.shape[3] // stride), data)
                     P = pend_out if pend_out is not None else fusion.Pending()
                     P.defer_conv(be.conv3x3_ring, dict(data_exec=data, ring=ring, wpk=wpk, cout=weight.shape[0], grid_idx=grid_idx,
-                                                       mapping_exec=mapping_exec, prologue=prologue, cfg=plan, stride=stride, **dil), data,
+                                                       mapping_exec=mapping_exec, prologue=prologue, cfg=plan, stride=stride, **dil, **x._dyn_kw()), data,
                                  registry=feats._deferred)
                     return placeholder, P
                 with timings.env("tensorwrapper/conv3x3_fused", 10):
                     return be.conv3x3_ring(data, ring, wpk, weight.shape[0], grid_idx, mapping_exec, prologue, None, cfg=plan,
-                                           stride=stride, **dil), pend_out
+                                           stride=stride, **dil, **x._dyn_kw()), pend_out
         if feats.engine == "fused" and fuse and op == "max_pool2d" and padding == 1:
             # the ResNet stem pool (3x3, stride 2): halo gather + max in one kernel, no padded tensor
             be = get_backend()
@@ -926,7 +944,7 @@ class TensorWrapper(torch.Tensor):
                 ring = feats.next_ring(data, padding)
                 feats._pad_memo = None
                 with timings.env("tensorwrapper/maxpool_fused", 10):
-                    return be.maxpool3x3s2_ring(data, ring, grid_idx, mapping_exec, prologue), pend_out
+                    return be.maxpool3x3s2_ring(data, ring, grid_idx, mapping_exec, prologue, **x._dyn_kw()), pend_out
         if feats.engine == "fused":
             # consecutive padded ops on the same tensor (e.g. the three CSP head branches on the 768-channel map)
             # share ONE halo gather and ring cache; the memo holds the source, so its address cannot be recycled
@@ -941,7 +959,7 @@ class TensorWrapper(torch.Tensor):
             else:
                 ring = feats.next_ring(data, padding)
                 with timings.env("tensorwrapper/pad", 10):
-                    args[0] = pad_ring(data, ring, grid_idx, mapping_exec, padding, prologue)
+                    args[0] = pad_ring(data, ring, grid_idx, mapping_exec, padding, prologue, feats.dyn)
                 feats._pad_memo = (data, padding, pro_key, args[0])
         else:
             data_transfer = self._transfer_from_prev()
@@ -1047,7 +1065,7 @@ class TensorWrapper(torch.Tensor):
             placeholder = torch.empty((data.shape[0], cout, data.shape[2], data.shape[3]), dtype=data.dtype, device=data.device,
                                       memory_format=torch.channels_last)
             Pn = pend_out if pend_out is not None else fusion.Pending()
-            Pn.defer_conv(be.head1x1, dict(data=data, wpk=wpk, cout=cout, prologue=prologue), data)
+            Pn.defer_conv(be.head1x1, dict(data=data, wpk=wpk, cout=cout, prologue=prologue, **x._dyn_kw()), data)
             Pn.conv[2]["head"] = True
             return placeholder, Pn
         if not be.conv1x1_supported(raw, weight, cv["stride"], 0, cv["dilation"], cv["groups"]):
@@ -1100,7 +1118,7 @@ class TensorWrapper(torch.Tensor):
             x._materialize()
         data = dense_layout(x._raw())
         wpk = fusion.packed_conv3x3_weight(weight, be.pack_conv3x3_weights)
-        launch_kw = dict(data=data, wpk=wpk, cout=cout, prologue=prologue, cfg=plan, stride=stride)
+        launch_kw = dict(data=data, wpk=wpk, cout=cout, prologue=prologue, cfg=plan, stride=stride, **x._dyn_kw())
         if fusion.DEFER_CONV and data.dtype in getattr(be, "supports_fusion_dtypes", ()):
             placeholder = torch.empty((data.shape[0], cout, data.shape[2] // stride, data.shape[3] // stride), dtype=data.dtype, device=data.device,
                                       memory_format=torch.channels_last)
@@ -1164,13 +1182,16 @@ class TensorWrapper(torch.Tensor):
             # as its epilogue (decoder: "upsample, += skip" -> one kernel).  The placeholder is never read or written.
             placeholder = empty_like_layout((src.shape[0], src.shape[1], H, W), src)
             return placeholder, fusion.Pending(interp=(src, H, W, align, rh, rw))
-        return be.interp_bilinear(src, H, W, align, rh, rw), None
+        return be.interp_bilinear(src, H, W, align, rh, rw, **args[0]._dyn_kw()), None
 
     def _func_batched(self, op, func, args, kwargs):
         """Ops with per-sample statistics (group_norm): fold the tile axis into the spatial axis so statistics
         run over all executed tiles of the (batch-size-1) frame, as the reference does (:600-633).
         Returns (result, pending-for-the-result)."""
         args = list(args)
+        if self._features is not None and self._features.dyn is not None:
+            raise NotImplementedError(f"{op} over all executed tiles needs the executed-tile count on the host (statistics run over exactly those "
+                                      "tiles): not available with a device-side count (block_graph=2); use block_graph=1")
         data = args[0].as_subclass(torch.Tensor)
         B, C, H, W = data.shape
         if op == "group_norm" and fusion.ENABLED and fusion.GROUP_NORM and self._features.engine == "fused":

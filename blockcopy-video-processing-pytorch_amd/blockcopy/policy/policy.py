@@ -64,27 +64,105 @@ def build_policy_optimizer_from_settings(settings: dict, net: PolicyNet) -> torc
                                centered=False, momentum=settings["block_optim_momentum"])
 
 
+class LazyCount:
+    """Executed-tile count of a frame whose decision was taken on the DEVICE and not waited for (``PolicyTrainRL.wait_free``): an
+    int-like that asks the device the first time the HOST really needs the number -- one event wait, long satisfied by then in the
+    normal case (statistics, the running cost before a training step).  ``row`` = the pinned mailbox row the policy-step kernel wrote
+    [n_exec, -, NaN flag, -], ``event`` = recorded right behind that launch."""
+
+    lazy = True
+
+    def __init__(self, row: torch.Tensor, event, total: int):
+        self._row, self._event, self._value, self.total = row, event, None, int(total)
+
+    def resolve(self) -> int:
+        if self._value is None:
+            self._event.synchronize()
+            n_exec, _, nan, _ = self._row.tolist()
+            assert nan == 0, "Policy net returned NaN's, maybe optimization problem?"
+            self._value, self._row, self._event = int(n_exec), None, None
+        return self._value
+
+    @property
+    def resolved(self) -> bool:
+        return self._value is not None or self._event.query()
+
+    def __int__(self):
+        return self.resolve()
+
+    __index__ = __int__
+
+    def __float__(self):
+        return float(self.resolve())
+
+    def __eq__(self, other):
+        return self.resolve() == other
+
+    def __hash__(self):
+        return id(self)
+
+    def __repr__(self):
+        return f"LazyCount({self._value if self._value is not None else 'pending'})"
+
+
+class LazyFraction:
+    """``count / total`` of a LazyCount, float-able (``policy_meta['perc_exec']`` of a frame decided on the device)."""
+
+    lazy = True
+
+    def __init__(self, count: LazyCount):
+        self.count = count
+
+    def __float__(self):
+        return float(self.count.resolve()) / self.count.total
+
+    def __repr__(self):
+        return f"LazyFraction({self.count!r} / {self.count.total})"
+
+
 class PolicyStats:
     """Running fraction of executed tiles."""
 
     def __init__(self):
         self.count_images = 0
-        self.exec = 0
+        self._exec = 0
+        self._pending = []      # LazyCounts not yet added to _exec (folded in when somebody reads the statistics)
         self.total = 0
+
+    @property
+    def exec(self) -> int:
+        if self._pending:
+            self._exec += sum(c.resolve() for c in self._pending)
+            del self._pending[:]
+        return self._exec
+
+    @exec.setter
+    def exec(self, value):
+        del self._pending[:]
+        self._exec = int(value)
 
     def add_policy_meta(self, policy_meta: dict) -> dict:
         grid = policy_meta["grid"]
         host = policy_meta.get("grid_host", None)
         known = policy_meta.pop("num_exec_known", None)
+        num_total = int(grid.numel())
+        self.count_images += grid.size(0)
+        self.total += num_total
+        policy_meta["num_total"] = num_total
+        if getattr(known, "lazy", False):
+            # decided on the device and not waited for: the host learns the number when it first asks (LazyCount)
+            policy_meta["num_exec"] = known
+            policy_meta["perc_exec"] = LazyFraction(known)
+            self._pending.append(known)
+            if len(self._pending) > 32:         # (keep the list short: counts this old resolve without waiting)
+                self._exec += sum(c.resolve() for c in self._pending[:-8])
+                del self._pending[:-8]
+            return policy_meta
         # count known from the device policy step / host mirror available -> no sync; otherwise the one D->H sync of the frame
         num_exec = int(known) if known is not None else (int(host.sum()) if host is not None else int(grid.sum()))
-        num_total = int(grid.numel())
         policy_meta["num_exec"] = num_exec
-        policy_meta["num_total"] = num_total
         policy_meta["perc_exec"] = float(num_exec) / num_total
-        self.count_images += grid.size(0)
-        self.exec += num_exec
-        self.total += num_total
+        self._exec += num_exec
         return policy_meta
 
     def get_exec_percentage(self):
@@ -239,6 +317,11 @@ class PolicyTrainRL(Policy, metaclass=abc.ABCMeta):
         # MI355X-first: sampling + count quantisation + index tables in ONE device kernel (bc_policy_step) on GPU frames;
         # the host only waits for the executed-tile count (it selects the captured graph).  False = the reference's host route.
         self.device_step = os.environ.get("BLOCKCOPY_DEVICE_POLICY", "1") != "0"
+        # MI355X-first, on top of the device step: do not wait for its executed-tile count either.  Needs an engine whose launches read
+        # the count from the device (core/graphs.py dynamic mode, block_graph = 2: BlockCopyModel switches this on); the host then
+        # learns the counts lazily (LazyCount) -- for the statistics, and for the running cost right before a training step
+        self.wait_free = False
+        self._pending_use = []        # perc_exec values (LazyFraction) not yet folded into the running cost
         self.rng_seed = None          # counter-based RNG of the device step: drawn from torch's generator at first use
         self.rng_counter = 0
         self._step_bufs = {}
@@ -246,11 +329,30 @@ class PolicyTrainRL(Policy, metaclass=abc.ABCMeta):
         self.block_target = block_target
         self.information_gain = information_gain
         self.momentum = cost_momentum
-        self.running_cost = None
+        self._running_cost = None
         self.net = policy_net
         self.complexity_weight_gamma = complexity_weight
         self.optimizer = optimizer
         self.at_least_one = at_least_one
+
+    @property
+    def running_cost(self):
+        """Exponential average of the executed fraction (reference policy.py:327-330); frames decided on the device without a wait
+        are folded in, in order, when the value is read."""
+        for use in self._pending_use:
+            self._fold(float(use))
+        del self._pending_use[:]
+        return self._running_cost
+
+    @running_cost.setter
+    def running_cost(self, value):
+        del self._pending_use[:]
+        self._running_cost = value
+
+    def _fold(self, block_use: float):
+        if self._running_cost is None:
+            self._running_cost = block_use
+        self._running_cost = self._running_cost * self.momentum + (1 - self.momentum) * block_use
 
     def forward(self, policy_meta: dict):
         shape = self.grid_shape(policy_meta)
@@ -287,6 +389,8 @@ class PolicyTrainRL(Policy, metaclass=abc.ABCMeta):
                 policy_meta["grid_probs"] = m.probs
         return self.stats.add_policy_meta(policy_meta)
 
+    MAILBOX_ROWS = 64      # pinned rows the device step reports its counts into, one per frame, reused round robin
+
     def _device_step(self, policy_meta: dict, grid_logits: torch.Tensor, shape):
         """Decision on the device: one launch samples, rounds the executed count up to the quantisation step and builds the
         index tables; an async copy mirrors the grid into pinned memory; ONE event wait then gives the host the executed-tile
@@ -299,24 +403,42 @@ class PolicyTrainRL(Policy, metaclass=abc.ABCMeta):
             self.rng_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         st = self._step_bufs.get((dev, n_total))
         if st is None:
+            # tables = [grid_idx | mapping_exec | counts(4)]: the layout the graph's table buffer has, so the engine takes it in ONE copy
+            tables = torch.zeros(2 * n_total + 4, dtype=torch.int32, device=dev)
             st = self._step_bufs[(dev, n_total)] = {
-                "grid": torch.zeros(n_total, dtype=torch.uint8, device=dev), "tables": torch.zeros(2 * n_total, dtype=torch.int32, device=dev),
-                "counts": torch.zeros(4, dtype=torch.int32, device=dev), "mailbox": torch.zeros(4, dtype=torch.int32).pin_memory(),
+                "grid": torch.zeros(n_total, dtype=torch.uint8, device=dev), "tables": tables, "counts": tables[2 * n_total:],
+                "mailbox": torch.zeros((self.MAILBOX_ROWS, 4), dtype=torch.int32).pin_memory(), "owners": [None] * self.MAILBOX_ROWS,
                 "host": torch.zeros(n_total, dtype=torch.uint8).pin_memory(), "event": torch.cuda.Event()}
         multiple = max(1, int(n_total * self.quantize_number_exec)) if self.quantize_number_exec > 0 else 1
         logits = grid_logits.detach().float().contiguous()
-        be.policy_step(logits, self.rng_seed, self.rng_counter, multiple, self.at_least_one, st["grid"], st["tables"], st["counts"], st["mailbox"])
+        row_k = self.rng_counter % self.MAILBOX_ROWS
+        if st["owners"][row_k] is not None:
+            st["owners"][row_k].resolve()      # (MAILBOX_ROWS frames old: answered long ago) the row is about to be rewritten
+        row = st["mailbox"][row_k]
+        be.policy_step(logits, self.rng_seed, self.rng_counter, multiple, self.at_least_one, st["grid"], st["tables"][:2 * n_total], st["counts"], row)
         self.rng_counter += 1
-        st["host"].copy_(st["grid"], non_blocking=True)
-        st["event"].record()
-        st["event"].synchronize()          # the frame's single wait: n_exec selects the captured graph
-        n_exec, _, nan, _ = st["mailbox"].tolist()
-        assert nan == 0, "Policy net returned NaN's, maybe optimization problem?"
-        grid = st["grid"].view(torch.bool).view(shape).clone()
-        policy_meta["grid"] = grid
-        policy_meta["grid_host"] = st["host"].view(torch.bool).view(shape).clone()
-        policy_meta["grid_tables"] = (st["tables"], n_exec)      # consumed by the engine instead of rebuilding them on the host
-        policy_meta["num_exec_known"] = n_exec
+        if self.wait_free:
+            # nobody waits: the engine's launches read the count from the device (dynamic graph), the host asks lazily
+            ev = torch.cuda.Event()
+            ev.record()
+            lazy = st["owners"][row_k] = LazyCount(row, ev, n_total)
+            grid = st["grid"].view(torch.bool).view(shape).clone()
+            policy_meta["grid"] = grid
+            policy_meta.pop("grid_host", None)
+            policy_meta["grid_tables"] = (st["tables"], None)
+            policy_meta["num_exec_known"] = lazy
+        else:
+            st["owners"][row_k] = None
+            st["host"].copy_(st["grid"], non_blocking=True)
+            st["event"].record()
+            st["event"].synchronize()          # the frame's single wait: n_exec selects the captured graph
+            n_exec, _, nan, _ = row.tolist()
+            assert nan == 0, "Policy net returned NaN's, maybe optimization problem?"
+            grid = st["grid"].view(torch.bool).view(shape).clone()
+            policy_meta["grid"] = grid
+            policy_meta["grid_host"] = st["host"].view(torch.bool).view(shape).clone()
+            policy_meta["grid_tables"] = (st["tables"], n_exec)      # consumed by the engine instead of rebuilding them on the host
+            policy_meta["num_exec_known"] = n_exec
         m = Bernoulli(logits=grid_logits)
         policy_meta["grid_log_probs"] = m.log_prob(grid.to(grid_logits.dtype)) if grid_logits.requires_grad or not self.graph_forward else None
         policy_meta["grid_probs"] = m.probs
@@ -359,9 +481,11 @@ class PolicyTrainRL(Policy, metaclass=abc.ABCMeta):
         grid = policy_meta["grid"]
         assert grid.dim() == 4
         block_use = policy_meta["perc_exec"]
-        if self.running_cost is None:
-            self.running_cost = block_use
-        self.running_cost = self.running_cost * self.momentum + (1 - self.momentum) * block_use
+        if getattr(block_use, "lazy", False):
+            self._pending_use.append(block_use)       # (folded in, in order, when the running cost is next read: before a training step)
+        else:
+            _ = self.running_cost                     # fold what is pending first: the average depends on the order
+            self._fold(float(block_use))
 
         if policy_meta["outputs_prev"] is not None and train:
             with torch.enable_grad():

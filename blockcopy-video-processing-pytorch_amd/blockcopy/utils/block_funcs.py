@@ -11,9 +11,10 @@ from .profiler import timings
 
 class SplitFunction(Function):
     @staticmethod
-    def forward(ctx, blocks, image, mapping_exec, grid_idx):
-        """Copy the executed tiles of ``image`` (N,C,H,W) into ``blocks`` (n_exec,C,bs,bs)."""
-        return get_backend().split(blocks, image, mapping_exec, grid_idx)
+    def forward(ctx, blocks, image, mapping_exec, grid_idx, dyn=None):
+        """Copy the executed tiles of ``image`` (N,C,H,W) into ``blocks`` (n_exec,C,bs,bs).  (``dyn``: device-side executed-tile
+        count of a ceiling-sized launch, HipBackend._arm; not part of the reference's signature.)"""
+        return get_backend().split(blocks, image, mapping_exec, grid_idx) if dyn is None else get_backend().split(blocks, image, mapping_exec, grid_idx, dyn=dyn)
 
     @staticmethod
     def backward(ctx, grad_x):
@@ -22,10 +23,11 @@ class SplitFunction(Function):
 
 class CombineFunction(Function):
     @staticmethod
-    def forward(ctx, blocks, out, grid_idx, mapping_exec):
+    def forward(ctx, blocks, out, grid_idx, mapping_exec, dyn=None):
         """Scatter ``blocks`` into the dense map ``out`` in place (other tiles keep the previous frame's values)."""
         with timings.env("block/combine_kernel", 20):
-            return get_backend().combine(blocks, out, grid_idx, mapping_exec)
+            be = get_backend()
+            return be.combine(blocks, out, grid_idx, mapping_exec) if dyn is None else be.combine(blocks, out, grid_idx, mapping_exec, dyn=dyn)
 
     @staticmethod
     def backward(ctx, grad_x):

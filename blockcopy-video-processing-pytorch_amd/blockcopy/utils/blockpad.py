@@ -20,10 +20,13 @@ def pad(features, transfer, grid_idx, exec_map, pad=1):
     return BlockPadFunction.apply(features, transfer, grid_idx, exec_map, pad)
 
 
-def pad_ring(features, ring, grid_idx, exec_map, pad=1, prologue=None):
+def pad_ring(features, ring, grid_idx, exec_map, pad=1, prologue=None, dyn=None):
     """Same result as transfer + pad of the reference, over a persistent per-layer ring cache.
-    ``prologue`` = (scale, shift, relu) fuses a pending per-channel affine + ReLU into the gather."""
-    return BlockPadRingFunction.apply(features, ring, grid_idx, exec_map, pad, prologue)
+    ``prologue`` = (scale, shift, relu) fuses a pending per-channel affine + ReLU into the gather; ``dyn`` = device-side executed-tile
+    count of a ceiling-sized launch (HipBackend._arm)."""
+    if dyn is None:
+        return BlockPadRingFunction.apply(features, ring, grid_idx, exec_map, pad, prologue)
+    return BlockPadRingFunction.apply(features, ring, grid_idx, exec_map, pad, prologue, dyn)
 
 
 class BlockPadFunction(Function):
@@ -40,10 +43,12 @@ class BlockPadFunction(Function):
 
 class BlockPadRingFunction(Function):
     @staticmethod
-    def forward(ctx, data_exec, ring, grid_idx, mapping_exec, pad, prologue=None):
+    def forward(ctx, data_exec, ring, grid_idx, mapping_exec, pad, prologue=None, dyn=None):
         _warn_tiny(data_exec.shape[2])
         with timings.env("block/pad_kernel", 20):
-            return get_backend().pad_ring(data_exec, ring, grid_idx, mapping_exec, pad, prologue)
+            if dyn is None:
+                return get_backend().pad_ring(data_exec, ring, grid_idx, mapping_exec, pad, prologue)
+            return get_backend().pad_ring(data_exec, ring, grid_idx, mapping_exec, pad, prologue, dyn=dyn)
 
     @staticmethod
     def backward(ctx, grad_x):

@@ -97,6 +97,24 @@ constexpr int MAX_WG = 256 * 8;  // 8 resident workgroups per CU on 256 CUs
 constexpr int UNROLL = 4;
 constexpr uint32_t SMALL_LAUNCH_VECTORS = 256u * 8u * 256u * 2u;   // < 2 vectors per resident lane of the chip
 
+// ------------------------------------------------------------------------------------------ executed-tile count on the device
+// A frame whose executed-tile count the HOST does not know when it launches (the policy decided on the device and nobody waited for
+// it: bc_dyn_set) runs launches that are sized for a ceiling -- every tile executed -- and read the actual count from device memory:
+// units of this launch = ceil(*ptr * num / den), never more than the host-side count.  Tile-indexed kernels (num / den = units per
+// executed tile) let the surplus workgroups exit before they touch anything; pointwise kernels over packed rows may round up into a
+// few garbage rows of the last tile, which nothing ever reads.  ptr == NULL: the host count is exact (every other frame).
+struct DynCount {
+    const int32_t *ptr = nullptr;
+    uint32_t num = 1, den = 1;
+};
+
+__device__ __forceinline__ uint32_t dyn_units(const DynCount &d, uint32_t host_units)
+{
+    if (!d.ptr) return host_units;
+    const unsigned long long n = ((unsigned long long)(uint32_t)*d.ptr * d.num + (d.den - 1)) / d.den;
+    return n < host_units ? (uint32_t)n : host_units;
+}
+
 // ------------------------------------------------------------------------------------------ gather / scatter
 struct TileGeom {
     FastDiv vpr, bs, C, GW, GH;  // vectors per tile row, tile size, channels, grid width/height
@@ -113,12 +131,14 @@ __global__ __launch_bounds__(WG) void k_tiles(typename VecOf<VB>::type *__restri
                                               const typename VecOf<VB>::type *__restrict__ packed_r,
                                               typename VecOf<VB>::type *__restrict__ dense_w,
                                               const typename VecOf<VB>::type *__restrict__ dense_r,
-                                              const int32_t *__restrict__ mapping_exec, TileGeom g)
+                                              const int32_t *__restrict__ mapping_exec, TileGeom g, DynCount dyn)
 {
     typedef typename VecOf<VB>::type V;
     const uint32_t stride = gridDim.x * WG;
     const uint32_t v0 = blockIdx.x * WG + threadIdx.x;
-    const uint32_t last = g.total - 1;
+    const uint32_t total = dyn_units(dyn, g.total);
+    if (blockIdx.x * WG >= total) return;            // (surplus workgroups of a ceiling-sized launch; also total == 0)
+    const uint32_t last = total - 1;
     uint32_t vc[U], rem[U], b[U], ig[U], di[U];
     V val[U];
 #pragma unroll
@@ -376,6 +396,7 @@ struct HaloGeom {
     FastDiv PP, BSP, GW, GH;  // padded plane (bs+2p)^2, padded row bs+2p, grid dims
     uint32_t C, bs, pad, n_total;
     uint32_t per_tile;        // C*PP output elements per executed tile
+    DynCount dyn;             // executed-tile count on the device (units = tiles = gridDim.y)
 };
 
 // One workgroup column (blockIdx.y) per executed tile; lanes run over the tile's contiguous output
@@ -393,6 +414,7 @@ __global__ __launch_bounds__(WG) void k_halo(T *__restrict__ out, const T *__res
     __shared__ int32_t nb_kind[9];  // 0 = features, 1 = other (transfer / ring), 2 = zero (beyond image border)
     __shared__ uint32_t own_g;
     const uint32_t b = blockIdx.y;
+    if (b >= dyn_units(g.dyn, gridDim.y)) return;     // surplus workgroups of a ceiling-sized launch (bc_dyn_set)
     if (threadIdx.x < 9) {
         const uint32_t ig = (uint32_t)mapping_exec[b];
         uint32_t t, gw, n, gh;
@@ -459,6 +481,7 @@ struct HaloLdsGeom {
     uint32_t per_tile;              // C*(bs+2p)^2
     uint32_t L;                     // output elements per workgroup
     uint32_t plane;                 // bs*bs
+    DynCount dyn;                   // executed-tile count on the device (units = tiles = gridDim.y)
 };
 
 constexpr int HALO_UM = 4;          // middle-run vectors per lane
@@ -479,6 +502,7 @@ __global__ __launch_bounds__(WG) void k_halo_lds(T *__restrict__ out, const T *_
     T *img = reinterpret_cast<T *>(reinterpret_cast<char *>(smem) + HALO_TBL);
 
     const uint32_t b = blockIdx.y;
+    if (b >= dyn_units(g.dyn, gridDim.y)) return;     // surplus workgroups of a ceiling-sized launch (bc_dyn_set)
     const uint32_t tile_elems = g.C * g.plane;
     if (threadIdx.x < 9) {
         const uint32_t ig = (uint32_t)mapping_exec[b];
@@ -645,6 +669,7 @@ struct HaloRowsGeom {
     uint32_t mid_items;     // C*BSP*vpr   source vectors per tile
     uint32_t edge_items;    // C*BSP*2p    edge elements per tile
     uint32_t edge_per_wg;
+    DynCount dyn;           // executed-tile count on the device (units = tiles = gridDim.y)
 };
 
 template <typename T, int VE> struct RowVec {
@@ -664,6 +689,7 @@ __global__ __launch_bounds__(WG) void k_halo_rows(T *__restrict__ out, const T *
     typedef typename RowVec<T, VE>::aligned_t SV;
     typedef typename RowVec<T, VE>::packed_t SVU;
     const uint32_t b = blockIdx.y;
+    if (b >= dyn_units(g.dyn, gridDim.y)) return;     // surplus workgroups of a ceiling-sized launch (bc_dyn_set)
     const uint32_t tile_elems = g.C * g.plane;
     const uint32_t bs = g.bs, p = g.pad, BSP = g.BSP.d;
 
@@ -1136,6 +1162,7 @@ struct HaloNhwcGeom {
     uint32_t C, bs, pad, n_total;
     uint32_t per_tile;        // BSP*BSP*K output vectors per executed tile
     uint32_t epv;             // elements per vector
+    DynCount dyn;             // executed-tile count on the device (units = tiles = gridDim.y)
 };
 
 template <int VB, typename T, bool RING, int DT>
@@ -1148,6 +1175,7 @@ __global__ __launch_bounds__(WG) void k_halo_nhwc(typename VecOf<VB>::type *__re
     typedef typename VecOf<VB>::type V;
     constexpr int VE = VB / (int)sizeof(T);
     const uint32_t b = blockIdx.y;
+    if (b >= dyn_units(g.dyn, gridDim.y)) return;
     const uint32_t bs = g.bs, p = g.pad, K = g.K.d;
     const uint32_t tile_vecs = bs * bs * K;          // vectors per packed tile
     const uint32_t RSV = 4 * p * bs * K;             // vectors per compact ring record (fat pixels x K)
@@ -1280,6 +1308,7 @@ __global__ __launch_bounds__(WG) void k_halo_add_nhwc(typename VecOf<VB>::type *
     typedef typename VecOf<VB>::type V;
     constexpr int VE = VB / (int)sizeof(T);
     const uint32_t b = blockIdx.y;
+    if (b >= dyn_units(g.dyn, gridDim.y)) return;
     const uint32_t bs = g.bs, p = g.pad, K = g.K.d;
     const uint32_t tile_vecs = bs * bs * K, RSV = 4 * p * bs * K;
     const uint32_t ig = (uint32_t)mapping_exec[b];
@@ -1373,6 +1402,7 @@ __global__ __launch_bounds__(WG) void k_halo_add_nhwc(typename VecOf<VB>::type *
 struct PoolGeom {
     FastDiv K, OB, GW, GH;    // vectors per fat pixel, output tile edge bs/2, grid dims
     uint32_t bs, n_total, per_tile;   // per_tile = OB*OB*K output vectors per executed tile
+    DynCount dyn;                     // executed-tile count on the device (units = tiles = gridDim.y)
 };
 
 template <typename T, int VE, int DT>
@@ -1384,6 +1414,7 @@ __global__ __launch_bounds__(WG) void k_maxpool3x3s2_nhwc(typename VecOf<sizeof(
 {
     typedef typename VecOf<sizeof(T) * VE>::type V;
     const uint32_t b = blockIdx.y, bs = g.bs, K = g.K.d;
+    if (b >= dyn_units(g.dyn, gridDim.y)) return;
     const uint32_t tile_vecs = bs * bs * K, RSV = 4 * bs * K;
     const uint32_t ig = (uint32_t)mapping_exec[b];
     uint32_t t0, gw, n0, gh;
@@ -1711,10 +1742,11 @@ __global__ __launch_bounds__(WG) void k_adaptive_avg_pool_nhwc(typename VecOf<si
 template <typename T, int Q>
 __global__ __launch_bounds__(WG) void k_affine_act_nhwc(T *__restrict__ out, const T *__restrict__ in, const T *__restrict__ add,
                                                         const float *__restrict__ scale, const float *__restrict__ shift,
-                                                        int relu, FastDiv Cq, uint32_t total)
+                                                        int relu, FastDiv Cq, uint32_t total_host, DynCount dyn)
 {
     typedef typename VecOf<sizeof(T) * Q>::type V;
     const uint32_t i = blockIdx.x * WG + threadIdx.x;
+    const uint32_t total = dyn_units(dyn, total_host);
     if (i >= total) return;
     uint32_t pix, q;
     fd_divmod(i, Cq, pix, q);
@@ -1742,6 +1774,7 @@ struct InterpNhwcGeom {
     uint32_t h, w, total;
     float rh, rw;
     int align;
+    DynCount dyn;     // executed-tile count on the device (units = output vectors)
 };
 
 // one fixed evaluation order for the 4-tap blend, so that the plain and the epilogue form of the kernel agree bit for bit
@@ -1764,7 +1797,7 @@ __global__ __launch_bounds__(WG) void k_interp_bilinear_nhwc(T *__restrict__ out
 {
     typedef typename VecOf<sizeof(T) * Q>::type V;
     const uint32_t i = blockIdx.x * WG + threadIdx.x;
-    if (i >= g.total) return;
+    if (i >= dyn_units(g.dyn, g.total)) return;
     uint32_t r, q, r2, ox, plane, oy;
     fd_divmod(i, g.Cq, r, q);
     fd_divmod(r, g.W, r2, ox);
@@ -1950,6 +1983,39 @@ struct ProfScope {
         else hipLaunchKernelGGL(kernel_, grid_, block_, lds_, st_, __VA_ARGS__);                                   \
     } while (0)
 
+// ---- executed-tile count on the device: bc_dyn_set ARMS the next launch only (the capable launchers take it at their first line,
+// armed or not, so an armed state can never leak into a later, unrelated launch of theirs)
+struct DynArm { const int32_t *ptr = nullptr; int ceiling = 0; };
+DynArm g_dyn_arm;
+
+DynArm dyn_take()
+{
+    const DynArm d = g_dyn_arm;
+    g_dyn_arm = DynArm{};
+    return d;
+}
+
+// tile-indexed launch (units = executed tiles x per_tile): the launch must have been sized for the ceiling
+bool dyn_tiles(const DynArm &a, int n_exec, uint32_t per_tile, DynCount &d)
+{
+    d = DynCount{};
+    if (!a.ptr) return true;
+    if (n_exec != a.ceiling) return false;
+    d.ptr = a.ptr; d.num = per_tile; d.den = 1;
+    return true;
+}
+
+// pointwise launch over `units` items that belong to the ceiling's tiles in equal shares (rounds up into the last tile's garbage rows)
+DynCount dyn_flat(const DynArm &a, unsigned long long units)
+{
+    DynCount d;
+    if (!a.ptr || a.ceiling <= 0) return d;
+    unsigned long long x = units, y = (unsigned long long)a.ceiling;
+    while (y) { const unsigned long long t = x % y; x = y; y = t; }
+    d.ptr = a.ptr; d.num = (uint32_t)(units / x); d.den = (uint32_t)((unsigned long long)a.ceiling / x);
+    return d;
+}
+
 int launch_status()
 {
     const hipError_t e = hipGetLastError();
@@ -1966,7 +2032,7 @@ int check_dense(int N, int C, int H, int W, int bs, int E)
 
 template <bool TO_PACKED>
 int launch_tiles(ProfScope &ps, void *packed, void *dense, const int32_t *mapping_exec, int n_exec,
-                 int N, int C, int H, int W, int bs, int E, hipStream_t st)
+                 int N, int C, int H, int W, int bs, int E, hipStream_t st, const DynArm &arm = DynArm{})
 {
     const int vb = pick_vb((size_t)bs * E, {packed, dense});
     TileGeom g;
@@ -1978,16 +2044,18 @@ int launch_tiles(ProfScope &ps, void *packed, void *dense, const int32_t *mappin
     // large ones amortise index math and keep UNROLL requests per lane in flight
     const bool small = g.total < SMALL_LAUNCH_VECTORS;
     const int grid = grid_exact(g.total, small ? 1 : UNROLL);
+    DynCount dyn;
+    if (!dyn_tiles(arm, n_exec, (uint32_t)C * bs * vpr, dyn)) return BC_ERR_SHAPE;
 #define BC_TILES(VB_)                                                                                          \
     case VB_:                                                                                                  \
         if (small)                                                                                             \
             BC_LAUNCH(ps, (k_tiles<VB_, TO_PACKED, 1>), dim3(grid), dim3(WG), 0, st,                           \
                       (VecOf<VB_>::type *)packed, (const VecOf<VB_>::type *)packed,                            \
-                      (VecOf<VB_>::type *)dense, (const VecOf<VB_>::type *)dense, mapping_exec, g);            \
+                      (VecOf<VB_>::type *)dense, (const VecOf<VB_>::type *)dense, mapping_exec, g, dyn);       \
         else                                                                                                   \
         BC_LAUNCH(ps, (k_tiles<VB_, TO_PACKED, UNROLL>), dim3(grid), dim3(WG), 0, st,                     \
                            (VecOf<VB_>::type *)packed, (const VecOf<VB_>::type *)packed,                       \
-                           (VecOf<VB_>::type *)dense, (const VecOf<VB_>::type *)dense, mapping_exec, g);       \
+                           (VecOf<VB_>::type *)dense, (const VecOf<VB_>::type *)dense, mapping_exec, g, dyn);  \
         break;
     switch (vb) { BC_TILES(16) BC_TILES(8) BC_TILES(4) BC_TILES(2) BC_TILES(1) }
 #undef BC_TILES
@@ -1997,9 +2065,10 @@ int launch_tiles(ProfScope &ps, void *packed, void *dense, const int32_t *mappin
 template <bool RING>
 int launch_halo_simple(ProfScope &ps, void *out, const void *features, const void *other_r, void *ring_w, const int32_t *grid_idx,
                        const int32_t *mapping_exec, int n_exec, int N, int C, int GH, int GW, int bs, int pad, int E,
-                       hipStream_t st)
+                       hipStream_t st, const DynCount &dyn = DynCount{})
 {
     HaloGeom g;
+    g.dyn = dyn;
     const uint32_t bsp = bs + 2 * pad;
     g.PP = make_fd(bsp * bsp); g.BSP = make_fd(bsp); g.GW = make_fd(GW); g.GH = make_fd(GH);
     g.C = C; g.bs = bs; g.pad = pad; g.n_total = (uint32_t)N * GH * GW;
@@ -2045,15 +2114,16 @@ int halo_kernel_choice(double bytes)
 template <bool RING>
 int launch_halo(ProfScope &ps, void *out, const void *features, const void *other_r, void *ring_w, const int32_t *grid_idx,
                 const int32_t *mapping_exec, int n_exec, int N, int C, int GH, int GW, int bs, int pad, int E,
-                hipStream_t st, int dt = 0, Prologue pr = Prologue{nullptr, nullptr, 0})
+                hipStream_t st, int dt = 0, Prologue pr = Prologue{nullptr, nullptr, 0}, const DynCount &dyn = DynCount{})
 {
     int choice = halo_kernel_choice(2.0 * n_exec * C * (double)(bs + 2 * pad) * (bs + 2 * pad) * E);
     if (dt != 0 && choice == HALO_SIMPLE) choice = HALO_ROWS;   // the element-wise fallback has no prologue
     if ((E != 2 && E != 4) || choice == HALO_SIMPLE)
-        return launch_halo_simple<RING>(ps, out, features, other_r, ring_w, grid_idx, mapping_exec, n_exec, N, C, GH, GW, bs, pad, E, st);
+        return launch_halo_simple<RING>(ps, out, features, other_r, ring_w, grid_idx, mapping_exec, n_exec, N, C, GH, GW, bs, pad, E, st, dyn);
     const int vb = pick_vb((size_t)bs * E, {features, other_r, ring_w});
     if (choice == HALO_ROWS) {
         HaloRowsGeom g;
+        g.dyn = dyn;
         const uint32_t bsp = bs + 2 * pad, vpr = (uint32_t)((size_t)bs * E / vb);
         g.BSP = make_fd(bsp); g.vpr = make_fd(vpr); g.P2 = make_fd(2 * pad); g.GW = make_fd(GW); g.GH = make_fd(GH);
         g.C = C; g.bs = bs; g.pad = pad; g.n_total = (uint32_t)N * GH * GW; g.plane = (uint32_t)bs * bs;
@@ -2079,6 +2149,7 @@ int launch_halo(ProfScope &ps, void *out, const void *features, const void *othe
         return launch_status();
     }
     HaloLdsGeom g;
+    g.dyn = dyn;
     const uint32_t bsp = bs + 2 * pad;
     g.BSP = make_fd(bsp); g.vpr = make_fd((uint32_t)((size_t)bs * E / vb)); g.P2 = make_fd(2 * pad);
     g.GW = make_fd(GW); g.GH = make_fd(GH);
@@ -2091,7 +2162,7 @@ int launch_halo(ProfScope &ps, void *out, const void *features, const void *othe
     const uint64_t rows_max = rows_mid < rows_edge ? rows_mid : rows_edge;
     if (rows_max < 2 && dt != 0) return BC_ERR_SHAPE;
     if (rows_max < 2)
-        return launch_halo_simple<RING>(ps, out, features, other_r, ring_w, grid_idx, mapping_exec, n_exec, N, C, GH, GW, bs, pad, E, st);
+        return launch_halo_simple<RING>(ps, out, features, other_r, ring_w, grid_idx, mapping_exec, n_exec, N, C, GH, GW, bs, pad, E, st, dyn);
     uint64_t L = (rows_max - 1) * bsp;
     const uint64_t total = (uint64_t)g.per_tile * n_exec;
     const uint64_t want = (total + 2047) / 2048, Lmin = 2048 / E;
@@ -2208,6 +2279,7 @@ struct ConvV2Args {
     int chosen;                                    // out: the decomposition that was launched
     int xcd_remap;                                 // 1: XCD-aware workgroup order (xcd_remap() in conv3x3_v2.inc)
     int dilation;                                  // 1, or 2 (bc_conv3x3_dil_ring_nhwc: part 9)
+    DynCount dyn;                                  // executed-tile count on the device, units = the launch's tiles (bc_dyn_set)
 };
 struct LaunchProf { bool on; struct { hipEvent_t a, b; } rec; };   // what BC_LAUNCH needs of a ProfScope
 
@@ -2266,6 +2338,7 @@ static int conv_v2_run(ConvV2Args &a)
     g.n_rows = best_plan.n_rows;
     g.cin_chunks = Cin / CV_CH;
     g.xcd = (uint32_t)a.xcd_remap;
+    g.dyn = a.dyn;
     size_t lds_bytes = best_plan.lds_bytes;
     if (lds_bytes < (size_t)min_lds) lds_bytes = min_lds;      // one workgroup per CU: two waves on every SIMD, no more
     const dim3 grid((g.n_rows + k.WMW - 1) / k.WMW, (unsigned)Cout / (32 * k.RN * k.WNW));
@@ -2350,6 +2423,7 @@ static int conv_v2_dil_run(ConvV2Args &a)
     g.n_rows = best_plan.n_rows;
     g.cin_chunks = a.Cin / CV_CH;
     g.xcd = (uint32_t)a.xcd_remap;
+    g.dyn = a.dyn;
     size_t lds_bytes = best_plan.lds_bytes;
     if (lds_bytes < (size_t)min_lds) lds_bytes = min_lds;
     const dim3 grid((g.n_rows + k.WMW - 1) / k.WMW, (unsigned)a.Cout / (32 * k.RN * k.WNW));
@@ -2437,6 +2511,7 @@ static int conv_wino_run(ConvV2Args &a)
     g.n_rows = plan.n_rows;
     g.cin_chunks = a.Cin / 32;
     g.xcd = (uint32_t)a.xcd_remap;
+    g.dyn = a.dyn;
     size_t lds_bytes = plan.lds_bytes;
     if (!(a.force_cfg & 0x100) && lds_bytes < (size_t)a.min_lds) lds_bytes = a.min_lds;
     const dim3 grid((plan.n_rows + k.WMW - 1) / k.WMW, (unsigned)a.Cout / (16 * k.WNW));
@@ -2515,6 +2590,7 @@ static int conv_wino32_run(ConvV2Args &a)
     g.n_rows = plan.n_slots;
     g.cin_chunks = a.Cin / 32;
     g.xcd = (uint32_t)a.xcd_remap;
+    g.dyn = a.dyn;
     const dim3 grid((plan.n_slots + 2 * k.WMW - 1) / (2 * k.WMW), (unsigned)a.Cout / (32 * k.WNW));
     switch (c) {
     case 0: launch_wino32_cfg<2, 2, 1>(ps, grid, plan.lds_bytes, a, g); break;
@@ -2556,6 +2632,7 @@ struct TuneState {
     // XCD-aware workgroup order of the conv kernels (xcd_remap in conv3x3_v2.inc).  Measured neutral on every layer shape of the configs
     // (profiles/r03/11: +-2 %, the weights of a layer are served by the Infinity Cache either way), so the launch order stays the default
     int xcd_remap = [] { const char *e = getenv("BC_XCD_REMAP"); return e ? atoi(e) : 0; }();
+    int head_preload = [] { const char *e = getenv("BC_HEAD_PRELOAD"); return e ? atoi(e) : 1; }();       // k_head1x1: all chunks of an M-block in flight at once
 } g_tune;
 
 
@@ -2569,6 +2646,8 @@ int bc_part_conv_v2_dil(void *);
 }
 #endif
 
+static DynCount g_conv_dyn;      // set by the exported conv launchers for the ONE launch_conv3x3_v2 call they make (bc_dyn_set)
+
 template <int DT, int S, int KS = 3>
 static int launch_conv3x3_v2(ProfScope &ps, void *out, const void *features, void *ring, const void *wpk, const int32_t *grid_idx,
                              const int32_t *mapping_exec, int n_exec, int Cin, int Cout, int GH, int GW, int bs,
@@ -2576,6 +2655,8 @@ static int launch_conv3x3_v2(ProfScope &ps, void *out, const void *features, voi
 {
     ConvV2Args a{out, features, ring, wpk, grid_idx, mapping_exec, n_exec, Cin, Cout, GH, GW, bs, S, pr, ep, st,
                  ps.on ? 1 : 0, ps.rec.a, ps.rec.b, g_tune.conv2_cfg, g_tune.conv2_min_lds, g_tune.conv_stamps, -2, g_tune.xcd_remap, 1};
+    a.dyn = g_conv_dyn;
+    g_conv_dyn = DynCount{};
     const double direct_flops = 2.0 * n_exec * (double)(bs / S) * (bs / S) * (KS * KS) * (double)Cin * Cout;
     if (DT == BC_F32 && S == 1 && KS == 3 && a.force_cfg >= 0 && (a.force_cfg & 0x600)) {       // Winograd forms (conv3x3_wino.inc, conv3x3_wino32.inc)
         ps.add_aux(direct_flops * 16.0 / 36.0);     // F(2x2,3x3): 16 multiplications per 2x2 outputs instead of 36
@@ -2624,6 +2705,7 @@ BC_EXPORT const char *bc_op_name(int op)
 BC_EXPORT int bc_split(void *blocks, const void *image, const int32_t *mapping_exec, int n_exec,
                        int N, int C, int H, int W, int bs, int E, void *stream)
 {
+    const DynArm arm = dyn_take();
     int rc = check_dense(N, C, H, W, bs, E);
     if (rc != BC_OK) return rc;
     if (n_exec < 0) return BC_ERR_SHAPE;
@@ -2631,12 +2713,13 @@ BC_EXPORT int bc_split(void *blocks, const void *image, const int32_t *mapping_e
     if (!blocks || !image || !mapping_exec) return BC_ERR_NULL;
     if (!aligned(blocks, E) || !aligned(image, E)) return BC_ERR_ALIGN;
     ProfScope ps(BC_OP_SPLIT, 2.0 * n_exec * C * bs * bs * E);
-    return launch_tiles<true>(ps, blocks, const_cast<void *>(image), mapping_exec, n_exec, N, C, H, W, bs, E, (hipStream_t)stream);
+    return launch_tiles<true>(ps, blocks, const_cast<void *>(image), mapping_exec, n_exec, N, C, H, W, bs, E, (hipStream_t)stream, arm);
 }
 
 BC_EXPORT int bc_combine(const void *blocks, void *out, const int32_t *mapping_exec, int n_exec,
                          int N, int C, int H, int W, int bs, int E, void *stream)
 {
+    const DynArm arm = dyn_take();
     int rc = check_dense(N, C, H, W, bs, E);
     if (rc != BC_OK) return rc;
     if (n_exec < 0) return BC_ERR_SHAPE;
@@ -2644,7 +2727,7 @@ BC_EXPORT int bc_combine(const void *blocks, void *out, const int32_t *mapping_e
     if (!blocks || !out || !mapping_exec) return BC_ERR_NULL;
     if (!aligned(blocks, E) || !aligned(out, E)) return BC_ERR_ALIGN;
     ProfScope ps(BC_OP_COMBINE, 2.0 * n_exec * C * bs * bs * E);
-    return launch_tiles<false>(ps, const_cast<void *>(blocks), out, mapping_exec, n_exec, N, C, H, W, bs, E, (hipStream_t)stream);
+    return launch_tiles<false>(ps, const_cast<void *>(blocks), out, mapping_exec, n_exec, N, C, H, W, bs, E, (hipStream_t)stream, arm);
 }
 
 BC_EXPORT int bc_combine_copy(const void *blocks, const void *prev, void *out, const int32_t *grid_idx,
@@ -2758,6 +2841,7 @@ BC_EXPORT int bc_head1x1_scatter_nhwc(void *out, const void *features, const voi
                                       int GH, int GW, int bs, int dtype, const float *in_scale, const float *in_shift, int in_relu,
                                       const float *out_shift, int scatter, void *stream)
 {
+    const DynArm arm = dyn_take();
     if (dtype < BC_F32 || dtype > BC_BF16) return BC_ERR_ELEM;
     if (n_exec < 0 || N <= 0 || Cin <= 0 || Cout <= 0 || Cout > 32 || GH <= 0 || GW <= 0 || bs <= 0) return BC_ERR_SHAPE;
     // a 32-pixel M-block is stored as 32 / run_px row segments of run_px = min(bs, 32) pixels: bs must divide 32 or be a multiple of it
@@ -2770,7 +2854,7 @@ BC_EXPORT int bc_head1x1_scatter_nhwc(void *out, const void *features, const voi
     if (!features && n_exec > 0) return BC_ERR_NULL;
     if (!weights_packed || (!out && !slots)) return BC_ERR_NULL;
     if (scatter && (!grid_idx || (!mapping_exec && n_exec > 0))) return BC_ERR_NULL;
-    if (scatter && !slots && !prev && n_exec < N * GH * GW) return BC_ERR_NULL;     // skipped tiles need the previous map
+    if (scatter && !slots && !prev && (n_exec < N * GH * GW || arm.ptr)) return BC_ERR_NULL;     // skipped tiles need the previous map
     const int E = dtype == BC_F32 ? 4 : 2;
     if ((uint64_t)N * GH * GW * bs * bs * (uint64_t)(Cin > Cout ? Cin : Cout) >= (1ull << 31)) return BC_ERR_RANGE;
     if (!aligned(out, 16) || !aligned(features, 16) || !aligned(weights_packed, 16) || !aligned(prev, 16) || !aligned(slots, 8)) return BC_ERR_ALIGN;
@@ -2779,7 +2863,9 @@ BC_EXPORT int bc_head1x1_scatter_nhwc(void *out, const void *features, const voi
     g.blocks_per_tile = bs * bs / 32;
     g.n_mblocks = (uint32_t)n_exec * g.blocks_per_tile;
     g.scatter = scatter ? 1 : 0;
-    g.copy_rows = (scatter && n_exec < N * GH * GW) ? (uint32_t)(N * GH * GW) * (uint32_t)bs : 0;
+    if (!dyn_tiles(arm, n_exec, 1, g.dyn)) return BC_ERR_SHAPE;
+    // (a count that is only known on the device may leave any tile skipped: the copy half is always on)
+    g.copy_rows = (scatter && (n_exec < N * GH * GW || arm.ptr)) ? (uint32_t)(N * GH * GW) * (uint32_t)bs : 0;
     // one round of 256 CUs x 2 workgroups x 4 waves at most; at least one wave per M-block or per two tile rows to look at
     uint32_t want = g.n_mblocks > (g.copy_rows + 1) / 2 ? g.n_mblocks : (g.copy_rows + 1) / 2;
     if (want > 2048u) want = 2048u;
@@ -2787,6 +2873,7 @@ BC_EXPORT int bc_head1x1_scatter_nhwc(void *out, const void *features, const voi
     g.n_waves = ((want + 3) / 4) * 4;
     g.run_px = bs < 32 ? bs : 32;
     g.runs = 32 / g.run_px;
+    g.preload = (uint32_t)g_tune.head_preload;
     Prologue pr{in_scale, in_shift, in_relu};
     const double px = (double)n_exec * bs * bs;
     // algorithmic bytes: packed features read; scatter: every skipped tile read once from the previous map + the whole map written
@@ -2987,30 +3074,36 @@ BC_EXPORT int bc_pad_ring(void *out, const void *features, void *ring, const int
                           const int32_t *mapping_exec, int n_exec,
                           int N, int C, int GH, int GW, int bs, int pad, int E, void *stream)
 {
+    const DynArm arm = dyn_take();
     int rc = check_halo(out, features, grid_idx, mapping_exec, n_exec, N, C, GH, GW, bs, pad, E);
     if (rc != BC_OK || n_exec == 0) return rc;
     if (!ring) return BC_ERR_NULL;
     if (!aligned(ring, E)) return BC_ERR_ALIGN;
+    DynCount dyn;
+    if (!dyn_tiles(arm, n_exec, 1, dyn)) return BC_ERR_SHAPE;
     ProfScope ps(BC_OP_PAD_RING, halo_bytes(n_exec, C, bs, pad, E));
     return launch_halo<true>(ps, out, features, ring, ring, grid_idx, mapping_exec, n_exec, N, C, GH, GW, bs, pad, E,
-                             (hipStream_t)stream);
+                             (hipStream_t)stream, 0, Prologue{nullptr, nullptr, 0}, dyn);
 }
 
 BC_EXPORT int bc_pad_ring_act(void *out, const void *features, void *ring, const int32_t *grid_idx,
                               const int32_t *mapping_exec, int n_exec, int N, int C, int GH, int GW, int bs, int pad,
                               int dtype, const float *scale, const float *shift, int relu, void *stream)
 {
+    const DynArm arm = dyn_take();
     if (dtype < BC_F32 || dtype > BC_BF16) return BC_ERR_ELEM;
     const int E = dtype == BC_F32 ? 4 : 2;
     int rc = check_halo(out, features, grid_idx, mapping_exec, n_exec, N, C, GH, GW, bs, pad, E);
     if (rc != BC_OK || n_exec == 0) return rc;
     if (!ring) return BC_ERR_NULL;
     if (!aligned(ring, E)) return BC_ERR_ALIGN;
+    DynCount dyn;
+    if (!dyn_tiles(arm, n_exec, 1, dyn)) return BC_ERR_SHAPE;
     ProfScope ps(BC_OP_PAD_RING, halo_bytes(n_exec, C, bs, pad, E));
     Prologue pr{scale, shift, relu};
     const int dt = (scale || shift || relu) ? dtype + 1 : 0;
     return launch_halo<true>(ps, out, features, ring, ring, grid_idx, mapping_exec, n_exec, N, C, GH, GW, bs, pad, E,
-                             (hipStream_t)stream, dt, pr);
+                             (hipStream_t)stream, dt, pr, dyn);
 }
 
 BC_EXPORT int bc_affine_act(void *out, const void *in, const void *add, const float *scale, const float *shift, int relu,
@@ -3089,6 +3182,7 @@ BC_EXPORT int bc_pad_ring_nhwc(void *out, const void *features, void *ring, cons
                                const int32_t *mapping_exec, int n_exec, int N, int C, int GH, int GW, int bs, int pad,
                                int elem_size, int dtype, const float *scale, const float *shift, int relu, void *stream)
 {
+    const DynArm arm = dyn_take();
     const int E = elem_size;
     if (E != 1 && E != 2 && E != 4 && E != 8) return BC_ERR_ELEM;
     const bool act = scale || shift || relu;
@@ -3107,6 +3201,7 @@ BC_EXPORT int bc_pad_ring_nhwc(void *out, const void *features, void *ring, cons
     g.C = C; g.bs = bs; g.pad = pad; g.n_total = (uint32_t)N * GH * GW;
     g.per_tile = (uint32_t)(bsp * bsp * K);
     g.epv = vb / E;
+    if (!dyn_tiles(arm, n_exec, 1, g.dyn)) return BC_ERR_SHAPE;
     const dim3 grid((g.per_tile + WG * UNROLL - 1) / (WG * UNROLL), (unsigned)n_exec);
     const long long delta = ((const char *)ring - (const char *)features) / vb;
     Prologue pr{scale, shift, relu};
@@ -3194,6 +3289,7 @@ BC_EXPORT int bc_conv1x1_nhwc(void *out, const void *features, const void *weigh
                               int dtype, const float *in_scale, const float *in_shift, int in_relu, const float *out_scale,
                               const float *out_shift, const void *out_add, int out_relu, void *stream)
 {
+    const DynArm arm = dyn_take();
     if (dtype < BC_F32 || dtype > BC_BF16) return BC_ERR_ELEM;
     if (n_tiles < 0 || Cin <= 0 || Cout <= 0 || bs <= 0 || (stride != 1 && stride != 2) || bs % stride) return BC_ERR_SHAPE;
     const int bso = bs / stride;
@@ -3212,6 +3308,7 @@ BC_EXPORT int bc_conv1x1_nhwc(void *out, const void *features, const void *weigh
         if (dtype != BC_F32 || stride != 1 || Cout % (64 * (2 - (c & 1))) != 0) return BC_ERR_SHAPE;
         if (!aligned(out_add, 16)) return BC_ERR_ALIGN;
         GemmGeom g{(uint32_t)n_tiles * (uint32_t)bs * (uint32_t)bs, (uint32_t)Cin, (uint32_t)Cout, (uint32_t)Cin / 32};
+        g.dyn = dyn_flat(arm, g.M);
         ps.add_aux(2.0 * g.M * (double)Cin * Cout);
         g_tune.conv_last_cfg = 0x800 | c;
         switch (c) {
@@ -3221,6 +3318,7 @@ BC_EXPORT int bc_conv1x1_nhwc(void *out, const void *features, const void *weigh
         default: return launch_gemm1x1<1, 1>(ps, out, features, weights_packed, g, pr, ept, st);
         }
     }
+    g_conv_dyn = dyn_flat(arm, (unsigned long long)n_tiles);      // (units = the launch's tiles: 8x8 re-tiles of the packed pixels, or the real tiles)
 #define BC_C1(DT_)                                                                                                         \
     (stride == 1 ? launch_conv3x3_v2<DT_, 1, 1>(ps, out, features, ring, weights_packed, nullptr, nullptr, n_tiles, Cin, Cout, 1, 1, bso, pr, ept, st) \
                  : launch_conv3x3_v2<DT_, 2, 1>(ps, out, features, ring, weights_packed, nullptr, nullptr, n_tiles, Cin, Cout, 1, 1, bso, pr, ept, st))
@@ -3228,6 +3326,14 @@ BC_EXPORT int bc_conv1x1_nhwc(void *out, const void *features, const void *weigh
     if (dtype == BC_F16) return BC_C1(BC_F16);
     return BC_C1(BC_BF16);
 #undef BC_C1
+}
+
+BC_EXPORT int bc_dyn_set(const void *n_exec_dev, int ceiling)
+{
+    if (n_exec_dev && (ceiling <= 0 || !aligned(n_exec_dev, 4))) return BC_ERR_SHAPE;
+    g_dyn_arm.ptr = static_cast<const int32_t *>(n_exec_dev);
+    g_dyn_arm.ceiling = n_exec_dev ? ceiling : 0;
+    return BC_OK;
 }
 
 BC_EXPORT int bc_tune_set(const char *key, int value)
@@ -3238,6 +3344,7 @@ BC_EXPORT int bc_tune_set(const char *key, int value)
     else if (!strcmp(key, "conv2_min_lds")) g_tune.conv2_min_lds = value;
     else if (!strcmp(key, "xcd_remap")) g_tune.xcd_remap = value;
     else if (!strcmp(key, "stem_min_lds")) g_tune.stem_min_lds = value;
+    else if (!strcmp(key, "head_preload")) g_tune.head_preload = value;
     else return BC_ERR_SHAPE;
     return BC_OK;
 }
@@ -3267,6 +3374,7 @@ BC_EXPORT int bc_conv3x3_ring_nhwc(void *out, const void *features, void *ring, 
                                    int GH, int GW, int bs, int dtype, const float *in_scale, const float *in_shift, int in_relu,
                                    const float *out_scale, const float *out_shift, const void *out_add, int out_relu, void *stream)
 {
+    const DynArm arm = dyn_take();
     if (dtype < BC_F32 || dtype > BC_BF16) return BC_ERR_ELEM;
     if (n_exec < 0 || N <= 0 || Cin <= 0 || Cout <= 0 || GH <= 0 || GW <= 0 || bs <= 0) return BC_ERR_SHAPE;
     if (Cin % CV_CH != 0 || Cout % 64 != 0) return BC_ERR_SHAPE;
@@ -3280,9 +3388,12 @@ BC_EXPORT int bc_conv3x3_ring_nhwc(void *out, const void *features, void *ring, 
     Prologue pr{in_scale, in_shift, in_relu};
     ProfScope ps(BC_OP_CONV3X3, 2.0 * n_exec * bs * bs * 9.0 * Cin * Cout);   // FLOPs, not bytes: the op is MFMA-bound
     // conv_impl = 1 selects the first-generation kernel (fp32 only; A/B runs); default: the CU-balanced kernel (conv3x3_v2.inc)
+    DynCount dyn;
+    if (!dyn_tiles(arm, n_exec, 1, dyn)) return BC_ERR_SHAPE;
     if (g_tune.conv_impl != 1 || dtype != BC_F32) {
         EpilogueT ept{out_scale, out_shift, out_add, out_relu};
         int rc;
+        g_conv_dyn = dyn;
         if (dtype == BC_F32)
             rc = launch_conv3x3_v2<BC_F32, 1>(ps, out, features, ring, weights_packed, grid_idx, mapping_exec, n_exec, Cin, Cout, GH, GW, bs, pr, ept, (hipStream_t)stream);
         else if (dtype == BC_F16)
@@ -3291,6 +3402,7 @@ BC_EXPORT int bc_conv3x3_ring_nhwc(void *out, const void *features, void *ring, 
             rc = launch_conv3x3_v2<BC_BF16, 1>(ps, out, features, ring, weights_packed, grid_idx, mapping_exec, n_exec, Cin, Cout, GH, GW, bs, pr, ept, (hipStream_t)stream);
         if (rc != BC_ERR_SHAPE || dtype != BC_F32) return rc;   // fp32 shapes the balanced kernel does not cover fall through
     }
+    if (dyn.ptr) return BC_ERR_SHAPE;       // (the first-generation kernel has no device-side count)
     g_tune.conv_last_cfg = -1;
     ps.add_aux(2.0 * n_exec * bs * bs * 9.0 * Cin * Cout);
     Epilogue ep{out_scale, out_shift, (const float *)out_add, out_relu};
@@ -3331,6 +3443,7 @@ BC_EXPORT int bc_conv3x3_dil_ring_nhwc(void *out, const void *features, void *ri
     if (dilation == 1)
         return bc_conv3x3_ring_nhwc(out, features, ring, weights_packed, grid_idx, mapping_exec, n_exec, N, Cin, Cout, GH, GW, bs, dtype,
                                     in_scale, in_shift, in_relu, out_scale, out_shift, out_add, out_relu, stream);
+    const DynArm arm = dyn_take();
     if (dtype < BC_F32 || dtype > BC_BF16) return BC_ERR_ELEM;
     if (dilation != 2 || n_exec < 0 || N <= 0 || Cin <= 0 || Cout <= 0 || GH <= 0 || GW <= 0 || bs <= 0) return BC_ERR_SHAPE;
     if (Cin % CV_CH != 0 || Cout % 32 != 0 || bs % 8 != 0 || bs > 248) return BC_ERR_SHAPE;
@@ -3348,6 +3461,7 @@ BC_EXPORT int bc_conv3x3_dil_ring_nhwc(void *out, const void *features, void *ri
     // (this part's dispatcher reads the dtype from the `stride` field: the stride of a dilated launch is always 1)
     ConvV2Args a{out, features, ring, weights_packed, grid_idx, mapping_exec, n_exec, Cin, Cout, GH, GW, bs, dtype, pr, ept, (hipStream_t)stream,
                  ps.on ? 1 : 0, ps.rec.a, ps.rec.b, g_tune.conv2_cfg, g_tune.conv2_min_lds, g_tune.conv_stamps, -2, g_tune.xcd_remap, 2};
+    if (!dyn_tiles(arm, n_exec, 1, a.dyn)) return BC_ERR_SHAPE;
 #if defined(BC_MONO)
     const int rc = dtype == BC_F32 ? conv_v2_dil_run<BC_F32>(a) : (dtype == BC_F16 ? conv_v2_dil_run<BC_F16>(a) : conv_v2_dil_run<BC_BF16>(a));
 #else
@@ -3374,6 +3488,7 @@ BC_EXPORT int bc_stem7x7s2_nhwc(void *out, const void *frame_state, const void *
                                 int N, int H, int W, int bs, int Cout, int dtype, const float *out_scale, const float *out_shift,
                                 const void *out_add, int out_relu, void *stream)
 {
+    const DynArm arm = dyn_take();
     if (dtype < BC_F32 || dtype > BC_BF16) return BC_ERR_ELEM;
     if (n_exec < 0 || N <= 0 || H <= 0 || W <= 0 || bs <= 0 || H % bs || W % bs) return BC_ERR_SHAPE;
     if (Cout != 64 || bs % 2 || (bs / 2) % ST_OW != 0 || (bs / 2) % ST_OH != 0) return BC_ERR_SHAPE;
@@ -3385,6 +3500,7 @@ BC_EXPORT int bc_stem7x7s2_nhwc(void *out, const void *frame_state, const void *
     g.H = H; g.W = W; g.bs = bs; g.GH = H / bs; g.GW = W / bs; g.n_exec = n_exec;
     g.patches_x = (bs / 2) / ST_OW;
     g.patches_per_tile = g.patches_x * ((bs / 2) / ST_OH);
+    if (!dyn_tiles(arm, n_exec, 1, g.dyn)) return BC_ERR_SHAPE;
     EpilogueT ep{out_scale, out_shift, out_add, out_relu};
     const int E = dtype == BC_F32 ? 4 : 2;
     size_t lds = ((size_t)3 * ST_WH * ST_WS + 64) * E + 16;
@@ -3420,6 +3536,7 @@ BC_EXPORT int bc_conv3x3s2_ring_nhwc(void *out, const void *features, void *ring
                                      int GH, int GW, int bs, int dtype, const float *in_scale, const float *in_shift, int in_relu,
                                      const float *out_scale, const float *out_shift, const void *out_add, int out_relu, void *stream)
 {
+    const DynArm arm = dyn_take();
     if (dtype < BC_F32 || dtype > BC_BF16) return BC_ERR_ELEM;
     if (n_exec < 0 || N <= 0 || Cin <= 0 || Cout <= 0 || GH <= 0 || GW <= 0 || bs <= 0 || bs % 2) return BC_ERR_SHAPE;
     const int bso = bs / 2;
@@ -3433,6 +3550,7 @@ BC_EXPORT int bc_conv3x3s2_ring_nhwc(void *out, const void *features, void *ring
     Prologue pr{in_scale, in_shift, in_relu};
     EpilogueT ept{out_scale, out_shift, out_add, out_relu};
     ProfScope ps(BC_OP_CONV3X3, 2.0 * n_exec * bso * bso * 9.0 * Cin * Cout);
+    if (!dyn_tiles(arm, n_exec, 1, g_conv_dyn)) return BC_ERR_SHAPE;
     if (dtype == BC_F32)
         return launch_conv3x3_v2<BC_F32, 2>(ps, out, features, ring, weights_packed, grid_idx, mapping_exec, n_exec, Cin, Cout, GH, GW, bso, pr, ept, (hipStream_t)stream);
     if (dtype == BC_F16)
@@ -3444,6 +3562,7 @@ BC_EXPORT int bc_pad_ring_add_nhwc(void *out, void *act_out, const void *feature
                                    const int32_t *grid_idx, const int32_t *mapping_exec, int n_exec, int N, int C, int GH, int GW,
                                    int bs, int pad, int dtype, const float *scale, const float *shift, int relu, void *stream)
 {
+    const DynArm arm = dyn_take();
     if (dtype < BC_F32 || dtype > BC_BF16) return BC_ERR_ELEM;
     const int E = dtype == BC_F32 ? 4 : 2;
     if (n_exec < 0 || N <= 0 || C <= 0 || GH <= 0 || GW <= 0 || bs <= 0 || pad < 1 || pad > bs) return BC_ERR_SHAPE;
@@ -3459,6 +3578,7 @@ BC_EXPORT int bc_pad_ring_add_nhwc(void *out, void *act_out, const void *feature
     g.C = C; g.bs = bs; g.pad = pad; g.n_total = (uint32_t)N * GH * GW;
     g.per_tile = (uint32_t)(bsp * bsp * K);
     g.epv = 16 / E;
+    if (!dyn_tiles(arm, n_exec, 1, g.dyn)) return BC_ERR_SHAPE;
     const dim3 grid((g.per_tile + WG * UNROLL - 1) / (WG * UNROLL), (unsigned)n_exec);
     const long long ring_delta = ((const char *)ring - (const char *)features) / 16;
     const long long add_delta = ((const char *)add - (const char *)features) / 16;
@@ -3478,6 +3598,7 @@ BC_EXPORT int bc_maxpool3x3s2_ring_nhwc(void *out, const void *features, void *r
                                         const int32_t *mapping_exec, int n_exec, int N, int C, int GH, int GW, int bs, int dtype,
                                         const float *scale, const float *shift, int relu, void *stream)
 {
+    const DynArm arm = dyn_take();
     if (dtype < BC_F32 || dtype > BC_BF16) return BC_ERR_ELEM;
     const int E = dtype == BC_F32 ? 4 : 2;
     if (n_exec < 0 || N <= 0 || C <= 0 || GH <= 0 || GW <= 0 || bs < 2 || (bs & 1)) return BC_ERR_SHAPE;
@@ -3490,6 +3611,7 @@ BC_EXPORT int bc_maxpool3x3s2_ring_nhwc(void *out, const void *features, void *r
     const uint32_t K = (uint32_t)((size_t)C * E / 16), OB = bs / 2;
     g.K = make_fd(K); g.OB = make_fd(OB); g.GW = make_fd(GW); g.GH = make_fd(GH);
     g.bs = bs; g.n_total = (uint32_t)N * GH * GW; g.per_tile = OB * OB * K;
+    if (!dyn_tiles(arm, n_exec, 1, g.dyn)) return BC_ERR_SHAPE;
     const dim3 grid((g.per_tile + WG - 1) / WG, (unsigned)n_exec);
     const long long delta = ((const char *)ring - (const char *)features) / 16;
     const bool act = scale || shift || relu;
@@ -3509,6 +3631,7 @@ BC_EXPORT int bc_maxpool3x3s2_ring_nhwc(void *out, const void *features, void *r
 BC_EXPORT int bc_affine_act_nhwc(void *out, const void *in, const void *add, const float *scale, const float *shift, int relu,
                                  long long pixels, int C, int dtype, void *stream)
 {
+    const DynArm arm = dyn_take();
     if (dtype < BC_F32 || dtype > BC_BF16) return BC_ERR_ELEM;
     if (pixels < 0 || C <= 0) return BC_ERR_SHAPE;
     if (pixels == 0) return BC_OK;
@@ -3521,8 +3644,9 @@ BC_EXPORT int bc_affine_act_nhwc(void *out, const void *in, const void *add, con
     const FastDiv Cq = make_fd((uint32_t)(C / q));
     const uint32_t total = (uint32_t)((uint64_t)pixels * (C / q));
     const int grid = grid_exact(total, 1);
+    const DynCount dyn = dyn_flat(arm, total);
     ProfScope ps(BC_OP_AFFINE, (add ? 3.0 : 2.0) * pixels * C * E);
-#define BC_AN(T_, Q_) BC_LAUNCH(ps, (k_affine_act_nhwc<T_, Q_>), dim3(grid), dim3(WG), 0, st, (T_ *)out, (const T_ *)in, (const T_ *)add, scale, shift, relu, Cq, total)
+#define BC_AN(T_, Q_) BC_LAUNCH(ps, (k_affine_act_nhwc<T_, Q_>), dim3(grid), dim3(WG), 0, st, (T_ *)out, (const T_ *)in, (const T_ *)add, scale, shift, relu, Cq, total, dyn)
 #define BC_ANQ(T_, QMAX_) do { if (q == QMAX_) BC_AN(T_, QMAX_); else if (q == QMAX_ / 2) BC_AN(T_, QMAX_ / 2);     \
                                else if (QMAX_ >= 8 && q == 2) BC_AN(T_, 2); else BC_AN(T_, 1); } while (0)
     if (dtype == BC_F32) BC_ANQ(float, 4);
@@ -3634,6 +3758,7 @@ BC_EXPORT int bc_interp_bilinear_act_nhwc(void *out, const void *in, long long p
                                           int align_corners, float rh, float rw, int dtype, const float *scale, const float *shift,
                                           const void *add, int relu, void *stream)
 {
+    const DynArm arm = dyn_take();
     if (dtype < BC_F32 || dtype > BC_BF16) return BC_ERR_ELEM;
     if (planes < 0 || C <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return BC_ERR_SHAPE;
     if (planes == 0) return BC_OK;
@@ -3648,6 +3773,7 @@ BC_EXPORT int bc_interp_bilinear_act_nhwc(void *out, const void *in, long long p
     g.Cq = make_fd((uint32_t)(C / q)); g.W = make_fd(W); g.H = make_fd(H);
     g.h = h; g.w = w; g.rh = rh; g.rw = rw; g.align = align_corners;
     g.total = (uint32_t)((uint64_t)planes * H * W * (C / q));
+    g.dyn = dyn_flat(arm, g.total);
     const int grid = grid_exact(g.total, 1);
     ProfScope ps(BC_OP_INTERP, ((double)planes * h * w + (double)planes * H * W * (add ? 2 : 1)) * C * E);
 #define BC_IN(T_, Q_) BC_LAUNCH(ps, (k_interp_bilinear_nhwc<T_, Q_>), dim3(grid), dim3(WG), 0, st, (T_ *)out, (const T_ *)in, g, ep)

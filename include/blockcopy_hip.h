@@ -92,6 +92,20 @@ int bc_combine_copy(const void *blocks, const void *prev, void *out, const int32
  * (s_memrealtime) in cell i -- graph kernel nodes cannot carry start / stop events; launch time = max(exit) - min(entry). */
 int bc_combine_copy_indirect(const void *blocks, const void *slots, const int32_t *grid_idx,
                              int N, int C, int H, int W, int bs, int elem_size, int align, void *stream);
+/* Executed-tile count known only on the DEVICE.  A policy that decides on the device (bc_policy_step) leaves the count in device memory;
+ * a host that does not want to wait for it launches every op of the frame sized for a CEILING (normally: every tile executed) and arms
+ * each launch with
+ *     bc_dyn_set(n_exec_dev, ceiling)      n_exec_dev: device int32, read when the kernel RUNS; ceiling: the n_exec the launch is sized for
+ * which applies to the NEXT launch of one of the functions below only (they consume it at entry; bc_dyn_set(NULL, 0) disarms).  The
+ * kernel then works on the first *n_exec_dev tiles / packed rows and its surplus workgroups exit at once, so ONE captured hipGraph
+ * serves every count (the reference needs the count on the host for every launch: int(grid.sum()) policy/policy.py:84, tensor shapes).
+ * Index tables: rows >= *n_exec_dev of mapping_exec are never read.  Capable: bc_split, bc_combine, bc_pad_ring, bc_pad_ring_act, bc_pad_ring_nhwc,
+ * bc_pad_ring_add_nhwc, bc_maxpool3x3s2_ring_nhwc, bc_conv3x3_ring_nhwc, bc_conv3x3s2_ring_nhwc, bc_conv3x3_dil_ring_nhwc,
+ * bc_conv1x1_nhwc, bc_stem7x7s2_nhwc, bc_head1x1_scatter_nhwc (the copy half then always runs), bc_affine_act_nhwc,
+ * bc_interp_bilinear(_act)_nhwc; bc_tile_copy_indirect takes the pointer as an argument.  Tile-indexed launches must be sized exactly
+ * for `ceiling` (BC_ERR_SHAPE otherwise); pointwise ones (affine, interp, conv1x1) scale their unit count by *n_exec_dev / ceiling. */
+int bc_dyn_set(const void *n_exec_dev, int ceiling);
+
 /* The network-INPUT stage of a graph-replayed frame: dst[tile] = src[tile] for every executed tile (mapping_exec) of two dense maps of
  * one geometry (N,C,H,W) -- src = the caller's frame, dst = the persistent frame-state map.  Equals the reference's
  * to_blocks(split) + combine_ of the network input (core/blockcopy.py:62-68, frame_state = "latest executed frame per block") without

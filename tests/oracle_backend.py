@@ -38,9 +38,48 @@ def _like(t, ref):
     return t.contiguous(memory_format=torch.channels_last) if _nhwc(ref) else t.contiguous()
 
 
+def _dynamic(fn):
+    """Checker form of a ceiling-sized launch with a device-side executed-tile count (HipBackend._arm / bc_dyn_set): with
+    ``dyn = (n_exec_dev, ceiling)`` the op is run on the first ``n = *n_exec_dev`` packed rows -- every 4-D tensor argument with
+    ``ceiling`` rows (also inside prologue / epilogue tuples) and the 1-D ``mapping_exec`` are cut to ``n`` -- and the result is padded
+    back to ``ceiling`` rows of NaN (rows nobody may consume: a consumer that does becomes loud)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *args, dyn=None, **kwargs):
+        if dyn is None:
+            return fn(self, *args, **kwargs)
+        n, ceiling = int(dyn[0][0]), int(dyn[1])
+        assert 0 <= n <= ceiling
+
+        def cut(a):
+            if isinstance(a, torch.Tensor) and ((a.dim() == 4 and a.shape[0] == ceiling) or (a.dim() == 1 and a.dtype == torch.int32 and a.numel() == ceiling)):
+                return a[:n]
+            if isinstance(a, tuple):
+                return tuple(cut(v) for v in a)
+            return a
+
+        def grow(r):
+            if isinstance(r, torch.Tensor) and r.dim() == 4 and r.shape[0] == n:
+                full = torch.full((ceiling,) + tuple(r.shape[1:]), float("nan"), dtype=r.dtype).contiguous(memory_format=torch.channels_last if _nhwc(r) else torch.contiguous_format)
+                full[:n] = r
+                return full
+            if isinstance(r, tuple):
+                return tuple(grow(v) for v in r)
+            return r
+
+        out = fn(self, *[cut(a) for a in args], **{k: cut(v) for k, v in kwargs.items()})
+        if fn.__name__ == "split":
+            return args[0]                       # (filled in place through the cut view)
+        return grow(out)
+
+    return wrapper
+
+
 class OracleBackend:
     name = "oracle-cpu"
 
+    @_dynamic
     def split(self, blocks, image, mapping_exec, grid_idx):
         if mapping_exec.numel():
             tmp = torch.empty(blocks.shape, dtype=blocks.dtype)
@@ -48,6 +87,7 @@ class OracleBackend:
             blocks.copy_(tmp)
         return blocks
 
+    @_dynamic
     def combine(self, blocks, out, grid_idx, mapping_exec):
         if mapping_exec.numel():
             tmp = out.contiguous()
@@ -100,6 +140,7 @@ class OracleBackend:
             O.c_combine(blocks, dst, m)
         return dst
 
+    @_dynamic
     def pad_ring(self, data_exec, ring, grid_idx, mapping_exec, pad, prologue=None):
         if _nhwc(data_exec):   # ring records are opaque to the host: the checker keeps its own (NCHW-style) convention
             return _like(self.pad_ring(data_exec.contiguous(), ring, grid_idx, mapping_exec, pad, prologue), data_exec)
@@ -117,6 +158,7 @@ class OracleBackend:
 
     supports_fusion_dtypes = (torch.float32,)
 
+    @_dynamic
     def affine_act(self, data, scale=None, shift=None, add=None, relu=False):
         y = data.float()
         if scale is not None:
@@ -134,6 +176,7 @@ class OracleBackend:
     def pad_ring_add_supported(data_exec, add):
         return _nhwc(data_exec) and add.shape == data_exec.shape and add.dtype == data_exec.dtype
 
+    @_dynamic
     def pad_ring_add(self, data_exec, add, ring, grid_idx, mapping_exec, pad, prologue):
         """residual gather == fused affine pass, then a plain halo gather of its result (ring keeps the activated values)."""
         scale, shift, relu = prologue
@@ -144,6 +187,7 @@ class OracleBackend:
     def maxpool3x3s2_supported(data_exec):
         return _nhwc(data_exec) and data_exec.shape[2] == data_exec.shape[3] and data_exec.shape[2] % 2 == 0
 
+    @_dynamic
     def maxpool3x3s2_ring(self, data_exec, ring, grid_idx, mapping_exec, prologue=None):
         """fused halo + pool == halo gather, then the stock pad-0 pool."""
         padded = self.pad_ring(data_exec, ring, grid_idx, mapping_exec, 1, prologue)
@@ -160,6 +204,7 @@ class OracleBackend:
     def pack_conv3x3_weights(weight):
         return weight.detach().contiguous().reshape(-1)        # the checker keeps the plain (Cout, Cin, 3, 3) order
 
+    @_dynamic
     def conv3x3_ring(self, data_exec, ring, wpk, cout, grid_idx, mapping_exec, prologue=None, epilogue=None, cfg=None, stride=1, dilation=1):
         padded = self.pad_ring(data_exec, ring, grid_idx, mapping_exec, dilation, prologue)
         w = wpk.reshape(cout, data_exec.shape[1], 3, 3)
@@ -174,6 +219,7 @@ class OracleBackend:
         return (data.dim() == 4 and _nhwc(data) and tuple(weight.shape[2:]) == (1, 1) and one(stride) in (1, 2) and one(padding) == 0
                 and one(dilation) == 1 and groups == 1 and data.dtype == torch.float32 and (data.shape[0] * data.shape[2] * data.shape[3]) % 64 == 0)
 
+    @_dynamic
     def conv1x1(self, data, wpk, cout, prologue=None, epilogue=None, cfg=None, stride=1):
         x = data
         if prologue is not None:
@@ -252,9 +298,11 @@ class OracleBackend:
     def pack_head1x1_weights(weight):
         return weight.detach().clone()
 
+    @_dynamic
     def head1x1(self, data, wpk, cout, prologue=None, epilogue=None, cfg=None, stride=1):
         return self.conv1x1(data, wpk, cout, prologue, epilogue)
 
+    @_dynamic
     def head1x1_scatter(self, data, wpk, cout, prologue, bias, grid_idx, mapping_exec, prev=None, out=None, slots=None, targets=None):
         """Checker form: pointwise conv by composition, then clone + scatter (the reference's non-in-place combine)."""
         if slots is not None:
@@ -292,6 +340,7 @@ class OracleBackend:
     def interp_epilogue_supported(data):
         return _nhwc(data)
 
+    @_dynamic
     def interp_bilinear(self, data, out_h, out_w, align_corners, rh, rw, epilogue=None):
         # floating-point op: the checker is stock PyTorch on the packed batch (per tile, no halo)
         y = _like(torch.nn.functional.interpolate(data.contiguous(), size=(out_h, out_w), mode="bilinear",

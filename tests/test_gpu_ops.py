@@ -1325,3 +1325,141 @@ def test_tile_copy_indirect_equals_split_then_combine(be, case, dtype):
             O.c_split(blocks, frame, m)
             O.c_combine(blocks, want, m)
         assert torch.equal(dst.cpu(), want), (case, "dynamic", k)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Device-side executed-tile count (bc_dyn_set, core/graphs.py dynamic mode): a launch sized for a CEILING of `total` tiles whose
+# kernel reads the actual count k from device memory must leave exactly what the exact launch on k tiles leaves -- the first k packed
+# rows, the ring cache, the dense maps -- bit for bit, whatever garbage the packed rows >= k and the table rows >= k hold.
+def _dyn_case(total, k, seed):
+    """(grid_idx, mapping of the k executed tiles, mapping padded to `total` rows with stale-but-valid entries)"""
+    rng = np.random.default_rng(seed)
+    grid = np.zeros(total, bool)
+    grid[rng.permutation(total)[:k]] = True
+    return grid, rng.permutation(total).astype(np.int32)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("geo", [(1, 2, 4, 16, 64, 64), (1, 3, 3, 8, 128, 64), (2, 2, 2, 4, 256, 128), (1, 2, 3, 32, 64, 128)])
+def test_dynamic_count_equals_exact_launch(be, geo, dtype):
+    N, GH, GW, bs, cin, cout = geo
+    total = N * GH * GW
+    g = torch.Generator().manual_seed(sum(geo))
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last)
+    n_dev = torch.zeros(4, dtype=torch.int32, device="cuda")
+    w3 = (torch.randn((cout, cin, 3, 3), generator=g) / (3 * cin ** 0.5)).to(dtype).cuda().contiguous(memory_format=torch.channels_last)
+    w1 = (torch.randn((cout, cin, 1, 1), generator=g) / cin ** 0.5).to(dtype).cuda()
+    wh = (torch.randn((19, cin, 1, 1), generator=g) / cin ** 0.5).to(dtype).cuda()
+    wpk3, wpk1 = be.pack_conv3x3_weights(w3), be.pack_conv3x3_weights(w1)
+    scale, shift = (torch.rand(cin, generator=g) + 0.5).cuda(), (torch.randn(cin, generator=g) * 0.2).cuda()
+    oscale, oshift = (torch.rand(cout, generator=g) + 0.5).cuda(), (torch.randn(cout, generator=g) * 0.2).cuda()
+    for k in (0, 1, total // 2, total - 1, total):
+        grid, stale = _dyn_case(total, k, 11 * k + 1)
+        gi, m = O.c_grid_mappings(grid.reshape(N, 1, GH, GW))
+        gi_d, m_d = _dev(gi), _dev(m)
+        m_full = stale.copy()
+        m_full[:k] = m                                    # rows >= k: stale but valid tile indices (what a previous frame left there)
+        m_full_d = _dev(m_full)
+        n_dev[0] = k
+        dyn = (n_dev, total)
+        x_full = cl((torch.randn((total, cin, bs, bs), generator=g) * 0.5).to(dtype).cuda())
+        add_full = cl((torch.randn((total, cout, bs, bs), generator=g) * 0.5).to(dtype).cuda())
+        x, add = cl(x_full[:k].clone()), cl(add_full[:k].clone())
+        ring0 = torch.randn((total, cin, 4 * bs), generator=g).to(dtype).cuda()
+
+        def both(fn_exact, fn_dyn, what, rings=True):
+            ra, rb = ring0.clone(), ring0.clone()
+            a = fn_exact(ra) if k else None
+            b_ = fn_dyn(rb)
+            for ya, yb in zip(a if isinstance(a, tuple) else (a,), b_ if isinstance(b_, tuple) else (b_,)):
+                if k:
+                    assert yb.shape[0] == total and torch.equal(ya, yb[:k]), (what, geo, k)
+            if rings:
+                assert torch.equal(ra, rb), (what, "ring", geo, k)
+
+        # halo gather / residual gather / fused pool
+        both(lambda r: be.pad_ring(x, r, gi_d, m_d, 1, (scale, shift, True)), lambda r: be.pad_ring(x_full, r, gi_d, m_full_d, 1, (scale, shift, True), dyn=dyn), "pad_ring")
+        if cin == cout:
+            both(lambda r: be.pad_ring_add(x, add, r, gi_d, m_d, 1, (scale, shift, True)),
+                 lambda r: be.pad_ring_add(x_full, add_full, r, gi_d, m_full_d, 1, (scale, shift, True), dyn=dyn), "pad_ring_add")
+        both(lambda r: be.maxpool3x3s2_ring(x, r, gi_d, m_d, (scale, shift, True)), lambda r: be.maxpool3x3s2_ring(x_full, r, gi_d, m_full_d, (scale, shift, True), dyn=dyn), "maxpool")
+        # the NCHW halo kernels (network input of models whose stem is not the fused kernel): rows / lds / simple forms by size
+        xn_full, xn = x_full.contiguous(), x.contiguous()
+        both(lambda r: be.pad_ring(xn, r, gi_d, m_d, 1, None), lambda r: be.pad_ring(xn_full, r, gi_d, m_full_d, 1, None, dyn=dyn), "pad_ring nchw")
+        both(lambda r: be.pad_ring(xn, r, gi_d, m_d, 1, (scale, shift, True)), lambda r: be.pad_ring(xn_full, r, gi_d, m_full_d, 1, (scale, shift, True), dyn=dyn), "pad_ring_act nchw")
+        # fused convs: every candidate decomposition of the ceiling launch (direct, Winograd, wide Winograd), stride 1 and 2
+        for stride in (1, 2):
+            if bs // stride < 4:
+                continue
+            cands = be.conv3x3_candidates(total, cin, cout, bs, x.element_size(), stride)
+            assert cands
+            for c in cands[::3] + cands[-1:]:
+                if k and c not in be.conv3x3_candidates(k, cin, cout, bs, x.element_size(), stride):
+                    continue
+                addk = cl(add_full[:k, :, ::stride, ::stride].clone()) if k else None
+                addf = cl(add_full[:, :, ::stride, ::stride].clone())
+                both(lambda r: be.conv3x3_ring(x, r, wpk3, cout, gi_d, m_d, (scale, shift, True), (oscale, oshift, addk, True), cfg=c, stride=stride),
+                     lambda r: be.conv3x3_ring(x_full, r, wpk3, cout, gi_d, m_full_d, (scale, shift, True), (oscale, oshift, addf, True), cfg=c, stride=stride, dyn=dyn),
+                     f"conv3x3 cfg {c} stride {stride}")
+        # pointwise conv (one-tap and GEMM forms), elementwise pass, per-tile bilinear
+        for c in be.conv1x1_candidates(x_full, cout, 1):
+            if k and c not in be.conv1x1_candidates(x, cout, 1):
+                continue
+            both(lambda r: be.conv1x1(x, wpk1, cout, (scale, shift, True), (oscale, oshift, add, True), cfg=c),
+                 lambda r: be.conv1x1(x_full, wpk1, cout, (scale, shift, True), (oscale, oshift, add_full, True), cfg=c, dyn=dyn), f"conv1x1 cfg {c}", rings=False)
+        both(lambda r: be.affine_act(x, scale, shift, None, True), lambda r: be.affine_act(x_full, scale, shift, None, True, dyn=dyn), "affine", rings=False)
+        both(lambda r: be.interp_bilinear(x, 2 * bs, 2 * bs, False, np.float32(0.5), np.float32(0.5), None),
+             lambda r: be.interp_bilinear(x_full, 2 * bs, 2 * bs, False, np.float32(0.5), np.float32(0.5), None, dyn=dyn), "interp", rings=False)
+        # gather / in-place scatter
+        dense = torch.randn((N, 5, GH * bs, GW * bs), generator=g).to(dtype).cuda()
+        pk_a, pk_b = torch.zeros((k, 5, bs, bs), dtype=dtype, device="cuda"), torch.zeros((total, 5, bs, bs), dtype=dtype, device="cuda")
+        if k:
+            be.split(pk_a, dense, m_d, gi_d)
+        be.split(pk_b, dense, m_full_d, gi_d, dyn=dyn)
+        assert torch.equal(pk_a, pk_b[:k]) and bool((pk_b[k:] == 0).all()), ("split", geo, k)
+        da, db = dense.clone(), dense.clone()
+        src = torch.randn((total, 5, bs, bs), generator=g).to(dtype).cuda()
+        if k:
+            be.combine(src[:k].contiguous(), da, gi_d, m_d)
+        be.combine(src, db, gi_d, m_full_d, dyn=dyn)
+        assert torch.equal(da, db), ("combine", geo, k)
+        # output stage: packed mode and scatter + copy
+        if be.head1x1_supported(x_full, wh):
+            wpkh = be.pack_head1x1_weights(wh)
+            bias = torch.randn(19, generator=g).cuda()
+            both(lambda r: be.head1x1(x, wpkh, 19, (scale, shift, True), (None, bias, None, False)),
+                 lambda r: be.head1x1(x_full, wpkh, 19, (scale, shift, True), (None, bias, None, False), dyn=dyn), "head packed", rings=False)
+            prev = cl(torch.randn((N, 19, GH * bs, GW * bs), generator=g).to(dtype).cuda())
+            oa, ob = cl(torch.full(prev.shape, 7.0, dtype=dtype).cuda()), cl(torch.full(prev.shape, 9.0, dtype=dtype).cuda())
+            if k:
+                be.head1x1_scatter(x, wpkh, 19, (scale, shift, True), bias, gi_d, m_d, prev=prev, out=oa)
+            else:
+                oa.copy_(prev)
+            be.head1x1_scatter(x_full, wpkh, 19, (scale, shift, True), bias, gi_d, m_full_d, prev=prev, out=ob, dyn=dyn)
+            assert torch.equal(oa, ob), ("head scatter", geo, k)
+    # an armed count never leaks into a later launch: exact launches right after armed ones behave as ever
+    n_dev[0] = 0
+    y = be.affine_act(x_full, scale, shift, None, True)
+    assert torch.equal(y, torch.relu(x_full.float() * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)).to(dtype))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_dynamic_count_stem(be, dtype):
+    """bc_stem7x7s2_nhwc with a device-side count: the first k packed rows equal the exact launch on k tiles."""
+    N, GH, GW, bs = 1, 2, 3, 64
+    total = N * GH * GW
+    g = torch.Generator().manual_seed(5)
+    fs = torch.randn((N, 3, GH * bs, GW * bs), generator=g).to(dtype).cuda()
+    w = (torch.randn((64, 3, 7, 7), generator=g) / 12).to(dtype).cuda().contiguous(memory_format=torch.channels_last)
+    wpk = be.pack_stem7x7_weights(w)
+    n_dev = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for k in (0, 1, 3, total):
+        grid, stale = _dyn_case(total, k, k + 3)
+        _, m = O.c_grid_mappings(grid.reshape(N, 1, GH, GW))
+        m_full = stale.copy()
+        m_full[:k] = m
+        n_dev[0] = k
+        got = be.stem7x7(fs, wpk, _dev(m_full), bs, None, dyn=(n_dev, total))
+        if k:
+            want = be.stem7x7(fs, wpk, _dev(m), bs, None)
+            assert torch.equal(want, got[:k]), k
