@@ -113,23 +113,30 @@ def measure_fps_with_upload(model, host_clips, n_clips: int, warmup_clips: int =
             bufs[i].copy_(frame, non_blocking=True)       # fp32 -> dtype conversion happens on the device side of the copy
             staged[i].record(copy)
 
-    def run(clip):
+    state = {"slot": 0, "primed": False}      # double-buffer slot of the next frame; whether that frame is already on its way
+
+    def run(clip, next_clip=None):
         if hasattr(model, "reset_temporal"):
             model.reset_temporal()
         preds = None
-        if prefetch:
-            upload(clip[0], 0)
+        if prefetch and not state["primed"]:
+            upload(clip[0], state["slot"])
         for t, frame in enumerate(clip):
             if prefetch:
-                if t + 1 < len(clip):
-                    upload(clip[t + 1], (t + 1) % 2)
-                compute.wait_event(staged[t % 2])
-                inputs = bufs[t % 2]
+                k = state["slot"]
+                # frame t + 1 -- or the first frame of the NEXT clip -- travels while frame t is computed
+                nxt = clip[t + 1] if t + 1 < len(clip) else (next_clip[0] if next_clip is not None else None)
+                if nxt is not None:
+                    upload(nxt, 1 - k)
+                state["primed"] = nxt is not None
+                compute.wait_event(staged[k])
+                inputs = bufs[k]
+                state["slot"] = 1 - k
             else:
                 inputs = frame.to(dev, non_blocking=True, dtype=dtype)
             out = model(inputs)
             if prefetch:
-                consumed[t % 2].record(compute)
+                consumed[k].record(compute)
             if t == len(clip) - 1:
                 out = torch.nn.functional.interpolate(out, size=inputs.shape[2:], mode="bilinear")
                 preds = out.detach().max(dim=1)[1]
@@ -162,7 +169,8 @@ def measure_fps_with_upload(model, host_clips, n_clips: int, warmup_clips: int =
     n_frames = 0
     for i in range(n_clips):
         clip = host_clips[i % len(host_clips)]
-        preds = run(clip)
+        nxt = host_clips[(i + 1) % len(host_clips)] if i + 1 < n_clips else None
+        preds = run(clip, nxt)
         n_frames += len(clip) * clip[0].shape[0]
     sync(dev)
     dt = time.perf_counter() - t0

@@ -32,6 +32,7 @@ class BlockCopyModel(nn.Module):
         # MI355X-first: replay the packed pipeline as a hipGraph (core/graphs.py): 1 = one graph per executed-tile count, 2 = ONE graph
         # for every count (launches sized for all tiles, the count read from the device: no wait for a device-side policy decision)
         self.use_graph = int(settings.get("block_graph", int(os.environ.get("BLOCKCOPY_GRAPH", "0"))))
+        self.block_target = settings.get("block_target", None)
         self._graphed = {}
         self.reset_temporal()
 
@@ -112,7 +113,7 @@ def prewarm(self, inputs, counts=None, **kwargs):
     key = (tuple(inputs.shape), inputs.dtype, inputs.device)
     gf = self._graphed.get(key)
     if gf is None:
-        gf = self._graphed[key] = GraphedFrame(inputs, self.block_size, dynamic=self.use_graph == 2)
+        gf = self._graphed[key] = GraphedFrame(inputs, self.block_size, dynamic=self.use_graph == 2, plan_fraction=self.block_target)
     total = gf.n_total
     if gf.dynamic:
         counts = [total]        # one graph serves every count: warm and capture it on the all-active frame
@@ -142,7 +143,7 @@ def _forward_graphed(self, inputs, **kwargs):
     key = (tuple(inputs.shape), inputs.dtype, inputs.device)
     gf = self._graphed.get(key)
     if gf is None:
-        gf = self._graphed[key] = GraphedFrame(inputs, self.block_size, dynamic=self.use_graph == 2)
+        gf = self._graphed[key] = GraphedFrame(inputs, self.block_size, dynamic=self.use_graph == 2, plan_fraction=self.block_target)
     grid = self.policy_meta["grid"]
     dev_tables = self.policy_meta.pop("grid_tables", None)
     if dev_tables is not None:

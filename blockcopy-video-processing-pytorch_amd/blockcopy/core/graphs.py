@@ -61,7 +61,7 @@ class _Bucket:
 class GraphedFrame:
     """Static buffers + captured graphs for one (input shape, dtype)."""
 
-    def __init__(self, inputs: torch.Tensor, block_size: int, dynamic: bool = False):
+    def __init__(self, inputs: torch.Tensor, block_size: int, dynamic: bool = False, plan_fraction: float = None):
         N, C, H, W = inputs.shape
         assert H % block_size == 0 and W % block_size == 0
         self.block_size = block_size
@@ -77,6 +77,11 @@ class GraphedFrame:
         self.counts = self.tables[2 * self.n_total:2 * self.n_total + COUNT_WORDS]     # counts[0] = this frame's executed-tile count
         self.slots = self.tables[2 * self.n_total + COUNT_WORDS:].view(torch.int64)
         self.dynamic = bool(dynamic) and hasattr(get_backend(), "tile_copy_indirect") and GRAPH_INPUT
+        # dynamic mode: the conv plan table is asked about the count the policy is EXPECTED to produce (its target fraction, rounded up to
+        # the policies' quantisation step), not about the ceiling the launches are sized for -- a decomposition that fills the chip with
+        # all tiles executed leaves most of it idle at 30 %
+        step = max(1, self.n_total // 16)
+        self.plan_count = None if plan_fraction is None else min(self.n_total, max(step, -(-int(round(plan_fraction * self.n_total)) // step) * step))
         self.state = PersistentState()
         self.buckets = {}
         self.pool = None
@@ -184,6 +189,7 @@ class GraphedFrame:
             # every launch on a packed tensor is sized for all tiles and reads the actual count from counts[0] (see module docstring)
             n_exec = self.n_total
             feats.dyn = (self.counts, self.n_total)
+            feats.plan_n_exec = self.plan_count
         dkw = {} if feats.dyn is None else {"dyn": feats.dyn}
         feats._mapping_exec = self.tables[self.n_total:self.n_total + n_exec]
         feats.n_exec, feats.n_total = n_exec, self.n_total

@@ -214,6 +214,9 @@ class BlockFeatures:
         # (n_exec_dev: device int32[1], ceiling) when the body is sized for a ceiling and the executed-tile count is read from the
         # device by every packed-tensor launch (core/graphs.py dynamic mode; include/blockcopy_hip.h bc_dyn_set); None = exact shapes
         self.dyn = None
+        # dynamic mode: the executed-tile count the conv plan table is asked about (the kernel FORM of a layer is chosen for the count
+        # the policy is expected to produce, the launch is sized for the ceiling); None = the actual count
+        self.plan_n_exec = None
 
     # ------------------------------------------------------------------ grid -> index tables
     def _process_grid(self, grid: torch.Tensor, meta_prev: "BlockFeatures" = None, grid_host: torch.Tensor = None) -> None:
@@ -992,6 +995,7 @@ class TensorWrapper(torch.Tensor):
         dil = 1 if padding == 1 else 2
         n_exec, cin, bs = data.shape[0], data.shape[1], data.shape[2]
         cout, n_total = weight.shape[0], grid_idx.numel()
+        n_plan = self._features.plan_n_exec or n_exec        # (dynamic graph: form chosen for the expected count, see BlockFeatures.plan_n_exec)
         stride = self._conv_stride(args, kwargs)
 
         def tuner():
@@ -1017,7 +1021,10 @@ class TensorWrapper(torch.Tensor):
             return be.conv3x3_candidates(n_exec, cin, cout, bs, data.element_size(), stride, **({} if dil == 1 else {"dilation": dil}))
 
         # (plan-table key: kernel-size field 3 for the plain form, 13 for dilation 2)
-        return fusion.conv3x3_plan(n_exec, bs, cin, cout, n_total, data.dtype, tuner, stride, ks=3 if dil == 1 else 13, candidates=candidates)
+        plan = fusion.conv3x3_plan(n_plan, bs, cin, cout, n_total, data.dtype, tuner, stride, ks=3 if dil == 1 else 13, candidates=candidates)
+        if plan is None and self._features.dyn is not None:
+            plan = -1       # (a library conv on a ceiling-sized packed tensor would compute every row: the own kernel reads the count)
+        return plan
 
     def _dense_pointwise_conv(self, args, kwargs):
         """conv2d on a dense (non-packed) TensorWrapper: 1x1 convs take the fused one-tap kernel; returns (result, pending) or None."""
@@ -1073,6 +1080,8 @@ class TensorWrapper(torch.Tensor):
         P = x._pending
         foldable = P is not None and P.add is None and not P.deferred
         n_px, cin, cout = raw.shape[0] * raw.shape[2] * raw.shape[3], raw.shape[1], weight.shape[0]
+        dyn_rows = x._dyn() is not None
+        n_px_plan = (x._features.plan_n_exec or raw.shape[0]) * raw.shape[2] * raw.shape[3] if dyn_rows else n_px
 
         def tuner():
             if not raw.is_cuda:
@@ -1094,7 +1103,9 @@ class TensorWrapper(torch.Tensor):
                 routes[str(c)] = (lambda c_: lambda: be.conv1x1(src, wpk, cout, pro, None, cfg=c_, stride=stride))(c)
             return be.time_routes(routes)
 
-        plan = fusion.conv3x3_plan(n_px // 64, 8, cin, cout, int(foldable), raw.dtype, tuner, stride, ks=1)
+        plan = fusion.conv3x3_plan(max(1, n_px_plan // 64), 8, cin, cout, int(foldable), raw.dtype, tuner, stride, ks=1)
+        if plan is None and dyn_rows:
+            plan = -1       # (see _conv3x3_plan: the library route would run on every row of the ceiling-sized tensor)
         if plan is None:
             return None
         if stride != 1 and plan >= 0:

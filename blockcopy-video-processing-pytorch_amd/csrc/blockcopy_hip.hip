@@ -2632,7 +2632,6 @@ struct TuneState {
     // XCD-aware workgroup order of the conv kernels (xcd_remap in conv3x3_v2.inc).  Measured neutral on every layer shape of the configs
     // (profiles/r03/11: +-2 %, the weights of a layer are served by the Infinity Cache either way), so the launch order stays the default
     int xcd_remap = [] { const char *e = getenv("BC_XCD_REMAP"); return e ? atoi(e) : 0; }();
-    int head_preload = [] { const char *e = getenv("BC_HEAD_PRELOAD"); return e ? atoi(e) : 1; }();       // k_head1x1: all chunks of an M-block in flight at once
 } g_tune;
 
 
@@ -2873,7 +2872,6 @@ BC_EXPORT int bc_head1x1_scatter_nhwc(void *out, const void *features, const voi
     g.n_waves = ((want + 3) / 4) * 4;
     g.run_px = bs < 32 ? bs : 32;
     g.runs = 32 / g.run_px;
-    g.preload = (uint32_t)g_tune.head_preload;
     Prologue pr{in_scale, in_shift, in_relu};
     const double px = (double)n_exec * bs * bs;
     // algorithmic bytes: packed features read; scatter: every skipped tile read once from the previous map + the whole map written
@@ -3344,7 +3342,6 @@ BC_EXPORT int bc_tune_set(const char *key, int value)
     else if (!strcmp(key, "conv2_min_lds")) g_tune.conv2_min_lds = value;
     else if (!strcmp(key, "xcd_remap")) g_tune.xcd_remap = value;
     else if (!strcmp(key, "stem_min_lds")) g_tune.stem_min_lds = value;
-    else if (!strcmp(key, "head_preload")) g_tune.head_preload = value;
     else return BC_ERR_SHAPE;
     return BC_OK;
 }

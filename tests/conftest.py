@@ -54,3 +54,14 @@ def oracle_backend():
     prev = bk.set_backend(OracleBackend())
     yield
     bk.set_backend(prev)
+
+
+@pytest.fixture(autouse=True)
+def _engine_is_restored():
+    """Every test starts (and leaves the next one) on the default engine: a test that selects the reference decomposition and fails --
+    or forgets -- must not change what later tests measure."""
+    from blockcopy.core import tensorwrapper as tw
+
+    tw.set_engine("fused")
+    yield
+    tw.set_engine("fused")

@@ -1440,7 +1440,8 @@ def test_dynamic_count_equals_exact_launch(be, geo, dtype):
     # an armed count never leaks into a later launch: exact launches right after armed ones behave as ever
     n_dev[0] = 0
     y = be.affine_act(x_full, scale, shift, None, True)
-    assert torch.equal(y, torch.relu(x_full.float() * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)).to(dtype))
+    want = torch.relu(x_full.float() * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    assert float((y.float() - want).abs().max()) <= (2e-6 if dtype == torch.float32 else 2e-3) * max(1.0, float(want.abs().max()))     # every row computed
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])

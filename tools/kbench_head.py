@@ -28,8 +28,7 @@ def main():
             scale, shift, bias = torch.rand(cin, device="cuda") + 0.5, torch.randn(cin, device="cuda"), torch.randn(cout, device="cuda")
             prev = cl(torch.randn((1, cout, GH * bs, GW * bs), device="cuda").to(dtype))
             out = torch.empty_like(prev)
-            for preload, cold in ((p, c) for p in ((0, 1) if os.environ.get("KBENCH_HEAD_AB") else (1,)) for c in (True, False)):
-                be.tune("head_preload", preload)
+            for cold in (True, False):
                 be.prof_reset()
                 for _ in range(12):
                     if cold:
@@ -41,7 +40,7 @@ def main():
                 r = be.prof_read("head1x1")
                 us = r["total_ms"] * 1e3 / r["launches"]
                 mb = r["total_bytes"] / r["launches"] / 1e6
-                print(f"{str(dtype)[6:]:8s} {name:20s} preload {preload} {'cold' if cold else 'warm'}: k_head1x1 {us:6.2f} us  {mb:6.1f} MB  {mb / us:5.2f} TB/s  {mb / us / 8:5.1%} of 8 TB/s", flush=True)
+                print(f"{str(dtype)[6:]:8s} {name:20s} {'cold' if cold else 'warm'}: k_head1x1 {us:6.2f} us  {mb:6.1f} MB  {mb / us:5.2f} TB/s  {mb / us / 8:5.1%} of 8 TB/s", flush=True)
             if os.environ.get("KBENCH_HEAD_AB"):
                 continue
             # the replaced sequence, timed with torch events (three launches incl. their gaps)
