@@ -84,7 +84,7 @@ def measure_fps(model, clips: Sequence[Sequence[torch.Tensor]], n_clips: int, wa
 
 
 @torch.no_grad()
-def measure_fps_with_upload(model, host_clips, n_clips: int, warmup_clips: int = 1, device="cuda", dtype=torch.float32, prefetch: bool = True):
+def measure_fps_with_upload(model, host_clips, n_clips: int, warmup_clips: int = 1, device="cuda", dtype=torch.float32, prefetch: bool = True, cross_clip: bool = True):
     """frames/s of the reference driver's FULL per-clip loop (semantic_segmentation/test_swiftnet.py:181-197): every frame
     starts in (pinned) host memory and is uploaded inside the timed region, and the last frame of each clip is upsampled to
     the input resolution, arg-maxed and copied back to the host (``preds = out.max(dim=1)[1].cpu()``).
@@ -169,7 +169,7 @@ def measure_fps_with_upload(model, host_clips, n_clips: int, warmup_clips: int =
     n_frames = 0
     for i in range(n_clips):
         clip = host_clips[i % len(host_clips)]
-        nxt = host_clips[(i + 1) % len(host_clips)] if i + 1 < n_clips else None
+        nxt = host_clips[(i + 1) % len(host_clips)] if (cross_clip and i + 1 < n_clips) else None
         preds = run(clip, nxt)
         n_frames += len(clip) * clip[0].shape[0]
     sync(dev)

@@ -999,11 +999,11 @@ class HipBackend:
     def policy_step(self, logits, seed: int, counter: int, multiple: int, at_least_one: bool, grid_u8, tables, counts, mailbox=None):
         """Device policy decision (include/blockcopy_hip.h bc_policy_step): Bernoulli(logits) + round-up-to-multiple + index
         tables in one launch.  ``grid_u8`` uint8[n_total], ``tables`` int32[2*n_total] = [grid_idx | mapping_exec], ``counts``
-        int32[4] are caller-owned device buffers; ``mailbox`` an optional pinned-host int32[4] that receives the counts."""
+        int32[4] are caller-owned device buffers; ``mailbox`` an optional pinned-host (or device) int32[4] that receives the counts as well."""
         assert _ok(logits, torch.float32) and logits.is_contiguous() and _ok(grid_u8, torch.uint8) and _ok(tables, torch.int32) and _ok(counts, torch.int32)
         n_total = logits.numel()
         assert grid_u8.numel() == n_total and tables.numel() == 2 * n_total and counts.numel() >= 4
-        assert mailbox is None or (mailbox.is_pinned() and mailbox.dtype == torch.int32 and mailbox.numel() >= 4)
+        assert mailbox is None or ((mailbox.is_pinned() or mailbox.is_cuda) and mailbox.dtype == torch.int32 and mailbox.numel() >= 4 and mailbox.is_contiguous())
         with torch.cuda.device_of(logits):
             self._check(self.lib.bc_policy_step(logits.data_ptr(), n_total, int(seed) & (2 ** 64 - 1), int(counter) & (2 ** 64 - 1),
                                                 int(multiple), int(bool(at_least_one)), grid_u8.data_ptr(), tables.data_ptr(),

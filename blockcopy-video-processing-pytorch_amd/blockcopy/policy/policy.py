@@ -74,13 +74,14 @@ class LazyCount:
 
     def __init__(self, row: torch.Tensor, event, total: int):
         self._row, self._event, self._value, self.total = row, event, None, int(total)
+        self.device_row = row          # [n_exec, -, NaN flag, -] where the kernel left it (device memory in wait-free mode): for device-side arithmetic
 
     def resolve(self) -> int:
         if self._value is None:
             self._event.synchronize()
             n_exec, _, nan, _ = self._row.tolist()
             assert nan == 0, "Policy net returned NaN's, maybe optimization problem?"
-            self._value, self._row, self._event = int(n_exec), None, None
+            self._value, self._row, self._event, self.device_row = int(n_exec), None, None, None
         return self._value
 
     @property
@@ -322,6 +323,11 @@ class PolicyTrainRL(Policy, metaclass=abc.ABCMeta):
         # learns the counts lazily (LazyCount) -- for the statistics, and for the running cost right before a training step
         self.wait_free = False
         self._pending_use = []        # perc_exec values (LazyFraction) not yet folded into the running cost
+        # wait-free mode: the SAME running cost as a float64 scalar on the device (identical IEEE operations in the same order, so the
+        # same bits), fed from the count words the policy-step kernel leaves in device memory -- the training step's complexity reward
+        # then needs no number from the host at all
+        self._rc_dev = None
+        self._pending_dev = []        # floats (host-known fractions) / device count rows not yet folded into _rc_dev
         self.rng_seed = None          # counter-based RNG of the device step: drawn from torch's generator at first use
         self.rng_counter = 0
         self._step_bufs = {}
@@ -347,7 +353,19 @@ class PolicyTrainRL(Policy, metaclass=abc.ABCMeta):
     @running_cost.setter
     def running_cost(self, value):
         del self._pending_use[:]
+        del self._pending_dev[:]
         self._running_cost = value
+        self._rc_dev = None
+
+    def _running_cost_dev(self, device) -> torch.Tensor:
+        """The running cost as a float64 0-d tensor on ``device``, pending frames folded in (no host synchronisation)."""
+        for use, total in self._pending_dev:
+            u = use if not isinstance(use, torch.Tensor) else use[0].to(torch.float64) / float(total)
+            if self._rc_dev is None:
+                self._rc_dev = torch.as_tensor(u, dtype=torch.float64, device=device).clone()
+            self._rc_dev = self._rc_dev * self.momentum + (1 - self.momentum) * u
+        del self._pending_dev[:]
+        return self._rc_dev
 
     def _fold(self, block_use: float):
         if self._running_cost is None:
@@ -408,13 +426,16 @@ class PolicyTrainRL(Policy, metaclass=abc.ABCMeta):
             st = self._step_bufs[(dev, n_total)] = {
                 "grid": torch.zeros(n_total, dtype=torch.uint8, device=dev), "tables": tables, "counts": tables[2 * n_total:],
                 "mailbox": torch.zeros((self.MAILBOX_ROWS, 4), dtype=torch.int32).pin_memory(), "owners": [None] * self.MAILBOX_ROWS,
+                # wait-free mode: the rows live in DEVICE memory (the running cost is folded from them by device arithmetic, and the host
+                # only reads a row when it asks for a LazyCount)
+                "mailbox_dev": torch.zeros((self.MAILBOX_ROWS, 4), dtype=torch.int32, device=dev),
                 "host": torch.zeros(n_total, dtype=torch.uint8).pin_memory(), "event": torch.cuda.Event()}
         multiple = max(1, int(n_total * self.quantize_number_exec)) if self.quantize_number_exec > 0 else 1
         logits = grid_logits.detach().float().contiguous()
         row_k = self.rng_counter % self.MAILBOX_ROWS
         if st["owners"][row_k] is not None:
             st["owners"][row_k].resolve()      # (MAILBOX_ROWS frames old: answered long ago) the row is about to be rewritten
-        row = st["mailbox"][row_k]
+        row = (st["mailbox_dev"] if self.wait_free else st["mailbox"])[row_k]
         be.policy_step(logits, self.rng_seed, self.rng_counter, multiple, self.at_least_one, st["grid"], st["tables"][:2 * n_total], st["counts"], row)
         self.rng_counter += 1
         if self.wait_free:
@@ -472,7 +493,10 @@ class PolicyTrainRL(Policy, metaclass=abc.ABCMeta):
             assert ig.dim() == 4
             return ig
 
-    def _get_reward_complexity(self, policy_meta: dict) -> float:
+    def _get_reward_complexity(self, policy_meta: dict):
+        if self.wait_free and (self._rc_dev is not None or self._pending_dev):
+            r = -(self._running_cost_dev(policy_meta["grid"].device) - self.block_target)       # float64 on the device: same operations, same bits
+            return r * r.abs()
         r = -float(self.running_cost - self.block_target)
         return r * abs(r)
 
@@ -481,11 +505,18 @@ class PolicyTrainRL(Policy, metaclass=abc.ABCMeta):
         grid = policy_meta["grid"]
         assert grid.dim() == 4
         block_use = policy_meta["perc_exec"]
-        if getattr(block_use, "lazy", False):
-            self._pending_use.append(block_use)       # (folded in, in order, when the running cost is next read: before a training step)
+        if self.wait_free:
+            if self._rc_dev is None and not self._pending_dev and (self._running_cost is not None or self._pending_use):
+                # (entering the wait-free mode with a history: the device copy starts from the host value -- one read, once)
+                self._rc_dev = torch.as_tensor(self.running_cost, dtype=torch.float64, device=grid.device)
+            lazy = getattr(block_use, "lazy", False)
+            self._pending_use.append(block_use if lazy else float(block_use))       # folded in, in order, whenever the HOST reads the running cost
+            self._pending_dev.append((block_use.count.device_row, block_use.count.total) if lazy else (float(block_use), 1))
         else:
             _ = self.running_cost                     # fold what is pending first: the average depends on the order
             self._fold(float(block_use))
+            self._rc_dev = None
+            del self._pending_dev[:]
 
         if policy_meta["outputs_prev"] is not None and train:
             with torch.enable_grad():

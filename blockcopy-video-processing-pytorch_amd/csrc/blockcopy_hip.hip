@@ -2341,7 +2341,8 @@ static int conv_v2_run(ConvV2Args &a)
     g.dyn = a.dyn;
     size_t lds_bytes = best_plan.lds_bytes;
     if (lds_bytes < (size_t)min_lds) lds_bytes = min_lds;      // one workgroup per CU: two waves on every SIMD, no more
-    const dim3 grid((g.n_rows + k.WMW - 1) / k.WMW, (unsigned)Cout / (32 * k.RN * k.WNW));
+    dim3 grid((g.n_rows + k.WMW - 1) / k.WMW, (unsigned)Cout / (32 * k.RN * k.WNW));
+    if (g.dyn.ptr && grid.x <= 65535u) { grid = dim3(grid.y, grid.x); g.xcd |= 2u; }     // device-side count: live rows first in dispatch order (xcd_remap, dyn_order)
     // (decompositions whose double-buffered patch images cannot fit the LDS are never chosen by conv2_plan and are not compiled)
 #define BC_CV2(RM_, RN_, WMW_, WNW_, WKW_)                                                                                   \
     do {                                                                                                                 \
@@ -2426,7 +2427,8 @@ static int conv_v2_dil_run(ConvV2Args &a)
     g.dyn = a.dyn;
     size_t lds_bytes = best_plan.lds_bytes;
     if (lds_bytes < (size_t)min_lds) lds_bytes = min_lds;
-    const dim3 grid((g.n_rows + k.WMW - 1) / k.WMW, (unsigned)a.Cout / (32 * k.RN * k.WNW));
+    dim3 grid((g.n_rows + k.WMW - 1) / k.WMW, (unsigned)a.Cout / (32 * k.RN * k.WNW));
+    if (g.dyn.ptr && grid.x <= 65535u) { grid = dim3(grid.y, grid.x); g.xcd |= 2u; }     // device-side count: live rows first in dispatch order (xcd_remap, dyn_order)
     switch (best) {
     case 3: launch_conv3x3_v2_cfg<DT, 1, 1, 4, 2, 1, SC_LO, 8, 1, 3, 2>(ps, grid, lds_bytes, a, g); break;
     case 5: launch_conv3x3_v2_cfg<DT, 1, 1, 2, 2, 2, SC_LO, 8, 1, 3, 2>(ps, grid, lds_bytes, a, g); break;
@@ -2514,7 +2516,8 @@ static int conv_wino_run(ConvV2Args &a)
     g.dyn = a.dyn;
     size_t lds_bytes = plan.lds_bytes;
     if (!(a.force_cfg & 0x100) && lds_bytes < (size_t)a.min_lds) lds_bytes = a.min_lds;
-    const dim3 grid((plan.n_rows + k.WMW - 1) / k.WMW, (unsigned)a.Cout / (16 * k.WNW));
+    dim3 grid((plan.n_rows + k.WMW - 1) / k.WMW, (unsigned)a.Cout / (16 * k.WNW));
+    if (g.dyn.ptr && grid.x <= 65535u) { grid = dim3(grid.y, grid.x); g.xcd |= 2u; }     // device-side count: live rows first in dispatch order (xcd_remap, dyn_order)
     switch (c) {
     case 0: launch_wino_cfg<2, 2, 4, 1>(ps, grid, lds_bytes, a, g); break;
     case 1: launch_wino_cfg<2, 2, 2, 2>(ps, grid, lds_bytes, a, g); break;
@@ -2591,7 +2594,8 @@ static int conv_wino32_run(ConvV2Args &a)
     g.cin_chunks = a.Cin / 32;
     g.xcd = (uint32_t)a.xcd_remap;
     g.dyn = a.dyn;
-    const dim3 grid((plan.n_slots + 2 * k.WMW - 1) / (2 * k.WMW), (unsigned)a.Cout / (32 * k.WNW));
+    dim3 grid((plan.n_slots + 2 * k.WMW - 1) / (2 * k.WMW), (unsigned)a.Cout / (32 * k.WNW));
+    if (g.dyn.ptr && grid.x <= 65535u) { grid = dim3(grid.y, grid.x); g.xcd |= 2u; }     // device-side count: live rows first in dispatch order (xcd_remap, dyn_order)
     switch (c) {
     case 0: launch_wino32_cfg<2, 2, 1>(ps, grid, plan.lds_bytes, a, g); break;
     case 1: launch_wino32_cfg<1, 4, 1>(ps, grid, plan.lds_bytes, a, g); break;

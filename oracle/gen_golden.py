@@ -385,8 +385,16 @@ def gen_csp_ref_modules(ref):
     ped = ref_loader.load_reference_csp(ref)
     out = {}
     clips = {"a": dict(N=1, H=128, W=256, block_size=32, n_frames=4, frame_seed0=77000, grid_seed=29),
-             "b": dict(N=1, H=256, W=512, block_size=128, n_frames=3, frame_seed0=78000, grid_seed=31)}
+             "b": dict(N=1, H=256, W=512, block_size=128, n_frames=3, frame_seed0=78000, grid_seed=31),
+             # BASELINE config C5 at its FULL size: 1024x2048, block 128 (grid 8x16), frame 0 all-active, then 38 of 128 tiles (30 %);
+             # the stride-4 head maps are stored as two 8-strided lattices (offsets 0 and 7) + absolute maximum
+             "c": dict(N=1, H=1024, W=2048, block_size=128, n_frames=3, frame_seed0=79000, grid_seed=37, subsample=dict(step=8, offsets=[0, 7]))}
+    only = set(os.environ.get("CSP_REF_CLIPS", "a,b,c").split(","))
+    if only != {"a", "b", "c"}:      # regenerate a subset: keep the other clips of the existing fixture
+        out.update({k: v for k, v in np.load(os.path.join(GOLD, "csp_ref_modules.npz")).items()})
     for tag, cfg in clips.items():
+        if tag not in only:
+            continue
         model_cfg, test_cfg = ref_loader.csp_r50_config(cfg["block_size"])
         with quiet():
             det = ped.det.CSPBlockCopy(train_cfg=None, test_cfg=test_cfg, **model_cfg)
@@ -396,6 +404,9 @@ def gen_csp_ref_modules(ref):
         det.load_state_dict(csp_ref_weights(sd), strict=True)
         det.eval()
         grids = tinycsp.tinycsp_grids(cfg)
+        if tag == "c":
+            GH, GW = cfg["H"] // cfg["block_size"], cfg["W"] // cfg["block_size"]
+            grids = [torch.ones(1, 1, GH, GW, dtype=torch.bool)] + [seeded.fixed_fraction_grid(cfg["grid_seed"] + t, 1, GH, GW, 38) for t in (1, 2)]
         det.policy = ref_loader.make_forced_policy(ref, cfg["block_size"], grids)
         rec = {}
         h1 = det.neck.register_forward_hook(lambda m, i, o: rec.__setitem__("neck", o[0].as_subclass(torch.Tensor).detach().clone()))
@@ -410,12 +421,18 @@ def gen_csp_ref_modules(ref):
                 res = det.simple_test(img, meta, rescale=False)
             assert isinstance(res, list) and len(res) == 1 and res[0].shape[1] == 5
             out[f"{tag}_grid{t}"] = grids[t].numpy()
+            sub = cfg.get("subsample")
             for k, m in zip(("cls", "reg", "offset"), rec["maps"]):
-                out[f"{tag}_{k}{t}"] = m.numpy().copy()
-            out[f"{tag}_neck{t}"] = rec["neck"][:, ::16, ::4, ::4].numpy().copy()      # packed tiles (n_exec, 768, bs/4, bs/4), strided sample
+                if sub is None:
+                    out[f"{tag}_{k}{t}"] = m.numpy().copy()
+                else:
+                    for o in sub["offsets"]:
+                        out[f"{tag}_{k}{t}_o{o}"] = m[:, :, o::sub["step"], o::sub["step"]].numpy().copy()
+                    out[f"{tag}_{k}{t}_absmax"] = np.float32(m.abs().max())
+            out[f"{tag}_neck{t}"] = rec["neck"][:, ::16, ::4, ::4].numpy().copy() if sub is None else rec["neck"][:, ::64, ::8, ::8].numpy().copy()      # packed tiles, strided sample
             out[f"{tag}_boxes{t}"] = res[0].copy()                                       # bbox2result(...)[class 0]: (k, 5) after NMS, top max_per_img
             kept.append(res[0].shape[0])
-            scores = torch.from_numpy(out[f"{tag}_cls{t}"]).sigmoid().reshape(-1)
+            scores = rec["maps"][0].sigmoid().reshape(-1)
             print(f"csp_ref_modules {tag} frame {t}: n_exec {int(grids[t].sum())}, scores > thr among top-1000: {int((scores.topk(min(1000, scores.numel()))[0] > 0.1).sum())}, kept {kept[-1]}")
         h1.remove(), h2.remove()
         if tag == "a":

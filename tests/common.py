@@ -188,9 +188,12 @@ def run_csp_ref_clip(G, tag, device, engine="fused", graph=0, channels_last=Fals
         det = det.to(memory_format=torch.channels_last)
     rec = {}
 
+    sub = cfg.get("subsample")       # full-size clip: strided lattices of the head maps instead of the maps (oracle/gen_golden.py)
+
     def neck_hook(mod, inp, out):
         o = out[0]
-        rec["neck"] = (o._plain() if hasattr(o, "_plain") else o)[:, ::16, ::4, ::4].float().cpu().clone()
+        o = o._plain() if hasattr(o, "_plain") else o
+        rec["neck"] = (o[:, ::16, ::4, ::4] if sub is None else o[:, ::64, ::8, ::8]).float().cpu().clone()
 
     hook = det.neck.register_forward_hook(neck_hook) if not graph else None     # (no host reads inside a graph capture)
     worst = dict(maps=0.0, neck=0.0, decode=0.0, e2e_match=1.0)
@@ -204,21 +207,30 @@ def run_csp_ref_clip(G, tag, device, engine="fused", graph=0, channels_last=Fals
                 with torch.no_grad():
                     dets, labels = det.simple_test(x)
                 for k, m in zip(("cls", "reg", "offset"), det.head_out):
-                    want = torch.from_numpy(G[f"{tag}_{k}{t}"])
-                    assert tuple(m.shape) == tuple(want.shape), (k, t, m.shape, want.shape)
-                    worst["maps"] = max(worst["maps"], float((m.float().cpu() - want).abs().max()) / max(1.0, float(want.abs().max())))
+                    m = m.float().cpu()
+                    if sub is None:
+                        want = torch.from_numpy(G[f"{tag}_{k}{t}"])
+                        assert tuple(m.shape) == tuple(want.shape), (k, t, m.shape, want.shape)
+                        worst["maps"] = max(worst["maps"], float((m - want).abs().max()) / max(1.0, float(want.abs().max())))
+                    else:
+                        scale = max(1.0, float(G[f"{tag}_{k}{t}_absmax"]))
+                        for o in sub["offsets"]:
+                            want = torch.from_numpy(G[f"{tag}_{k}{t}_o{o}"])
+                            worst["maps"] = max(worst["maps"], float((m[:, :, o::sub["step"], o::sub["step"]] - want).abs().max()) / scale)
+                        worst["maps"] = max(worst["maps"], abs(float(m.abs().max()) - float(G[f"{tag}_{k}{t}_absmax"])) / scale)
                 if not graph:    # (a captured body does not run Python hooks on replay)
                     want = torch.from_numpy(G[f"{tag}_neck{t}"])
                     assert rec["neck"].shape == want.shape, (rec["neck"].shape, want.shape)
                     worst["neck"] = max(worst["neck"], float((rec["neck"] - want).abs().max()) / max(1.0, float(want.abs().max())))
                 boxes = torch.from_numpy(G[f"{tag}_boxes{t}"])
-                # decode + NMS of the FIXTURE's maps: every decision (top-k, threshold, suppression, cap) has the reference's inputs
-                fm = [torch.from_numpy(G[f"{tag}_{k}{t}"]).to(device) for k in ("cls", "reg", "offset")]
-                got, lab = det.bbox_head.get_bboxes(*fm, img_shape=(cfg["H"], cfg["W"]), **kw)
-                if tuple(got.shape) != tuple(boxes.shape) or int(lab.abs().sum()) != 0:
-                    worst["decode"] = -1.0
-                elif worst["decode"] >= 0 and boxes.numel():
-                    worst["decode"] = max(worst["decode"], float((got.float().cpu() - boxes).abs().max()))
+                if sub is None:
+                    # decode + NMS of the FIXTURE's maps: every decision (top-k, threshold, suppression, cap) has the reference's inputs
+                    fm = [torch.from_numpy(G[f"{tag}_{k}{t}"]).to(device) for k in ("cls", "reg", "offset")]
+                    got, lab = det.bbox_head.get_bboxes(*fm, img_shape=(cfg["H"], cfg["W"]), **kw)
+                    if tuple(got.shape) != tuple(boxes.shape) or int(lab.abs().sum()) != 0:
+                        worst["decode"] = -1.0
+                    elif worst["decode"] >= 0 and boxes.numel():
+                        worst["decode"] = max(worst["decode"], float((got.float().cpu() - boxes).abs().max()))
                 # end to end: own maps differ by rounding, so a borderline decision may flip -- count the boxes reproduced
                 e2e = dets.float().cpu()
                 if boxes.shape[0]:
