@@ -69,7 +69,7 @@ def parse_args(argv=None):
     ap.add_argument("--graph", type=int, default=None,
                     help="hipGraph replay of the packed pipeline: 0 = eager launches, 1 = one graph per executed-tile count, 2 = ONE graph for "
                          "every count (launches sized for all tiles, count read from the device; no wait for a device-side policy decision). "
-                         "Default: 2 for the online-RL policies, 1 otherwise")
+                         "Default: 2 for the online-RL policies in fp16, 1 otherwise")
     ap.add_argument("--config", default=None, choices=["C2", "C3", "C3h", "C4", "C5"],
                     help="BASELINE.json config preset: C2 (default workload), C3 = --policy rl_semseg --target 0.3, C3h = the reference's own speed "
                          "scenario (configs/swiftnet_rn18/swiftnet_rn18_rl05_speed.sh: rl_semseg, target 0.5, --half, batch 2, train-interval 3), "
@@ -96,7 +96,10 @@ def parse_args(argv=None):
     elif args.config == "C5":
         args.workload, args.target, args.backbone = "csp", 0.3, "csp_resnet50"
     if args.graph is None:
-        args.graph = 2 if (args.policy.startswith("rl_") and args.workload != "csp" and args.channels_last) else 1
+        # measured (profiles/r04): with an online-RL policy the ONE dynamic graph (no wait for the device-side decision) wins where the
+        # frame is short -- fp16, batch 2: C3h 882-905 vs 819 fps -- and loses ~10 % to the sixteen per-count graphs in fp32 batch 1
+        # (C3 499-508 vs 560-562), whose conv plans are tuned per count while the dynamic graph runs one plan for every count
+        args.graph = 2 if (args.policy.startswith("rl_") and args.workload != "csp" and args.channels_last and args.half) else 1
     return args
 
 
