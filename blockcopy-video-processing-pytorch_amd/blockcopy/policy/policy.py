@@ -460,9 +460,10 @@ class PolicyTrainRL(Policy, metaclass=abc.ABCMeta):
             policy_meta["grid_host"] = st["host"].view(torch.bool).view(shape).clone()
             policy_meta["grid_tables"] = (st["tables"], n_exec)      # consumed by the engine instead of rebuilding them on the host
             policy_meta["num_exec_known"] = n_exec
-        m = Bernoulli(logits=grid_logits)
-        policy_meta["grid_log_probs"] = m.log_prob(grid.to(grid_logits.dtype)) if grid_logits.requires_grad or not self.graph_forward else None
-        policy_meta["grid_probs"] = m.probs
+        # probabilities / log-probabilities of the decision are bookkeeping for optim(): they are derived THERE, i.e. their small
+        # launches queue behind the frame's block pipeline instead of in front of it (the host is on the critical path right here:
+        # the GPU has nothing to do until the frame's graph is launched)
+        policy_meta["_decision_logits"] = grid_logits
 
     @torch.no_grad()
     def _forward_nograd_graph(self, policy_meta: dict) -> torch.Tensor:
@@ -501,6 +502,16 @@ class PolicyTrainRL(Policy, metaclass=abc.ABCMeta):
         return r * abs(r)
 
     def optim(self, policy_meta: dict, train=True) -> dict:
+        logits = policy_meta.pop("_decision_logits", None)
+        if logits is not None:          # (device step: see _device_step)
+            with torch.enable_grad():   # (the log-probabilities of a frame that will be trained on carry the policy net's autograd graph)
+                # Bernoulli(logits).probs / .log_prob(grid) written out (torch/distributions/bernoulli.py: sigmoid; minus the binary cross
+                # entropy with logits): the distribution object VALIDATES its arguments with `.all()` -- a device synchronisation in the
+                # constructor and another one in log_prob, i.e. the host would wait here for the whole frame it has just enqueued
+                want_lp = logits.requires_grad or not self.graph_forward
+                policy_meta["grid_log_probs"] = (-F.binary_cross_entropy_with_logits(logits, policy_meta["grid"].to(logits.dtype), reduction="none")
+                                                 if want_lp else None)
+                policy_meta["grid_probs"] = torch.sigmoid(logits)
         policy_meta["output_repr"] = self.information_gain.get_output_repr(policy_meta)
         grid = policy_meta["grid"]
         assert grid.dim() == 4
