@@ -217,6 +217,20 @@ def pmc_traffic():
     return (t.get("k_combine_copy_bytes_per_launch"), t.get("k_head1x1_bytes_per_launch")), t.get("source"), per_kernel
 
 
+def rocprof_cross_check(kernel_prefix):
+    """(avg launch us, frames in the window) of the roofline kernel in the COMMITTED rocprofv3 kernel trace of this command's graph replays
+    (profiles/rocprof_latest.json, written by tools/trace_summary.py from a separate profiled run), or (None, None)."""
+    path = os.path.join(ROOT, "profiles", "rocprof_latest.json")
+    if not os.path.exists(path):
+        return None, None
+    with open(path) as f:
+        t = json.load(f)
+    for name, v in t.get("kernels", {}).items():
+        if name.startswith(kernel_prefix):
+            return v.get("avg_us"), t.get("window_frames")
+    return None, None
+
+
 def _free_port():
     import socket
 
@@ -628,6 +642,12 @@ def main(argv=None):
                              "(graph kernel nodes cannot carry events)")
         achieved = (cc["total_bytes"] / (cc["total_ms"] * 1e-3) / 1e9) if cc["total_ms"] > 0 else 0.0
         traffic, traffic_src, traffic_kernels = pmc_traffic()
+        # the same kernel in the committed rocprofv3 trace of the graph replays (default workload only: that is what was profiled)
+        rocprof_fields = {}
+        if config_name(args) == "C2" and not args.half and args.batch == 1 and str(cc.get("kernel", "")).startswith("k_head1x1") and cc["launches"]:
+            rp_us, rp_frames = rocprof_cross_check("k_head1x1<0")
+            if rp_us:
+                rocprof_fields = {"rocprof_avg_launch_us": rp_us, "rocprof_frac": cc["total_bytes"] / cc["launches"] / (rp_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
         if traffic_kernels:
             # committed PMC measurement (profiles/traffic_latest.json: rocprofv3 --pmc passes of tools/pmc_driver.py at these shapes)
             details["pmc_traffic"] = traffic_kernels
@@ -650,6 +670,7 @@ def main(argv=None):
                          "launches": cc["launches"], "avg_launch_us": (1e3 * cc["total_ms"] / cc["launches"]) if cc["launches"] else None,
                          **({"p50_us": cc["p50_us"], "min_us": cc["min_us"], "max_us": cc["max_us"]} if "p50_us" in cc else {}),
                          "algorithmic_bytes_per_launch": (cc["total_bytes"] / cc["launches"]) if cc["launches"] else None,
+                         **rocprof_fields,
                          "method": cc["method"]},
             **({"per_rank_fps": {"min": min(per_rank), "max": max(per_rank), "all": [round(v, 1) for v in per_rank]}} if world > 1 else {}),
             "kernels": extra,

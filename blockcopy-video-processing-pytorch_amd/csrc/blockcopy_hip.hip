@@ -2281,6 +2281,16 @@ struct ConvV2Args {
     int dilation;                                  // 1, or 2 (bc_conv3x3_dil_ring_nhwc: part 9)
     DynCount dyn;                                  // executed-tile count on the device, units = the launch's tiles (bc_dyn_set)
 };
+
+// Workgroup order of a conv launch (bit 0 of ConvGeom2::xcd): the tuning knob if it is set, else XCD-aware exactly where the eight L2s
+// together would otherwise stream more weight bytes (one copy each) than the launch has activation bytes -- the stages with few, small
+// tiles: layer3 / layer4 of the segmentation backbones, the dilated stage of the detector.
+static inline uint32_t conv_xcd_order(const ConvV2Args &a)
+{
+    if (a.xcd_remap >= 0) return (uint32_t)a.xcd_remap & 1u;
+    const double weights = 9.0 * a.Cin * a.Cout, acts = (double)a.n_exec * a.bs * a.bs * (a.Cin + a.Cout);
+    return 8.0 * weights > acts ? 1u : 0u;
+}
 struct LaunchProf { bool on; struct { hipEvent_t a, b; } rec; };   // what BC_LAUNCH needs of a ProfScope
 
 #if defined(BC_MONO) || (BC_PART != 0 && BC_PART != 7 && BC_PART != 8)
@@ -2337,7 +2347,7 @@ static int conv_v2_run(ConvV2Args &a)
     g.patches_per_tile = best_plan.patches_per_tile;
     g.n_rows = best_plan.n_rows;
     g.cin_chunks = Cin / CV_CH;
-    g.xcd = (uint32_t)a.xcd_remap;
+    g.xcd = conv_xcd_order(a);
     g.dyn = a.dyn;
     size_t lds_bytes = best_plan.lds_bytes;
     if (lds_bytes < (size_t)min_lds) lds_bytes = min_lds;      // one workgroup per CU: two waves on every SIMD, no more
@@ -2423,7 +2433,7 @@ static int conv_v2_dil_run(ConvV2Args &a)
     g.patches_per_tile = best_plan.patches_per_tile;
     g.n_rows = best_plan.n_rows;
     g.cin_chunks = a.Cin / CV_CH;
-    g.xcd = (uint32_t)a.xcd_remap;
+    g.xcd = conv_xcd_order(a);
     g.dyn = a.dyn;
     size_t lds_bytes = best_plan.lds_bytes;
     if (lds_bytes < (size_t)min_lds) lds_bytes = min_lds;
@@ -2512,7 +2522,7 @@ static int conv_wino_run(ConvV2Args &a)
     g.patches_per_tile = a.bs == 4 ? 1 : (a.bs / 8) * (a.bs / 8);
     g.n_rows = plan.n_rows;
     g.cin_chunks = a.Cin / 32;
-    g.xcd = (uint32_t)a.xcd_remap;
+    g.xcd = conv_xcd_order(a);
     g.dyn = a.dyn;
     size_t lds_bytes = plan.lds_bytes;
     if (!(a.force_cfg & 0x100) && lds_bytes < (size_t)a.min_lds) lds_bytes = a.min_lds;
@@ -2592,7 +2602,7 @@ static int conv_wino32_run(ConvV2Args &a)
     g.patches_per_tile = (a.bs / 8) * (a.bs / 8);
     g.n_rows = plan.n_slots;
     g.cin_chunks = a.Cin / 32;
-    g.xcd = (uint32_t)a.xcd_remap;
+    g.xcd = conv_xcd_order(a);
     g.dyn = a.dyn;
     dim3 grid((plan.n_slots + 2 * k.WMW - 1) / (2 * k.WMW), (unsigned)a.Cout / (32 * k.WNW));
     if (g.dyn.ptr && grid.x <= 65535u) { grid = dim3(grid.y, grid.x); g.xcd |= 2u; }     // device-side count: live rows first in dispatch order (xcd_remap, dyn_order)
@@ -2633,9 +2643,12 @@ struct TuneState {
     int conv_last_cfg = -2;   // decomposition of the most recent bc_conv3x3_ring_nhwc launch (-1: first-generation kernel)
     int stem_min_lds = [] { const char *e = getenv("BC_STEM_MINLDS"); return e ? atoi(e) : 84 * 1024; }();
     int conv2_min_lds = [] { const char *e = getenv("BC_CONV2_MINLDS"); return e ? atoi(e) : 84 * 1024; }();   // bytes; > 80 KB = one workgroup per CU
-    // XCD-aware workgroup order of the conv kernels (xcd_remap in conv3x3_v2.inc).  Measured neutral on every layer shape of the configs
-    // (profiles/r03/11: +-2 %, the weights of a layer are served by the Infinity Cache either way), so the launch order stays the default
-    int xcd_remap = [] { const char *e = getenv("BC_XCD_REMAP"); return e ? atoi(e) : 0; }();
+    // XCD-aware workgroup order of the conv kernels (xcd_remap in conv3x3_v2.inc): 0 launch order, 1 XCD-aware, -1 (default) XCD-aware
+    // where the weights outweigh the activations of the launch (conv_xcd_order).  In TIME the two orders are equal on every layer shape
+    // of the configs (profiles/r03/11, r04/22: +-1 %, the re-fetched weights are served by the Infinity Cache); in TRAFFIC the XCD-aware
+    // order cuts the weight-dominated launches to a third (PMC, profiles/r04/21: layer4 Winograd 7.76x -> 2.52x of the algorithmic bytes,
+    // direct 4.57x -> 2.12x, dilated detector stage 5.8x -> 3.35x) -- fabric bandwidth a concurrent copy or replica does not have to share
+    int xcd_remap = [] { const char *e = getenv("BC_XCD_REMAP"); return e ? atoi(e) : -1; }();
 } g_tune;
 
 

@@ -846,6 +846,38 @@ def test_fused_conv3x3_every_decomposition(be, cfg):
         be.tune("conv2_cfg", -1)
 
 
+@pytest.mark.parametrize("cfg", [6, 0x207, 0x20c, 0x20d, 0x404])
+def test_conv_result_does_not_depend_on_the_workgroup_order(be, cfg):
+    """Which workgroup computes which (patch row, channel group) is a placement matter only (xcd_remap in csrc/conv3x3_v2.inc: launch
+    order, XCD-aware order, and the default that picks the XCD-aware order where the weights outweigh the activations): output and ring
+    cache are bit-identical under all three, on grids whose workgroup count is and is not a multiple of the 8 XCDs."""
+    gen = torch.Generator().manual_seed(900 + cfg)
+    rng = np.random.default_rng(900 + cfg)
+    be.tune("conv2_cfg", cfg)
+    try:
+        for (Cin, Cout, bs, GH, GW, frac) in [(256, 256, 8, 3, 5, 0.7), (512, 512, 4, 4, 7, 0.5), (128, 128, 16, 2, 3, 1.0)]:
+            T = GH * GW
+            if cfg not in be.conv3x3_candidates(T, Cin, Cout, bs, 4, 1):
+                continue
+            g = rng.random(T) < frac
+            g[0] = True
+            gi, m = O.c_grid_mappings(g.reshape(1, 1, GH, GW))
+            gi_d, m_d = _dev(gi), _dev(m)
+            feats = _cl(torch.randn((len(m), Cin, bs, bs), generator=gen).cuda())
+            wpk = be.pack_conv3x3_weights((torch.randn((Cout, Cin, 3, 3), generator=gen) * 0.05).cuda())
+            ring0 = torch.randn((T, Cin, 4 * bs), generator=gen).cuda()
+            outs = []
+            for order in (0, 1, -1):
+                be.tune("xcd_remap", order)
+                ring = ring0.clone()
+                outs.append((be.conv3x3_ring(feats, ring, wpk, Cout, gi_d, m_d, None, None), ring))
+            for out, ring in outs[1:]:
+                assert torch.equal(out, outs[0][0]) and torch.equal(ring, outs[0][1]), (cfg, Cin, bs)
+    finally:
+        be.tune("conv2_cfg", -1)
+        be.tune("xcd_remap", -1)
+
+
 def test_fused_conv3x3_generations_agree(be):
     """First-generation kernel (conv_impl = 1) and the CU-balanced one on the same launch: same ring state, outputs equal
     to summation order."""

@@ -70,6 +70,11 @@ def main():
     blocks = torch.empty((n, 3, 128, 128), device="cuda")
     run("split network input (64,3,128,128)", 2.0 * n * 3 * 128 * 128 * 4, lambda: be.split(blocks, img, m, gi))
     run("combine_ frame_state (64,3,128,128)", 2.0 * n * 3 * 128 * 128 * 4, lambda: be.combine(blocks, img, gi, m))
+    # the network-input stage of a graph-replayed frame (round 4): executed tiles of the caller's frame straight into the frame state,
+    # source address through a device word
+    src = torch.randn((1, 3, 1024, 2048), device="cuda")
+    slot = torch.tensor([src.data_ptr()], dtype=torch.int64).cuda()
+    run("tile_copy_indirect network input (64 tiles of 3x128x128)", 2.0 * n * 3 * 128 * 128 * 4, lambda: be.tile_copy_indirect(img, slot, m, 128))
     # channels-last halo gathers still on the default path: stride-2 conv inputs, stem pool
     for (C, bs, name) in [(64, 32, "pad_ring_nhwc layer2.0.conv1 input (64,64,32,32)"), (128, 16, "pad_ring_nhwc layer3.0.conv1 input (64,128,16,16)"),
                           (256, 8, "pad_ring_nhwc layer4.0.conv1 input (64,256,8,8)")]:

@@ -1,11 +1,14 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 --kernel-trace CSV of bench.py: per-frame kernel time inside the timed clips.
 
-usage: trace_summary.py <kernel_trace.csv> <frames_in_window> [skip_last_frames] [gathers_per_frame]
+usage: trace_summary.py <kernel_trace.csv> <frames_in_window> [skip_last_frames] [gathers_per_frame] [out.json]
 The window is delimited by the gather (k_tiles<.., true>) launches: two per SwiftNet frame (network input + SPP output), one per
-CSP frame (network input)."""
+CSP frame (network input).  out.json: the per-kernel averages of the window in machine-readable form (profiles/rocprof_latest.json
+is what bench.py reports beside its own event-based duration of the roofline kernel)."""
 import collections
 import csv
+import json
+import re
 import sys
 
 
@@ -30,6 +33,19 @@ def main():
     print(f"{'kernel':100s} {'ms/frame':>9s} {'calls/frm':>9s} {'avg_us':>8s}")
     for n, (t, c) in sorted(agg.items(), key=lambda x: -x[1][0])[:40]:
         print(f"{n:100s} {t / 1e6 / n_frames:9.3f} {c / n_frames:9.1f} {t / c / 1e3:8.1f}")
+    if len(sys.argv) > 5:
+        full = collections.defaultdict(lambda: [0, 0])
+        for s, e, n in sel:
+            m = re.search(r"(k_\w+(?:<[^(]*>)?)\(", n)
+            a = full[m.group(1) if m else n[:80]]
+            a[0] += e - s
+            a[1] += 1
+        with open(sys.argv[5], "w") as f:
+            json.dump({"source": "rocprofv3 --kernel-trace of `python bench.py` (hipGraph replays), summarised by tools/trace_summary.py",
+                       "window_frames": n_frames, "wall_ms_per_frame": (fe - fs) / 1e6 / n_frames, "gpu_busy_ms_per_frame": busy / 1e6 / n_frames,
+                       "launches_per_frame": len(sel) / n_frames,
+                       "kernels": {n: {"avg_us": t / c / 1e3, "calls_per_frame": c / n_frames} for n, (t, c) in sorted(full.items(), key=lambda x: -x[1][0])}},
+                      f, indent=1)
 
 
 if __name__ == "__main__":
