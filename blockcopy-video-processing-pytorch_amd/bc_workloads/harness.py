@@ -84,7 +84,8 @@ def measure_fps(model, clips: Sequence[Sequence[torch.Tensor]], n_clips: int, wa
 
 
 @torch.no_grad()
-def measure_fps_with_upload(model, host_clips, n_clips: int, warmup_clips: int = 1, device="cuda", dtype=torch.float32, prefetch: bool = True, cross_clip: bool = True):
+def measure_fps_with_upload(model, host_clips, n_clips: int, warmup_clips: int = 1, device="cuda", dtype=torch.float32, prefetch: bool = True, cross_clip: bool = True,
+                            fused_tail: bool = None):
     """frames/s of the reference driver's FULL per-clip loop (semantic_segmentation/test_swiftnet.py:181-197): every frame
     starts in (pinned) host memory and is uploaded inside the timed region, and the last frame of each clip is upsampled to
     the input resolution, arg-maxed and copied back to the host (``preds = out.max(dim=1)[1].cpu()``).
@@ -92,24 +93,34 @@ def measure_fps_with_upload(model, host_clips, n_clips: int, warmup_clips: int =
     ``prefetch=False`` is the reference's own form: ``inputs.to(device, non_blocking=True)`` on the compute stream, i.e. the
     25 MB upload of frame t sits between the models of frames t-1 and t, and ``.cpu()`` of the predictions blocks the host at the
     end of every clip.  ``prefetch=True`` is the MI355X-first form of the same loop: frame t+1 travels on a copy stream into the
-    other half of a double buffer while frame t is computed (PCIe and compute overlap), and the predictions of a clip travel back
+    next of three device buffers while frame t is computed (PCIe and compute overlap), and the predictions of a clip travel back
     into pinned host memory on a second copy stream while the next clip is already being enqueued -- every clip's predictions still end
-    up on the host (checked one clip later), the host just does not stall for them."""
+    up on the host (checked one clip later), the host just does not stall for them.  ``fused_tail`` (default: with ``prefetch``): the
+    prediction map of the last frame comes from ``blockcopy.utils.postprocess.upsample_argmax`` (one pass over the logits) instead of
+    the two stock ops with their 160 MB intermediate; same predictions (tests/test_gpu_ops.py)."""
+    if fused_tail is None:
+        fused_tail = prefetch
+    if fused_tail:
+        from blockcopy.utils.postprocess import upsample_argmax
     dev = torch.device(device)
     host_clips = [[f.pin_memory() if not f.is_pinned() else f for f in clip] for clip in host_clips]
     compute = torch.cuda.current_stream(dev)
     copy = torch.cuda.Stream(dev) if prefetch else None
     shape = host_clips[0][0].shape
-    bufs = [torch.empty(shape, dtype=dtype, device=dev) for _ in range(2)]
-    staged = [torch.cuda.Event() for _ in range(2)]      # upload into bufs[i] finished
-    consumed = [torch.cuda.Event() for _ in range(2)]    # model finished reading bufs[i]
+    # THREE device buffers: the upload of frame t + 1 reuses the buffer of frame t - 2, and the HOST makes sure that frame is through
+    # (an event query that has long succeeded in the steady state) -- with two buffers the copy stream itself had to wait for frame t - 1
+    # (a device-side cross-stream dependency per frame; measured, profiles/r04/41: the four event operations per frame cost 3.4 %)
+    NB = 3 if prefetch else 2
+    bufs = [torch.empty(shape, dtype=dtype, device=dev) for _ in range(NB)]
+    staged = [torch.cuda.Event() for _ in range(NB)]      # upload into bufs[i] finished
+    consumed = [torch.cuda.Event() for _ in range(NB)]    # model finished reading bufs[i]
 
     # double-buffered download of the per-clip predictions, on a stream of its own (behind the uploads it would delay the next clip's first frame)
     down = {"n": 0, "host": [None, None], "ev": [None, None], "stream": torch.cuda.Stream(dev) if prefetch else None}
 
     def upload(frame, i):
+        consumed[i].synchronize()                          # (the frame that read bufs[i] three frames ago)
         with torch.cuda.stream(copy):
-            copy.wait_event(consumed[i])
             bufs[i].copy_(frame, non_blocking=True)       # fp32 -> dtype conversion happens on the device side of the copy
             staged[i].record(copy)
 
@@ -127,19 +138,24 @@ def measure_fps_with_upload(model, host_clips, n_clips: int, warmup_clips: int =
                 # frame t + 1 -- or the first frame of the NEXT clip -- travels while frame t is computed
                 nxt = clip[t + 1] if t + 1 < len(clip) else (next_clip[0] if next_clip is not None else None)
                 if nxt is not None:
-                    upload(nxt, 1 - k)
+                    upload(nxt, (k + 1) % NB)
                 state["primed"] = nxt is not None
-                compute.wait_event(staged[k])
+                # the HOST waits for the upload (requested one frame ago: long finished), not the compute stream: the frame's graph is
+                # then enqueued without any cross-stream dependency in front of it
+                staged[k].synchronize()
                 inputs = bufs[k]
-                state["slot"] = 1 - k
+                state["slot"] = (k + 1) % NB
             else:
                 inputs = frame.to(dev, non_blocking=True, dtype=dtype)
             out = model(inputs)
             if prefetch:
                 consumed[k].record(compute)
             if t == len(clip) - 1:
-                out = torch.nn.functional.interpolate(out, size=inputs.shape[2:], mode="bilinear")
-                preds = out.detach().max(dim=1)[1]
+                if fused_tail:
+                    preds = upsample_argmax(out.detach(), tuple(inputs.shape[2:]))
+                else:
+                    out = torch.nn.functional.interpolate(out, size=inputs.shape[2:], mode="bilinear")
+                    preds = out.detach().max(dim=1)[1]
                 if prefetch:
                     k = down["n"] % 2
                     down["n"] += 1
@@ -160,7 +176,7 @@ def measure_fps_with_upload(model, host_clips, n_clips: int, warmup_clips: int =
                     preds = preds.cpu()
         return preds
 
-    for i in range(2):
+    for i in range(NB):
         consumed[i].record(compute)
     for i in range(warmup_clips):
         run(host_clips[i % len(host_clips)])
@@ -175,4 +191,5 @@ def measure_fps_with_upload(model, host_clips, n_clips: int, warmup_clips: int =
     sync(dev)
     dt = time.perf_counter() - t0
     assert preds is not None and tuple(preds.shape) == (shape[0], shape[2], shape[3])
+    measure_fps_with_upload.last_predictions = preds.clone()      # (host tensor: the last clip's prediction map, for the tests)
     return n_frames / dt, dt, n_frames

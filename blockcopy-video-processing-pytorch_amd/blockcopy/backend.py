@@ -135,6 +135,8 @@ def load_library(path: str = None) -> ctypes.CDLL:
         "bc_conv1x1_nhwc": [p, p, p] + [i] * 6 + [p, p, i, p, p, p, i, p],
         "bc_conv1x1_candidates": [i, i, i, i, i, i, ctypes.POINTER(i), i],
         "bc_interp_bilinear_nhwc": [p, p, ctypes.c_longlong, i, i, i, i, i, i, ctypes.c_float, ctypes.c_float, i, p],
+        "bc_upsample_argmax": [p, p, i, i, i, i, i, i, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, i,
+                               ctypes.c_float, ctypes.c_float, i, p],
         "bc_interp_bilinear_act_nhwc": [p, p, ctypes.c_longlong, i, i, i, i, i, i, ctypes.c_float, ctypes.c_float, i, p, p, p, i, p],
         "bc_affine_act": [p, p, p, p, p, i, ctypes.c_longlong, i, ctypes.c_longlong, i, p],
         "bc_bn_train_fwd": [p, p, i, i, ctypes.c_longlong, p, p, p, p, p, p, p, ctypes.c_float, ctypes.c_float, i, p, ctypes.c_longlong, p],
@@ -942,6 +944,26 @@ class HipBackend:
     def interp_epilogue_supported(data):
         """Deferred interpolation (epilogue fused into the resampling launch) exists for channels-last tensors."""
         return data.dim() == 4 and is_nhwc(data) and data.dtype in _DTYPE_CODE
+
+    def upsample_argmax(self, logits, size, align_corners=False):
+        """int64 (N, H, W): arg-max over dim 1 of F.interpolate(logits, size, mode='bilinear', align_corners=...), without the
+        (N, C, H, W) intermediate (include/blockcopy_hip.h bc_upsample_argmax).  Any dense layout of ``logits``."""
+        assert _ok(logits, *_DTYPE_CODE) and logits.dim() == 4
+        N, C, h, w = logits.shape
+        H, W = int(size[0]), int(size[1])
+        out = torch.empty((N, H, W), dtype=torch.int64, device=logits.device)
+        f32 = np.float32                   # (ATen's area_pixel_compute_scale of a `size=` call, in float32)
+        if align_corners:
+            rh, rw = (f32(h - 1) / f32(H - 1) if H > 1 else f32(0)), (f32(w - 1) / f32(W - 1) if W > 1 else f32(0))
+        else:
+            rh, rw = f32(h) / f32(H), f32(w) / f32(W)
+        sn, sc, sy, sx = logits.stride()
+        if out.numel() > 0:
+            with torch.cuda.device_of(logits):
+                self._check(self.lib.bc_upsample_argmax(out.data_ptr(), logits.data_ptr(), N, C, h, w, H, W, sn, sc, sy, sx, int(bool(align_corners)),
+                                                        float(rh), float(rw), _DTYPE_CODE[logits.dtype], self._stream()),
+                            "upsample_argmax")
+        return out
 
     def interp_bilinear(self, data, out_h, out_w, align_corners, rh, rw, epilogue=None, dyn=None):
         """per-tile bilinear resampling (planes = all leading dims); arithmetic of torch's upsample_bilinear2d.

@@ -1835,6 +1835,43 @@ __global__ __launch_bounds__(WG) void k_interp_bilinear_nhwc(T *__restrict__ out
     reinterpret_cast<V *>(out)[i] = *reinterpret_cast<const V *>(res);
 }
 
+// ------------------------------------------------------------------------------------------ prediction map of a segmentation clip
+// Bilinear upsampling of a logits map to the input resolution followed by the per-pixel arg-max over the classes, in one pass: what the
+// reference's driver does with the last frame of a clip (semantic_segmentation/test_swiftnet.py:190-194: F.interpolate(out, size,
+// mode='bilinear') then out.max(dim=1)[1]) as two library passes over a 160 MB intermediate (19 classes at 1024 x 2048) that nothing
+// else reads.  One thread per output pixel: the four neighbours of every class are read through the caches (a 4x upsampling re-reads
+// each source pixel 16 times), the interpolated value is formed and rounded exactly like k_interp_bilinear_nhwc does (= ATen's
+// upsample_bilinear2d), and the running maximum keeps the FIRST maximal class; a NaN wins over everything, as in torch.max.
+struct UpArgGeom {
+    uint32_t C, h, w, H, W;
+    long long sn, sc, sy, sx;      // element strides of the logits map (any layout)
+    float rh, rw;
+    int align;
+    uint32_t total;                // N * H * W
+};
+
+template <typename T>
+__global__ __launch_bounds__(WG) void k_upsample_argmax(long long *__restrict__ out, const T *__restrict__ in, UpArgGeom g)
+{
+    const uint32_t i = blockIdx.x * WG + threadIdx.x;
+    if (i >= g.total) return;
+    const uint32_t ox = i % g.W, r = i / g.W, oy = r % g.H, n = r / g.H;
+    uint32_t y0, yp, x0, xp; float ly1, lx1;
+    src_index(g.rh, oy, g.align, g.h, y0, yp, ly1);
+    src_index(g.rw, ox, g.align, g.w, x0, xp, lx1);
+    const float ly0 = 1.0f - ly1, lx0 = 1.0f - lx1;
+    const T *p00 = in + (long long)n * g.sn + (long long)y0 * g.sy + (long long)x0 * g.sx;
+    const long long dx = (long long)xp * g.sx, dy = (long long)yp * g.sy;
+    float best = 0.0f;
+    uint32_t arg = 0;
+    for (uint32_t c = 0; c < g.C; ++c) {
+        const T *q = p00 + (long long)c * g.sc;
+        const float v = Cvt<T>::ld_round(bilerp(Cvt<T>::ld(q), Cvt<T>::ld(q + dx), Cvt<T>::ld(q + dy), Cvt<T>::ld(q + dy + dx), lx0, lx1, ly0, ly1));
+        if (c == 0 || v > best || (v != v && best == best)) { best = v; arg = c; }
+    }
+    out[i] = (long long)arg;
+}
+
 // ------------------------------------------------------------------------------------------ NMS (detector post-processing)
 // Replaces nms_kernel + the host-side sweep of Pedestron/mmdet/ops/nms/src/nms_kernel.cu:23-130.  Same blocking as the
 // reference for the mask (64 boxes x 64 boxes per workgroup, one 64-bit word per box and column block -- a CDNA wavefront
@@ -3805,6 +3842,27 @@ BC_EXPORT int bc_interp_bilinear_nhwc(void *out, const void *in, long long plane
                                       int align_corners, float rh, float rw, int dtype, void *stream)
 {
     return bc_interp_bilinear_act_nhwc(out, in, planes, C, h, w, H, W, align_corners, rh, rw, dtype, nullptr, nullptr, nullptr, 0, stream);
+}
+
+BC_EXPORT int bc_upsample_argmax(long long *out, const void *in, int N, int C, int h, int w, int H, int W, long long sn, long long sc,
+                                 long long sy, long long sx, int align_corners, float rh, float rw, int dtype, void *stream)
+{
+    if (dtype < BC_F32 || dtype > BC_BF16) return BC_ERR_ELEM;
+    if (N <= 0 || C <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return BC_ERR_SHAPE;
+    if (!out || !in) return BC_ERR_NULL;
+    if ((uint64_t)N * H * W >= (1ull << 31) || (uint64_t)N * C * h * w >= (1ull << 31)) return BC_ERR_RANGE;
+    const int E = dtype == BC_F32 ? 4 : 2;
+    if (!aligned(out, 8) || !aligned(in, E)) return BC_ERR_ALIGN;
+    UpArgGeom g;
+    g.C = C; g.h = h; g.w = w; g.H = H; g.W = W; g.sn = sn; g.sc = sc; g.sy = sy; g.sx = sx; g.rh = rh; g.rw = rw; g.align = align_corners;
+    g.total = (uint32_t)((uint64_t)N * H * W);
+    const int grid = grid_exact(g.total, 1);
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps(BC_OP_INTERP, (double)N * h * w * C * E + (double)N * H * W * 8.0);
+    if (dtype == BC_F32) BC_LAUNCH(ps, (k_upsample_argmax<float>), dim3(grid), dim3(WG), 0, st, out, (const float *)in, g);
+    else if (dtype == BC_F16) BC_LAUNCH(ps, (k_upsample_argmax<__half>), dim3(grid), dim3(WG), 0, st, out, (const __half *)in, g);
+    else BC_LAUNCH(ps, (k_upsample_argmax<hip_bfloat16>), dim3(grid), dim3(WG), 0, st, out, (const hip_bfloat16 *)in, g);
+    return launch_status();
 }
 
 BC_EXPORT int bc_grid_tables(const uint8_t *grid, int n_total, int32_t *grid_idx, int32_t *mapping_exec,

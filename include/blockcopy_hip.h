@@ -235,6 +235,14 @@ int bc_interp_bilinear_act_nhwc(void *out, const void *in, long long planes, int
                                 int align_corners, float rh, float rw, int dtype, const float *scale, const float *shift,
                                 const void *add, int relu, void *stream);
 
+/* prediction map of a segmentation frame: out[n][y][x] (int64) = arg-max over the C classes of the logits map `in`, bilinearly
+ * resampled to (H, W) with torch's upsample_bilinear2d arithmetic (align_corners as given; rh / rw = the source-index scales, in / out
+ * for a `size=` call) -- the reference driver's F.interpolate(out, size, mode='bilinear') + out.max(dim=1)[1]
+ * (semantic_segmentation/test_swiftnet.py:190-194) without the (N, C, H, W) intermediate.  `in` may have any layout: sn / sc / sy /
+ * sx are its element strides.  Ties: the first maximal class; NaN is maximal (torch.max). */
+int bc_upsample_argmax(long long *out, const void *in, int N, int C, int h, int w, int H, int W, long long sn, long long sc,
+                       long long sy, long long sx, int align_corners, float rh, float rw, int dtype, void *stream);
+
 /* fused halo gather + 3x3 / stride 1 / pad 1 convolution of a packed channels-last tile batch on the matrix cores:
  * out = epilogue(conv3x3(prologue(halo-padded tiles))) in ONE launch, without materialising the padded tensor.
  * Replaces, for one padded conv layer of the reference (core/tensorwrapper.py:478-527: BlockPad.apply, then the stock

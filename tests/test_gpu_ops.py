@@ -1496,3 +1496,37 @@ def test_dynamic_count_stem(be, dtype):
         if k:
             want = be.stem7x7(fs, wpk, _dev(m), bs, None)
             assert torch.equal(want, got[:k]), k
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("nhwc", [True, False])
+def test_upsample_argmax_equals_interpolate_then_max(be, dtype, nhwc):
+    """bc_upsample_argmax == F.interpolate(mode='bilinear') + max(dim=1)[1] (the reference driver's prediction map,
+    semantic_segmentation/test_swiftnet.py:190-194) on the same device: identical class per pixel wherever the two best interpolated
+    scores are not within rounding distance of each other (the kernel's fused multiply-adds round differently from the library's in the
+    last bit), and never a class whose score is below the maximum by more than that."""
+    import torch.nn.functional as F
+    from blockcopy.utils.postprocess import upsample_argmax
+
+    gen = torch.Generator().manual_seed(77)
+    for (N, C, h, w, H, W) in [(1, 19, 32, 64, 128, 256), (2, 19, 16, 24, 64, 96), (1, 5, 7, 9, 23, 31), (1, 1, 4, 4, 8, 8), (1, 19, 256, 512, 1024, 2048)]:
+        x = torch.randn((N, C, h, w), generator=gen).cuda().to(dtype)
+        if nhwc:
+            x = x.contiguous(memory_format=torch.channels_last)
+        up = F.interpolate(x, size=(H, W), mode="bilinear")
+        want = up.max(dim=1)[1]
+        got = upsample_argmax(x, (H, W))
+        assert got.dtype == torch.int64 and tuple(got.shape) == (N, H, W)
+        diff = got != want
+        if bool(diff.any()):
+            upf = up.float()
+            chosen = torch.gather(upf, 1, got.unsqueeze(1)).squeeze(1)
+            best = upf.max(dim=1)[0]
+            tol = 2e-6 if dtype == torch.float32 else 2e-3
+            assert bool(((best - chosen)[diff] <= tol * best.abs().clamp(min=1.0)[diff]).all()), "a class below the maximum was chosen"
+            assert int(diff.sum()) <= max(2, got.numel() // 20000), int(diff.sum())
+    # NaN is maximal, ties take the first class
+    x = torch.zeros((1, 4, 2, 2)).cuda()
+    assert int(upsample_argmax(x, (4, 4)).abs().sum()) == 0
+    x[0, 2, 0, 0] = float("nan")
+    assert int(upsample_argmax(x, (2, 2))[0, 0, 0]) == 2
