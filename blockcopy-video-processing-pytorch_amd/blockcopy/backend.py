@@ -130,7 +130,9 @@ def load_library(path: str = None) -> ctypes.CDLL:
         "bc_conv3x3_dil_candidates": [i, i, i, i, i, i, ctypes.POINTER(i), i],
         "bc_pred3x3_nhwc": [p, p, p, p, i, i, i, i, i, i, p],
         "bc_spp_levels_nhwc": [p, p, p, p, p, i, i, i, i, i, ctypes.POINTER(i), i, p],
+        "bc_spp_levels_n_nhwc": [p, p, p, p, p, i, i, i, i, i, i, ctypes.POINTER(i), i, p],
         "bc_spp_fuse_nhwc": [p, p, p, p, p, p, i, i, i, i, i, ctypes.POINTER(i), i, i, p],
+        "bc_spp_fuse_n_nhwc": [p, p, p, p, p, p, i, i, i, i, i, i, ctypes.POINTER(i), i, i, p],
         "bc_stem7x7s2_nhwc": [p, p, p, p] + [i] * 7 + [p, p, p, i, p],
         "bc_conv1x1_nhwc": [p, p, p] + [i] * 6 + [p, p, i, p, p, p, i, p],
         "bc_conv1x1_candidates": [i, i, i, i, i, i, ctypes.POINTER(i), i],
@@ -516,35 +518,38 @@ class HipBackend:
         return self.pack_conv3x3_weights(w)
 
     def spp_levels(self, x, scale, shift, w, grids):
-        """lv[bin][CO] of every level: conv1x1_l(relu(bn_l(adaptive_avg_pool2d(x, grid_l)))); bins of level l start at sum of the earlier grids."""
-        _, C, H, W = x.shape
+        """lv[bin][CO] of every level: conv1x1_l(relu(bn_l(adaptive_avg_pool2d(x, grid_l)))); bins of level l start at sum of the earlier grids.
+        A batch of B maps (B, C, H, W) gives (B, bins, CO) in the same launch."""
+        B, C, H, W = x.shape
         L, CO = w.shape[0], w.shape[2]
         assert tuple(w.shape) == (L, C, CO) and w.dtype == torch.float32 and w.is_contiguous() and len(grids) == L
+        assert is_nhwc(x) or C == 1
         for v in (scale, shift):
             assert v is None or (_ok(v, torch.float32) and tuple(v.shape) == (L, C) and v.is_contiguous())
         n_bins = sum(gh * gw for gh, gw in grids)
-        lv = torch.empty((n_bins, CO), dtype=x.dtype, device=x.device)
+        lv = torch.empty((B, n_bins, CO) if B > 1 else (n_bins, CO), dtype=x.dtype, device=x.device)
         garr = (ctypes.c_int * (2 * L))(*[int(v) for g in grids for v in g])
         ptr = lambda t: t.data_ptr() if t is not None else None
         with torch.cuda.device_of(x):
-            self._check(self.lib.bc_spp_levels_nhwc(lv.data_ptr(), x.data_ptr(), ptr(scale), ptr(shift), w.data_ptr(), H, W, C, CO, L, garr,
-                                                    _DTYPE_CODE[x.dtype], self._stream()), "spp_levels_nhwc")
+            self._check(self.lib.bc_spp_levels_n_nhwc(lv.data_ptr(), x.data_ptr(), ptr(scale), ptr(shift), w.data_ptr(), B, H, W, C, CO, L, garr,
+                                                      _DTYPE_CODE[x.dtype], self._stream()), "spp_levels_nhwc")
         return lv
 
     def spp_fuse(self, x, lv, scale, shift, wpk, grids, cout):
-        """conv1x1_f(relu(bn_f(cat[x, upsampled levels]))) without the upsampled maps or the concatenation; returns (1, cout, H, W) channels-last."""
-        _, C, H, W = x.shape
-        L, CO = len(grids), lv.shape[1]
+        """conv1x1_f(relu(bn_f(cat[x, upsampled levels]))) without the upsampled maps or the concatenation; returns (B, cout, H, W) channels-last."""
+        B, C, H, W = x.shape
+        L, CO = len(grids), lv.shape[-1]
         K = C + L * CO
         for v in (scale, shift):
             assert v is None or (_ok(v, torch.float32) and v.numel() == K and v.is_contiguous())
         assert lv.dtype == x.dtype and lv.is_contiguous() and wpk.dtype == torch.float32 and wpk.numel() == cout * ((K + 31) // 32 * 32)
-        out = torch.empty((1, H, W, cout), dtype=x.dtype, device=x.device).permute(0, 3, 1, 2)
+        assert lv.numel() == B * sum(gh * gw for gh, gw in grids) * CO
+        out = torch.empty((B, H, W, cout), dtype=x.dtype, device=x.device).permute(0, 3, 1, 2)
         garr = (ctypes.c_int * (2 * L))(*[int(v) for g in grids for v in g])
         ptr = lambda t: t.data_ptr() if t is not None else None
         with torch.cuda.device_of(x):
-            self._check(self.lib.bc_spp_fuse_nhwc(out.data_ptr(), x.data_ptr(), lv.data_ptr(), ptr(scale), ptr(shift), wpk.data_ptr(), H, W, C, CO, L, garr,
-                                                  cout, _DTYPE_CODE[x.dtype], self._stream()), "spp_fuse_nhwc")
+            self._check(self.lib.bc_spp_fuse_n_nhwc(out.data_ptr(), x.data_ptr(), lv.data_ptr(), ptr(scale), ptr(shift), wpk.data_ptr(), B, H, W, C, CO, L, garr,
+                                                    cout, _DTYPE_CODE[x.dtype], self._stream()), "spp_fuse_nhwc")
         return out
 
     # ---- dense 3x3 conv to <= 4 output channels (detector prediction convs on the combined map): bc_pred3x3_nhwc

@@ -126,12 +126,8 @@ def forward(module, x):
     if not x0.is_contiguous(memory_format=torch.channels_last) or not be.spp_supported(x0[:1], CO, L, N, grids):
         return _generic_tail(module, x0, x)
     lscale, lshift, lw, fscale, fshift, fw = _params(module, blocks, be)
-    outs = []
-    for b in range(B):
-        xb = x0[b:b + 1]
-        lv = be.spp_levels(xb, lscale, lshift, lw, grids)
-        outs.append(be.spp_fuse(xb, lv, fscale, fshift, fw, grids, N))
-    out = outs[0] if B == 1 else torch.cat(outs, 0).contiguous(memory_format=torch.channels_last)
+    lv = be.spp_levels(x0, lscale, lshift, lw, grids)          # (the whole batch in one launch each: the maps are independent)
+    out = be.spp_fuse(x0, lv, fscale, fshift, fw, grids, N)
     return type(x)._wrap_like(out, x, False)
 
 

@@ -3004,17 +3004,18 @@ static int spp_geom(SppGeom &g, int H, int W, int C, int CO, int L, const int32_
     return BC_OK;
 }
 
-BC_EXPORT int bc_spp_levels_nhwc(void *lv, const void *x, const float *scale, const float *shift, const float *weights, int H, int W, int C, int CO,
-                                 int L, const int32_t *grids, int dtype, void *stream)
+BC_EXPORT int bc_spp_levels_n_nhwc(void *lv, const void *x, const float *scale, const float *shift, const float *weights, int B, int H, int W, int C,
+                                   int CO, int L, const int32_t *grids, int dtype, void *stream)
 {
     if (dtype < BC_F32 || dtype > BC_BF16) return BC_ERR_ELEM;
+    if (B <= 0 || B > 65535) return BC_ERR_SHAPE;
     SppGeom g;
     const int rc = spp_geom(g, H, W, C, CO, L, grids, 0);
     if (rc != BC_OK) return rc;
     if (!lv || !x || !weights) return BC_ERR_NULL;
     const int E = dtype == BC_F32 ? 4 : 2;
     if (!aligned(lv, E) || !aligned(x, 16) || !aligned(scale, 4) || !aligned(shift, 4) || !aligned(weights, 4)) return BC_ERR_ALIGN;
-    ProfScope ps(BC_OP_AFFINE, (double)L * H * W * C * E);
+    ProfScope ps(BC_OP_AFFINE, (double)B * L * H * W * C * E);
     hipStream_t st = (hipStream_t)stream;
     const size_t lds_bytes = ((size_t)(256 / (C / 4) + 1) * C + (size_t)C * CO) * sizeof(float);       // partial sums, activated means, the level's weights
     if (lds_bytes > 150 * 1024) return BC_ERR_SHAPE;
@@ -3024,16 +3025,23 @@ BC_EXPORT int bc_spp_levels_nhwc(void *lv, const void *x, const float *scale, co
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spp_levels<DT_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);   \
         lv_attr[DT_] = lds_bytes;                                                                                                                      \
     }                                                                                                                                                  \
-    BC_LAUNCH(ps, (k_spp_levels<DT_>), dim3(g.n_bins), dim3(256), lds_bytes, st, (CvType<DT_>::T *)lv, (const CvType<DT_>::T *)x, scale, shift, weights, g)
+    BC_LAUNCH(ps, (k_spp_levels<DT_>), dim3(g.n_bins, B), dim3(256), lds_bytes, st, (CvType<DT_>::T *)lv, (const CvType<DT_>::T *)x, scale, shift, weights, g)
     if (dtype == BC_F32) { BC_SL(BC_F32); } else if (dtype == BC_F16) { BC_SL(BC_F16); } else { BC_SL(BC_BF16); }
 #undef BC_SL
     return launch_status();
 }
 
-BC_EXPORT int bc_spp_fuse_nhwc(void *out, const void *x, const void *lv, const float *scale, const float *shift, const void *weights_packed, int H, int W,
-                               int C, int CO, int L, const int32_t *grids, int N, int dtype, void *stream)
+BC_EXPORT int bc_spp_levels_nhwc(void *lv, const void *x, const float *scale, const float *shift, const float *weights, int H, int W, int C, int CO,
+                                 int L, const int32_t *grids, int dtype, void *stream)
+{
+    return bc_spp_levels_n_nhwc(lv, x, scale, shift, weights, 1, H, W, C, CO, L, grids, dtype, stream);
+}
+
+BC_EXPORT int bc_spp_fuse_n_nhwc(void *out, const void *x, const void *lv, const float *scale, const float *shift, const void *weights_packed, int B,
+                                 int H, int W, int C, int CO, int L, const int32_t *grids, int N, int dtype, void *stream)
 {
     if (dtype < BC_F32 || dtype > BC_BF16) return BC_ERR_ELEM;
+    if (B <= 0 || B > 65535) return BC_ERR_SHAPE;
     SppGeom g;
     const int rc = spp_geom(g, H, W, C, CO, L, grids, N);
     if (rc != BC_OK) return rc;
@@ -3041,15 +3049,15 @@ BC_EXPORT int bc_spp_fuse_nhwc(void *out, const void *x, const void *lv, const f
     if (!out || !x || !lv || !weights_packed) return BC_ERR_NULL;
     const int E = dtype == BC_F32 ? 4 : 2;
     if (!aligned(out, E) || !aligned(x, E) || !aligned(lv, E) || !aligned(weights_packed, 16) || !aligned(scale, 4) || !aligned(shift, 4)) return BC_ERR_ALIGN;
-    ProfScope ps(BC_OP_CONV3X3, 2.0 * H * W * (double)g.K * N);
-    ps.add_aux(2.0 * H * W * (double)(((g.K + 31) / 32) * 32) * N);
+    ProfScope ps(BC_OP_CONV3X3, 2.0 * B * H * W * (double)g.K * N);
+    ps.add_aux(2.0 * B * H * W * (double)(((g.K + 31) / 32) * 32) * N);
     hipStream_t st = (hipStream_t)stream;
     const size_t kp = (size_t)((g.K + 31) / 32) * 32;
     // two stages + the level maps (fp32) + the block's folded BN + per (row, level) bilinear taps and weights
     const size_t lds_bytes = (size_t)2 * (64 * 9 + 2 * 256) * 16 + ((size_t)g.n_bins * CO + 2 * kp + 64 * SPP_MAX_LEVELS * 6) * 4;
     if (lds_bytes > 150 * 1024) return BC_ERR_SHAPE;
     static size_t attr_set[3] = {0, 0, 0};
-    const dim3 grid((H * W + 63) / 64, N / 64);
+    const dim3 grid((H * W + 63) / 64, N / 64, B);
 #define BC_SF(DT_)                                                                                                                                   \
     if (lds_bytes > attr_set[DT_] && lds_bytes > 48 * 1024) {                                                                                          \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spp_fuse<DT_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);     \
@@ -3060,6 +3068,12 @@ BC_EXPORT int bc_spp_fuse_nhwc(void *out, const void *x, const void *lv, const f
     if (dtype == BC_F32) { BC_SF(BC_F32); } else if (dtype == BC_F16) { BC_SF(BC_F16); } else { BC_SF(BC_BF16); }
 #undef BC_SF
     return launch_status();
+}
+
+BC_EXPORT int bc_spp_fuse_nhwc(void *out, const void *x, const void *lv, const float *scale, const float *shift, const void *weights_packed, int H, int W,
+                               int C, int CO, int L, const int32_t *grids, int N, int dtype, void *stream)
+{
+    return bc_spp_fuse_n_nhwc(out, x, lv, scale, shift, weights_packed, 1, H, W, C, CO, L, grids, N, dtype, stream);
 }
 
 BC_EXPORT int bc_combine_copy_cells(const void *blocks, int N, int C, int H, int W, int bs, int E, int align)

@@ -160,6 +160,11 @@ int bc_spp_levels_nhwc(void *lv, const void *x, const float *scale, const float 
                        int L, const int32_t *grids, int dtype, void *stream);
 int bc_spp_fuse_nhwc(void *out, const void *x, const void *lv, const float *scale, const float *shift, const void *weights_packed, int H, int W,
                      int C, int CO, int L, const int32_t *grids, int N, int dtype, void *stream);
+/* the same two over a batch of B independent maps in one launch each: x (B, H, W, C), lv (B, bins, CO), out (B, H, W, N) */
+int bc_spp_levels_n_nhwc(void *lv, const void *x, const float *scale, const float *shift, const float *weights, int B, int H, int W, int C,
+                         int CO, int L, const int32_t *grids, int dtype, void *stream);
+int bc_spp_fuse_n_nhwc(void *out, const void *x, const void *lv, const float *scale, const float *shift, const void *weights_packed, int B,
+                       int H, int W, int C, int CO, int L, const int32_t *grids, int N, int dtype, void *stream);
 /* number of timing cells (= workgroups) such a launch writes, or a negative error code */
 int bc_combine_copy_cells(const void *blocks, int N, int C, int H, int W, int bs, int elem_size, int align);
 

@@ -245,6 +245,7 @@ class OracleBackend:
 
     def spp_levels(self, x, scale, shift, w, grids):
         F = torch.nn.functional
+        B = x.shape[0]
         out = []
         for l, (gh, gw) in enumerate(grids):
             p = F.adaptive_avg_pool2d(x.contiguous(), (gh, gw))
@@ -253,15 +254,18 @@ class OracleBackend:
             if shift is not None:
                 p = p + shift[l].view(1, -1, 1, 1)
             p = torch.relu(p)
-            out.append(p.permute(0, 2, 3, 1).reshape(gh * gw, -1) @ w[l])
-        return torch.cat(out, 0).contiguous()
+            out.append(p.permute(0, 2, 3, 1).reshape(B, gh * gw, -1) @ w[l])
+        lv = torch.cat(out, 1).contiguous()
+        return lv if B > 1 else lv[0]
 
     def spp_fuse(self, x, lv, scale, shift, wpk, grids, cout):
         F = torch.nn.functional
+        B = x.shape[0]
         H, W = x.shape[2:]
+        lv = lv.reshape(B, -1, lv.shape[-1])
         parts, b0 = [x.contiguous()], 0
         for gh, gw in grids:
-            m = lv[b0:b0 + gh * gw].reshape(1, gh, gw, -1).permute(0, 3, 1, 2).contiguous()
+            m = lv[:, b0:b0 + gh * gw].reshape(B, gh, gw, -1).permute(0, 3, 1, 2).contiguous()
             parts.append(F.interpolate(m, (H, W), mode="bilinear", align_corners=False))
             b0 += gh * gw
         cat = torch.cat(parts, 1)

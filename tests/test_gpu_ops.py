@@ -717,6 +717,28 @@ def test_spp_levels_and_fuse_match_the_stock_ops(be, dtype, tol):
         assert err <= tol * max(1.0, want.abs().max().item()), (case, "fuse", err)
 
 
+def test_spp_kernels_on_a_batch_equal_the_maps_one_by_one(be):
+    """bc_spp_levels_n_nhwc / bc_spp_fuse_n_nhwc over a batch of maps (one launch each, image = a grid dimension) give, image by
+    image, bit for bit what the single-map launches give."""
+    gen = torch.Generator().manual_seed(23)
+    for (B, C, CO, N, H, W, grids) in [(2, 128, 42, 128, 32, 64, [(8, 16), (4, 8), (2, 4)]), (3, 64, 10, 64, 7, 13, [(3, 5), (2, 2)])]:
+        L = len(grids)
+        x = _cl(torch.randn((B, C, H, W), generator=gen).cuda())
+        lw = be.pack_spp_level_weights([(torch.randn((CO, C, 1, 1), generator=gen) * (2.0 / C) ** 0.5).cuda() for _ in range(L)])
+        K = C + L * CO
+        fw = be.pack_spp_fuse_weights((torch.randn((N, K, 1, 1), generator=gen) * (2.0 / K) ** 0.5).cuda())
+        lsc, lsh = (torch.rand((L, C), generator=gen) + 0.5).cuda(), (torch.randn((L, C), generator=gen) * 0.2).cuda()
+        fsc, fsh = (torch.rand(K, generator=gen) + 0.5).cuda(), (torch.randn(K, generator=gen) * 0.2).cuda()
+        lv = be.spp_levels(x, lsc, lsh, lw, grids)
+        out = be.spp_fuse(x, lv, fsc, fsh, fw, grids, N)
+        assert tuple(lv.shape) == (B, sum(a * b for a, b in grids), CO) and tuple(out.shape) == (B, N, H, W)
+        for b in range(B):
+            xb = _cl(x[b:b + 1].clone())
+            lv1 = be.spp_levels(xb, lsc, lsh, lw, grids)
+            assert torch.equal(lv[b], lv1), (B, b, "levels")
+            assert torch.equal(out[b:b + 1], be.spp_fuse(xb, lv1, fsc, fsh, fw, grids, N)), (B, b, "fuse")
+
+
 def test_dense_map_routes_prediction_convs_only(be):
     """to_tensor's DenseMap: conv2d to <= 4 channels goes through bc_pred3x3_nhwc (spy), everything else behaves like -- and
     returns -- a plain tensor; the result equals the library conv within fp32 summation order."""
