@@ -472,13 +472,18 @@ class HipBackend:
             return direct
         # fp32 3x3: the Winograd F(2x2,3x3) stream of csrc/conv3x3_wino.inc follows (16 values per (cin, cout)): U = G g Gt computed
         # in fp64, wino[nb16][chunk][step][q][lane = 16*kq + n][w] = U[f][32*chunk + 8*step + 2*kq + t][16*nb16 + n], 2*f + t = 4*q + w
-        G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64, device=w0.device)
-        U = torch.einsum("xi,ocij,yj->xyco", G, w0.double(), G).reshape(16, Cin, Cout).float()             # f = 4*xi + nu, cin, cout
+        # G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1] applied along both filter axes as plain device arithmetic (no host constant: this may
+        # run while a hipGraph is being captured, where a host-to-device copy is not permitted)
+        def g_rows(t, dim):
+            a, b, c = t.unbind(dim)
+            return torch.stack([a, 0.5 * (a + b + c), 0.5 * (a - b + c), c], dim)
+        U64 = g_rows(g_rows(w0.double(), 2), 3).permute(2, 3, 1, 0)                                          # xi, nu, cin, cout (fp64)
+        U = U64.reshape(16, Cin, Cout).float()                                                              # f = 4*xi + nu, cin, cout
         U = U.reshape(16, Cin // 32, 4, 4, 2, Cout // 16, 16).permute(5, 1, 2, 0, 4, 3, 6)                  # nb, chunk, step, f, t, kq, n
         U16 = U.reshape(Cout // 16, Cin // 32, 4, 8, 4, 4, 16).permute(0, 1, 2, 3, 5, 6, 4)                 # nb, chunk, step, q, kq, n, w
         # third stream: the wide wave tile of csrc/conv3x3_wino32.inc (32 output channels per wave, 4-channel sub-steps):
         # wino32[nb32][chunk][ss][q][lane = 32*h + n][w] = U[f][32*chunk + 4*ss + 2*h + t][32*nb32 + n], 2*f + t = 4*q + w
-        V = torch.einsum("xi,ocij,yj->xyco", G, w0.double(), G).reshape(8, 2, Cin // 32, 8, 2, 2, Cout // 32, 32).float()   # q, f%2, chunk, ss, h, t, nb, n
+        V = U64.reshape(8, 2, Cin // 32, 8, 2, 2, Cout // 32, 32).float()                                      # q, f%2, chunk, ss, h, t, nb, n
         V = V.permute(6, 2, 3, 0, 4, 7, 1, 5)                                                               # nb, chunk, ss, q, h, n, f%2, t
         return torch.cat([direct, U16.contiguous().view(-1), V.contiguous().view(-1)])
 

@@ -118,9 +118,30 @@ def _store(k, tensors, value):
     if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
         return value   # memory of a graph's private pool must not outlive the capture as a cached constant
     if len(_cache) > 4096:
-        _cache.clear()
+        _evict()
     _cache[k] = (value, tuple(weakref.ref(t) if t is not None else None for t in tensors))
     return value
+
+
+def _evict():
+    """Make room WITHOUT forgetting what live models still use: entries of dead tensors and of superseded versions of live ones (a
+    parameter that is trained in place -- the online policy -- leaves one entry per optimizer step) go first; only if that frees less
+    than a quarter, the oldest half goes too.  (Clearing everything, as this used to do, made a later graph capture re-derive -- inside
+    the capture -- the packed weights of a model that had been warmed up: found by the GPU suite when enough tests had filled the cache.)"""
+    def stale(k, refs):
+        for part, r in zip([p for p in k if isinstance(p, tuple) or p is None][-len(refs):], refs):
+            if r is None:
+                continue
+            t = r()
+            if t is None or part is None or t._version != part[2] or t.data_ptr() != part[1]:
+                return True
+        return False
+
+    for k in [k for k, (_, refs) in _cache.items() if stale(k, refs)]:
+        del _cache[k]
+    if len(_cache) > 3072:
+        for k in list(_cache)[:len(_cache) // 2]:
+            del _cache[k]
 
 
 def channel_vector(t: torch.Tensor) -> torch.Tensor:

@@ -565,3 +565,25 @@ def test_c1_cpu_plumbing_4x512x1024_block128_all_active(oracle_backend, golden_d
         got = model.base_model.forward_down(xw.to_blocks(grid, grid))
         for w, g in zip(want, got):
             assert float((g.combine().to_tensor() - w).abs().max()) <= 1e-4 * max(1.0, float(w.abs().max()))
+
+
+def test_derived_parameter_cache_evicts_the_dead_before_the_living():
+    """core/fusion.py keeps derived per-parameter tensors (folded BN vectors, packed conv weights).  When the cache fills up -- an online
+    policy leaves one entry per optimizer step -- the entries of freed tensors and of superseded versions go, those of live, unchanged
+    parameters stay: a model that was warmed up must not have to re-derive its packed weights inside a later graph capture."""
+    from blockcopy.core import fusion
+
+    fusion.clear_cache()
+    live = torch.nn.Parameter(torch.arange(8.0))
+    v_live = fusion.channel_vector(live)
+    trained = torch.nn.Parameter(torch.zeros(4))
+    for step in range(4200):                      # (in-place updates: a new version, hence a new entry, per step)
+        with torch.no_grad():
+            trained.add_(1.0)
+        fusion.channel_vector(trained)
+        if step % 7 == 0:
+            fusion.channel_vector(torch.nn.Parameter(torch.ones(3)))      # (dies at once)
+    assert len(fusion._cache) <= 4097
+    assert fusion.channel_vector(live) is v_live, "the live parameter's entry was dropped"
+    assert float(fusion.channel_vector(trained)[0]) == 4200.0
+    fusion.clear_cache()
