@@ -148,6 +148,12 @@ def build_workload(args, policy, dtype, device, rank, graph=None):
     from bc_workloads import harness
 
     graph = args.graph if graph is None else graph
+    # the online-RL policy draws its initial weights and its sampling seed from torch's generator: fixed per (rank, policy), so that a
+    # config's executed fraction -- and with it its frames/s -- is the same from run to run
+    import random
+
+    torch.manual_seed(20260 + 1000 * rank)
+    random.seed(20260 + 1000 * rank)
     if args.workload == "csp":
         from bc_workloads.csp import build_csp
 
