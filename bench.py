@@ -672,7 +672,7 @@ def main(argv=None):
                        "clips_per_rank": args.steps, "parallelism": f"{world} independent replica(s), no collective",
                        "exec_fraction": exec_frac, "warmup_s": warm_s},
             # frames/s of the reference driver's complete loop (test_swiftnet.py:181-197: per-frame H->D upload from pinned memory, last-frame
-            # upsample + argmax + predictions to the host) with upload / download double-buffered on copy streams; PCIe-inclusive, never `value`
+            # upsample + argmax + predictions to the host) with uploads and the download on copy streams (harness.measure_fps_with_upload); PCIe-inclusive, never `value`
             **({"value_reference_loop": extra["upload_inclusive"]["double_buffered_upload"]} if "upload_inclusive" in extra else {}),
             "roofline": {"kernel": cc.get("kernel") or ("k_combine_copy_ind (fused scatter+copy of the logits map, a node of the frame's hipGraph)" if stamp_us
                                                         else "k_combine_copy (fused scatter+copy of the logits map)"), "bound": "hbm", "achieved": achieved,

@@ -124,7 +124,7 @@ def measure_fps_with_upload(model, host_clips, n_clips: int, warmup_clips: int =
             bufs[i].copy_(frame, non_blocking=True)       # fp32 -> dtype conversion happens on the device side of the copy
             staged[i].record(copy)
 
-    state = {"slot": 0, "primed": False}      # double-buffer slot of the next frame; whether that frame is already on its way
+    state = {"slot": 0, "primed": False}      # device buffer of the next frame; whether that frame is already on its way
 
     def run(clip, next_clip=None):
         if hasattr(model, "reset_temporal"):
