@@ -152,7 +152,9 @@ def build_workload(args, policy, dtype, device, rank, graph=None):
     # config's executed fraction -- and with it its frames/s -- is the same from run to run
     import random
 
-    torch.manual_seed(20260 + 1000 * rank)
+    import torch as _torch          # (the module-level name is only bound inside a worker process; tools import this function directly)
+
+    _torch.manual_seed(20260 + 1000 * rank)
     random.seed(20260 + 1000 * rank)
     if args.workload == "csp":
         from bc_workloads.csp import build_csp
