@@ -133,6 +133,7 @@ def load_library(path: str = None) -> ctypes.CDLL:
         "bc_spp_levels_n_nhwc": [p, p, p, p, p, i, i, i, i, i, i, ctypes.POINTER(i), i, p],
         "bc_spp_fuse_nhwc": [p, p, p, p, p, p, i, i, i, i, i, ctypes.POINTER(i), i, i, p],
         "bc_spp_fuse_n_nhwc": [p, p, p, p, p, p, i, i, i, i, i, i, ctypes.POINTER(i), i, i, p],
+        "bc_spp_fuse_packed_nhwc": [p, p, p, p, p, p, p, i, i, i, i, i, i, i, ctypes.POINTER(i), i, i, p],
         "bc_stem7x7s2_nhwc": [p, p, p, p] + [i] * 7 + [p, p, p, i, p],
         "bc_conv1x1_nhwc": [p, p, p] + [i] * 6 + [p, p, i, p, p, p, i, p],
         "bc_conv1x1_candidates": [i, i, i, i, i, i, ctypes.POINTER(i), i],
@@ -540,9 +541,27 @@ class HipBackend:
                                                       _DTYPE_CODE[x.dtype], self._stream()), "spp_levels_nhwc")
         return lv
 
-    def spp_fuse(self, x, lv, scale, shift, wpk, grids, cout):
-        """conv1x1_f(relu(bn_f(cat[x, upsampled levels]))) without the upsampled maps or the concatenation; returns (B, cout, H, W) channels-last."""
+    def spp_fuse(self, x, lv, scale, shift, wpk, grids, cout, packed=None):
+        """conv1x1_f(relu(bn_f(cat[x, upsampled levels]))) without the upsampled maps or the concatenation; returns (B, cout, H, W) channels-last.
+        ``packed`` = (mapping_exec int32[n_exec], bs): ONE map, result (n_exec, cout, bs, bs) channels-last = the executed tiles only
+        (bc_spp_fuse_packed_nhwc: what the gather of the dense result would give)."""
         B, C, H, W = x.shape
+        if packed is not None:
+            mapping_exec, bs = packed
+            assert B == 1 and _ok(mapping_exec, torch.int32) and H % bs == 0 and W % bs == 0
+            L, CO = len(grids), lv.shape[-1]
+            K = C + L * CO
+            assert lv.dtype == x.dtype and lv.is_contiguous() and wpk.dtype == torch.float32 and wpk.numel() == cout * ((K + 31) // 32 * 32)
+            n_exec = mapping_exec.numel()
+            out = torch.empty((n_exec, bs, bs, cout), dtype=x.dtype, device=x.device).permute(0, 3, 1, 2)
+            garr = (ctypes.c_int * (2 * L))(*[int(v) for g in grids for v in g])
+            ptr = lambda t: t.data_ptr() if t is not None else None
+            if n_exec > 0:
+                with torch.cuda.device_of(x):
+                    self._check(self.lib.bc_spp_fuse_packed_nhwc(out.data_ptr(), x.data_ptr(), lv.data_ptr(), ptr(scale), ptr(shift), wpk.data_ptr(),
+                                                                 mapping_exec.data_ptr(), n_exec, int(bs), H, W, C, CO, L, garr, cout,
+                                                                 _DTYPE_CODE[x.dtype], self._stream()), "spp_fuse_packed_nhwc")
+            return out
         L, CO = len(grids), lv.shape[-1]
         K = C + L * CO
         for v in (scale, shift):

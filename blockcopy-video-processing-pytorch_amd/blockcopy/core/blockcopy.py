@@ -184,9 +184,9 @@ def blockcopy_noblocks(func):
         if packed and isinstance(x, blockcopy.TensorWrapper) and not args:
             from . import spp_fused            # the reference's pyramid-pooling module: two launches instead of 15 (csrc/spp.inc)
 
-            fast = spp_fused.forward(self, x)
+            fast = spp_fused.forward(self, x, like)
         x = fast if fast is not None else func(self, x)
-        if packed:
+        if packed and not (fast is not None and blockcopy.is_block(fast)):      # (the fast route may hand the executed tiles back packed)
             x = blockcopy.to_tensorwrapper(x).to_blocks_like(like)
         return x
 

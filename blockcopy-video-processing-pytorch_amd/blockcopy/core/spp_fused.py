@@ -13,8 +13,13 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+import os
+
 from . import fusion
 from ..backend import get_backend
+
+# the last block computes the executed tiles only and returns them packed (bc_spp_fuse_packed_nhwc); 0 = dense result + gather
+PACKED_RESULT = os.environ.get("BLOCKCOPY_SPP_PACKED", "1") != "0"
 
 
 def _block_parts(block):
@@ -100,8 +105,10 @@ def _params(module, blocks, be):
     return out
 
 
-def forward(module, x):
-    """The module's forward on the dense TensorWrapper ``x`` through the two-launch route, or None (caller runs the generic route)."""
+def forward(module, x, like=None):
+    """The module's forward on the dense TensorWrapper ``x`` through the two-launch route, or None (caller runs the generic route).
+    ``like`` = the packed tensor the dense map was combined from: with one map per launch and exact tile counts the second launch then
+    computes the executed tiles only and the result comes back PACKED (the caller must not re-pack it)."""
     if not fusion.SPP_FUSED or not fusion.ENABLED or torch.is_grad_enabled():
         return None
     be = get_backend()
@@ -127,6 +134,12 @@ def forward(module, x):
         return _generic_tail(module, x0, x)
     lscale, lshift, lw, fscale, fshift, fw = _params(module, blocks, be)
     lv = be.spp_levels(x0, lscale, lshift, lw, grids)          # (the whole batch in one launch each: the maps are independent)
+    feats = like.get_features() if like is not None else None
+    if (PACKED_RESULT and B == 1 and feats is not None and feats.dyn is None and feats.engine == "fused" and getattr(be, "spp_fuse_packed_ok", True)):
+        mapping_exec = like.get_mapping_exec()
+        bs = H // like.get_grid_idx().shape[2]
+        out = be.spp_fuse(x0, lv, fscale, fshift, fw, grids, N, packed=(mapping_exec, bs))
+        return type(x)._wrap_like(out, like, True)
     out = be.spp_fuse(x0, lv, fscale, fshift, fw, grids, N)
     return type(x)._wrap_like(out, x, False)
 

@@ -3001,6 +3001,7 @@ static int spp_geom(SppGeom &g, int H, int W, int C, int CO, int L, const int32_
     }
     for (int l = L; l < SPP_MAX_LEVELS; ++l) { g.gh[l] = g.gw[l] = 1; g.bin0[l] = nb; }
     g.n_bins = nb; g.K = C + L * CO; g.N = N;
+    g.mapping = nullptr; g.bs = 0; g.GW = 0; g.n_rows = 0;
     return BC_OK;
 }
 
@@ -3037,27 +3038,35 @@ BC_EXPORT int bc_spp_levels_nhwc(void *lv, const void *x, const float *scale, co
     return bc_spp_levels_n_nhwc(lv, x, scale, shift, weights, 1, H, W, C, CO, L, grids, dtype, stream);
 }
 
-BC_EXPORT int bc_spp_fuse_n_nhwc(void *out, const void *x, const void *lv, const float *scale, const float *shift, const void *weights_packed, int B,
-                                 int H, int W, int C, int CO, int L, const int32_t *grids, int N, int dtype, void *stream)
+static int spp_fuse_impl(void *out, const void *x, const void *lv, const float *scale, const float *shift, const void *weights_packed, int B,
+                         int H, int W, int C, int CO, int L, const int32_t *grids, int N, int dtype, const int32_t *mapping_exec, int n_exec, int bs,
+                         void *stream)
 {
     if (dtype < BC_F32 || dtype > BC_BF16) return BC_ERR_ELEM;
     if (B <= 0 || B > 65535) return BC_ERR_SHAPE;
     SppGeom g;
     const int rc = spp_geom(g, H, W, C, CO, L, grids, N);
     if (rc != BC_OK) return rc;
+    if (mapping_exec) {
+        // packed result: rows = the pixels of the executed tiles of ONE map
+        if (B != 1 || bs <= 0 || H % bs != 0 || W % bs != 0 || n_exec < 0 || n_exec > (H / bs) * (W / bs)) return BC_ERR_SHAPE;
+        if (n_exec == 0) return BC_OK;
+        g.mapping = mapping_exec; g.bs = bs; g.GW = W / bs; g.n_rows = (uint32_t)n_exec * bs * bs;
+    }
+    const uint32_t rows = mapping_exec ? g.n_rows : (uint32_t)(H * W);
     if (N <= 0 || N % 64 != 0) return BC_ERR_SHAPE;
     if (!out || !x || !lv || !weights_packed) return BC_ERR_NULL;
     const int E = dtype == BC_F32 ? 4 : 2;
     if (!aligned(out, E) || !aligned(x, E) || !aligned(lv, E) || !aligned(weights_packed, 16) || !aligned(scale, 4) || !aligned(shift, 4)) return BC_ERR_ALIGN;
-    ProfScope ps(BC_OP_CONV3X3, 2.0 * B * H * W * (double)g.K * N);
-    ps.add_aux(2.0 * B * H * W * (double)(((g.K + 31) / 32) * 32) * N);
+    ProfScope ps(BC_OP_CONV3X3, 2.0 * B * rows * (double)g.K * N);
+    ps.add_aux(2.0 * B * rows * (double)(((g.K + 31) / 32) * 32) * N);
     hipStream_t st = (hipStream_t)stream;
     const size_t kp = (size_t)((g.K + 31) / 32) * 32;
     // two stages + the level maps (fp32) + the block's folded BN + per (row, level) bilinear taps and weights
     const size_t lds_bytes = (size_t)2 * (64 * 9 + 2 * 256) * 16 + ((size_t)g.n_bins * CO + 2 * kp + 64 * SPP_MAX_LEVELS * 6) * 4;
     if (lds_bytes > 150 * 1024) return BC_ERR_SHAPE;
     static size_t attr_set[3] = {0, 0, 0};
-    const dim3 grid((H * W + 63) / 64, N / 64, B);
+    const dim3 grid((rows + 63) / 64, N / 64, B);
 #define BC_SF(DT_)                                                                                                                                   \
     if (lds_bytes > attr_set[DT_] && lds_bytes > 48 * 1024) {                                                                                          \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spp_fuse<DT_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);     \
@@ -3070,10 +3079,24 @@ BC_EXPORT int bc_spp_fuse_n_nhwc(void *out, const void *x, const void *lv, const
     return launch_status();
 }
 
+BC_EXPORT int bc_spp_fuse_n_nhwc(void *out, const void *x, const void *lv, const float *scale, const float *shift, const void *weights_packed, int B,
+                                 int H, int W, int C, int CO, int L, const int32_t *grids, int N, int dtype, void *stream)
+{
+    return spp_fuse_impl(out, x, lv, scale, shift, weights_packed, B, H, W, C, CO, L, grids, N, dtype, nullptr, 0, 0, stream);
+}
+
 BC_EXPORT int bc_spp_fuse_nhwc(void *out, const void *x, const void *lv, const float *scale, const float *shift, const void *weights_packed, int H, int W,
                                int C, int CO, int L, const int32_t *grids, int N, int dtype, void *stream)
 {
-    return bc_spp_fuse_n_nhwc(out, x, lv, scale, shift, weights_packed, 1, H, W, C, CO, L, grids, N, dtype, stream);
+    return spp_fuse_impl(out, x, lv, scale, shift, weights_packed, 1, H, W, C, CO, L, grids, N, dtype, nullptr, 0, 0, stream);
+}
+
+BC_EXPORT int bc_spp_fuse_packed_nhwc(void *out, const void *x, const void *lv, const float *scale, const float *shift, const void *weights_packed,
+                                      const int32_t *mapping_exec, int n_exec, int bs, int H, int W, int C, int CO, int L, const int32_t *grids, int N,
+                                      int dtype, void *stream)
+{
+    if (!mapping_exec) return BC_ERR_NULL;
+    return spp_fuse_impl(out, x, lv, scale, shift, weights_packed, 1, H, W, C, CO, L, grids, N, dtype, mapping_exec, n_exec, bs, stream);
 }
 
 BC_EXPORT int bc_combine_copy_cells(const void *blocks, int N, int C, int H, int W, int bs, int E, int align)

@@ -165,6 +165,12 @@ int bc_spp_levels_n_nhwc(void *lv, const void *x, const float *scale, const floa
                          int CO, int L, const int32_t *grids, int dtype, void *stream);
 int bc_spp_fuse_n_nhwc(void *out, const void *x, const void *lv, const float *scale, const float *shift, const void *weights_packed, int B,
                        int H, int W, int C, int CO, int L, const int32_t *grids, int N, int dtype, void *stream);
+/* the fuse launch with a PACKED result (one map): only the pixels of the executed tiles are computed, out (n_exec, bs, bs, N) = what
+ * bc_split of the dense result would give -- the re-packing gather after the dense module (core/blockcopy.py:118-121, to_blocks_like)
+ * and the never-used pixels of the skipped tiles disappear.  H, W multiples of bs; mapping_exec as everywhere (flat grid positions). */
+int bc_spp_fuse_packed_nhwc(void *out, const void *x, const void *lv, const float *scale, const float *shift, const void *weights_packed,
+                            const int32_t *mapping_exec, int n_exec, int bs, int H, int W, int C, int CO, int L, const int32_t *grids, int N,
+                            int dtype, void *stream);
 /* number of timing cells (= workgroups) such a launch writes, or a negative error code */
 int bc_combine_copy_cells(const void *blocks, int N, int C, int H, int W, int bs, int elem_size, int align);
 

@@ -258,7 +258,14 @@ class OracleBackend:
         lv = torch.cat(out, 1).contiguous()
         return lv if B > 1 else lv[0]
 
-    def spp_fuse(self, x, lv, scale, shift, wpk, grids, cout):
+    def spp_fuse(self, x, lv, scale, shift, wpk, grids, cout, packed=None):
+        if packed is not None:      # checker form of bc_spp_fuse_packed_nhwc: the dense result, then the tiles of the executed positions
+            mapping_exec, bs = packed
+            dense = type(self).spp_fuse(self, x, lv, scale, shift, wpk, grids, cout)      # (the class's method: an instance-level spy counts calls)
+            GW = dense.shape[3] // bs
+            tiles = [dense[0, :, (int(ig) // GW) * bs:(int(ig) // GW + 1) * bs, (int(ig) % GW) * bs:(int(ig) % GW + 1) * bs] for ig in mapping_exec.tolist()]
+            out = torch.stack(tiles) if tiles else dense.new_zeros((0, cout, bs, bs))
+            return out.contiguous(memory_format=torch.channels_last)
         F = torch.nn.functional
         B = x.shape[0]
         H, W = x.shape[2:]

@@ -739,6 +739,37 @@ def test_spp_kernels_on_a_batch_equal_the_maps_one_by_one(be):
             assert torch.equal(out[b:b + 1], be.spp_fuse(xb, lv1, fsc, fsh, fw, grids, N)), (B, b, "fuse")
 
 
+def test_spp_fuse_packed_result_equals_the_gather_of_the_dense_result(be):
+    """bc_spp_fuse_packed_nhwc computes the executed tiles only and returns them packed: bit for bit bc_split of the dense launch's
+    result (same rows, same arithmetic), for ragged last row tiles, one tile, all tiles, none."""
+    gen = torch.Generator().manual_seed(29)
+    rng = np.random.default_rng(29)
+    for (C, CO, N, GH, GW, bs, grids) in [(128, 42, 128, 8, 16, 4, [(8, 16), (4, 8), (2, 4)]), (64, 10, 64, 3, 5, 2, [(3, 5), (2, 2)]), (128, 42, 128, 2, 2, 8, [(2, 2)])]:
+        H, W, L = GH * bs, GW * bs, len(grids)
+        x = _cl(torch.randn((1, C, H, W), generator=gen).cuda())
+        lw = be.pack_spp_level_weights([(torch.randn((CO, C, 1, 1), generator=gen) * (2.0 / C) ** 0.5).cuda() for _ in range(L)])
+        K = C + L * CO
+        fw = be.pack_spp_fuse_weights((torch.randn((N, K, 1, 1), generator=gen) * (2.0 / K) ** 0.5).cuda())
+        fsc, fsh = (torch.rand(K, generator=gen) + 0.5).cuda(), (torch.randn(K, generator=gen) * 0.2).cuda()
+        lv = be.spp_levels(x, None, None, lw, grids)
+        dense = be.spp_fuse(x, lv, fsc, fsh, fw, grids, N)
+        for frac in (0.5, 1.0, 0.0, None):
+            g = np.zeros(GH * GW, bool)
+            if frac is None:
+                g[int(rng.integers(GH * GW))] = True
+            else:
+                g[rng.random(GH * GW) < frac] = True
+                if frac == 1.0:
+                    g[:] = True
+            gi, m = O.c_grid_mappings(g.reshape(1, 1, GH, GW))
+            gi_d, m_d = _dev(gi), _dev(m)
+            got = be.spp_fuse(x, lv, fsc, fsh, fw, grids, N, packed=(m_d, bs))
+            assert tuple(got.shape) == (len(m), N, bs, bs)
+            if len(m):
+                want = be.split(torch.empty_like(got), dense, m_d, gi_d)
+                assert torch.equal(got, want), (C, bs, frac)
+
+
 def test_dense_map_routes_prediction_convs_only(be):
     """to_tensor's DenseMap: conv2d to <= 4 channels goes through bc_pred3x3_nhwc (spy), everything else behaves like -- and
     returns -- a plain tensor; the result equals the library conv within fp32 summation order."""
