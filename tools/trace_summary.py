@@ -2,8 +2,8 @@
 """Summarise a rocprofv3 --kernel-trace CSV of bench.py: per-frame kernel time inside the timed clips.
 
 usage: trace_summary.py <kernel_trace.csv> <frames_in_window> [skip_last_frames] [gathers_per_frame] [out.json]
-The window is delimited by the gather (k_tiles<.., true>) launches: two per SwiftNet frame (network input + SPP output), one per
-CSP frame (network input).  out.json: the per-kernel averages of the window in machine-readable form (profiles/rocprof_latest.json
+The window is delimited by the input-stage launches of the frames (k_tile_copy_ind, one per graph-replayed frame); traces without
+them: by the gather (k_tiles<.., true>) launches, `gathers_per_frame` per frame.  out.json: the per-kernel averages of the window in machine-readable form (profiles/rocprof_latest.json
 is what bench.py reports beside its own event-based duration of the roofline kernel)."""
 import collections
 import csv
@@ -17,7 +17,12 @@ def main():
     skip = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     rows = list(csv.DictReader(open(path)))
     ks = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows)
-    marks = [s for s, e, n in ks if "k_tiles<" in n and ", true" in n]
+    # frame markers: the input stage of a graph-replayed frame (k_tile_copy_ind, one per frame) where the trace has it, else the gathers
+    marks = [s for s, e, n in ks if "k_tile_copy_ind<" in n]
+    if marks and len(sys.argv) > 4:
+        sys.argv[4] = "1"
+    if not marks:
+        marks = [s for s, e, n in ks if "k_tiles<" in n and ", true" in n]
     per_frame = int(sys.argv[4]) if len(sys.argv) > 4 else 2
     fe = marks[-per_frame * skip] if skip else ks[-1][1] + 1
     fs = marks[-per_frame * (skip + n_frames)]
