@@ -3062,20 +3062,29 @@ static int spp_fuse_impl(void *out, const void *x, const void *lv, const float *
     ps.add_aux(2.0 * B * rows * (double)(((g.K + 31) / 32) * 32) * N);
     hipStream_t st = (hipStream_t)stream;
     const size_t kp = (size_t)((g.K + 31) / 32) * 32;
-    // two stages + the level maps (fp32) + the block's folded BN + per (row, level) bilinear taps and weights
-    const size_t lds_bytes = (size_t)2 * (64 * 9 + 2 * 256) * 16 + ((size_t)g.n_bins * CO + 2 * kp + 64 * SPP_MAX_LEVELS * 6) * 4;
+    // two stages per K group + the level maps (fp32) + the block's folded BN + per (row, level) bilinear taps and weights
+    const size_t stage_bytes = (size_t)2 * (64 * 9 + 2 * 256) * 16, table_bytes = ((size_t)g.n_bins * CO + 2 * kp + 64 * SPP_MAX_LEVELS * 6) * 4;
+    // two K groups (512 threads, csrc/spp.inc) where the kernel's preload path covers the shape and the second pair of stages fits
+    static const int ks_knob = [] { const char *e = getenv("BC_SPP_KS"); return e ? atoi(e) : 2; }();
+    const bool pre = kp / 32 <= 8 && C % 32 == 0 && C / 32 <= 4;
+    const int KS = (ks_knob >= 2 && pre && kp / 32 >= 2 && 2 * stage_bytes + table_bytes <= 150 * 1024) ? 2 : 1;
+    const size_t lds_bytes = KS * stage_bytes + table_bytes;
     if (lds_bytes > 150 * 1024) return BC_ERR_SHAPE;
-    static size_t attr_set[3] = {0, 0, 0};
+    static size_t attr_set[3][2] = {{0, 0}, {0, 0}, {0, 0}};
     const dim3 grid((rows + 63) / 64, N / 64, B);
-#define BC_SF(DT_)                                                                                                                                   \
-    if (lds_bytes > attr_set[DT_] && lds_bytes > 48 * 1024) {                                                                                          \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spp_fuse<DT_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);     \
-        attr_set[DT_] = lds_bytes;                                                                                                                     \
-    }                                                                                                                                                  \
-    BC_LAUNCH(ps, (k_spp_fuse<DT_>), grid, dim3(256), lds_bytes, st, (CvType<DT_>::T *)out, (const CvType<DT_>::T *)x, (const CvType<DT_>::T *)lv, \
-                             scale, shift, (const uint4 *)weights_packed, g)
+#define BC_SF2(DT_, KS_)                                                                                                                             \
+    do {                                                                                                                                               \
+        if (lds_bytes > attr_set[DT_][KS_ - 1] && lds_bytes > 48 * 1024) {                                                                             \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spp_fuse<DT_, KS_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+            attr_set[DT_][KS_ - 1] = lds_bytes;                                                                                                        \
+        }                                                                                                                                              \
+        BC_LAUNCH(ps, (k_spp_fuse<DT_, KS_>), grid, dim3(256 * KS_), lds_bytes, st, (CvType<DT_>::T *)out, (const CvType<DT_>::T *)x,               \
+                  (const CvType<DT_>::T *)lv, scale, shift, (const uint4 *)weights_packed, g);                                                        \
+    } while (0)
+#define BC_SF(DT_) do { if (KS == 2) BC_SF2(DT_, 2); else BC_SF2(DT_, 1); } while (0)
     if (dtype == BC_F32) { BC_SF(BC_F32); } else if (dtype == BC_F16) { BC_SF(BC_F16); } else { BC_SF(BC_BF16); }
 #undef BC_SF
+#undef BC_SF2
     return launch_status();
 }
 
