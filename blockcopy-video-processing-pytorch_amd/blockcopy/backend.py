@@ -486,7 +486,15 @@ class HipBackend:
         # wino32[nb32][chunk][ss][q][lane = 32*h + n][w] = U[f][32*chunk + 4*ss + 2*h + t][32*nb32 + n], 2*f + t = 4*q + w
         V = U64.reshape(8, 2, Cin // 32, 8, 2, 2, Cout // 32, 32).float()                                      # q, f%2, chunk, ss, h, t, nb, n
         V = V.permute(6, 2, 3, 0, 4, 7, 1, 5)                                                               # nb, chunk, ss, q, h, n, f%2, t
-        return torch.cat([direct, U16.contiguous().view(-1), V.contiguous().view(-1)])
+        # fourth stream: Winograd F(4x4,3x3) of csrc/conv3x3_wino4.inc (36 values per (cin, cout)), U = G g Gt in fp64 with
+        # G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]:
+        # wino4[cb][chunk][f = 6*xi + nu][lane = 16*kq + n][j] = U[f][16*chunk + 4*kq + j][16*cb + n]
+        def g4_rows(t, dim):
+            a, b, c = t.unbind(dim)
+            return torch.stack([a / 4, -(a + b + c) / 6, -(a - b + c) / 6, a / 24 + b / 12 + c / 6, a / 24 - b / 12 + c / 6, c], dim)
+        U4 = g4_rows(g4_rows(w0.double(), 2), 3).permute(2, 3, 1, 0).reshape(36, Cin, Cout).float()          # f, cin, cout
+        U4 = U4.reshape(36, Cin // 16, 4, 4, Cout // 16, 16).permute(4, 1, 0, 2, 5, 3)                      # cb, chunk, f, kq, n, j
+        return torch.cat([direct, U16.contiguous().view(-1), V.contiguous().view(-1), U4.contiguous().view(-1)])
 
     # ---- pyramid pooling of a dense map in two launches (csrc/spp.inc): bc_spp_levels_nhwc + bc_spp_fuse_nhwc
     SPP_LDS_LIMIT = 150 * 1024      # both launchers refuse (BC_ERR_SHAPE) above this much dynamic LDS
@@ -606,12 +614,12 @@ class HipBackend:
     def conv3x3_candidates(self, n_exec, cin, cout, bs, elem_size=4, stride=1, dilation=1):
         """Decomposition indices of the balanced conv kernel that cover this layer shape (bs = input tile size), straight from
         the library's launcher rules (bc_conv3x3_candidates / bc_conv3x3_dil_candidates)."""
-        buf = (ctypes.c_int * 64)()
+        buf = (ctypes.c_int * 128)()
         dt = 0 if elem_size == 4 else 1
         if dilation != 1:
-            n = self.lib.bc_conv3x3_dil_candidates(dt, int(dilation), int(n_exec), int(cin), int(cout), int(bs), buf, 64)
+            n = self.lib.bc_conv3x3_dil_candidates(dt, int(dilation), int(n_exec), int(cin), int(cout), int(bs), buf, 128)
         else:
-            n = self.lib.bc_conv3x3_candidates(dt, int(stride), int(n_exec), int(cin), int(cout), int(bs), buf, 64)
+            n = self.lib.bc_conv3x3_candidates(dt, int(stride), int(n_exec), int(cin), int(cout), int(bs), buf, 128)
         if n < 0:
             return []
         return [int(buf[k]) for k in range(n)]
@@ -657,7 +665,7 @@ class HipBackend:
         N, _, GH, GW = grid_idx.shape
         B, C, bs, _ = data_exec.shape
         n_exec = mapping_exec.numel()
-        assert n_exec == B and wpk.numel() in (9 * C * cout, 41 * C * cout)     # (fp32: direct + two Winograd streams)
+        assert n_exec == B and wpk.numel() in (9 * C * cout, 77 * C * cout)     # (fp32: direct + three Winograd streams)
         assert dilation in (1, 2) and (dilation == 1 or stride == 1)
         assert tuple(ring.shape) == (N * GH * GW, C, 4 * dilation * bs), (ring.shape, (N * GH * GW, C, 4 * dilation * bs))
         assert stride in (1, 2) and bs % stride == 0

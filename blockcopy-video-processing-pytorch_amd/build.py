@@ -9,14 +9,14 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = [os.path.join(HERE, "csrc", "blockcopy_hip.hip")]
 HDR = [os.path.join(os.path.dirname(HERE), "include", "blockcopy_hip.h")] + [os.path.join(HERE, "csrc", f) for f in
-                                                                             ("conv3x3_mfma.inc", "conv3x3_v2.inc", "conv3x3_wino.inc", "conv3x3_wino32.inc", "stem7x7.inc", "head1x1.inc", "pred3x3.inc", "gemm1x1.inc", "spp.inc")]
+                                                                             ("conv3x3_mfma.inc", "conv3x3_v2.inc", "conv3x3_wino.inc", "conv3x3_wino32.inc", "conv3x3_wino4.inc", "stem7x7.inc", "head1x1.inc", "pred3x3.inc", "gemm1x1.inc", "spp.inc")]
 OUT = os.path.join(HERE, "lib", "libblockcopy_hip.so")
 OBJ_DIR = os.path.join(HERE, "lib", "obj")
 ARCH = "gfx950"
 # the one source is compiled as 7 translation units (-DBC_PART=n, see ConvV2Args in csrc/blockcopy_hip.hip): part 0 = everything
 # but the decompositions of the fused conv kernel, parts 1..6 = one (dtype, kernel size) slice of them each, part 7 = its Winograd form,
-# part 8 = the wide-tile Winograd form, part 9 = the dilation-2 form of the direct kernel
-PARTS = list(range(10))
+# part 8 = the wide-tile Winograd form, part 9 = the dilation-2 form of the direct kernel, part 10 = the Winograd F(4x4,3x3) form
+PARTS = list(range(11))
 
 
 def hipcc() -> str:

@@ -2244,6 +2244,7 @@ int check_halo(const void *out, const void *features, const int32_t *grid_idx, c
 #include "conv3x3_v2.inc"
 #include "conv3x3_wino.inc"
 #include "conv3x3_wino32.inc"
+#include "conv3x3_wino4.inc"
 #include "stem7x7.inc"
 #include "head1x1.inc"
 #include "pred3x3.inc"
@@ -2330,7 +2331,7 @@ static inline uint32_t conv_xcd_order(const ConvV2Args &a)
 }
 struct LaunchProf { bool on; struct { hipEvent_t a, b; } rec; };   // what BC_LAUNCH needs of a ProfScope
 
-#if defined(BC_MONO) || (BC_PART != 0 && BC_PART != 7 && BC_PART != 8)
+#if defined(BC_MONO) || (BC_PART != 0 && BC_PART != 7 && BC_PART != 8 && BC_PART != 10)
 template <int DT, int RM, int RN, int WMW, int WNW, int WKW, int SC, int PW, int S, int KS, int D = 1>
 static void launch_conv3x3_v2_cfg(LaunchProf &ps, dim3 grid, size_t lds_bytes, const ConvV2Args &a, const ConvGeom2 &g)
 {
@@ -2659,7 +2660,80 @@ static int conv_wino32_run(ConvV2Args &a)
 extern "C" int bc_part_conv_wino32(void *p) { return conv_wino32_run(*static_cast<ConvV2Args *>(p)); }
 #endif
 
-#if BC_PART != 0 && BC_PART != 7 && BC_PART != 8 && BC_PART != 9
+// ---- host side of conv3x3_wino4.inc (Winograd F(4x4,3x3), fp32 / stride 1, tiles of a multiple of 16 pixels or 8x8 tiles):
+// decompositions (WNW, WFW, NB) of 8 waves; code 0x1000 | index
+struct Wino4Cfg { int WNW, WFW, NB; };
+static const Wino4Cfg WINO4_CFGS[] = {{4, 2, 1}, {2, 4, 1}, {2, 4, 2}};
+constexpr int WINO4_N = (int)(sizeof(WINO4_CFGS) / sizeof(WINO4_CFGS[0]));
+
+struct Wino4Plan { long long wgs; size_t lds_bytes; uint32_t n_rows; };
+static bool wino4_plan(const Wino4Cfg &k, int n_exec, int Cin, int Cout, int bs, Wino4Plan &p)
+{
+    if (!(bs % 16 == 0 || bs == 8) || bs > 240 || Cin % 16 != 0 || Cout % (16 * k.NB * k.WNW) != 0) return false;
+    const size_t raw = (size_t)(bs == 8 ? 4 * 100 : 324) * 64, vimg = (size_t)36 * 1024;
+    p.lds_bytes = 2 * raw + 2 * vimg;
+    if (p.lds_bytes < (size_t)8 * 16384) p.lds_bytes = 8 * 16384;      // the output stage: one [256 pixels][16 channels] area per wave
+    const long long slots = bs == 8 ? ((long long)n_exec + 3) / 4 : (long long)n_exec * (bs / 16) * (bs / 16);     // M-blocks
+    p.n_rows = (uint32_t)slots;
+    p.wgs = slots * (Cout / (16 * k.NB * k.WNW));
+    return true;
+}
+
+#if defined(BC_MONO) || BC_PART == 10
+template <int TS, int WNW, int WFW, int NB>
+static void launch_wino4_ts(LaunchProf &ps, dim3 grid, size_t lds_bytes, const ConvV2Args &a, const ConvGeom2 &g)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_wino4<TS, WNW, WFW, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+        attr_set = true;
+    }
+    // the F(4x4) stream follows the direct and the two F(2x2) streams (pack_conv3x3_weights: 9 + 16 + 16 + 36 values per pair)
+    const float4 *w4 = reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(a.wpk) + (size_t)41 * a.Cin * a.Cout);
+    BC_LAUNCH(ps, (k_conv3x3_wino4<TS, WNW, WFW, NB>), grid, dim3(512), lds_bytes, a.st, (float *)a.out, (const uint4 *)a.features,
+              (long long)(((const char *)a.ring - (const char *)a.features) / 16), (uint4 *)a.ring, w4, a.grid_idx, a.mapping_exec, g, a.pr, a.ep, a.stamps);
+}
+
+template <int WNW, int WFW, int NB>
+static void launch_wino4_cfg(LaunchProf &ps, dim3 grid, size_t lds_bytes, const ConvV2Args &a, const ConvGeom2 &g)
+{
+    if (a.bs == 8) launch_wino4_ts<8, WNW, WFW, NB>(ps, grid, lds_bytes, a, g);
+    else launch_wino4_ts<16, WNW, WFW, NB>(ps, grid, lds_bytes, a, g);
+}
+
+static int conv_wino4_run(ConvV2Args &a)
+{
+    const int c = a.force_cfg & 0xff;
+    if (c >= WINO4_N) return BC_ERR_SHAPE;
+    const Wino4Cfg &k = WINO4_CFGS[c];
+    Wino4Plan plan;
+    if (!wino4_plan(k, a.n_exec, a.Cin, a.Cout, a.bs, plan)) return BC_ERR_SHAPE;
+    LaunchProf ps{a.prof_on != 0, {a.ev_a, a.ev_b}};
+    ConvGeom2 g;
+    g.Cin = a.Cin; g.Cout = a.Cout; g.bs = a.bs; g.GH = a.GH; g.GW = a.GW; g.n_exec = a.n_exec;
+    g.patches_x = a.bs == 8 ? 1 : a.bs / 16;
+    g.patches_per_tile = a.bs == 8 ? 1 : (a.bs / 16) * (a.bs / 16);
+    g.n_rows = plan.n_rows;
+    g.cin_chunks = a.Cin / 16;
+    g.xcd = conv_xcd_order(a);
+    g.dyn = a.dyn;
+    dim3 grid(plan.n_rows, (unsigned)a.Cout / (16 * k.NB * k.WNW));
+    if (g.dyn.ptr && grid.x <= 65535u) { grid = dim3(grid.y, grid.x); g.xcd |= 2u; }     // device-side count: live rows first in dispatch order (xcd_remap, dyn_order)
+    switch (c) {
+    case 0: launch_wino4_cfg<4, 2, 1>(ps, grid, plan.lds_bytes, a, g); break;
+    case 1: launch_wino4_cfg<2, 4, 1>(ps, grid, plan.lds_bytes, a, g); break;
+    default: launch_wino4_cfg<2, 4, 2>(ps, grid, plan.lds_bytes, a, g); break;
+    }
+    a.chosen = a.force_cfg & 0x10ff;
+    return launch_status();
+}
+#endif
+
+#if BC_PART == 10
+extern "C" int bc_part_conv_wino4(void *p) { return conv_wino4_run(*static_cast<ConvV2Args *>(p)); }
+#endif
+
+#if BC_PART != 0 && BC_PART != 7 && BC_PART != 8 && BC_PART != 9 && BC_PART != 10
 // this slice: dtype (BC_PART - 1) / 2, kernel size 3 (odd parts) or 1 (even parts), both strides
 #define BC_PART_NAME2(n_) bc_part_conv_v2_##n_
 #define BC_PART_NAME(n_) BC_PART_NAME2(n_)
@@ -2695,6 +2769,7 @@ int bc_part_conv_v2_1(void *); int bc_part_conv_v2_2(void *); int bc_part_conv_v
 int bc_part_conv_v2_4(void *); int bc_part_conv_v2_5(void *); int bc_part_conv_v2_6(void *);
 int bc_part_conv_wino(void *);
 int bc_part_conv_wino32(void *);
+int bc_part_conv_wino4(void *);
 int bc_part_conv_v2_dil(void *);
 }
 #endif
@@ -2711,6 +2786,16 @@ static int launch_conv3x3_v2(ProfScope &ps, void *out, const void *features, voi
     a.dyn = g_conv_dyn;
     g_conv_dyn = DynCount{};
     const double direct_flops = 2.0 * n_exec * (double)(bs / S) * (bs / S) * (KS * KS) * (double)Cin * Cout;
+    if (DT == BC_F32 && S == 1 && KS == 3 && a.force_cfg >= 0 && (a.force_cfg & 0x1000)) {      // Winograd F(4x4,3x3) (conv3x3_wino4.inc)
+        ps.add_aux(direct_flops * 36.0 / 144.0);    // 36 multiplications per 4x4 outputs instead of 144
+#if defined(BC_MONO)
+        const int rcw = conv_wino4_run(a);
+#else
+        const int rcw = bc_part_conv_wino4(&a);
+#endif
+        if (a.chosen >= 0) g_tune.conv_last_cfg = a.chosen;
+        return rcw;
+    }
     if (DT == BC_F32 && S == 1 && KS == 3 && a.force_cfg >= 0 && (a.force_cfg & 0x600)) {       // Winograd forms (conv3x3_wino.inc, conv3x3_wino32.inc)
         ps.add_aux(direct_flops * 16.0 / 36.0);     // F(2x2,3x3): 16 multiplications per 2x2 outputs instead of 36
 #if defined(BC_MONO)
@@ -3347,6 +3432,10 @@ static int conv_candidates(int dtype, int stride, int ks, int n_exec, int Cin, i
         Wino32Plan wp32;
         for (int c = 0; c < WINO32_N && n < max_out; ++c)
             if (wino32_plan(WINO32_CFGS[c], n_exec, Cin, Cout, bs, wp32)) out[n++] = c | 0x400;
+        // the F(4x4,3x3) form (conv3x3_wino4.inc)
+        Wino4Plan wp4;
+        for (int c = 0; c < WINO4_N && n < max_out; ++c)
+            if (wino4_plan(WINO4_CFGS[c], n_exec, Cin, Cout, bs, wp4)) out[n++] = c | 0x1000;
     }
     // the plain-GEMM form of a pointwise conv (fp32, stride 1; gemm1x1.inc): workgroup tiles 128x128, 128x64, 64x128, 64x64
     if (dtype == BC_F32 && stride == 1 && ks == 1 && Cin % 32 == 0) {

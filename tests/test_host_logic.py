@@ -401,13 +401,13 @@ def test_conv3x3_weight_packing_matches_the_header_formula():
     Cout, Cin = 64, 96
     w = torch.arange(Cout * Cin * 9, dtype=torch.float32).reshape(Cout, Cin, 3, 3)
     both = HipBackend.pack_conv3x3_weights(w)
-    assert both.numel() == 41 * Cout * Cin      # fp32 3x3: the direct stream, then the two Winograd F(2x2,3x3) streams (16 values per pair each)
+    assert both.numel() == 77 * Cout * Cin      # fp32 3x3: the direct stream, the two Winograd F(2x2,3x3) streams (16 values per pair each), the F(4x4,3x3) stream (36)
     wpk = both[:9 * Cout * Cin].reshape(Cout // 32, Cin // 32, 9, 4, 64, 4)
     assert wpk.numel() == w.numel() and sorted(wpk.reshape(-1).tolist()) == sorted(w.reshape(-1).tolist())
     # Winograd stream: wino[nb16][chunk][step][q][lane = 16*kq + n][e] = (G g Gt)[f][cin = 32*chunk + 8*step + 2*kq + t][cout = 16*nb16 + n], 2*f + t = 4*q + e
     wr = torch.randn(Cout, Cin, 3, 3, dtype=torch.float64, generator=torch.Generator().manual_seed(1))
     wino = HipBackend.pack_conv3x3_weights(wr.float())[9 * Cout * Cin:25 * Cout * Cin].reshape(Cout // 16, Cin // 32, 4, 8, 64, 4)
-    wide = HipBackend.pack_conv3x3_weights(wr.float())[25 * Cout * Cin:].reshape(Cout // 32, Cin // 32, 8, 8, 64, 4)
+    wide = HipBackend.pack_conv3x3_weights(wr.float())[25 * Cout * Cin:41 * Cout * Cin].reshape(Cout // 32, Cin // 32, 8, 8, 64, 4)
     G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64)
     rngw = np.random.default_rng(1)
     for _ in range(300):
@@ -423,6 +423,14 @@ def test_conv3x3_weight_packing_matches_the_header_formula():
         cin, cout = 32 * chunk + 4 * ss + 2 * (lane // 32) + t, 32 * nb + lane % 32
         U = G @ wr.float().double()[cout, cin] @ G.T
         assert abs(float(wide[nb, chunk, ss, q, lane, e]) - float(U[f // 4, f % 4])) <= 1e-6
+    # F(4x4,3x3) stream: wino4[cb][chunk][f][lane = 16*kq + n][j] = (G4 g G4t)[f][cin = 16*chunk + 4*kq + j][cout = 16*cb + n], f = 6*xi + nu
+    w4s = HipBackend.pack_conv3x3_weights(wr.float())[41 * Cout * Cin:].reshape(Cout // 16, Cin // 16, 36, 64, 4)
+    G4 = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], dtype=torch.float64)
+    for _ in range(300):
+        cb, chunk, f, lane, j = (int(rngw.integers(n)) for n in (Cout // 16, Cin // 16, 36, 64, 4))
+        cin, cout = 16 * chunk + 4 * (lane // 16) + j, 16 * cb + lane % 16
+        U = G4 @ wr.float().double()[cout, cin] @ G4.T
+        assert abs(float(w4s[cb, chunk, f, lane, j]) - float(U[f // 6, f % 6])) <= 1e-6
     rng = np.random.default_rng(0)
     for _ in range(500):
         nb, chunk, tap, cg, lane, j = (int(rng.integers(n)) for n in (Cout // 32, Cin // 32, 9, 4, 64, 4))
