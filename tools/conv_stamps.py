@@ -62,6 +62,12 @@ def main():
         print(f"   dispatch {us:.1f} us; a workgroup lives {per_wg:.0f} s_memtime ticks x {rounds:.2f} rounds => ~{ghz:.2f} GHz shader clock during the launch; "
               f"{flops / us / 1e6:.1f} TFLOP/s = {flops / us / 1e6 / 157.3:.0%} of the 2.4 GHz peak = {flops / us / 1e6 / (157.3 * ghz / 2.4):.0%} of the MFMA issue slots at that clock")
         print("   " + " | ".join(f"{n} {seg[:, i].mean():.0f} (max {seg[:, i].max():.0f})" for i, n in enumerate(names)))
+        if (s[:, 6] != 0).all():      # s_memrealtime at entry / exit of every workgroup (100 MHz): the launch's timeline in microseconds
+            r0, r1 = s[:, 6].double() / 100.0, s[:, 7].double() / 100.0
+            o = r0.min()
+            life = (r1 - r0)
+            print(f"   timeline (us): first start 0, last start {float((r0 - o).max()):.2f}, first end {float((r1 - o).min()):.2f}, last end {float((r1 - o).max()):.2f}; "
+                  f"a workgroup lives {float(life.mean()):.2f} us (min {float(life.min()):.2f}, max {float(life.max()):.2f}) => {per_wg / float(life.mean()) / 1e3:.2f} GHz while it runs")
 
 
 if __name__ == "__main__":
