@@ -2670,8 +2670,9 @@ struct Wino4Plan { long long wgs; size_t lds_bytes; uint32_t n_rows; };
 static bool wino4_plan(const Wino4Cfg &k, int n_exec, int Cin, int Cout, int bs, Wino4Plan &p)
 {
     if (!(bs % 16 == 0 || bs == 8) || bs > 240 || Cin % 16 != 0 || Cout % (16 * k.NB * k.WNW) != 0) return false;
+    if (bs == 8 && !(k.WFW == 4 && k.NB == 1)) return false;      // (four 8x8 slots: one staging vector more per thread; the other forms would spill)
     const size_t raw = (size_t)(bs == 8 ? 4 * 100 : 324) * 64, vimg = (size_t)36 * 1024;
-    p.lds_bytes = 2 * raw + 2 * vimg + (size_t)2 * Cin * sizeof(float);      // + the activation coefficients
+    p.lds_bytes = 2 * raw + 2 * vimg + (size_t)2 * Cin * sizeof(float) + 2 * 512 * 8;      // + the activation coefficients + the ring-refresh plan
     if (p.lds_bytes < (size_t)8 * 16384) p.lds_bytes = 8 * 16384;      // the output stage: one [256 pixels][16 channels] area per wave
     const long long slots = bs == 8 ? ((long long)n_exec + 3) / 4 : (long long)n_exec * (bs / 16) * (bs / 16);     // M-blocks
     p.n_rows = (uint32_t)slots;
@@ -2697,8 +2698,9 @@ static void launch_wino4_ts(LaunchProf &ps, dim3 grid, size_t lds_bytes, const C
 template <int WNW, int WFW, int NB>
 static void launch_wino4_cfg(LaunchProf &ps, dim3 grid, size_t lds_bytes, const ConvV2Args &a, const ConvGeom2 &g)
 {
-    if (a.bs == 8) launch_wino4_ts<8, WNW, WFW, NB>(ps, grid, lds_bytes, a, g);
-    else launch_wino4_ts<16, WNW, WFW, NB>(ps, grid, lds_bytes, a, g);
+    if (a.bs == 8) {
+        if constexpr (WFW == 4 && NB == 1) launch_wino4_ts<8, WNW, WFW, NB>(ps, grid, lds_bytes, a, g);
+    } else launch_wino4_ts<16, WNW, WFW, NB>(ps, grid, lds_bytes, a, g);
 }
 
 static int conv_wino4_run(ConvV2Args &a)
