@@ -2762,6 +2762,7 @@ struct TuneState {
     // order cuts the weight-dominated launches to a third (PMC, profiles/r04/21: layer4 Winograd 7.76x -> 2.52x of the algorithmic bytes,
     // direct 4.57x -> 2.12x, dilated detector stage 5.8x -> 3.35x) -- fabric bandwidth a concurrent copy or replica does not have to share
     int xcd_remap = [] { const char *e = getenv("BC_XCD_REMAP"); return e ? atoi(e) : -1; }();
+    int head_split = [] { const char *e = getenv("BC_HEAD_SPLIT"); return e ? atoi(e) : 0; }();            // 1: k_head1x1_s for fp32 / Cout <= 20 (measured neutral in the frame, profiles/r05/09: stays off)
 } g_tune;
 
 
@@ -2946,6 +2947,25 @@ static int launch_head1x1(ProfScope &ps, void *out, const void *features, const 
     return launch_status();
 }
 
+// fp32 / Cout <= 20: the 16 + 4 output-channel split of head1x1.inc (k_head1x1_s)
+template <int CIN>
+static int launch_head1x1_s(ProfScope &ps, void *out, const void *features, const void *wpk, const void *prev, const void *slots,
+                            const int32_t *grid_idx, const int32_t *mapping_exec, const HeadGeom &g, const Prologue &pr,
+                            const float *out_shift, hipStream_t st)
+{
+    constexpr int PXV_ = CIN / 4;
+    constexpr size_t lds_bytes = (size_t)4 * 32 * ((PXV_ < 16 ? PXV_ : 16) + 1) * 16 + (size_t)PXV_ * 4 * 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_head1x1_s<CIN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        attr_set = true;
+    }
+    const dim3 grid(g.n_waves / 4);
+    BC_LAUNCH(ps, (k_head1x1_s<CIN>), grid, dim3(256), lds_bytes, st, (float *)out, (const uint4 *)features, (const uint4 *)wpk, (const float *)prev,
+              (const unsigned long long *)slots, grid_idx, mapping_exec, g, pr, out_shift);
+    return launch_status();
+}
+
 BC_EXPORT int bc_tile_copy_indirect(void *dst, const void *src_slot, const int32_t *mapping_exec, const int32_t *n_exec_dev, int n_exec,
                                     int N, int C, int H, int W, int bs, int E, int align, void *stream)
 {
@@ -3008,7 +3028,8 @@ BC_EXPORT int bc_head1x1_scatter_nhwc(void *out, const void *features, const voi
     g.copy_rows = (scatter && (n_exec < N * GH * GW || arm.ptr)) ? (uint32_t)(N * GH * GW) * (uint32_t)bs : 0;
     // one round of 256 CUs x 2 workgroups x 4 waves at most; at least one wave per M-block or per two tile rows to look at
     uint32_t want = g.n_mblocks > (g.copy_rows + 1) / 2 ? g.n_mblocks : (g.copy_rows + 1) / 2;
-    if (want > 2048u) want = 2048u;
+    static const uint32_t wave_cap = [] { const char *e = getenv("BC_HEAD_WAVES"); return e ? (uint32_t)atoi(e) : 2048u; }();      // (measurement knob)
+    if (want > wave_cap) want = wave_cap;
     if (want < 1u) want = 1u;
     g.n_waves = ((want + 3) / 4) * 4;
     g.run_px = bs < 32 ? bs : 32;
@@ -3022,6 +3043,11 @@ BC_EXPORT int bc_head1x1_scatter_nhwc(void *out, const void *features, const voi
     ps.add_aux(2.0 * px * Cin * 32.0);
     hipStream_t st = (hipStream_t)stream;
 #define BC_HD(DT_, CIN_) return launch_head1x1<DT_, CIN_>(ps, out, features, weights_packed, prev, slots, grid_idx, mapping_exec, g, pr, out_shift, st)
+    if (dtype == BC_F32 && Cout <= 20 && g_tune.head_split) {      // the matrix work cut to 16 + 4 output channels (k_head1x1_s)
+        ps.add_aux(2.0 * px * Cin * 20.0 - 2.0 * px * Cin * 32.0);
+        if (Cin == 64) return launch_head1x1_s<64>(ps, out, features, weights_packed, prev, slots, grid_idx, mapping_exec, g, pr, out_shift, st);
+        return launch_head1x1_s<128>(ps, out, features, weights_packed, prev, slots, grid_idx, mapping_exec, g, pr, out_shift, st);
+    }
     if (dtype == BC_F32) { if (Cin == 64) BC_HD(BC_F32, 64); BC_HD(BC_F32, 128); }
     if (dtype == BC_F16) { if (Cin == 64) BC_HD(BC_F16, 64); if (Cin == 128) BC_HD(BC_F16, 128); BC_HD(BC_F16, 256); }
     if (Cin == 64) BC_HD(BC_BF16, 64);
@@ -3532,6 +3558,7 @@ BC_EXPORT int bc_tune_set(const char *key, int value)
     else if (!strcmp(key, "conv2_cfg")) g_tune.conv2_cfg = value;
     else if (!strcmp(key, "conv2_min_lds")) g_tune.conv2_min_lds = value;
     else if (!strcmp(key, "xcd_remap")) g_tune.xcd_remap = value;
+    else if (!strcmp(key, "head_split")) g_tune.head_split = value;
     else if (!strcmp(key, "stem_min_lds")) g_tune.stem_min_lds = value;
     else return BC_ERR_SHAPE;
     return BC_OK;
@@ -3552,6 +3579,7 @@ BC_EXPORT int bc_tune_get(const char *key, int *value)
     else if (!strcmp(key, "conv2_cfg")) *value = g_tune.conv2_cfg;
     else if (!strcmp(key, "conv2_min_lds")) *value = g_tune.conv2_min_lds;
     else if (!strcmp(key, "xcd_remap")) *value = g_tune.xcd_remap;
+    else if (!strcmp(key, "head_split")) *value = g_tune.head_split;
     else if (!strcmp(key, "conv_last_cfg")) *value = g_tune.conv_last_cfg;
     else return BC_ERR_SHAPE;
     return BC_OK;

@@ -1261,6 +1261,17 @@ def test_adaptive_avg_pool_nhwc(be, dtype, tol):
         assert float((got.float() - want).abs().max()) <= tol * max(1.0, float(want.abs().max())), (N, C, H, W, oh, ow)
 
 
+@pytest.mark.parametrize("geo", [(1, 2, 4, 32, 128, 19), (2, 3, 2, 8, 64, 1), (1, 1, 2, 64, 64, 5), (1, 2, 2, 16, 128, 20), (1, 2, 2, 32, 64, 17)])
+def test_head1x1_split_form_same_contract(be, geo):
+    """k_head1x1_s (fp32, Cout <= 20: 16 output channels on 16x16x4 + up to 4 on 4x4x1 matrix instructions; off by default, measured
+    neutral in the frame) under the whole contract of the test below."""
+    be.tune("head_split", 1)
+    try:
+        test_head1x1_prologue_conv_bias_scatter_copy(be, geo, torch.float32, 2e-5)
+    finally:
+        be.tune("head_split", 0)
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
 @pytest.mark.parametrize("geo", [(1, 2, 4, 32, 128, 19), (2, 3, 2, 8, 64, 1), (1, 2, 3, 16, 128, 32), (1, 1, 2, 64, 64, 5), (1, 4, 4, 8, 256, 19)])
 def test_head1x1_prologue_conv_bias_scatter_copy(be, geo, dtype, tol):
