@@ -542,7 +542,7 @@ def main(argv=None):
             peak = 157.3 if dtype == torch.float32 else 2516.0
             tf = r["total_aux"] / (r["total_ms"] * 1e-3) / 1e12          # matrix FLOPs actually issued
             tf_alg = r["total_bytes"] / (r["total_ms"] * 1e-3) / 1e12    # FLOPs of the direct definition 2*px*k*k*Cin*Cout
-            extra["roofline_conv"] = {"kernel": "k_conv3x3_wino / k_conv3x3_wino32 (Winograd: 16/36 of the direct multiplications) + k_conv3x3_v2 (direct, "
+            extra["roofline_conv"] = {"kernel": "k_conv3x3_wino4 (Winograd F(4x4,3x3): 36/144 of the direct multiplications) + k_conv3x3_wino / k_conv3x3_wino32 (F(2x2,3x3): 16/36) + k_conv3x3_v2 (direct, "
                                                 "stride 2, 1x1) + k_stem7x7; per-layer form: details file",
                                       "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "issued_frac": tf / peak,
                                       "effective_TFLOPs": tf_alg, "effective_frac": tf_alg / peak, "traffic": None,
@@ -607,6 +607,13 @@ def main(argv=None):
             dfps, _, _ = harness.measure_fps(dense, clips[:1], n_clips=max(1, min(args.steps, 3)), warmup_clips=1, device=device)
             extra["dense_gpu_fps"] = dfps
             extra["speedup_vs_dense_gpu"] = fps / dfps
+            if "upload_inclusive" in extra:
+                # the dense model in the SAME upload-inclusive loop (per-frame upload, last-frame upsample / argmax / predictions to the host):
+                # the like-for-like denominator of `value_reference_loop`
+                ddfps, _, _ = harness.measure_fps_with_upload(dense, hclips, n_clips=max(1, min(args.steps, 3)), warmup_clips=1, device=device,
+                                                              dtype=dtype, prefetch=True, fused_tail=True)
+                extra["upload_inclusive"]["dense_double_buffered_upload"] = ddfps
+                extra["upload_inclusive"]["speedup_vs_dense_reference_loop"] = extra["upload_inclusive"]["double_buffered_upload"] / ddfps
             del dense
             if args.also_half and not args.half:
                 # secondary measurement, outside the timed region: the identical workload in fp16
@@ -654,13 +661,16 @@ def main(argv=None):
                       method="dispatch-attached HIP events (hipExtLaunchKernelGGL) over one eager clip run inside bench.py right after the timed region "
                              "(graph kernel nodes cannot carry events)")
         achieved = (cc["total_bytes"] / (cc["total_ms"] * 1e-3) / 1e9) if cc["total_ms"] > 0 else 0.0
+        # (the segmentation logits map: batch x 19 classes x H/4 x W/4)
+        pure_scatter = None if is_csp else 2.0 * args.batch * 19 * (args.height // 4) * (args.width // 4) * (2 if args.half else 4)
         traffic, traffic_src, traffic_kernels = pmc_traffic()
         # the same kernel in the committed rocprofv3 trace of the graph replays (default workload only: that is what was profiled)
         rocprof_fields = {}
         if config_name(args) == "C2" and not args.half and args.batch == 1 and str(cc.get("kernel", "")).startswith("k_head1x1") and cc["launches"]:
             rp_us, rp_frames = rocprof_cross_check("k_head1x1<0")
             if rp_us:
-                rocprof_fields = {"rocprof_avg_launch_us": rp_us, "rocprof_frac": cc["total_bytes"] / cc["launches"] / (rp_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+                rocprof_fields = {"rocprof_avg_launch_us": rp_us, "rocprof_frac": cc["total_bytes"] / cc["launches"] / (rp_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                  "rocprof_source": "committed profiles/rocprof_latest.json (a separate rocprofv3 --kernel-trace run of this command), NOT measured in this run"}
         if traffic_kernels:
             # committed PMC measurement (profiles/traffic_latest.json: rocprofv3 --pmc passes of tools/pmc_driver.py at these shapes)
             details["pmc_traffic"] = traffic_kernels
@@ -680,6 +690,11 @@ def main(argv=None):
                                                         else "k_combine_copy (fused scatter+copy of the logits map)"), "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None if is_csp else (traffic[1] if cc.get("kernel") else traffic[0]),     # (PMC passes exist for the SwiftNet map shapes)
+                         "traffic_source": None if is_csp else "committed profiles/traffic_latest.json (separate rocprofv3 --pmc passes), NOT measured in this run",
+                         # SURVEY.md 8(d)'s PURE scatter+copy count of the same launch (2 * N * C * H * W * E: every tile of the output map read
+                         # once and written once) over the measured duration -- the launch also reads the conv's input features, see `frac`
+                         **({"pure_scatter_bytes_per_launch": pure_scatter, "frac_pure_scatter": pure_scatter / (1e-3 * cc["total_ms"] / cc["launches"]) / 1e9 / HBM_PEAK_GBS}
+                            if cc["launches"] and pure_scatter else {}),
                          "launches": cc["launches"], "avg_launch_us": (1e3 * cc["total_ms"] / cc["launches"]) if cc["launches"] else None,
                          **({"p50_us": cc["p50_us"], "min_us": cc["min_us"], "max_us": cc["max_us"]} if "p50_us" in cc else {}),
                          "algorithmic_bytes_per_launch": (cc["total_bytes"] / cc["launches"]) if cc["launches"] else None,

@@ -19,6 +19,8 @@ gather of the 768-channel head input shared by the three head branches, and devi
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -107,10 +109,37 @@ class CSPNeck(nn.Module):
         self.p3_l2, self.p4_l2, self.p5_l2 = L2Norm(256, 10), L2Norm(256, 10), L2Norm(256, 10)
 
     def forward(self, inputs):
-        p3 = self.p3_l2(self.p3(inputs[0]))
-        p4 = self.p4_l2(self.p4(inputs[1]))
-        p5 = self.p5_l2(self.p5(inputs[2]))
+        ups = [self.p3(inputs[0]), self.p4(inputs[1]), self.p5(inputs[2])]
+        fused = self._l2norm_cat_fused(ups)
+        if fused is not None:
+            return (fused,)
+        p3, p4, p5 = self.p3_l2(ups[0]), self.p4_l2(ups[1]), self.p5_l2(ups[2])
         return (torch.cat([p3, p4, p5], dim=1),)
+
+    def _l2norm_cat_fused(self, ups):
+        """The three L2Norms and the concatenation as one pass per level straight into the 768-channel tensor (bc_l2norm_cat_nhwc:
+        each level is read once and written once; the stock route is six elementwise / reduction passes per level plus the cat).
+        Channels-last GPU tensors only; anything else (CPU oracle runs, NCHW models) takes the stock ops."""
+        x0 = ups[0]
+        if not (torch.is_tensor(x0) and x0.is_cuda) or os.environ.get("BLOCKCOPY_FUSED_NECK", "1") == "0":
+            return None
+        from blockcopy.backend import get_backend
+
+        be = get_backend()
+        raws = [u._materialize()._raw() if hasattr(u, "_raw") else u for u in ups]
+        if not (hasattr(be, "l2norm_cat") and all(be.l2norm_cat_supported(r) and r.shape[0] == raws[0].shape[0] and r.shape[2:] == raws[0].shape[2:]
+                                                   and r.dtype == raws[0].dtype for r in raws)):
+            return None
+        B, _, H, W = raws[0].shape
+        c_total = sum(r.shape[1] for r in raws)
+        out = torch.empty((B, H, W, c_total), dtype=raws[0].dtype, device=raws[0].device).permute(0, 3, 1, 2)
+        off = 0
+        for r, l2 in zip(raws, (self.p3_l2, self.p4_l2, self.p5_l2)):
+            be.l2norm_cat(out, off, r, l2.weight.detach().float().contiguous(), l2.eps)
+            off += r.shape[1]
+        if hasattr(x0, "_raw"):
+            return type(x0)._wrap_result(out, x0)
+        return out
 
 
 # ----------------------------------------------------------------------------------------------- head

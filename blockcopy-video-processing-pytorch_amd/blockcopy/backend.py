@@ -147,6 +147,7 @@ def load_library(path: str = None) -> ctypes.CDLL:
         "bc_adaptive_avg_pool_nhwc": [p, p, i, i, i, i, i, i, i, p],
         "bc_group_norm_affine_nhwc": [p, ctypes.c_longlong, i, i, i, ctypes.c_float, p, p, p, p, p, ctypes.c_longlong, p],
         "bc_nms_sorted": [p, i, ctypes.c_float, p, p, p, p],
+        "bc_l2norm_cat_nhwc": [p, p, p, ctypes.c_longlong, i, i, i, ctypes.c_float, i, p],
         "bc_policy_step": [p, i, ctypes.c_ulonglong, ctypes.c_ulonglong, i, i, p, p, p, p, p, p],
         "bc_policy_features": [p, i, i, i, p, p, p, p, p],
         "bc_dyn_set": [p, i],
@@ -878,6 +879,24 @@ class HipBackend:
                                                         scale.data_ptr(), shift.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()), "bn_train_stats_nhwc")
         return self.affine_act(x, scale, shift, None, relu), save_mean, save_invstd
 
+    # -- L2 normalisation of every pixel over its channels, scaled, written into a channel slice of a wider tensor (bc_l2norm_cat_nhwc)
+    @staticmethod
+    def l2norm_cat_supported(x, out=None):
+        if not (x.is_cuda and x.dim() == 4 and x.dtype in _DTYPE_CODE and x.numel() > 0 and is_nhwc(x)):
+            return False
+        ve = 16 // x.element_size()
+        return x.shape[1] % ve == 0 and x.shape[1] // ve <= 256
+
+    def l2norm_cat(self, out, c_off, x, weight, eps):
+        """out[:, c_off : c_off + C] = weight[c] * x / (||x||_2 over channels + eps), channels-last tensors of one spatial shape."""
+        B, C, H, W = x.shape
+        assert self.l2norm_cat_supported(x) and out.dtype == x.dtype and is_nhwc(out) and out.shape[0] == B and tuple(out.shape[2:]) == (H, W)
+        assert _ok(weight, torch.float32) and weight.numel() == C and 0 <= c_off and c_off + C <= out.shape[1]
+        with torch.cuda.device_of(x):
+            self._check(self.lib.bc_l2norm_cat_nhwc(out.data_ptr(), x.data_ptr(), weight.data_ptr(), B * H * W, C, out.shape[1], int(c_off), float(eps),
+                                                    _DTYPE_CODE[x.dtype], self._stream()), "l2norm_cat_nhwc")
+        return out
+
     # -- group_norm over all executed tiles as a per-channel affine map (one read of the tensor)
     @staticmethod
     def group_norm_affine_supported(data, groups):
@@ -1115,7 +1134,7 @@ class HipBackend:
         order = dets[:, 4].sort(0, descending=True)[1]
         srt = dets.index_select(0, order).contiguous()
         cb = (n + 63) // 64
-        ws = torch.empty(n * cb, dtype=torch.int64, device=dets.device)
+        ws = torch.empty(n * cb + n, dtype=torch.int64, device=dets.device)      # suppression words + per-box in-block suppressors
         keep = torch.empty(n, dtype=torch.int32, device=dets.device)
         count = torch.empty(1, dtype=torch.int32, device=dets.device)
         with torch.cuda.device_of(dets):

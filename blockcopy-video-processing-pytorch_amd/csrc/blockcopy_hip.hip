@@ -1873,60 +1873,243 @@ __global__ __launch_bounds__(WG) void k_upsample_argmax(long long *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------ NMS (detector post-processing)
-// Replaces nms_kernel + the host-side sweep of Pedestron/mmdet/ops/nms/src/nms_kernel.cu:23-130.  Same blocking as the
-// reference for the mask (64 boxes x 64 boxes per workgroup, one 64-bit word per box and column block -- a CDNA wavefront
-// is exactly one such block), but the greedy suppression sweep also runs on the device: ONE wavefront keeps the running
-// `removed` bitmap with one 64-bit word per lane (up to 64*64 = 4096 boxes) and walks the boxes in score order, so the
-// (n x n/64) mask never crosses PCIe and nothing synchronises.
-__device__ __forceinline__ float nms_iou(const float *a, const float *b)
+// Greedy non-maximum suppression of score-sorted boxes in ONE launch (round 5; replaces the mask kernel + host sweep of
+// Pedestron/mmdet/ops/nms/src/nms_kernel.cu:23-130 -- the reference copies an (n x n/64)-word mask to the host and sweeps it there).
+// Rule (the reference's, bit for bit): box j is suppressed by an earlier KEPT box i when IoU(i, j) > thr, IoU with the +1 pixel convention.
+//   phase 1, many workgroups: only the UPPER-triangular 64 x 64 tiles of the pair matrix exist (a box is only ever suppressed by an earlier
+//            one).  A workgroup of four waves owns one tile: lane = row, each wave a quarter of the columns (the column box is
+//            wave-uniform: scalar operands), and stores its 16-bit piece of the row's 64-bit word directly.  Diagonal tiles also leave
+//            the transposed word of every box (its possible suppressors INSIDE its own block: the IoU is symmetric) behind the matrix.
+//   phase 2, the workgroup that finishes LAST (device-scope ticket; nobody spins): pulls the words into LDS (n <= ~1000: n * (ceil(n / 64)
+//            + 1) words <= 150 KB; larger inputs sweep out of L2) and walks the column blocks with ONE wave, lane j = box j of the block:
+//              a removed bitmap with word w in lane w; after a block is resolved its kept lanes OR their words for the LATER blocks
+//                                          into it (lane-parallel reads, DPP reduction per word);
+//              inside the block the greedy rule is resolved as a fixed point instead of a walk: a box whose possible suppressors are all
+//                                          decided is decided (kept iff none of them was kept); each trip settles at least the first
+//                                          undecided box, typically all of them in two or three trips (64-bit ballots).
+//            The kept positions leave in ascending order (block by block, through popcount prefixes).
+struct NmsGeom { int n, words, tiles, lds_rows; };
+
+__device__ __forceinline__ bool nms_suppresses(float ax1, float ay1, float ax2, float ay2, float a_area, float bx1, float by1, float bx2, float by2,
+                                               float b_area, float thr)
 {
-    const float left = fmaxf(a[0], b[0]), right = fminf(a[2], b[2]);
-    const float top = fmaxf(a[1], b[1]), bottom = fminf(a[3], b[3]);
-    const float width = fmaxf(right - left + 1.f, 0.f), height = fmaxf(bottom - top + 1.f, 0.f);
-    const float interS = width * height;
-    const float Sa = (a[2] - a[0] + 1) * (a[3] - a[1] + 1);
-    const float Sb = (b[2] - b[0] + 1) * (b[3] - b[1] + 1);
-    return interS / (Sa + Sb - interS);
+    const float iw = fmaxf(fminf(ax2, bx2) - fmaxf(ax1, bx1) + 1.f, 0.f), ih = fmaxf(fminf(ay2, by2) - fmaxf(ay1, by1) + 1.f, 0.f);
+    const float inter = iw * ih;
+    return inter / (a_area + b_area - inter) > thr;
 }
 
-__global__ __launch_bounds__(64) void k_nms_mask(int n, float thresh, const float *__restrict__ boxes,
-                                                 unsigned long long *__restrict__ mask, int col_blocks)
+// 64-bit value of lane `src` (wave-uniform index) as a scalar: two v_readlane_b32, no LDS round trip
+__device__ __forceinline__ unsigned long long nms_readlane64(unsigned long long v, int src)
 {
-    const int row_start = blockIdx.y, col_start = blockIdx.x;
-    const int row_size = min(n - row_start * 64, 64), col_size = min(n - col_start * 64, 64);
-    __shared__ float bb[64 * 5];
-    if ((int)threadIdx.x < col_size) {
-#pragma unroll
-        for (int k = 0; k < 5; ++k) bb[threadIdx.x * 5 + k] = boxes[(64 * col_start + threadIdx.x) * 5 + k];
-    }
-    __syncthreads();
-    if ((int)threadIdx.x < row_size) {
-        const int cur = 64 * row_start + threadIdx.x;
-        const float *cb = boxes + cur * 5;
-        unsigned long long t = 0;
-        const int start = row_start == col_start ? (int)threadIdx.x + 1 : 0;
-        for (int i = start; i < col_size; ++i)
-            if (nms_iou(cb, bb + i * 5) > thresh) t |= 1ULL << i;
-        mask[(size_t)cur * col_blocks + col_start] = t;
-    }
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)v, src);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(v >> 32), src);
+    return ((unsigned long long)hi << 32) | lo;
 }
 
-__global__ __launch_bounds__(64) void k_nms_sweep(int n, int col_blocks, const unsigned long long *__restrict__ mask,
-                                                  int32_t *__restrict__ keep, int32_t *__restrict__ count)
+// OR over the 64 lanes of a wave (result valid in every lane): row-wise prefix through DPP, row totals broadcast, lane 63 read back
+__device__ __forceinline__ unsigned int nms_wave_or32(unsigned int v)
 {
-    const int lane = threadIdx.x;
-    unsigned long long remv = 0;        // lane w owns word w of the removed bitmap
-    int num = 0;
-    for (int i = 0; i < n; ++i) {
-        const int nblock = i >> 6, inblock = i & 63;
-        const unsigned long long w = __shfl(remv, nblock, 64);
-        if (!((w >> inblock) & 1ULL)) {            // wave-uniform: every lane sees the same word
-            if (lane == 0) keep[num] = i;
-            ++num;
-            if (lane < col_blocks && lane >= nblock) remv |= mask[(size_t)i * col_blocks + lane];
+    v |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);     // row_shr:1
+    v |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);     // row_shr:2
+    v |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);     // row_shr:4
+    v |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);     // row_shr:8
+    v |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);     // row_bcast:15 -> rows 1, 3
+    v |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);     // row_bcast:31 -> rows 2, 3
+    return (unsigned int)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__global__ __launch_bounds__(256) void k_nms(NmsGeom g, float thr, const float *__restrict__ boxes, unsigned long long *__restrict__ mask,
+                                             int32_t *__restrict__ keep, int32_t *__restrict__ count, unsigned int *__restrict__ ticket)
+{
+    extern __shared__ unsigned long long nms_lds[];          // phase 2: the words (n rows of W, then n transposed diagonal words) if they fit
+    __shared__ float colbox[64 * 5];
+    __shared__ unsigned short pieces[2][4][64];
+    __shared__ int last_flag;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = g.n, W = g.words;
+    unsigned long long *lowm = mask + (size_t)n * W;         // [n]: suppressors of a box inside its own block (bit i: box 64 * block + i, i < own position)
+    // ---- phase 1: tile (rb, cb), cb >= rb, of the upper triangle; tiles are numbered row by row
+    {
+        int rb = 0, t = (int)blockIdx.x;
+        while (t >= W - rb) { t -= W - rb; ++rb; }
+        const int cb = rb + t;
+        const int ncol = min(64, n - 64 * cb);
+        if (tid < ncol * 5) colbox[tid] = boxes[(size_t)64 * cb * 5 + tid];
+        if (tid + 256 < ncol * 5) colbox[tid + 256] = boxes[(size_t)64 * cb * 5 + tid + 256];
+        __syncthreads();
+        const int row = 64 * rb + lane;
+        if (row < n) {
+            const float *rbx = boxes + (size_t)row * 5;
+            const float x1 = rbx[0], y1 = rbx[1], x2 = rbx[2], y2 = rbx[3];
+            const float area = (x2 - x1 + 1.f) * (y2 - y1 + 1.f);
+            unsigned int up = 0, low = 0;
+#pragma unroll 4
+            for (int k = 0; k < 16; ++k) {
+                const int c = 16 * wave + k;               // column inside the tile (wave-uniform)
+                if (c >= ncol) break;
+                const float cx1 = colbox[c * 5], cy1 = colbox[c * 5 + 1], cx2 = colbox[c * 5 + 2], cy2 = colbox[c * 5 + 3];
+                const float c_area = (cx2 - cx1 + 1.f) * (cy2 - cy1 + 1.f);
+                // (the arguments in the order the greedy rule tests them: earlier box first)
+                const bool later = cb > rb || c > lane;
+                const bool hit = later ? nms_suppresses(x1, y1, x2, y2, area, cx1, cy1, cx2, cy2, c_area, thr)
+                                       : (c != lane && nms_suppresses(cx1, cy1, cx2, cy2, c_area, x1, y1, x2, y2, area, thr));
+                if (hit) { if (later) up |= 1u << k; else low |= 1u << k; }
+            }
+            pieces[0][wave][lane] = (unsigned short)up;
+            pieces[1][wave][lane] = (unsigned short)low;
+        }
+        __syncthreads();
+        // whole 64-bit words, write-through (sc1): the workgroup that sweeps reads them with sc1 loads, no cache maintenance in between
+        if (wave == 0 && row < n) {
+            const unsigned long long wu = (unsigned long long)pieces[0][0][lane] | ((unsigned long long)pieces[0][1][lane] << 16) |
+                                          ((unsigned long long)pieces[0][2][lane] << 32) | ((unsigned long long)pieces[0][3][lane] << 48);
+            __hip_atomic_store(mask + (size_t)row * W + cb, wu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cb == rb) {
+                const unsigned long long wl = (unsigned long long)pieces[1][0][lane] | ((unsigned long long)pieces[1][1][lane] << 16) |
+                                              ((unsigned long long)pieces[1][2][lane] << 32) | ((unsigned long long)pieces[1][3][lane] << 48);
+                __hip_atomic_store(lowm + row, wl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
-    if (lane == 0) *count = num;
+    // ---- who is last?  The storing wave drains its stores, the workgroup meets, ONE lane takes the ticket (MI355X_MICROARCH.md, inter-
+    //      workgroup visibility: sc1 stores + drained + agent-scope counter; inputs too large for the LDS sweep add the release / acquire pair)
+    const bool in_lds = g.lds_rows >= n;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        if (!in_lds) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        const unsigned int old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_flag = old == (unsigned int)(g.tiles - 1);
+        if (last_flag) {
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (ready for the next launch)
+            if (!in_lds) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        }
+    }
+    __syncthreads();
+    if (!last_flag) return;
+    // ---- phase 2
+    const int total_words = n * W + n;
+    if (in_lds) {
+        // 8-byte sc1 loads, 32 in flight per thread; words left of a row's diagonal block were never written and are never read
+        for (int i0 = 0; i0 < total_words; i0 += 256 * 32) {
+            unsigned long long v[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) {
+                const int i = i0 + u * 256 + tid;
+                const int r = i / W, w = i - r * W;
+                const bool need = i < total_words && (i >= n * W || w >= (r >> 6));
+                v[u] = need ? __hip_atomic_load(mask + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < 32; ++u) {
+                const int i = i0 + u * 256 + tid;
+                if (i < total_words) nms_lds[i] = v[u];
+            }
+        }
+    }
+    __syncthreads();
+    const unsigned long long *rows = in_lds ? nms_lds : mask;
+    const unsigned long long *lows = in_lds ? nms_lds + (size_t)n * W : lowm;
+    if (wave == 0) {
+        int n_kept = 0;                                       // wave-uniform
+        unsigned long long remv = 0;                          // lane w: word w of the removed bitmap (W <= 64)
+        unsigned long long part[17];                          // (W <= 17) this lane's share of the words of the later blocks
+#pragma unroll
+        for (int w = 0; w < 17; ++w) part[w] = 0ull;
+        for (int b = 0; b < W; ++b) {
+            const int nrow = min(64, n - 64 * b);
+            const unsigned long long rem_b = nms_readlane64(remv, b);      // removed by the kept boxes of the earlier blocks
+            const unsigned long long valid = nrow == 64 ? ~0ull : ((1ull << nrow) - 1ull);
+            const unsigned long long mine = lane < nrow ? lows[64 * b + lane] : 0ull;       // my possible suppressors inside the block
+            unsigned long long und = ~rem_b & valid, kw = 0;  // undecided / kept boxes of the block (wave-uniform)
+            while (und) {
+                const bool me = (und >> lane) & 1ull;
+                const bool by_kept = (mine & kw) != 0ull, pending = (mine & und) != 0ull;
+                const unsigned long long now_kept = __ballot(me && !by_kept && !pending);
+                const unsigned long long now_gone = __ballot(me && by_kept);
+                kw |= now_kept;
+                und &= ~(now_kept | now_gone);
+            }
+            const bool kept_me = (kw >> lane) & 1ull;
+            if (kept_me) keep[n_kept + __builtin_popcountll(kw & ((1ull << lane) - 1ull))] = 64 * b + lane;
+            n_kept += __builtin_popcountll(kw);
+            // the kept boxes of this block suppress into the later blocks.  Up to 17 words (the LDS sweep): every lane ORs its own row's
+            // later words into per-lane partial words (registers, no cross-lane traffic); only the NEXT block's word is reduced over the
+            // lanes now (one DPP reduction per block).  Wider inputs: every later word is reduced right away, four per trip.
+            const unsigned long long *my_row = rows + (size_t)(64 * b + (lane < nrow ? lane : 0)) * W;
+            if (W <= 17) {
+#pragma unroll
+                for (int w = 1; w < 17; ++w)
+                    if (w > b && w < W && kept_me) part[w] |= my_row[w];
+                if (b + 1 < W) {
+                    unsigned long long nxt = 0;
+#pragma unroll
+                    for (int w = 1; w < 17; ++w)
+                        if (w == b + 1) nxt = part[w];
+                    const unsigned long long red = ((unsigned long long)nms_wave_or32((unsigned int)(nxt >> 32)) << 32) | nms_wave_or32((unsigned int)nxt);
+                    if (lane == b + 1) remv |= red;
+                }
+            } else {
+                for (int w0 = b + 1; w0 < W; w0 += 4) {
+                    unsigned long long v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] = (kept_me && w0 + u < W) ? my_row[w0 + u] : 0ull;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const unsigned long long red = ((unsigned long long)nms_wave_or32((unsigned int)(v[u] >> 32)) << 32) | nms_wave_or32((unsigned int)v[u]);
+                        if (lane == w0 + u) remv |= red;
+                    }
+                }
+            }
+        }
+        if (lane == 0) *count = n_kept;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ L2 normalisation into a channel slice
+// out[p][c_off + c] = weight[c] * (x[p][c] / (sqrt(sum_c x[p][c]^2) + eps)) for the pixels p of a channels-last tensor: the detector
+// neck's L2Norm (Pedestron/mmdet/models/necks/csp_neck.py:85 -- pow, sum over channels, sqrt, + eps, div, scale: six elementwise /
+// reduction passes) AND its channel concatenation (csp_neck.py:83) in one read and one write.  One wave per pixel and trip: a lane holds
+// C / 64 / 4 float4 (C <= 1024), the sum of squares goes through a fixed-order DPP reduction.
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void k_l2norm_cat(T *__restrict__ out, const T *__restrict__ x, const float *__restrict__ weight, long long n_pix,
+                                                    uint32_t C, uint32_t C_total, uint32_t c_off, float eps)
+{
+    constexpr int EPV = 16 / sizeof(T);
+    const uint32_t lane = threadIdx.x & 63, vecs = C / EPV;
+    const long long wave0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (long long)gridDim.x * 4;
+    for (long long p = wave0; p < n_pix; p += n_waves) {
+        uint4 v[NV];
+        float sq = 0.0f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const uint32_t q = lane + 64 * k;
+            v[k] = q < vecs ? reinterpret_cast<const uint4 *>(x + (size_t)p * C)[q] : make_uint4(0u, 0u, 0u, 0u);
+            const T *e = reinterpret_cast<const T *>(&v[k]);
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) { const float f = Cvt<T>::ld(e + j); sq = fmaf(f, f, sq); }
+        }
+        // wave sum, fixed order: row prefix (DPP), row totals to the last row, lane 63 read back
+        sq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sq), 0x111, 0xf, 0xf, false));
+        sq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sq), 0x112, 0xf, 0xf, false));
+        sq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sq), 0x114, 0xf, 0xf, false));
+        sq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sq), 0x118, 0xf, 0xf, false));
+        sq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sq), 0x142, 0xa, 0xf, false));
+        sq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sq), 0x143, 0xc, 0xf, false));
+        const float norm = sqrtf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sq), 63))) + eps;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const uint32_t q = lane + 64 * k;
+            if (q >= vecs) continue;
+            uint4 o;
+            T *eo = reinterpret_cast<T *>(&o);
+            const T *e = reinterpret_cast<const T *>(&v[k]);
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) eo[j] = Cvt<T>::st(weight[q * EPV + j] * (Cvt<T>::ld(e + j) / norm));
+            reinterpret_cast<uint4 *>(out + (size_t)p * C_total + c_off)[q] = o;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------ host helpers
@@ -3346,16 +3529,45 @@ BC_EXPORT int bc_affine_act(void *out, const void *in, const void *add, const fl
     return launch_status();
 }
 
+// one device-scope ticket per stream that has run an NMS (concurrent launches on different streams must not share one)
+__device__ unsigned int g_nms_tickets[64];
+
 BC_EXPORT int bc_nms_sorted(const float *boxes, int n, float iou_thr, unsigned long long *mask_ws, int32_t *keep,
                             int32_t *count, void *stream)
 {
     if (n < 0 || n > 4096) return BC_ERR_SHAPE;
     if (!count || (n > 0 && (!boxes || !mask_ws || !keep))) return BC_ERR_NULL;
     hipStream_t st = (hipStream_t)stream;
-    const int cb = (n + 63) / 64;
+    if (n == 0) { (void)hipMemsetAsync(count, 0, sizeof(int32_t), st); return launch_status(); }
+    static std::mutex mu;
+    static void *slot_of[64];
+    static int n_slots = 0;
+    static unsigned int *tickets = nullptr;
+    int slot = -1;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!tickets && hipGetSymbolAddress((void **)&tickets, HIP_SYMBOL(g_nms_tickets)) != hipSuccess) return launch_status();
+        for (int i = 0; i < n_slots; ++i)
+            if (slot_of[i] == stream) slot = i;
+        if (slot < 0) {
+            if (n_slots == 64) return BC_ERR_SHAPE;      // (more than 64 streams running detectors in one process)
+            slot_of[n_slots] = stream;
+            slot = n_slots++;
+        }
+    }
+    NmsGeom g;
+    g.n = n; g.words = (n + 63) / 64; g.tiles = g.words * (g.words + 1) / 2;
+    // phase 2 in LDS: the n x words matrix and the n transposed diagonal words
+    const size_t all = ((size_t)n * g.words + n) * sizeof(unsigned long long);
+    g.lds_rows = all <= (size_t)150 * 1024 ? n : 0;
+    const size_t lds_bytes = g.lds_rows ? all : 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nms), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_set = true;
+    }
     ProfScope ps(BC_OP_NMS, 20.0 * n);
-    if (n > 0) hipLaunchKernelGGL(k_nms_mask, dim3(cb, cb), dim3(64), 0, st, n, iou_thr, boxes, mask_ws, cb);
-    BC_LAUNCH(ps, k_nms_sweep, dim3(1), dim3(64), 0, st, n, cb, mask_ws, keep, count);
+    BC_LAUNCH(ps, k_nms, dim3(g.tiles), dim3(256), lds_bytes, st, g, iou_thr, boxes, mask_ws, keep, count, tickets + slot);
     return launch_status();
 }
 
@@ -3900,6 +4112,34 @@ static int launch_group_stats(const void *features, long long n_pix, int C, int 
         BC_LAUNCH(ps, (k_group_stats<hip_bfloat16, 8>), dim3(n_wg), dim3(WG), 0, st, (const VecOf<16>::type *)features, (uint32_t)n_pix, K, rows_per_wg, workspace);
     hipLaunchKernelGGL(k_group_finalize, dim3(groups), dim3(WG), 0, st, (const float *)workspace, n_wg, (uint32_t)C, (uint32_t)(C / groups),
                        (double)n_pix * (C / groups), eps, gamma, beta, scale, shift, bn);
+    return launch_status();
+}
+
+/* L2 normalisation over the channels of every pixel, scaled per channel, written into channels [c_off, c_off + C) of a wider
+ * channels-last tensor (see k_l2norm_cat) */
+BC_EXPORT int bc_l2norm_cat_nhwc(void *out, const void *x, const float *weight, long long n_pix, int C, int C_total, int c_off, float eps, int dtype,
+                                 void *stream)
+{
+    if (dtype < BC_F32 || dtype > BC_BF16) return BC_ERR_ELEM;
+    const int E = dtype == BC_F32 ? 4 : 2, epv = 16 / E;
+    if (n_pix < 0 || C <= 0 || C_total < C || c_off < 0 || c_off + C > C_total || C % epv || c_off % epv || C_total % epv || C / epv > 256) return BC_ERR_SHAPE;
+    if (n_pix == 0) return BC_OK;
+    if (!out || !x || !weight) return BC_ERR_NULL;
+    if ((uint64_t)n_pix * (uint64_t)C_total >= (1ull << 40)) return BC_ERR_RANGE;
+    if (!aligned(out, 16) || !aligned(x, 16)) return BC_ERR_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    long long wgs = (n_pix + 3) / 4;
+    if (wgs > 256 * 8) wgs = 256 * 8;
+    ProfScope ps(BC_OP_AFFINE, 2.0 * n_pix * C * E);
+    const int nv = (C / epv + 63) / 64;
+#define BC_L2(T_, NV_) BC_LAUNCH(ps, (k_l2norm_cat<T_, NV_>), dim3((unsigned)wgs), dim3(256), 0, st, (T_ *)out, (const T_ *)x, weight, n_pix, (uint32_t)C, \
+                                 (uint32_t)C_total, (uint32_t)c_off, eps)
+#define BC_L2T(T_) do { if (nv == 1) BC_L2(T_, 1); else if (nv == 2) BC_L2(T_, 2); else BC_L2(T_, 4); } while (0)
+    if (dtype == BC_F32) BC_L2T(float);
+    else if (dtype == BC_F16) BC_L2T(__half);
+    else BC_L2T(hip_bfloat16);
+#undef BC_L2T
+#undef BC_L2
     return launch_status();
 }
 

@@ -384,11 +384,21 @@ int bc_maxpool3x3s2_ring_nhwc(void *out, const void *features, void *ring, const
                               const int32_t *mapping_exec, int n_exec, int N, int C, int GH, int GW, int bs, int dtype,
                               const float *scale, const float *shift, int relu, void *stream);
 
+/* the detector neck's L2Norm AND channel concatenation in one pass (Pedestron/mmdet/models/necks/csp_neck.py:83-85: x.pow(2).sum(1).sqrt()
+ * + eps, x / norm, * weight, then torch.cat of the three levels): for the n_pix pixels of a channels-last tensor x (n_pix, C),
+ *     out[p][c_off + c] = weight[c] * (x[p][c] / (sqrt(sum_c x[p][c]^2) + eps))
+ * written into channels [c_off, c_off + C) of the channels-last tensor out (n_pix, C_total).  fp32 arithmetic (sum of squares in a fixed
+ * order), one rounding at the store.  C, c_off, C_total multiples of 16 / elem_size, C <= 256 * 16 / elem_size. */
+int bc_l2norm_cat_nhwc(void *out, const void *x, const float *weight, long long n_pix, int C, int C_total, int c_off, float eps, int dtype,
+                       void *stream);
+
 /* detector post-processing (config C5).  replaces nms_kernel + the host sweep of
  * Pedestron/mmdet/ops/nms/src/nms_kernel.cu:23-130: boxes (n,5) float32 [x1,y1,x2,y2,score] ALREADY sorted by score
  * descending, n <= 4096; IoU with the +1 pixel convention, suppression when IoU > iou_thr.  mask_ws: device scratch of
- * n*ceil(n/64) 64-bit words.  Writes keep[0..count) = kept positions in the sorted order (ascending) and *count, all
- * on the device (the reference copies the mask to the host and sweeps there). */
+ * n*ceil(n/64) + n 64-bit words (the upper-triangular suppression words and, per box, its suppressors inside its own block of 64).
+ * Writes keep[0..count) = kept positions in the sorted order (ascending) and *count, all on the device and in ONE launch: the
+ * workgroup that finishes its tile of the pair matrix last resolves the greedy rule (the reference copies the mask to the host and
+ * sweeps there).  Launches on different streams may overlap; at most 64 distinct streams per process. */
 int bc_nms_sorted(const float *boxes, int n, float iou_thr, unsigned long long *mask_ws, int32_t *keep,
                   int32_t *count, void *stream);
 

@@ -454,7 +454,7 @@ def test_channels_last_float_ops(be, dtype, tol):
 
 
 def test_nms_matches_oracle(be):
-    """Device NMS (mask kernel + single-wave sweep) vs the oracle restatement of nms_kernel.cu: identical kept index
+    """Device NMS (one launch: upper-triangular suppression tiles, the last workgroup resolves the greedy rule) vs the oracle restatement of nms_kernel.cu: identical kept index
     sets on random boxes, heavy-overlap clusters, n not a multiple of 64, n = 1 and n = 0 (scores are distinct: the
     order among tied scores is unspecified in the reference too)."""
     rng = np.random.default_rng(0)
