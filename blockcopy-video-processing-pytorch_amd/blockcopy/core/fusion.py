@@ -164,7 +164,7 @@ def packed_conv3x3_weight(weight: torch.Tensor, pack) -> torch.Tensor:
     return v
 
 
-CONV_MODE = os.environ.get("BLOCKCOPY_CONV", "auto")   # auto | native | winograd | library
+CONV_MODE = os.environ.get("BLOCKCOPY_CONV", "auto")   # auto | native | winograd | winograd-wide | winograd4 | library
 CONV_TUNE = os.environ.get("BLOCKCOPY_CONV_TUNE", "1") != "0"   # auto mode: measure a layer shape the plan table does not know (eager runs only)
 _conv_plans = {}      # (n_exec, bs, cin, cout, n_total, dtype, stride, ks) -> None (library conv) | decomposition code (-1 = library's own choice)
 DEFER_CONV = os.environ.get("BLOCKCOPY_DEFER_CONV", "1") != "0"   # fused convs launch lazily with the recorded elementwise work as epilogue
@@ -181,6 +181,7 @@ TUNE_EPILOGUE_COST = os.environ.get("BLOCKCOPY_TUNE_EPILOGUE_COST", "1") != "0"
 CONV_TUNE_LOG = []    # (key, {candidate: microseconds}, choice) of every measurement, for the bench report
 WINOGRAD_FLAG = 0x600  # decomposition codes with one of these bits run a Winograd F(2x2,3x3) form (0x200: csrc/conv3x3_wino.inc,
 WINOGRAD_WIDE = 0x400  # 0x400: the wide wave tile of csrc/conv3x3_wino32.inc)
+WINOGRAD_F4 = 0x1000   # codes with this bit: the Winograd F(4x4,3x3) form of csrc/conv3x3_wino4.inc
 
 # Plan table persistence.  A plan decides which KERNEL FORM a layer runs in (library conv / direct MFMA form / Winograd form), and
 # the forms differ by fp32 rounding, so a run is only reproducible -- from run to run and from rank to rank -- with a fixed table.
@@ -275,20 +276,25 @@ def conv3x3_plan(n_exec: int, bs: int, cin: int, cout: int, n_total: int, dtype,
     """How to run one padded 3x3 conv layer (or, ``ks=1``, one pointwise conv): ``None`` = halo gather + library conv, ``int`` =
     the fused halo+conv kernel with that decomposition code (-1: the library's cost model; codes with WINOGRAD_FLAG: Winograd form).
 
-    ``BLOCKCOPY_CONV`` = ``library`` | ``native`` (direct MFMA form everywhere) | ``winograd`` / ``winograd-wide`` (every layer that
-    lists a Winograd candidate of the 16-channel / the wide wave tile runs its first one, the rest the direct form) | ``auto``: the plan table decides (see PLAN_FILE above); a shape it
+    ``BLOCKCOPY_CONV`` = ``library`` | ``native`` (direct MFMA form everywhere) | ``winograd`` / ``winograd-wide`` / ``winograd4`` (every layer that
+    lists a Winograd candidate of the 16-channel F(2x2) / the wide F(2x2) / the F(4x4) form runs its first one, the rest the direct form) | ``auto``: the plan table decides (see PLAN_FILE above); a shape it
     does not know is MEASURED once (``tuner()`` times the library route and every decomposition on the live tensors -- the conv
     library's own solver-search idea -- never during graph capture) or, untuned, follows a fixed rule."""
     if CONV_MODE == "library":
         return None
     if CONV_MODE == "native":
         return -1
-    if CONV_MODE in ("winograd", "winograd-wide"):
+    if CONV_MODE in ("winograd", "winograd-wide", "winograd4"):
         if ks == 3 and stride == 1 and dtype == torch.float32 and candidates is not None:
-            flag = WINOGRAD_WIDE if CONV_MODE == "winograd-wide" else 0x200
-            wino = [c for c in candidates() if c >= 0 and (c & flag)]
+            flag = WINOGRAD_WIDE if CONV_MODE == "winograd-wide" else (WINOGRAD_F4 if CONV_MODE == "winograd4" else 0x200)
+            cands = [c for c in candidates() if c >= 0]
+            wino = [c for c in cands if c & flag]
             if wino:
                 return wino[0]
+            if CONV_MODE == "winograd4":      # (tiles the F(4x4) form does not cover: 4x4 tiles, sizes that are no multiple of 16: the F(2x2) form)
+                wino = [c for c in cands if c & 0x200]
+                if wino:
+                    return wino[0]
         return -1
     key = (n_exec, bs, cin, cout, n_total, dtype, stride, ks)
     PLAN_KEYS_SEEN[key] = PLAN_KEYS_SEEN.get(key, 0) + 1

@@ -2695,8 +2695,9 @@ static bool wino_plan(const WinoCfg &k, int n_exec, int Cin, int Cout, int bs, W
     if (bs == 4 && k.MB * k.WMW > 2) return false;
     const size_t img = (size_t)k.WMW * k.MB * (bs == 4 ? 4 * 36 : 100) * 9 * 16;
     const size_t red = (size_t)k.WMW * k.WNW * (k.WKW - 1) * k.MB * 16 * 64 * sizeof(float);
-    p.lds_bytes = 2 * img > red ? 2 * img : red;
-    if (k.SH) p.lds_bytes = 2 * img + 2 * (size_t)16 * 16 * 36 * sizeof(float);      // + two transformed images
+    const size_t coeffs = (size_t)2 * Cin * sizeof(float);                            // the activation coefficients, behind the images
+    p.lds_bytes = 2 * img + coeffs > red ? 2 * img + coeffs : red;
+    if (k.SH) p.lds_bytes = 2 * img + 2 * (size_t)16 * 16 * 36 * sizeof(float) + coeffs;      // + two transformed images
     if (p.lds_bytes > 160 * 1024 - 2048 - 1024) return false;
     const long long slots = bs == 4 ? ((long long)n_exec + 3) / 4 : (long long)n_exec * (bs / 8) * (bs / 8);     // M-blocks
     p.n_rows = (uint32_t)((slots + k.MB - 1) / k.MB);

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--margin", type=float, default=0.03)
     ap.add_argument("--dry-run", action="store_true")
     ap.add_argument("--max-mb", type=float, default=1500.0, help="skip shapes whose activations exceed this many MB")
+    ap.add_argument("--all-forms", action="store_true", help="time EVERY candidate form of the fused kernel (direct, both F(2x2) forms, F(4x4)), not only F(4x4)")
     a = ap.parse_args()
     be = bk.get_backend()
     doc = json.load(open(PLAN))
@@ -37,7 +38,7 @@ def main():
         cur = plans[text]
         if dt != "f32" or stride != 1 or ks != 3 or cur is None or n_total < n or n_total <= 1:
             continue
-        cands = [c for c in be.conv3x3_candidates(n, cin, cout, bs, 4, 1) if c & 0x1000]
+        cands = [c for c in be.conv3x3_candidates(n, cin, cout, bs, 4, 1) if (c & 0x1000) or (a.all_forms and c != cur)]
         if not cands or n * bs * bs * max(cin, cout) * 4 / 1e6 > a.max_mb:
             continue
         gh = 1
@@ -62,10 +63,10 @@ def main():
         else:
             kept += 1
             tag = "keep"
-        log.append(f"{text:38s} {cur:#6x} {times[cur]:8.1f} us | best F(4x4) {best:#6x} {times[best]:8.1f} us {tag}")
+        log.append(f"{text:38s} {cur:#6x} {times[cur]:8.1f} us | best {'other' if a.all_forms else 'F(4x4)'} {best:#6x} {times[best]:8.1f} us {tag}")
         print(log[-1], flush=True)
         del feats, ring, w, wpk
-    print(f"{changed} entries switched to F(4x4), {kept} kept")
+    print(f"{changed} entries switched, {kept} kept")
     if not a.dry_run:
         tmp = PLAN + ".tmp"
         with open(tmp, "w") as fh:
