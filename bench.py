@@ -510,7 +510,17 @@ def main(argv=None):
 
     extra, details = {}, {}
     per_rank = replicas.gather_scalars(args.steps * CLIP_LEN * args.batch / elapsed_local, world)
+    # per-rank record for the details file: fps, executed fraction, conv plan table (first 48 bits of its hash: equal on every rank = equal
+    # kernel forms per layer), live-tuned shapes -- what makes the first multi-GPU run self-explaining
+    from blockcopy.core import fusion as _fusion
+    per_rank_exec = replicas.gather_scalars(float(exec_frac), world)
+    per_rank_plan = replicas.gather_scalars(float(int(_fusion.conv_plan_hash()[:12], 16)), world)
+    per_rank_tuned = replicas.gather_scalars(float(_fusion.PLAN_STATS["tuned_live"]), world)
+    per_rank_ms = replicas.gather_scalars(1e3 * elapsed_local / args.steps, world)
     if rank == 0:
+        details["per_rank"] = [{"rank": r, "fps": round(per_rank[r], 2), "ms_per_step": round(per_rank_ms[r], 3), "exec_fraction": round(per_rank_exec[r], 4),
+                                "conv_plan_hash48": f"{int(per_rank_plan[r]):012x}", "shapes_tuned_live": int(per_rank_tuned[r])} for r in range(world)]
+        details["per_rank_plans_equal"] = len(set(int(v) for v in per_rank_plan)) == 1
         # halo-gather kernel statistics from one extra, untimed clip (events around all 21 launches per frame)
         be.prof_reset()
         be.prof_enable(["pad_ring", "split", "combine", "conv3x3", "head1x1", "combine_copy"])

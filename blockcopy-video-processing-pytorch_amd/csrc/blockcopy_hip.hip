@@ -2858,6 +2858,7 @@ static bool wino4_plan(const Wino4Cfg &k, int n_exec, int Cin, int Cout, int bs,
     const size_t raw = (size_t)(bs == 8 ? 4 * 100 : 324) * 64, vimg = (size_t)36 * 1024;
     p.lds_bytes = 2 * raw + 2 * vimg + (size_t)2 * Cin * sizeof(float) + 2 * 512 * 8;      // + the activation coefficients + the ring-refresh plan
     if (p.lds_bytes < (size_t)8 * 16384) p.lds_bytes = 8 * 16384;      // the output stage: one [256 pixels][16 channels] area per wave
+    if (p.lds_bytes > 160 * 1024 - 2048 - 1024) return false;          // (very wide layers: the coefficient table no longer fits)
     const long long slots = bs == 8 ? ((long long)n_exec + 3) / 4 : (long long)n_exec * (bs / 16) * (bs / 16);     // M-blocks
     p.n_rows = (uint32_t)slots;
     p.wgs = slots * (Cout / (16 * k.NB * k.WNW));

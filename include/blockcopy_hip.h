@@ -348,10 +348,16 @@ int bc_adaptive_avg_pool_nhwc(void *out, const void *in, int N, int C, int H, in
  * form (fp32, stride 1, 3x3: csrc/conv3x3_wino.inc; index = its own decomposition table, 11..13 = the variants whose input
  * transform is computed once per workgroup) | 0x400 for its wide wave tile (csrc/conv3x3_wino32.inc) | 0x800 (pointwise convs,
  * fp32, stride 1: bc_conv1x1_candidates) for the plain-GEMM form csrc/gemm1x1.inc (index 0..3 = workgroup tile 128x128, 128x64,
- * 64x128, 64x64; reads the same packed one-tap weight stream).  At most 64 codes.
- * The Winograd form reads a second weight stream placed behind the direct one in weights_packed (fp32 3x3 only):
+ * 64x128, 64x64; reads the same packed one-tap weight stream) | 0x1000 for the Winograd F(4x4,3x3) form (fp32, stride 1, 3x3, tiles
+ * of a multiple of 16 pixels or 8x8 tiles: csrc/conv3x3_wino4.inc; index 0..2 = (columns of 16*NB output channels, frequency groups,
+ * NB) = (4,2,1), (2,4,1), (2,4,2) of its eight waves).  At most 128 codes.
+ * The Winograd forms read further weight streams placed behind the direct one in weights_packed (fp32 3x3 only; 9 + 16 + 16 + 36 = 77
+ * floats per (cin, cout) pair in all: direct, F(2x2) 16-channel tile, F(2x2) wide tile (conv3x3_wino32.inc), F(4x4)):
  *   wino[nb16][chunk][step < 4][q < 8][lane = 16*kq + n][e < 4] = (G g Gt)[f][cin = 32*chunk + 8*step + 2*kq + t][cout = 16*nb16 + n],
- *   2*f + t = 4*q + e, f = 4*xi + nu, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]  (16 * Cin * Cout floats after the 9 * Cin * Cout). */
+ *   2*f + t = 4*q + e, f = 4*xi + nu, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]  (16 * Cin * Cout floats after the 9 * Cin * Cout);
+ *   wino4[cb][chunk][f < 36][lane = 16*kq + n][j < 4] = (G4 g G4t)[f][cin = 16*chunk + 4*kq + j][cout = 16*cb + n], f = 6*xi + nu,
+ *   G4 = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]  (36 * Cin * Cout floats after the first 41 * Cin * Cout;
+ *   products computed in fp64, rounded once).  A caller that never forces a 0x1000 code may pass a buffer without the last stream. */
 /* The same fused halo + 3x3 conv with DILATION 2 (padding = dilation = 2, stride 1): the dilated last stage of a detector backbone
  * (Pedestron/mmdet/models/backbones/resnet.py:155-162; reference path: BlockPadFunction with pad 2 + F.conv2d(dilation=2),
  * core/tensorwrapper.py:529-575).  Everything as bc_conv3x3_ring_nhwc except: taps 2 pixels apart, halo / zero border 2 pixels
@@ -456,7 +462,7 @@ int bc_prof_enable(unsigned op_mask);
 int bc_prof_reset(void);
 int bc_prof_read(int op, long long *launches, double *total_ms, double *total_bytes);
 /* second total of the same launches; BC_OP_CONV3X3: matrix FLOPs actually ISSUED (total_bytes holds the FLOPs of the direct
- * definition 2*px*k*k*Cin*Cout; the Winograd form issues 16/36 of them, the stem kernel its zero-padded K segments) */
+ * definition 2*px*k*k*Cin*Cout; the Winograd F(2x2) forms issue 16/36 of them, the F(4x4) form 36/144, the stem kernel its zero-padded K segments) */
 int bc_prof_read_aux(int op, double *total_aux);
 
 #ifdef __cplusplus
