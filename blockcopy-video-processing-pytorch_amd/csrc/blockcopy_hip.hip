@@ -3133,7 +3133,7 @@ static int launch_head1x1(ProfScope &ps, void *out, const void *features, const 
 }
 
 // fp32 / Cout <= 20: the 16 + 4 output-channel split of head1x1.inc (k_head1x1_s)
-template <int CIN>
+template <int CIN, int LEAN = 0>
 static int launch_head1x1_s(ProfScope &ps, void *out, const void *features, const void *wpk, const void *prev, const void *slots,
                             const int32_t *grid_idx, const int32_t *mapping_exec, const HeadGeom &g, const Prologue &pr,
                             const float *out_shift, hipStream_t st)
@@ -3142,11 +3142,11 @@ static int launch_head1x1_s(ProfScope &ps, void *out, const void *features, cons
     constexpr size_t lds_bytes = (size_t)4 * 32 * ((PXV_ < 16 ? PXV_ : 16) + 1) * 16 + (size_t)PXV_ * 4 * 16;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_head1x1_s<CIN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_head1x1_s<CIN, LEAN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         attr_set = true;
     }
     const dim3 grid(g.n_waves / 4);
-    BC_LAUNCH(ps, (k_head1x1_s<CIN>), grid, dim3(256), lds_bytes, st, (float *)out, (const uint4 *)features, (const uint4 *)wpk, (const float *)prev,
+    BC_LAUNCH(ps, (k_head1x1_s<CIN, LEAN>), grid, dim3(256), lds_bytes, st, (float *)out, (const uint4 *)features, (const uint4 *)wpk, (const float *)prev,
               (const unsigned long long *)slots, grid_idx, mapping_exec, g, pr, out_shift);
     return launch_status();
 }
@@ -3213,8 +3213,10 @@ BC_EXPORT int bc_head1x1_scatter_nhwc(void *out, const void *features, const voi
     g.copy_rows = (scatter && (n_exec < N * GH * GW || arm.ptr)) ? (uint32_t)(N * GH * GW) * (uint32_t)bs : 0;
     // one round of 256 CUs x 2 workgroups x 4 waves at most; at least one wave per M-block or per two tile rows to look at
     uint32_t want = g.n_mblocks > (g.copy_rows + 1) / 2 ? g.n_mblocks : (g.copy_rows + 1) / 2;
+    const bool lean = dtype == BC_F32 && Cout <= 20 && g_tune.head_split == 2 && Cin == 128;
+    if (lean) want = g.n_mblocks + g.copy_rows / 4;      // (three waves per SIMD: the waves behind the M-blocks only copy)
     static const uint32_t wave_cap = [] { const char *e = getenv("BC_HEAD_WAVES"); return e ? (uint32_t)atoi(e) : 2048u; }();      // (measurement knob)
-    if (want > wave_cap) want = wave_cap;
+    if (want > (lean ? wave_cap + wave_cap / 2 : wave_cap)) want = lean ? wave_cap + wave_cap / 2 : wave_cap;
     if (want < 1u) want = 1u;
     g.n_waves = ((want + 3) / 4) * 4;
     g.run_px = bs < 32 ? bs : 32;
@@ -3230,6 +3232,7 @@ BC_EXPORT int bc_head1x1_scatter_nhwc(void *out, const void *features, const voi
 #define BC_HD(DT_, CIN_) return launch_head1x1<DT_, CIN_>(ps, out, features, weights_packed, prev, slots, grid_idx, mapping_exec, g, pr, out_shift, st)
     if (dtype == BC_F32 && Cout <= 20 && g_tune.head_split) {      // the matrix work cut to 16 + 4 output channels (k_head1x1_s)
         ps.add_aux(2.0 * px * Cin * 20.0 - 2.0 * px * Cin * 32.0);
+        if (g_tune.head_split == 2 && Cin == 128) return launch_head1x1_s<128, 1>(ps, out, features, weights_packed, prev, slots, grid_idx, mapping_exec, g, pr, out_shift, st);
         if (Cin == 64) return launch_head1x1_s<64>(ps, out, features, weights_packed, prev, slots, grid_idx, mapping_exec, g, pr, out_shift, st);
         return launch_head1x1_s<128>(ps, out, features, weights_packed, prev, slots, grid_idx, mapping_exec, g, pr, out_shift, st);
     }

@@ -1261,11 +1261,12 @@ def test_adaptive_avg_pool_nhwc(be, dtype, tol):
         assert float((got.float() - want).abs().max()) <= tol * max(1.0, float(want.abs().max())), (N, C, H, W, oh, ow)
 
 
+@pytest.mark.parametrize("split", [1, 2])
 @pytest.mark.parametrize("geo", [(1, 2, 4, 32, 128, 19), (2, 3, 2, 8, 64, 1), (1, 1, 2, 64, 64, 5), (1, 2, 2, 16, 128, 20), (1, 2, 2, 32, 64, 17)])
-def test_head1x1_split_form_same_contract(be, geo):
-    """k_head1x1_s (fp32, Cout <= 20: 16 output channels on 16x16x4 + up to 4 on 4x4x1 matrix instructions; off by default, measured
-    neutral in the frame) under the whole contract of the test below."""
-    be.tune("head_split", 1)
+def test_head1x1_split_form_same_contract(be, geo, split):
+    """k_head1x1_s (fp32, Cout <= 20: 16 output channels on 16x16x4 + up to 4 on 4x4x1 matrix instructions; split = 2: its three-waves-per-SIMD
+    variant; off by default, measured neutral in the frame) under the whole contract of the test below."""
+    be.tune("head_split", split)
     try:
         test_head1x1_prologue_conv_bias_scatter_copy(be, geo, torch.float32, 2e-5)
     finally:
