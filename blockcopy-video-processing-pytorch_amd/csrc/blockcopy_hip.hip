@@ -1888,7 +1888,7 @@ __global__ __launch_bounds__(WG) void k_upsample_argmax(long long *__restrict__ 
 //                                          decided is decided (kept iff none of them was kept); each trip settles at least the first
 //                                          undecided box, typically all of them in two or three trips (64-bit ballots).
 //            The kept positions leave in ascending order (block by block, through popcount prefixes).
-struct NmsGeom { int n, words, tiles, lds_rows; };
+struct NmsGeom { int n, words, tiles, lds_rows; FastDiv fdw; };
 
 __device__ __forceinline__ bool nms_suppresses(float ax1, float ay1, float ax2, float ay2, float a_area, float bx1, float by1, float bx2, float by2,
                                                float b_area, float thr)
@@ -1918,35 +1918,39 @@ __device__ __forceinline__ unsigned int nms_wave_or32(unsigned int v)
     return (unsigned int)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-__global__ __launch_bounds__(256) void k_nms(NmsGeom g, float thr, const float *__restrict__ boxes, unsigned long long *__restrict__ mask,
-                                             int32_t *__restrict__ keep, int32_t *__restrict__ count, unsigned int *__restrict__ ticket)
+__global__ __launch_bounds__(1024) void k_nms(NmsGeom g, float thr, const float *__restrict__ boxes, unsigned long long *__restrict__ mask,
+                                              int32_t *__restrict__ keep, int32_t *__restrict__ count, unsigned int *__restrict__ ticket,
+                                              unsigned long long *__restrict__ dbg)
 {
-    extern __shared__ unsigned long long nms_lds[];          // phase 2: the words (n rows of W, then n transposed diagonal words) if they fit
+    // dbg (bc_tune_set_ptr("conv_stamps", ...), measurement only): 100 MHz stamps -- [2 b], [2 b + 1] = entry / ticket of workgroup b; the
+    // sweeping workgroup adds [2 tiles ..]: entry, ticket, words in LDS, sweep done
+    const unsigned long long t_in = dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    extern __shared__ unsigned long long nms_lds[];          // phase 2: the words (n rows of W | 1, then n transposed diagonal words) if they fit
     __shared__ float colbox[64 * 5];
-    __shared__ unsigned short pieces[2][4][64];
+    __shared__ __attribute__((aligned(16))) unsigned char pieces[2][64][16];
     __shared__ int last_flag;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = g.n, W = g.words;
     unsigned long long *lowm = mask + (size_t)n * W;         // [n]: suppressors of a box inside its own block (bit i: box 64 * block + i, i < own position)
-    // ---- phase 1: tile (rb, cb), cb >= rb, of the upper triangle; tiles are numbered row by row
+    // ---- phase 1: tile (rb, cb), cb >= rb, of the upper triangle; tiles are numbered row by row.  Sixteen waves: lane = row, a wave takes
+    //      four columns (the column box is wave-uniform: scalar operands) and leaves its four bits of the row's word in LDS
     {
         int rb = 0, t = (int)blockIdx.x;
         while (t >= W - rb) { t -= W - rb; ++rb; }
         const int cb = rb + t;
         const int ncol = min(64, n - 64 * cb);
-        if (tid < ncol * 5) colbox[tid] = boxes[(size_t)64 * cb * 5 + tid];
-        if (tid + 256 < ncol * 5) colbox[tid + 256] = boxes[(size_t)64 * cb * 5 + tid + 256];
-        __syncthreads();
         const int row = 64 * rb + lane;
+        const float *rbx = boxes + (size_t)min(row, n - 1) * 5;
+        const float x1 = rbx[0], y1 = rbx[1], x2 = rbx[2], y2 = rbx[3];
+        if (tid < ncol * 5) colbox[tid] = boxes[(size_t)64 * cb * 5 + tid];
+        __syncthreads();
         if (row < n) {
-            const float *rbx = boxes + (size_t)row * 5;
-            const float x1 = rbx[0], y1 = rbx[1], x2 = rbx[2], y2 = rbx[3];
             const float area = (x2 - x1 + 1.f) * (y2 - y1 + 1.f);
             unsigned int up = 0, low = 0;
-#pragma unroll 4
-            for (int k = 0; k < 16; ++k) {
-                const int c = 16 * wave + k;               // column inside the tile (wave-uniform)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = 4 * wave + k;                // column inside the tile (wave-uniform)
                 if (c >= ncol) break;
                 const float cx1 = colbox[c * 5], cy1 = colbox[c * 5 + 1], cx2 = colbox[c * 5 + 2], cy2 = colbox[c * 5 + 3];
                 const float c_area = (cx2 - cx1 + 1.f) * (cy2 - cy1 + 1.f);
@@ -1956,23 +1960,20 @@ __global__ __launch_bounds__(256) void k_nms(NmsGeom g, float thr, const float *
                                        : (c != lane && nms_suppresses(cx1, cy1, cx2, cy2, c_area, x1, y1, x2, y2, area, thr));
                 if (hit) { if (later) up |= 1u << k; else low |= 1u << k; }
             }
-            pieces[0][wave][lane] = (unsigned short)up;
-            pieces[1][wave][lane] = (unsigned short)low;
+            pieces[0][lane][wave] = (unsigned char)up;
+            pieces[1][lane][wave] = (unsigned char)low;
         }
         __syncthreads();
         // whole 64-bit words, write-through (sc1): the workgroup that sweeps reads them with sc1 loads, no cache maintenance in between
-        if (wave == 0 && row < n) {
-            const unsigned long long wu = (unsigned long long)pieces[0][0][lane] | ((unsigned long long)pieces[0][1][lane] << 16) |
-                                          ((unsigned long long)pieces[0][2][lane] << 32) | ((unsigned long long)pieces[0][3][lane] << 48);
-            __hip_atomic_store(mask + (size_t)row * W + cb, wu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (cb == rb) {
-                const unsigned long long wl = (unsigned long long)pieces[1][0][lane] | ((unsigned long long)pieces[1][1][lane] << 16) |
-                                              ((unsigned long long)pieces[1][2][lane] << 32) | ((unsigned long long)pieces[1][3][lane] << 48);
-                __hip_atomic_store(lowm + row, wl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+        if (wave < 2 && row < n && (wave == 0 || cb == rb)) {
+            const uint4 pc = *reinterpret_cast<const uint4 *>(pieces[wave][lane]);
+            auto squeeze = [](unsigned int x) { return (x & 0xfu) | ((x >> 4) & 0xf0u) | ((x >> 8) & 0xf00u) | ((x >> 12) & 0xf000u); };
+            const unsigned long long word = (unsigned long long)(squeeze(pc.x) | (squeeze(pc.y) << 16)) |
+                                            ((unsigned long long)(squeeze(pc.z) | (squeeze(pc.w) << 16)) << 32);
+            __hip_atomic_store(wave == 0 ? mask + (size_t)row * W + cb : lowm + row, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    // ---- who is last?  The storing wave drains its stores, the workgroup meets, ONE lane takes the ticket (MI355X_MICROARCH.md, inter-
+    // ---- who is last?  The storing waves drain their stores, the workgroup meets, ONE lane takes the ticket (MI355X_MICROARCH.md, inter-
     //      workgroup visibility: sc1 stores + drained + agent-scope counter; inputs too large for the LDS sweep add the release / acquire pair)
     const bool in_lds = g.lds_rows >= n;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1981,6 +1982,7 @@ __global__ __launch_bounds__(256) void k_nms(NmsGeom g, float thr, const float *
         if (!in_lds) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         const unsigned int old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last_flag = old == (unsigned int)(g.tiles - 1);
+        if (dbg) { dbg[2 * blockIdx.x] = t_in; dbg[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime(); }
         if (last_flag) {
             __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (ready for the next launch)
             if (!in_lds) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -1989,39 +1991,56 @@ __global__ __launch_bounds__(256) void k_nms(NmsGeom g, float thr, const float *
     __syncthreads();
     if (!last_flag) return;
     // ---- phase 2
-    const int total_words = n * W + n;
+    if (dbg && tid == 0) { dbg[2 * g.tiles] = t_in; dbg[2 * g.tiles + 1] = __builtin_amdgcn_s_memrealtime(); }
+    const int Ws = in_lds ? (W | 1) : W;                     // row stride of the words the sweep reads: odd in LDS (a lane per row: 64 rows, 64 banks)
     if (in_lds) {
-        // 8-byte sc1 loads, 32 in flight per thread; words left of a row's diagonal block were never written and are never read
-        for (int i0 = 0; i0 < total_words; i0 += 256 * 32) {
-            unsigned long long v[32];
+        // 8-byte sc1 loads, all of a thread's loads in flight at once (1024 threads: the whole matrix is one or two batches); words left of
+        // a row's diagonal block were never written and are never read: zeros
+        constexpr int NL = 18;
+        const int total_words = n * W + n;
+        for (int i0 = 0; i0 < total_words; i0 += 1024 * NL) {
+            unsigned long long v[NL];
 #pragma unroll
-            for (int u = 0; u < 32; ++u) {
-                const int i = i0 + u * 256 + tid;
-                const int r = i / W, w = i - r * W;
+            for (int u = 0; u < NL; ++u) {
+                const int i = i0 + u * 1024 + tid;
+                const int r = (int)fd_div((uint32_t)i, g.fdw), w = i - r * W;
                 const bool need = i < total_words && (i >= n * W || w >= (r >> 6));
                 v[u] = need ? __hip_atomic_load(mask + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
             }
 #pragma unroll
-            for (int u = 0; u < 32; ++u) {
-                const int i = i0 + u * 256 + tid;
-                if (i < total_words) nms_lds[i] = v[u];
+            for (int u = 0; u < NL; ++u) {
+                const int i = i0 + u * 1024 + tid;
+                const int r = (int)fd_div((uint32_t)i, g.fdw), w = i - r * W;
+                if (i < total_words) nms_lds[i < n * W ? r * Ws + w : n * Ws + (i - n * W)] = v[u];
             }
         }
     }
     __syncthreads();
-    const unsigned long long *rows = in_lds ? nms_lds : mask;
-    const unsigned long long *lows = in_lds ? nms_lds + (size_t)n * W : lowm;
-    if (wave == 0) {
+    if (dbg && tid == 0) dbg[2 * g.tiles + 2] = __builtin_amdgcn_s_memrealtime();
+    if (wave != 0) return;
+    // (two instances: LDS or global addresses known at compile time -- a generic pointer would make every read a flat load)
+    auto sweep = [&](auto lds_tag) {
+        constexpr bool L = decltype(lds_tag)::value;
+        auto low_word = [&](int r) -> unsigned long long {
+            if constexpr (L) return nms_lds[n * Ws + r]; else return lowm[r];
+        };
+        auto row_word = [&](int r, int w) -> unsigned long long {
+            if constexpr (L) return nms_lds[r * Ws + w]; else return mask[(size_t)r * W + w];
+        };
         int n_kept = 0;                                       // wave-uniform
         unsigned long long remv = 0;                          // lane w: word w of the removed bitmap (W <= 64)
         unsigned long long part[17];                          // (W <= 17) this lane's share of the words of the later blocks
 #pragma unroll
         for (int w = 0; w < 17; ++w) part[w] = 0ull;
+        unsigned long long mine = lane < n ? low_word(lane) : 0ull;             // my possible suppressors inside the block
         for (int b = 0; b < W; ++b) {
             const int nrow = min(64, n - 64 * b);
             const unsigned long long rem_b = nms_readlane64(remv, b);      // removed by the kept boxes of the earlier blocks
             const unsigned long long valid = nrow == 64 ? ~0ull : ((1ull << nrow) - 1ull);
-            const unsigned long long mine = lane < nrow ? lows[64 * b + lane] : 0ull;       // my possible suppressors inside the block
+            const int my_r = 64 * b + (lane < nrow ? lane : 0);
+            // (off the dependency chain: the next block's own words and this row's word for the next block are on their way meanwhile)
+            const unsigned long long mine_next = 64 * (b + 1) + lane < n ? low_word(64 * (b + 1) + lane) : 0ull;
+            const unsigned long long row_next = b + 1 < W ? row_word(my_r, b + 1) : 0ull;
             unsigned long long und = ~rem_b & valid, kw = 0;  // undecided / kept boxes of the block (wave-uniform)
             while (und) {
                 const bool me = (und >> lane) & 1ull;
@@ -2032,29 +2051,31 @@ __global__ __launch_bounds__(256) void k_nms(NmsGeom g, float thr, const float *
                 und &= ~(now_kept | now_gone);
             }
             const bool kept_me = (kw >> lane) & 1ull;
-            if (kept_me) keep[n_kept + __builtin_popcountll(kw & ((1ull << lane) - 1ull))] = 64 * b + lane;
-            n_kept += __builtin_popcountll(kw);
             // the kept boxes of this block suppress into the later blocks.  Up to 17 words (the LDS sweep): every lane ORs its own row's
             // later words into per-lane partial words (registers, no cross-lane traffic); only the NEXT block's word is reduced over the
             // lanes now (one DPP reduction per block).  Wider inputs: every later word is reduced right away, four per trip.
-            const unsigned long long *my_row = rows + (size_t)(64 * b + (lane < nrow ? lane : 0)) * W;
             if (W <= 17) {
-#pragma unroll
-                for (int w = 1; w < 17; ++w)
-                    if (w > b && w < W && kept_me) part[w] |= my_row[w];
                 if (b + 1 < W) {
-                    unsigned long long nxt = 0;
+                    unsigned long long nxt = kept_me ? row_next : 0ull;
 #pragma unroll
                     for (int w = 1; w < 17; ++w)
-                        if (w == b + 1) nxt = part[w];
+                        nxt |= w == b + 1 ? part[w] : 0ull;
                     const unsigned long long red = ((unsigned long long)nms_wave_or32((unsigned int)(nxt >> 32)) << 32) | nms_wave_or32((unsigned int)nxt);
                     if (lane == b + 1) remv |= red;
                 }
+                // (words at or left of the diagonal are zeros or never looked at again: no test on b.  No test on W either -- a test would
+                //  put every read and its wait behind a branch of its own: the reads past the row's end fetch words of the next row (the
+                //  LDS image has 17 spare words behind it) into partial words nobody looks at; all 15 reads are in flight together)
+                unsigned long long x[15];
+#pragma unroll
+                for (int w = 2; w < 17; ++w) x[w - 2] = row_word(my_r, L ? w : min(w, W - 1));
+#pragma unroll
+                for (int w = 2; w < 17; ++w) part[w] |= kept_me ? x[w - 2] : 0ull;
             } else {
                 for (int w0 = b + 1; w0 < W; w0 += 4) {
                     unsigned long long v[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) v[u] = (kept_me && w0 + u < W) ? my_row[w0 + u] : 0ull;
+                    for (int u = 0; u < 4; ++u) v[u] = (kept_me && w0 + u < W) ? row_word(my_r, w0 + u) : 0ull;
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const unsigned long long red = ((unsigned long long)nms_wave_or32((unsigned int)(v[u] >> 32)) << 32) | nms_wave_or32((unsigned int)v[u]);
@@ -2062,9 +2083,14 @@ __global__ __launch_bounds__(256) void k_nms(NmsGeom g, float thr, const float *
                     }
                 }
             }
+            if (kept_me) keep[n_kept + __builtin_popcountll(kw & ((1ull << lane) - 1ull))] = 64 * b + lane;
+            n_kept += __builtin_popcountll(kw);
+            mine = mine_next;
         }
         if (lane == 0) *count = n_kept;
-    }
+    };
+    if (in_lds) sweep(std::true_type{}); else sweep(std::false_type{});
+    if (dbg && lane == 0) dbg[2 * g.tiles + 3] = __builtin_amdgcn_s_memrealtime();
 }
 
 // ------------------------------------------------------------------------------------------ L2 normalisation into a channel slice
@@ -3562,8 +3588,9 @@ BC_EXPORT int bc_nms_sorted(const float *boxes, int n, float iou_thr, unsigned l
     }
     NmsGeom g;
     g.n = n; g.words = (n + 63) / 64; g.tiles = g.words * (g.words + 1) / 2;
+    g.fdw = make_fd((uint32_t)g.words);
     // phase 2 in LDS: the n x words matrix and the n transposed diagonal words
-    const size_t all = ((size_t)n * g.words + n) * sizeof(unsigned long long);
+    const size_t all = ((size_t)n * (g.words | 1) + n + 17) * sizeof(unsigned long long);     // (odd row stride, 17 spare words: see the kernel)
     g.lds_rows = all <= (size_t)150 * 1024 ? n : 0;
     const size_t lds_bytes = g.lds_rows ? all : 0;
     static bool attr_set = false;
@@ -3572,7 +3599,7 @@ BC_EXPORT int bc_nms_sorted(const float *boxes, int n, float iou_thr, unsigned l
         attr_set = true;
     }
     ProfScope ps(BC_OP_NMS, 20.0 * n);
-    BC_LAUNCH(ps, k_nms, dim3(g.tiles), dim3(256), lds_bytes, st, g, iou_thr, boxes, mask_ws, keep, count, tickets + slot);
+    BC_LAUNCH(ps, k_nms, dim3(g.tiles), dim3(1024), lds_bytes, st, g, iou_thr, boxes, mask_ws, keep, count, tickets + slot, g_tune.conv_stamps);
     return launch_status();
 }
 

@@ -33,3 +33,16 @@ for n, spread in [(1000, 400.0), (1000, 1500.0), (1000, 100.0), (300, 200.0), (4
     want = O.c_nms(dets, 0.5)
     got = order[keep[:k].long()].cpu().numpy()
     print(f"n {n:5d} spread {spread:6.0f}: {us:7.1f} us per call, {k} kept, {'== oracle' if np.array_equal(np.sort(got), np.sort(want)) else 'MISMATCH'}", flush=True)
+    # timeline of one launch (100 MHz stamps)
+    W = (n + 63) // 64
+    tiles = W * (W + 1) // 2
+    st = torch.zeros(2 * tiles + 8, dtype=torch.int64, device="cuda")
+    be.tune_ptr("conv_stamps", st)
+    fn()
+    torch.cuda.synchronize()
+    be.tune_ptr("conv_stamps", None)
+    s = st.cpu().numpy().astype(np.int64)
+    t0 = s[0:2 * tiles:2].min()
+    rel = lambda v: (v - t0) / 100.0
+    print(f"        tiles: first entry 0, last entry {rel(s[0:2 * tiles:2].max()):.2f}, tickets {rel(s[1:2 * tiles:2].min()):.2f} .. {rel(s[1:2 * tiles:2].max()):.2f} us; "
+          f"sweeping workgroup: entry {rel(s[2 * tiles]):.2f}, ticket {rel(s[2 * tiles + 1]):.2f}, words in LDS {rel(s[2 * tiles + 2]):.2f}, done {rel(s[2 * tiles + 3]):.2f} us", flush=True)
