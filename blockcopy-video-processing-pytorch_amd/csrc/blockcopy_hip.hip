@@ -1877,18 +1877,18 @@ __global__ __launch_bounds__(WG) void k_upsample_argmax(long long *__restrict__ 
 // Pedestron/mmdet/ops/nms/src/nms_kernel.cu:23-130 -- the reference copies an (n x n/64)-word mask to the host and sweeps it there).
 // Rule (the reference's, bit for bit): box j is suppressed by an earlier KEPT box i when IoU(i, j) > thr, IoU with the +1 pixel convention.
 //   phase 1, many workgroups: only the UPPER-triangular 64 x 64 tiles of the pair matrix exist (a box is only ever suppressed by an earlier
-//            one).  A workgroup of four waves owns one tile: lane = row, each wave a quarter of the columns (the column box is
-//            wave-uniform: scalar operands), and stores its 16-bit piece of the row's 64-bit word directly.  Diagonal tiles also leave
+//            one).  A workgroup of sixteen waves owns one tile: lane = row, each wave four of the columns (the column box is
+//            wave-uniform: scalar operands); the row's 64-bit word is put together in LDS and stored whole.  Diagonal tiles also leave
 //            the transposed word of every box (its possible suppressors INSIDE its own block: the IoU is symmetric) behind the matrix.
-//   phase 2, the workgroup that finishes LAST (device-scope ticket; nobody spins): pulls the words into LDS (n <= ~1000: n * (ceil(n / 64)
-//            + 1) words <= 150 KB; larger inputs sweep out of L2) and walks the column blocks with ONE wave, lane j = box j of the block:
+//   phase 2, the workgroup that finishes LAST (device-scope ticket; nobody spins): pulls the words into LDS (n <= 1024: n * ((ceil(n / 64)
+//            | 1) + 1) words <= 150 KB; larger inputs sweep out of L2) and walks the column blocks with ONE wave, lane j = box j of the block:
 //              a removed bitmap with word w in lane w; after a block is resolved its kept lanes OR their words for the LATER blocks
 //                                          into it (lane-parallel reads, DPP reduction per word);
 //              inside the block the greedy rule is resolved as a fixed point instead of a walk: a box whose possible suppressors are all
 //                                          decided is decided (kept iff none of them was kept); each trip settles at least the first
 //                                          undecided box, typically all of them in two or three trips (64-bit ballots).
 //            The kept positions leave in ascending order (block by block, through popcount prefixes).
-struct NmsGeom { int n, words, tiles, lds_rows; FastDiv fdw; };
+struct NmsGeom { int n, words, tiles, lds_rows, row_shift; };
 
 __device__ __forceinline__ bool nms_suppresses(float ax1, float ay1, float ax2, float ay2, float a_area, float bx1, float by1, float bx2, float by2,
                                                float b_area, float thr)
@@ -1994,26 +1994,28 @@ __global__ __launch_bounds__(1024) void k_nms(NmsGeom g, float thr, const float 
     if (dbg && tid == 0) { dbg[2 * g.tiles] = t_in; dbg[2 * g.tiles + 1] = __builtin_amdgcn_s_memrealtime(); }
     const int Ws = in_lds ? (W | 1) : W;                     // row stride of the words the sweep reads: odd in LDS (a lane per row: 64 rows, 64 banks)
     if (in_lds) {
-        // 8-byte sc1 loads, all of a thread's loads in flight at once (1024 threads: the whole matrix is one or two batches); words left of
-        // a row's diagonal block were never written and are never read: zeros
-        constexpr int NL = 18;
-        const int total_words = n * W + n;
-        for (int i0 = 0; i0 < total_words; i0 += 1024 * NL) {
+        // 8-byte sc1 loads, all of a thread's loads in flight at once (1024 threads: the whole matrix is one batch).  The loads carry no
+        // condition (a load under a condition is a branch with its own wait: one round trip to memory each) and the addresses no
+        // division (one workgroup does all of this: its instruction count is the time): rows are walked as if they had 2^k words.
+        // Words left of a row's diagonal block were never written: whatever the workspace held; the sweep never looks at them
+        constexpr int NL = 17;
+        const int sh = g.row_shift, wmask = (1 << sh) - 1, total = n << sh;
+        unsigned long long lo_v = 0;
+        if (tid < n) lo_v = __hip_atomic_load(lowm + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // (n <= 1024 in here)
+        for (int i0 = 0; i0 < total; i0 += 1024 * NL) {
             unsigned long long v[NL];
 #pragma unroll
             for (int u = 0; u < NL; ++u) {
-                const int i = i0 + u * 1024 + tid;
-                const int r = (int)fd_div((uint32_t)i, g.fdw), w = i - r * W;
-                const bool need = i < total_words && (i >= n * W || w >= (r >> 6));
-                v[u] = need ? __hip_atomic_load(mask + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                const int i = i0 + u * 1024 + tid, r = i >> sh, w = i & wmask;
+                v[u] = __hip_atomic_load(mask + min(r * W + w, n * W - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
 #pragma unroll
             for (int u = 0; u < NL; ++u) {
-                const int i = i0 + u * 1024 + tid;
-                const int r = (int)fd_div((uint32_t)i, g.fdw), w = i - r * W;
-                if (i < total_words) nms_lds[i < n * W ? r * Ws + w : n * Ws + (i - n * W)] = v[u];
+                const int i = i0 + u * 1024 + tid, r = i >> sh, w = i & wmask;
+                if (w < W && r < n) nms_lds[r * Ws + w] = v[u];
             }
         }
+        if (tid < n) nms_lds[n * Ws + tid] = lo_v;
     }
     __syncthreads();
     if (dbg && tid == 0) dbg[2 * g.tiles + 2] = __builtin_amdgcn_s_memrealtime();
@@ -3588,10 +3590,11 @@ BC_EXPORT int bc_nms_sorted(const float *boxes, int n, float iou_thr, unsigned l
     }
     NmsGeom g;
     g.n = n; g.words = (n + 63) / 64; g.tiles = g.words * (g.words + 1) / 2;
-    g.fdw = make_fd((uint32_t)g.words);
+    g.row_shift = 0;
+    while ((1 << g.row_shift) < g.words) ++g.row_shift;
     // phase 2 in LDS: the n x words matrix and the n transposed diagonal words
     const size_t all = ((size_t)n * (g.words | 1) + n + 17) * sizeof(unsigned long long);     // (odd row stride, 17 spare words: see the kernel)
-    g.lds_rows = all <= (size_t)150 * 1024 ? n : 0;
+    g.lds_rows = (all <= (size_t)150 * 1024 && n <= 1024) ? n : 0;
     const size_t lds_bytes = g.lds_rows ? all : 0;
     static bool attr_set = false;
     if (!attr_set) {

@@ -458,7 +458,8 @@ def test_nms_matches_oracle(be):
     sets on random boxes, heavy-overlap clusters, n not a multiple of 64, n = 1 and n = 0 (scores are distinct: the
     order among tied scores is unspecified in the reference too)."""
     rng = np.random.default_rng(0)
-    for n, spread in [(1000, 400.0), (300, 60.0), (65, 30.0), (64, 30.0), (1, 10.0), (0, 1.0), (777, 150.0)]:
+    for n, spread in [(1000, 400.0), (300, 60.0), (65, 30.0), (64, 30.0), (1, 10.0), (0, 1.0), (777, 150.0),
+                      (1024, 200.0), (1025, 200.0), (1088, 300.0), (1100, 300.0), (17, 5.0)]:   # (either side of the LDS sweep's limit)
         xy = rng.random((n, 2)) * spread
         wh = rng.random((n, 2)) * 60 + 5
         score = (rng.permutation(n)[:, None] + 1.0) / (n + 1.0) if n else np.zeros((0, 1))
