@@ -137,6 +137,7 @@ def load_library(path: str = None) -> ctypes.CDLL:
         "bc_stem7x7s2_nhwc": [p, p, p, p] + [i] * 7 + [p, p, p, i, p],
         "bc_conv1x1_nhwc": [p, p, p] + [i] * 6 + [p, p, i, p, p, p, i, p],
         "bc_conv1x1_candidates": [i, i, i, i, i, i, ctypes.POINTER(i), i],
+        "bc_conv_upsample_arm": [p, i, i, i, ctypes.c_float, ctypes.c_float],
         "bc_interp_bilinear_nhwc": [p, p, ctypes.c_longlong, i, i, i, i, i, i, ctypes.c_float, ctypes.c_float, i, p],
         "bc_upsample_argmax": [p, p, i, i, i, i, i, i, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, i,
                                ctypes.c_float, ctypes.c_float, i, p],
@@ -730,8 +731,19 @@ class HipBackend:
         n = self.lib.bc_conv1x1_candidates(_DTYPE_CODE[data.dtype], int(stride), geo[0], data.shape[1], int(cout), geo[1], buf, 64)
         return [int(buf[k]) for k in range(max(n, 0))]
 
-    def conv1x1(self, data, wpk, cout, prologue=None, epilogue=None, cfg=None, stride=1, dyn=None):
-        """relu?(conv1x1(prologue(data)) * scale + shift + add) of a channels-last tensor in one launch (bc_conv1x1_nhwc)."""
+    def conv1x1_upsample_supported(self, launch_kw, interp) -> bool:
+        """Can the deferred pointwise conv ``launch_kw`` (the keyword arguments of conv1x1) carry "+ bilinear(interp[0])" in its epilogue
+        (bc_conv_upsample_arm)?  Same packed tiles, power-of-two square output tiles, stride 1, a coarser map with the conv's output channels."""
+        src, H, W, align, rh, rw = interp
+        data, cout = launch_kw["data"], launch_kw["cout"]
+        B, C, h, w = data.shape
+        return (launch_kw.get("stride", 1) == 1 and data.is_cuda and src.is_cuda and src.dtype == data.dtype and src.dim() == 4
+                and is_nhwc(src) and src.shape[0] == B and src.shape[1] == cout and src.shape[2] == src.shape[3]
+                and (h, w) == (H, W) and H == W and H >= 8 and (H & (H - 1)) == 0 and self.conv1x1_geometry(data, 1) is not None)
+
+    def conv1x1(self, data, wpk, cout, prologue=None, epilogue=None, cfg=None, stride=1, dyn=None, upsample=None):
+        """relu?(conv1x1(prologue(data)) * scale + shift + add) of a channels-last tensor in one launch (bc_conv1x1_nhwc).
+        ``upsample = (src, out_tile, align_corners, rh, rw)``: + bilinear(src) per tile before the add / ReLU (bc_conv_upsample_arm)."""
         assert _ok(data, *_DTYPE_CODE) and _ok(wpk, data.dtype)
         B, C, H, W = data.shape
         n_tiles, bs = self.conv1x1_geometry(data, stride)
@@ -747,10 +759,18 @@ class HipBackend:
         if out.numel() > 0:
             with torch.cuda.device_of(data):
                 want = int(cfg) if cfg is not None else self._conv_cfg_pinned
+                if upsample is not None and want >= 0 and (want & 0x800):
+                    want = -1       # (the GEMM form has no resampling epilogue: the library picks a direct decomposition)
                 if want != self._conv_cfg:
                     self._check(self.lib.bc_tune_set(b"conv2_cfg", want), "tune_set")
                     self._conv_cfg = want
                 self._arm(dyn)
+                if upsample is not None:
+                    usrc, out_bs, ualign, urh, urw = upsample
+                    usrc = usrc.contiguous(memory_format=torch.channels_last)
+                    assert stride == 1 and bs == 8 and usrc.dtype == data.dtype and usrc.shape[0] == B and usrc.shape[1] == cout
+                    self._check(self.lib.bc_conv_upsample_arm(usrc.data_ptr(), int(usrc.shape[2]), int(out_bs), int(bool(ualign)),
+                                                              float(urh), float(urw)), "conv_upsample_arm")
                 self._check(self.lib.bc_conv1x1_nhwc(out.data_ptr(), data.data_ptr(), wpk.data_ptr(), n_tiles, C, cout, bs, int(stride),
                                                      _DTYPE_CODE[data.dtype], ptr(isc), ptr(ish), int(bool(irelu)), ptr(osc), ptr(osh),
                                                      ptr(oadd), int(bool(orelu)), self._stream()), "conv1x1_nhwc")

@@ -32,10 +32,15 @@ class Pending:
     happened yet (the stored data is an unwritten placeholder of the right shape) and will carry the rest of the record
     as its epilogue, e.g. a decoder's ``x = upsample(x); x += skip`` becomes one kernel."""
 
-    __slots__ = ("scale", "shift", "add", "relu", "interp", "add_version", "conv", "src_guard")
+    __slots__ = ("scale", "shift", "add", "relu", "interp", "add_version", "conv", "src_guard", "up", "up_guard")
 
-    def __init__(self, scale=None, shift=None, add=None, relu=False, interp=None, add_version=None, conv=None, src_guard=None):
+    def __init__(self, scale=None, shift=None, add=None, relu=False, interp=None, add_version=None, conv=None, src_guard=None, up=None,
+                 up_guard=None):
         self.scale, self.shift, self.add, self.relu, self.interp = scale, shift, add, relu, interp
+        # "+ bilinear(up[0])" carried by a deferred pointwise conv: up = the interp record of a deferred resampling that was added to
+        # the conv's (not yet computed) result -- a decoder's `x = upsample(x); x += conv1x1(skip)` is then the conv launch alone
+        # (backend.conv1x1(upsample=...)); like `add` it ends the affine-only state of the record
+        self.up, self.up_guard = up, up_guard
         self.add_version = add._version if (add is not None and add_version is None) else add_version
         # (tensor, version) of the input a deferred producer will read at launch time (see checked_source)
         self.src_guard = src_guard if src_guard is not None else ((interp[0], interp[0]._version) if interp is not None else None)
@@ -45,7 +50,7 @@ class Pending:
         self.conv = conv
 
     def copy(self):
-        return Pending(self.scale, self.shift, self.add, self.relu, self.interp, self.add_version, self.conv, self.src_guard)
+        return Pending(self.scale, self.shift, self.add, self.relu, self.interp, self.add_version, self.conv, self.src_guard, self.up, self.up_guard)
 
     @property
     def deferred(self):
@@ -80,13 +85,14 @@ class Pending:
     def check_source(self):
         """Loud error if the input of a deferred producer (conv / resampling) was written in place after the op was recorded:
         the launch happens when the value is needed, so it would silently see the new contents."""
-        if self.src_guard is not None and self.src_guard[0]._version != self.src_guard[1]:
+        if ((self.src_guard is not None and self.src_guard[0]._version != self.src_guard[1])
+                or (self.up_guard is not None and self.up_guard[0]._version != self.up_guard[1])):
             raise RuntimeError("blockcopy lazy fusion: the input of a deferred conv / interpolation was modified in place before the "
                                "result was consumed; consume the result first or set BLOCKCOPY_DEFER_CONV=0 / BLOCKCOPY_FUSE=0")
 
     @property
     def affine_only(self):
-        return self.add is None and not self.relu
+        return self.add is None and not self.relu and self.up is None
 
 
 _cache = {}
@@ -168,6 +174,7 @@ CONV_MODE = os.environ.get("BLOCKCOPY_CONV", "auto")   # auto | native | winogra
 CONV_TUNE = os.environ.get("BLOCKCOPY_CONV_TUNE", "1") != "0"   # auto mode: measure a layer shape the plan table does not know (eager runs only)
 _conv_plans = {}      # (n_exec, bs, cin, cout, n_total, dtype, stride, ks) -> None (library conv) | decomposition code (-1 = library's own choice)
 DEFER_CONV = os.environ.get("BLOCKCOPY_DEFER_CONV", "1") != "0"   # fused convs launch lazily with the recorded elementwise work as epilogue
+UPSAMPLE_EPILOGUE = os.environ.get("BLOCKCOPY_UPSAMPLE_EPILOGUE", "1") != "0"   # upsample(x) + conv1x1(skip): the resampling rides in the conv's epilogue
 POINTWISE = os.environ.get("BLOCKCOPY_POINTWISE", "1") != "0"     # 1x1 convs through the fused kernel's one-tap form (prologue / epilogue fusion)
 GROUP_NORM = os.environ.get("BLOCKCOPY_GROUP_NORM", "1") != "0"   # group_norm on packed tiles as a recorded per-channel affine map (one stats pass)
 ADAPTIVE_POOL = os.environ.get("BLOCKCOPY_ADAPTIVE_POOL", "1") != "0"   # adaptive_avg_pool2d of dense channels-last maps (pyramid pooling) in the library's kernel

@@ -446,6 +446,9 @@ class TensorWrapper(torch.Tensor):
             if P.conv is not None:        # deferred fused halo+conv: launch now, the rest of the record is its epilogue
                 launch, kw, state = P.conv
                 plain = P.scale is None and P.shift is None and add is None and not P.relu
+                if P.up is not None:      # + bilinear(coarser map) in the epilogue of the pointwise conv
+                    usrc, uH, uW, ualign, urh, urw = P.up
+                    kw = dict(kw, upsample=(usrc, uH, ualign, urh, urw))
                 out = launch(epilogue=None if plain else (P.scale, P.shift, add, P.relu), **kw)
                 state["launched"] = True
             elif P.interp is not None:    # deferred interpolation: resample now, the rest of the record is its epilogue
@@ -794,6 +797,17 @@ class TensorWrapper(torch.Tensor):
         P = x._pending if inplace else x._pending.copy()
         if isinstance(y, TensorWrapper) and y._pending is not None:
             q = y._pending
+            if (fusion.UPSAMPLE_EPILOGUE and P.interp is not None and P.conv is None and P.scale is None and P.shift is None
+                    and q.conv is not None and q.interp is None and q.up is None and q.affine_only and not q.conv[2]["launched"]
+                    and hasattr(be, "conv1x1_upsample_supported") and q.conv[0] == getattr(be, "conv1x1", None)
+                    and be.conv1x1_upsample_supported(q.conv[1], P.interp)):
+                # upsample(x) + conv1x1(skip), neither computed yet: the sum becomes the conv launch with the resampling in its epilogue
+                R = q.copy()
+                R.up, R.up_guard = P.interp, P.src_guard
+                if inplace:
+                    x._pending = R
+                    return x, None, True
+                return x._sibling(R), None, True
             if q.scale is None and q.affine_only and not q.deferred:      # (raw_y + shift_y): fold the shift, add the raw tensor
                 P.shift = fusion.add_shifts(P.shift, q.shift)
                 P.set_add(y._raw())

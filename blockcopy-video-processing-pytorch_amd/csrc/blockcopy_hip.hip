@@ -2243,6 +2243,10 @@ DynArm dyn_take()
     return d;
 }
 
+// ---- bc_conv_upsample_arm: "+ bilinear(src)" term for the epilogue of the NEXT bc_conv1x1_nhwc (taken and cleared at its first lines)
+struct UpsampleArm { const void *src = nullptr; int src_bs = 0, out_bs = 0, align = 0; float rh = 0.0f, rw = 0.0f; };
+UpsampleArm g_up_arm;
+
 // tile-indexed launch (units = executed tiles x per_tile): the launch must have been sized for the ceiling
 bool dyn_tiles(const DynArm &a, int n_exec, uint32_t per_tile, DynCount &d)
 {
@@ -2875,7 +2879,7 @@ extern "C" int bc_part_conv_wino32(void *p) { return conv_wino32_run(*static_cas
 // ---- host side of conv3x3_wino4.inc (Winograd F(4x4,3x3), fp32 / stride 1, tiles of a multiple of 16 pixels or 8x8 tiles):
 // decompositions (WNW, WFW, NB) of 8 waves; code 0x1000 | index
 struct Wino4Cfg { int WNW, WFW, NB; };
-static const Wino4Cfg WINO4_CFGS[] = {{4, 2, 1}, {2, 4, 1}, {2, 4, 2}};
+static const Wino4Cfg WINO4_CFGS[] = {{4, 2, 1}, {2, 4, 1}, {2, 4, 2}, {4, 2, 2}};
 constexpr int WINO4_N = (int)(sizeof(WINO4_CFGS) / sizeof(WINO4_CFGS[0]));
 
 struct Wino4Plan { long long wgs; size_t lds_bytes; uint32_t n_rows; };
@@ -2937,7 +2941,8 @@ static int conv_wino4_run(ConvV2Args &a)
     switch (c) {
     case 0: launch_wino4_cfg<4, 2, 1>(ps, grid, plan.lds_bytes, a, g); break;
     case 1: launch_wino4_cfg<2, 4, 1>(ps, grid, plan.lds_bytes, a, g); break;
-    default: launch_wino4_cfg<2, 4, 2>(ps, grid, plan.lds_bytes, a, g); break;
+    case 2: launch_wino4_cfg<2, 4, 2>(ps, grid, plan.lds_bytes, a, g); break;
+    default: launch_wino4_cfg<4, 2, 2>(ps, grid, plan.lds_bytes, a, g); break;
     }
     a.chosen = a.force_cfg & 0x10ff;
     return launch_status();
@@ -3752,6 +3757,8 @@ BC_EXPORT int bc_conv1x1_nhwc(void *out, const void *features, const void *weigh
                               const float *out_shift, const void *out_add, int out_relu, void *stream)
 {
     const DynArm arm = dyn_take();
+    const UpsampleArm up = g_up_arm;                // (one shot: bc_conv_upsample_arm)
+    g_up_arm = UpsampleArm{};
     if (dtype < BC_F32 || dtype > BC_BF16) return BC_ERR_ELEM;
     if (n_tiles < 0 || Cin <= 0 || Cout <= 0 || bs <= 0 || (stride != 1 && stride != 2) || bs % stride) return BC_ERR_SHAPE;
     const int bso = bs / stride;
@@ -3762,6 +3769,16 @@ BC_EXPORT int bc_conv1x1_nhwc(void *out, const void *features, const void *weigh
     if (!aligned(out, 16) || !aligned(features, 16) || !aligned(weights_packed, 16) || !aligned(out_add, 8)) return BC_ERR_ALIGN;
     Prologue pr{in_scale, in_shift, in_relu};
     EpilogueT ept{out_scale, out_shift, out_add, out_relu};
+    if (up.src) {
+        // "+ bilinear(src)" in the epilogue: the direct one-tap form on 8x8 re-tiles of whole power-of-two tiles
+        if (stride != 1 || bs != 8 || (g_tune.conv2_cfg >= 0 && (g_tune.conv2_cfg & 0x800))) return BC_ERR_SHAPE;
+        if (!aligned(up.src, dtype == BC_F32 ? 16 : 8)) return BC_ERR_ALIGN;
+        int lg = 0;
+        while ((1 << lg) < up.out_bs) ++lg;
+        if ((1 << lg) != up.out_bs || up.out_bs < 8 || ((long long)n_tiles * 64) % ((long long)up.out_bs * up.out_bs) != 0) return BC_ERR_SHAPE;
+        ept.up_src = up.src; ept.up_bs = (uint32_t)up.src_bs; ept.up_obs_log2 = (uint32_t)lg;
+        ept.up_rh = up.rh; ept.up_rw = up.rw; ept.up_align = up.align;
+    }
     ProfScope ps(BC_OP_CONV3X3, 2.0 * n_tiles * bso * bso * (double)Cin * Cout);
     void *ring = const_cast<void *>(features);      // (unused by the one-tap form)
     hipStream_t st = (hipStream_t)stream;
@@ -3788,6 +3805,13 @@ BC_EXPORT int bc_conv1x1_nhwc(void *out, const void *features, const void *weigh
     if (dtype == BC_F16) return BC_C1(BC_F16);
     return BC_C1(BC_BF16);
 #undef BC_C1
+}
+
+BC_EXPORT int bc_conv_upsample_arm(const void *src, int src_bs, int out_bs, int align_corners, float rh, float rw)
+{
+    if (src && (src_bs <= 0 || out_bs <= 0)) return BC_ERR_SHAPE;
+    g_up_arm = UpsampleArm{src, src_bs, out_bs, align_corners, rh, rw};
+    return BC_OK;
 }
 
 BC_EXPORT int bc_dyn_set(const void *n_exec_dev, int ceiling)

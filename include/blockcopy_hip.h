@@ -294,6 +294,15 @@ int bc_conv1x1_nhwc(void *out, const void *features, const void *weights_packed,
                     int dtype, const float *in_scale, const float *in_shift, int in_relu, const float *out_scale,
                     const float *out_shift, const void *out_add, int out_relu, void *stream);
 int bc_conv1x1_candidates(int dtype, int stride, int n_tiles, int Cin, int Cout, int bs_in, int *out, int max_out);
+/* A decoder's  x = F.interpolate(x, 2x, 'bilinear'); x += conv1x1(skip)  (semantic_segmentation/models/util.py _Upsample.forward; the
+ * reference resamples the packed tiles, every tile by itself, then adds) as the EPILOGUE of the 1x1 conv: arms the NEXT bc_conv1x1_nhwc
+ * (consumed at its entry, like bc_dyn_set) with "+ bilinear(src)":  out[t][y][x][c] = conv(...)*out_scale + out_shift + bilinear(src[t])[y][x][c]
+ * (+ out_add, ReLU), src = the coarser packed map (n_exec, src_bs, src_bs, Cout) in the tensor dtype, out_bs = the real tile size of
+ * `out` (a power of two >= 8; the armed call itself sees 8x8 re-tiles: bs = 8, stride 1, the direct one-tap form), rh / rw / align_corners =
+ * the source-index scale of F.interpolate (in / out for align_corners = 0).  Index arithmetic, clamping at the TILE border and rounding
+ * are those of bc_interp_bilinear_nhwc on the packed batch.  No resampling launch, no round trip of the sum through memory.
+ * BC_ERR_SHAPE from the armed call when it cannot carry the term (stride 2, a GEMM-form decomposition forced, tile size not 2^k). */
+int bc_conv_upsample_arm(const void *src, int src_bs, int out_bs, int align_corners, float rh, float rw);
 
 /* network-input stage in ONE launch: (bs+6)^2 window gather from the frame-state map + the 7x7 / stride 2 / pad 3 conv of the
  * 3-channel frame (ResNet stem) + epilogue, on the matrix cores.  Replaces, for the first padded op of the reference pipeline,

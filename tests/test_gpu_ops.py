@@ -1179,6 +1179,114 @@ def test_pointwise_conv(be, dtype, tol):
     be.tune("conv2_cfg", -1)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_pointwise_conv_with_upsample_epilogue(be, dtype):
+    """bc_conv_upsample_arm + bc_conv1x1_nhwc == bc_conv1x1_nhwc, then bc_interp_bilinear_act_nhwc with the conv's result as its residual
+    (the decoder's `x = upsample(x); x += conv1x1(skip)` as two launches): bit for bit in fp32 (same products, one commutative sum), within
+    one rounding of the tensor dtype in 16 bit (the two-launch route rounds the conv's result before the sum).  Tiles of 8 / 16 / 32
+    pixels from coarser tiles of half the size (and a 4x step), with and without prologue / bias / trailing residual + ReLU; the arm is
+    consumed by one call; shapes the epilogue cannot carry are refused loudly."""
+    gen = torch.Generator().manual_seed(29)
+    for (B, Cin, Cout, bs, sbs, align) in [(6, 64, 128, 16, 8, False), (3, 128, 128, 32, 16, False), (5, 256, 128, 8, 4, False), (2, 64, 64, 32, 8, True),
+                                           (7, 64, 128, 16, 8, True)]:
+        x = _cl(torch.randn((B, Cin, bs, bs), generator=gen).cuda().to(dtype))
+        low = _cl(torch.randn((B, Cout, sbs, sbs), generator=gen).cuda().to(dtype))
+        w = (torch.randn((Cout, Cin, 1, 1), generator=gen) * (2.0 / Cin) ** 0.5).cuda().to(dtype)
+        wpk = be.pack_conv3x3_weights(w)
+        isc, ish = (torch.rand(Cin, generator=gen) + 0.5).cuda(), (torch.randn(Cin, generator=gen) * 0.1).cuda()
+        osh = (torch.randn(Cout, generator=gen) * 0.1).cuda()
+        add = _cl(torch.randn((B, Cout, bs, bs), generator=gen).cuda().to(dtype))
+        rh = np.float32(sbs - 1) / np.float32(bs - 1) if align else np.float32(sbs) / np.float32(bs)
+        interp = (low, bs, bs, align, rh, rh)
+        kw = dict(data=x, wpk=wpk, cout=Cout, stride=1)
+        assert be.conv1x1_upsample_supported(kw, interp)
+        cands = [None] + [c for c in be.conv1x1_candidates(x, Cout, 1) if not c & 0x800]
+        for cfg in cands:
+            for pro, epi in ((None, None), ((isc, ish, True), (None, osh, None, False)), (None, (None, osh, add, True))):
+                skip = be.conv1x1(x, wpk, Cout, pro, None if epi is None else (epi[0], epi[1], None, False), cfg=cfg)
+                want = be.interp_bilinear(low, bs, bs, align, rh, rh, (None, None, skip, False))
+                if epi is not None and (epi[2] is not None or epi[3]):
+                    want = be.affine_act(want, None, None, epi[2], epi[3])
+                got = be.conv1x1(x, wpk, Cout, pro, epi, cfg=cfg, upsample=(low, bs, align, rh, rh))
+                if dtype == torch.float32:
+                    assert torch.equal(got.contiguous(), want.contiguous()), (B, Cin, Cout, bs, sbs, align, cfg, pro is not None, epi is not None)
+                else:
+                    eps = 2.0 ** (-10 if dtype == torch.float16 else -7)
+                    err = (got.float() - want.float()).abs().max().item()
+                    assert err <= 2 * eps * max(1.0, want.float().abs().max().item()), (dtype, B, Cin, Cout, bs, cfg, err)
+                # the arm was one-shot: the same call without it gives the plain conv again
+                again = be.conv1x1(x, wpk, Cout, pro, None if epi is None else (epi[0], epi[1], None, False), cfg=cfg)
+                assert torch.equal(again.contiguous(), skip.contiguous())
+    be.tune("conv2_cfg", -1)
+    # not carried: stride 2, tiles that are not a power of two, another tile count, other channels
+    x = _cl(torch.randn((4, 64, 16, 16), generator=gen).cuda().to(dtype))
+    low = _cl(torch.randn((4, 128, 8, 8), generator=gen).cuda().to(dtype))
+    wpk = be.pack_conv3x3_weights(torch.randn((128, 64, 1, 1), generator=gen).cuda().to(dtype))
+    ok = (low, 16, 16, False, np.float32(0.5), np.float32(0.5))
+    assert be.conv1x1_upsample_supported(dict(data=x, wpk=wpk, cout=128, stride=1), ok)
+    assert not be.conv1x1_upsample_supported(dict(data=x, wpk=wpk, cout=128, stride=2), ok)
+    assert not be.conv1x1_upsample_supported(dict(data=x, wpk=wpk, cout=128, stride=1), (low[:3], 16, 16, False, np.float32(0.5), np.float32(0.5)))
+    assert not be.conv1x1_upsample_supported(dict(data=x, wpk=wpk, cout=128, stride=1), (low[:, :64], 16, 16, False, np.float32(0.5), np.float32(0.5)))
+    x24 = _cl(torch.randn((4, 64, 24, 24), generator=gen).cuda().to(dtype))
+    low12 = _cl(torch.randn((4, 128, 12, 12), generator=gen).cuda().to(dtype))
+    assert not be.conv1x1_upsample_supported(dict(data=x24, wpk=wpk, cout=128, stride=1), (low12, 24, 24, False, np.float32(0.5), np.float32(0.5)))
+    with pytest.raises(Exception):      # the library itself refuses a tile size that is not 2^k (BC_ERR_SHAPE), and the arm is gone afterwards
+        be.conv1x1(x24, wpk, 128, None, None, upsample=(low12, 24, False, np.float32(0.5), np.float32(0.5)))
+    plain = be.conv1x1(x24, wpk, 128, None, None)
+    assert torch.isfinite(plain.float()).all()
+
+
+def test_decoder_upsample_add_rides_in_the_lateral_conv(be, monkeypatch):
+    """Engine routing: `x = F.interpolate(x, 2x, 'bilinear'); x += conv1x1(skip)` on packed tensors is ONE conv launch (no resampling
+    launch) and gives what the two-launch route gives (BLOCKCOPY_UPSAMPLE_EPILOGUE=0)."""
+    import torch.nn.functional as F
+
+    import blockcopy
+    from blockcopy.core import fusion
+
+    def packed(c, h, w_):
+        t = blockcopy.to_tensorwrapper(torch.randn((1, c, h, w_), generator=gen).cuda().contiguous(memory_format=torch.channels_last))
+        t.process_temporal_features(None)
+        grid = torch.ones(1, 1, 2, 4, dtype=torch.bool)
+        return t.to_blocks(grid.cuda(), grid)
+
+    gen = torch.Generator().manual_seed(31)
+    calls = {"interp": 0, "conv1x1": 0, "up": 0}
+    real_interp, real_conv = be.interp_bilinear, be.conv1x1
+
+    def interp(*a, **k):
+        calls["interp"] += 1
+        return real_interp(*a, **k)
+
+    def conv(*a, **k):
+        calls["conv1x1"] += 1
+        calls["up"] += int(k.get("upsample") is not None)
+        return real_conv(*a, **k)
+
+    monkeypatch.setattr(be, "interp_bilinear", interp)
+    monkeypatch.setattr(be, "conv1x1", conv)
+    w = (torch.randn((128, 64, 1, 1), generator=gen) * 0.2).cuda()
+    bias = (torch.randn(128, generator=gen) * 0.1).cuda()
+    outs = {}
+    for flag in (True, False):
+        monkeypatch.setattr(fusion, "UPSAMPLE_EPILOGUE", flag)
+        for k in calls:
+            calls[k] = 0
+        gen.manual_seed(31)
+        x, skip = packed(128, 16, 32), packed(64, 32, 64)       # 8 tiles of 8x8 (coarse) and of 16x16 (skip)
+        s = F.conv2d(skip, w, bias)
+        y = F.interpolate(x, (16, 16), mode="bilinear")
+        y += s
+        outs[flag] = torch.relu(y)._plain().clone()
+        if flag:
+            assert calls["interp"] == 0 and calls["up"] == 1, calls      # (conv1x1 also counts the plan tuner's trial launches of a new shape)
+        else:
+            assert calls["interp"] == 1 and calls["up"] == 0, calls
+    # (the two routes may run different decompositions of the conv -- the GEMM form cannot carry the term --: same sum, another order)
+    err = (outs[True] - outs[False]).abs().max().item()
+    assert err <= 2e-5 * max(1.0, outs[False].abs().max().item()), err
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
 def test_group_norm_affine_matches_the_batched_group_norm(be, dtype, tol):
     """bc_group_norm_affine_nhwc: group_norm over ALL executed tiles (the reference's batched form, core/tensorwrapper.py:600-633:
