@@ -1405,6 +1405,7 @@ struct PoolGeom {
     DynCount dyn;                     // executed-tile count on the device (units = tiles = gridDim.y)
 };
 
+constexpr int MP_U = 2;
 template <typename T, int VE, int DT>
 __global__ __launch_bounds__(WG) void k_maxpool3x3s2_nhwc(typename VecOf<sizeof(T) * VE>::type *__restrict__ out,
                                                           const typename VecOf<sizeof(T) * VE>::type *__restrict__ features,
@@ -1438,15 +1439,19 @@ __global__ __launch_bounds__(WG) void k_maxpool3x3s2_nhwc(typename VecOf<sizeof(
             else { nbb[k] = other_delta + (long long)g_in * RSV; nbr[k] = true; }
         }
     }
-    const uint32_t f = blockIdx.x * WG + threadIdx.x;
-    if (f >= g.per_tile) return;
+    V *__restrict__ rec = ring_w + (long long)ig * RSV;
+    // MP_U output vectors per lane behind ONE pair of dependent table lookups (the lookups are two memory round trips: with one
+    // vector per lane they were as long as the lane's whole life)
+#pragma unroll
+    for (int u = 0; u < MP_U; ++u) {
+    const uint32_t f = (blockIdx.x * MP_U + u) * WG + threadIdx.x;
+    if (f >= g.per_tile) continue;
     uint32_t pix, kq, oy, ox;
     fd_divmod(f, g.K, pix, kq);
     fd_divmod(pix, g.OB, oy, ox);
     float sc[VE], sh[VE];
     load_coeffs<VE>(pr.scale, kq * VE, 1.0f, sc);
     load_coeffs<VE>(pr.shift, kq * VE, 0.0f, sh);
-    V *__restrict__ rec = ring_w + (long long)ig * RSV;
 
     V raw[9];
     bool zero[9], ring[9];
@@ -1506,6 +1511,7 @@ __global__ __launch_bounds__(WG) void k_maxpool3x3s2_nhwc(typename VecOf<sizeof(
 #pragma unroll
     for (int j = 0; j < VE; ++j) r[j] = Cvt<T>::st(best[j]);
     out[(size_t)b * g.per_tile + f] = res;
+    }
 }
 
 // ------------------------------------------------------------------------------------------ GroupNorm over all executed tiles (NHWC)
@@ -4099,7 +4105,7 @@ BC_EXPORT int bc_maxpool3x3s2_ring_nhwc(void *out, const void *features, void *r
     g.K = make_fd(K); g.OB = make_fd(OB); g.GW = make_fd(GW); g.GH = make_fd(GH);
     g.bs = bs; g.n_total = (uint32_t)N * GH * GW; g.per_tile = OB * OB * K;
     if (!dyn_tiles(arm, n_exec, 1, g.dyn)) return BC_ERR_SHAPE;
-    const dim3 grid((g.per_tile + WG - 1) / WG, (unsigned)n_exec);
+    const dim3 grid((g.per_tile + WG * MP_U - 1) / (WG * MP_U), (unsigned)n_exec);
     const long long delta = ((const char *)ring - (const char *)features) / 16;
     const bool act = scale || shift || relu;
     Prologue pr{scale, shift, relu};
