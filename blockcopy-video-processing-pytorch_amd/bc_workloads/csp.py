@@ -197,6 +197,18 @@ class CSPHead(nn.Module):
         Returns (det_bboxes (k,5), det_labels (k,))."""
         h, w = cls_score.shape[-2:]
         dev, s = cls_score.device, self.stride
+        if cls_score.is_cuda and os.environ.get("BLOCKCOPY_FUSED_DECODE", "1") != "0" and 0 < nms_pre < h * w and nms_pre <= 4096:
+            # MI355X-first: top-k on the score map, then ONE decode launch and ONE NMS launch that reads the candidate count from the
+            # device -- the reference's ~40 elementwise / indexing launches and its two host round trips (score mask, NMS sweep)
+            # become five launches and the one read of the kept count (bc_csp_decode, bc_nms_sorted_dev; same boxes bit for bit)
+            from blockcopy.backend import get_backend
+
+            # (maps no larger than nms_pre take the route below: without a top-k the reference keeps the candidates in raster order)
+            scores, top = cls_score[0].reshape(-1).float().sigmoid().topk(nms_pre)
+            heights = bbox_pred[0].reshape(-1)[top].exp()
+            off = offset_pred[0].reshape(2, -1)[:, top]
+            dets = get_backend().csp_decode_nms(scores, top, heights, off[0], off[1], w, s, self.wh_ratio, img_shape, score_thr, iou_thr, max_per_img)
+            return dets, torch.zeros(dets.shape[0], dtype=torch.long, device=dev)
         scores = cls_score[0].permute(1, 2, 0).reshape(-1).float().sigmoid()
         heights = bbox_pred[0].permute(1, 2, 0).reshape(-1).exp()
         offs = offset_pred[0].permute(1, 2, 0).reshape(-1, 2)

@@ -138,6 +138,8 @@ def load_library(path: str = None) -> ctypes.CDLL:
         "bc_conv1x1_nhwc": [p, p, p] + [i] * 6 + [p, p, i, p, p, p, i, p],
         "bc_conv1x1_candidates": [i, i, i, i, i, i, ctypes.POINTER(i), i],
         "bc_conv_upsample_arm": [p, i, i, i, ctypes.c_float, ctypes.c_float],
+        "bc_nms_sorted_dev": [p, i, p, ctypes.c_float, p, p, p, p],
+        "bc_csp_decode": [p, p, p, p, p, i, i, i, ctypes.c_float, i, i, ctypes.c_float, p, p, p],
         "bc_interp_bilinear_nhwc": [p, p, ctypes.c_longlong, i, i, i, i, i, i, ctypes.c_float, ctypes.c_float, i, p],
         "bc_upsample_argmax": [p, p, i, i, i, i, i, i, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, i,
                                ctypes.c_float, ctypes.c_float, i, p],
@@ -1163,6 +1165,29 @@ class HipBackend:
         k = int(count.item())
         inds = order[keep[:k].long()].sort(0)[0]
         return dets[inds, :], inds
+
+    def csp_decode_nms(self, scores, top, heights, off_y, off_x, map_w, stride, wh_ratio, img_shape, score_thr, iou_thr, max_out):
+        """The detector decode between top-k and the kept boxes without a host round trip in between (bc_csp_decode +
+        bc_nms_sorted_dev): ``scores`` / ``top`` = the output of ``topk`` on the score map (sorted descending, flat positions), ``heights`` /
+        ``off_y`` / ``off_x`` gathered at ``top``.  Returns the kept boxes (k, 5) in descending score order, at most ``max_out``; the
+        only D->H read is the kept count."""
+        assert _ok(scores, torch.float32) and _ok(top, torch.int64) and _ok(heights, torch.float32) and _ok(off_y, torch.float32) and _ok(off_x, torch.float32)
+        k = scores.numel()
+        assert 0 < k <= 4096 and top.numel() == k and heights.numel() == k and off_y.numel() == k and off_x.numel() == k
+        dev = scores.device
+        dets = torch.empty((k, 5), dtype=torch.float32, device=dev)
+        cnt = torch.empty(2, dtype=torch.int32, device=dev)           # [selected, kept]
+        ws = torch.empty(k * ((k + 63) // 64) + k, dtype=torch.int64, device=dev)
+        keep = torch.empty(k, dtype=torch.int32, device=dev)
+        with torch.cuda.device_of(scores):
+            self._check(self.lib.bc_csp_decode(scores.contiguous().data_ptr(), top.contiguous().data_ptr(), heights.contiguous().data_ptr(),
+                                               off_y.contiguous().data_ptr(), off_x.contiguous().data_ptr(), k, int(map_w), int(stride),
+                                               float(wh_ratio), int(img_shape[0]), int(img_shape[1]), float(score_thr), dets.data_ptr(),
+                                               cnt.data_ptr(), self._stream()), "csp_decode")
+            self._check(self.lib.bc_nms_sorted_dev(dets.data_ptr(), k, cnt.data_ptr(), float(iou_thr), ws.data_ptr(), keep.data_ptr(),
+                                                   cnt.data_ptr() + 4, self._stream()), "nms_sorted_dev")
+        n_keep = int(cnt[1].item())
+        return dets[keep[:min(n_keep, int(max_out))].long()]
 
     # -- C. measurement -----------------------------------------------------------------------------------
     def tune(self, key: str, value: int):

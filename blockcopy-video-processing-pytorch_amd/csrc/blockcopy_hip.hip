@@ -1926,7 +1926,7 @@ __device__ __forceinline__ unsigned int nms_wave_or32(unsigned int v)
 
 __global__ __launch_bounds__(1024) void k_nms(NmsGeom g, float thr, const float *__restrict__ boxes, unsigned long long *__restrict__ mask,
                                               int32_t *__restrict__ keep, int32_t *__restrict__ count, unsigned int *__restrict__ ticket,
-                                              unsigned long long *__restrict__ dbg)
+                                              unsigned long long *__restrict__ dbg, const int32_t *__restrict__ n_dev)
 {
     // dbg (bc_tune_set_ptr("conv_stamps", ...), measurement only): 100 MHz stamps -- [2 b], [2 b + 1] = entry / ticket of workgroup b; the
     // sweeping workgroup adds [2 tiles ..]: entry, ticket, words in LDS, sweep done
@@ -1937,6 +1937,18 @@ __global__ __launch_bounds__(1024) void k_nms(NmsGeom g, float thr, const float 
     __shared__ int last_flag;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // box count known only on the device (bc_nms_sorted_dev: the launch is sized for g.n boxes, *n_dev <= g.n of them exist): the
+    // geometry is rederived here, surplus workgroups leave before they touch anything (and take no ticket)
+    if (n_dev) {
+        const int nd = min(max(*n_dev, 0), g.n);
+        g.n = nd; g.words = (nd + 63) / 64; g.tiles = g.words * (g.words + 1) / 2;
+        g.row_shift = 0;
+        while ((1 << g.row_shift) < g.words) ++g.row_shift;
+        if ((int)blockIdx.x >= g.tiles) {
+            if (nd == 0 && blockIdx.x == 0 && tid == 0) *count = 0;
+            return;
+        }
+    }
     const int n = g.n, W = g.words;
     unsigned long long *lowm = mask + (size_t)n * W;         // [n]: suppressors of a box inside its own block (bit i: box 64 * block + i, i < own position)
     // ---- phase 1: tile (rb, cb), cb >= rb, of the upper triangle; tiles are numbered row by row.  Sixteen waves: lane = row, a wave takes
@@ -2099,6 +2111,51 @@ __global__ __launch_bounds__(1024) void k_nms(NmsGeom g, float thr, const float 
     };
     if (in_lds) sweep(std::true_type{}); else sweep(std::false_type{});
     if (dbg && lane == 0) dbg[2 * g.tiles + 3] = __builtin_amdgcn_s_memrealtime();
+}
+
+// ------------------------------------------------------------------------------------------ detector decode (centre / scale / offset head)
+// The arithmetic between the head's top-k and its NMS (Pedestron/mmdet/models/anchor_heads/csp_head.py:229-284 get_bboxes_single +
+// csp_height2bbox): position of candidate k from its flat index, centre = cell centre + offset * stride, height = exp(scale) * stride
+// (the exp is the caller's: heights[]), width = wh_ratio * height, box clamped to the image, [x1, y1, x2, y2, score] rows in the
+// candidates' order -- and the NUMBER of candidates whose score exceeds the threshold (scores come sorted descending from the top-k,
+// so those are the first n_sel rows: what the reference selects with a boolean mask and a host round trip).  One launch instead of
+// ~25 elementwise ones; every operation is the single IEEE operation the reference's tensor expression performs, in its order (no
+// contraction), so the boxes are the reference's bit for bit.
+struct DecodeGeom { int k, W, stride; float wh_ratio, x_max, y_max, thr; };
+
+__global__ __launch_bounds__(1024) void k_csp_decode(DecodeGeom g, const float *__restrict__ scores, const long long *__restrict__ top,
+                                                     const float *__restrict__ heights, const float *__restrict__ off_y,
+                                                     const float *__restrict__ off_x, float *__restrict__ dets, int32_t *__restrict__ n_sel)
+{
+    __shared__ int wave_cnt[16];
+    const float sf = (float)g.stride, half = (float)(g.stride / 2);
+    int mine = 0;
+    for (int k = threadIdx.x; k < g.k; k += 1024) {
+        const long long i = top[k];
+        const int row = (int)(i / g.W), col = (int)(i - (long long)row * g.W);
+        const float px = __fadd_rn((float)(col * g.stride), half), py = __fadd_rn((float)(row * g.stride), half);
+        const float x = __fadd_rn(px, __fmul_rn(off_x[k], sf)), y = __fadd_rn(py, __fmul_rn(off_y[k], sf));
+        const float hh = __fmul_rn(heights[k], sf);
+        const float a = __fmul_rn(__fmul_rn(g.wh_ratio, hh), 0.5f), b = __fmul_rn(hh, 0.5f);      // (x / 2 == x * 0.5 exactly)
+        float *d = dets + (size_t)k * 5;
+        d[0] = fminf(fmaxf(__fsub_rn(x, a), 0.0f), g.x_max);
+        d[1] = fminf(fmaxf(__fsub_rn(y, b), 0.0f), g.y_max);
+        d[2] = fminf(fmaxf(__fadd_rn(x, a), 0.0f), g.x_max);
+        d[3] = fminf(fmaxf(__fadd_rn(y, b), 0.0f), g.y_max);
+        const float sc = scores[k];
+        d[4] = sc;
+        mine += sc > g.thr ? 1 : 0;
+    }
+    // count: wave sums (DPP-free: ballots would need one pass per trip), then 16 partials
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+    if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < 16; ++w) t += wave_cnt[w];
+        *n_sel = t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------ L2 normalisation into a channel slice
@@ -3576,8 +3633,8 @@ BC_EXPORT int bc_affine_act(void *out, const void *in, const void *add, const fl
 // one device-scope ticket per stream that has run an NMS (concurrent launches on different streams must not share one)
 __device__ unsigned int g_nms_tickets[64];
 
-BC_EXPORT int bc_nms_sorted(const float *boxes, int n, float iou_thr, unsigned long long *mask_ws, int32_t *keep,
-                            int32_t *count, void *stream)
+static int nms_launch(const float *boxes, int n, const int32_t *n_dev, float iou_thr, unsigned long long *mask_ws, int32_t *keep,
+                      int32_t *count, void *stream)
 {
     if (n < 0 || n > 4096) return BC_ERR_SHAPE;
     if (!count || (n > 0 && (!boxes || !mask_ws || !keep))) return BC_ERR_NULL;
@@ -3613,7 +3670,33 @@ BC_EXPORT int bc_nms_sorted(const float *boxes, int n, float iou_thr, unsigned l
         attr_set = true;
     }
     ProfScope ps(BC_OP_NMS, 20.0 * n);
-    BC_LAUNCH(ps, k_nms, dim3(g.tiles), dim3(1024), lds_bytes, st, g, iou_thr, boxes, mask_ws, keep, count, tickets + slot, g_tune.conv_stamps);
+    BC_LAUNCH(ps, k_nms, dim3(g.tiles), dim3(1024), lds_bytes, st, g, iou_thr, boxes, mask_ws, keep, count, tickets + slot, g_tune.conv_stamps, n_dev);
+    return launch_status();
+}
+
+BC_EXPORT int bc_nms_sorted(const float *boxes, int n, float iou_thr, unsigned long long *mask_ws, int32_t *keep,
+                            int32_t *count, void *stream)
+{
+    return nms_launch(boxes, n, nullptr, iou_thr, mask_ws, keep, count, stream);
+}
+
+BC_EXPORT int bc_nms_sorted_dev(const float *boxes, int n_max, const int32_t *n_dev, float iou_thr, unsigned long long *mask_ws,
+                                int32_t *keep, int32_t *count, void *stream)
+{
+    if (!n_dev) return BC_ERR_NULL;
+    if (n_max <= 0) return BC_ERR_SHAPE;
+    return nms_launch(boxes, n_max, n_dev, iou_thr, mask_ws, keep, count, stream);
+}
+
+BC_EXPORT int bc_csp_decode(const float *scores, const long long *top, const float *heights, const float *off_y, const float *off_x,
+                            int k, int map_w, int stride, float wh_ratio, int img_h, int img_w, float score_thr, float *dets,
+                            int32_t *n_sel, void *stream)
+{
+    if (k < 0 || map_w <= 0 || stride <= 0 || img_h <= 0 || img_w <= 0) return BC_ERR_SHAPE;
+    if (!n_sel || (k > 0 && (!scores || !top || !heights || !off_y || !off_x || !dets))) return BC_ERR_NULL;
+    DecodeGeom g{k, map_w, stride, wh_ratio, (float)(img_w - 1), (float)(img_h - 1), score_thr};
+    ProfScope ps(BC_OP_NMS, 44.0 * k);
+    BC_LAUNCH(ps, k_csp_decode, dim3(1), dim3(1024), 0, (hipStream_t)stream, g, scores, top, heights, off_y, off_x, dets, n_sel);
     return launch_status();
 }
 

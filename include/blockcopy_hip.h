@@ -416,6 +416,19 @@ int bc_l2norm_cat_nhwc(void *out, const void *x, const float *weight, long long 
  * sweeps there).  Launches on different streams may overlap; at most 64 distinct streams per process. */
 int bc_nms_sorted(const float *boxes, int n, float iou_thr, unsigned long long *mask_ws, int32_t *keep,
                   int32_t *count, void *stream);
+/* the same with the box count known only on the DEVICE: the launch and mask_ws are sized for n_max rows, the kernel works on the first
+ * min(*n_dev, n_max) of them (*n_dev = 0: *count = 0).  With bc_csp_decode below a detector's decode needs no host round trip
+ * between the head's top-k and the kept boxes (the reference syncs for the score mask, csp_head.py:268-284, and again inside nms). */
+int bc_nms_sorted_dev(const float *boxes, int n_max, const int32_t *n_dev, float iou_thr, unsigned long long *mask_ws, int32_t *keep,
+                      int32_t *count, void *stream);
+/* centre / scale / offset head decode between top-k and NMS (Pedestron/mmdet/models/anchor_heads/csp_head.py:229-284 get_bboxes_single:
+ * csp_height2bbox + clamp + score mask): candidate k = flat map position top[k] (row-major, map_w columns) with score scores[k] (sorted
+ * descending: the output of top-k), heights[k] = exp(scale prediction), off_y / off_x[k] its offsets.  Writes dets[k] = [x1, y1, x2, y2,
+ * score]: centre (col * stride + stride / 2 + off_x * stride, row ... off_y ...), height heights * stride, width wh_ratio * height, clamped
+ * to [0, img_w - 1] x [0, img_h - 1]; and *n_sel = the number of scores > score_thr (= the rows the reference keeps: a prefix).  Every
+ * operation is the single fp32 operation of the reference's tensor expression, in its order: identical boxes.  One launch for ~25. */
+int bc_csp_decode(const float *scores, const long long *top, const float *heights, const float *off_y, const float *off_x, int k,
+                  int map_w, int stride, float wh_ratio, int img_h, int img_w, float score_thr, float *dets, int32_t *n_sel, void *stream);
 
 /* device policy step: the per-frame decision of the online-RL policies without leaving the GPU.
  * Replaces, in one launch: Bernoulli(logits).sample() + `.cpu()` (policy/policy.py:283-288), quantize_number_exec_grid

@@ -487,6 +487,29 @@ def test_nms_matches_oracle(be):
         assert np.array_equal(inds.cpu().numpy(), O.c_nms(dets, thr)), thr
 
 
+def test_csp_decode_matches_the_tensor_expression(be, monkeypatch):
+    """bc_csp_decode + bc_nms_sorted_dev (top-k -> boxes -> score mask -> NMS with the candidate count read on the device) == the
+    reference's tensor expression (csp_head.py:229-284 as restated in bc_workloads.csp.CSPHead.get_bboxes with BLOCKCOPY_FUSED_DECODE=0):
+    identical boxes, bit for bit, in the same order -- incl. no candidate above the threshold, every candidate above it, more kept
+    boxes than max_per_img, heights large enough to clamp at all four image borders."""
+    from bc_workloads.csp import CSPHead
+
+    head = CSPHead()
+    gen = torch.Generator().manual_seed(41)
+    for (h, w, bias, hs, thr, pre, cap) in [(64, 128, -3.0, 0.5, 0.1, 1000, 100), (64, 128, -9.0, 0.5, 0.1, 1000, 100), (64, 128, 4.0, 0.3, 0.1, 1000, 100),
+                                            (48, 80, -1.0, 1.5, 0.3, 300, 500), (64, 128, 0.0, 0.2, 0.05, 2000, 100), (40, 40, -2.0, 0.8, 0.1, 1599, 50)]:
+        cls = (torch.randn((1, 1, h, w), generator=gen) * 2.0 + bias).cuda()
+        reg = (torch.randn((1, 1, h, w), generator=gen) * hs + 2.0).cuda()
+        off = (torch.randn((1, 2, h, w), generator=gen) * 0.4).cuda().contiguous(memory_format=torch.channels_last)
+        shape = (h * 4 - 3, w * 4 - 5)
+        monkeypatch.setenv("BLOCKCOPY_FUSED_DECODE", "0")
+        want, wl = head.get_bboxes(cls, reg, off, shape, nms_pre=pre, score_thr=thr, iou_thr=0.5, max_per_img=cap)
+        monkeypatch.setenv("BLOCKCOPY_FUSED_DECODE", "1")
+        got, gl = head.get_bboxes(cls, reg, off, shape, nms_pre=pre, score_thr=thr, iou_thr=0.5, max_per_img=cap)
+        assert tuple(got.shape) == tuple(want.shape) and tuple(gl.shape) == tuple(wl.shape), (h, w, bias, got.shape, want.shape)
+        assert torch.equal(got, want), (h, w, bias, float((got - want).abs().max()))
+
+
 def test_plain_c_consumer_runs():
     """The PyTorch-free C++ consumer of the ABI (tests/abi_c) passes its own checks on the device."""
     import subprocess
