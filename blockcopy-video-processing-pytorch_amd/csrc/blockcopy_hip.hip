@@ -1401,6 +1401,7 @@ __global__ __launch_bounds__(WG) void k_halo_add_nhwc(typename VecOf<VB>::type *
 // reference.  One lane = one 16-byte vector of one output pixel; 3x3 neighbour table wave-uniform as in k_halo_nhwc.
 struct PoolGeom {
     FastDiv K, OB, GW, GH;    // vectors per fat pixel, output tile edge bs/2, grid dims
+    FastDiv OBP;              // OB / 8 when the lanes walk the tile in 8x8-pixel patches (OB % 8 == 0), else d = 0
     uint32_t bs, n_total, per_tile;   // per_tile = OB*OB*K output vectors per executed tile
     DynCount dyn;                     // executed-tile count on the device (units = tiles = gridDim.y)
 };
@@ -1448,7 +1449,14 @@ __global__ __launch_bounds__(WG) void k_maxpool3x3s2_nhwc(typename VecOf<sizeof(
     if (f >= g.per_tile) continue;
     uint32_t pix, kq, oy, ox;
     fd_divmod(f, g.K, pix, kq);
-    fd_divmod(pix, g.OB, oy, ox);
+    if (g.OBP.d) {
+        // 8x8-pixel patches instead of whole output rows: the three input rows of an output row are shared with the rows above and
+        // below, which a row-by-row walk hands to other workgroups (other XCDs: re-fetched from memory, 1.38x the algorithmic bytes)
+        uint32_t py, pxx;
+        const uint32_t q = pix & 63u;
+        fd_divmod(pix >> 6, g.OBP, py, pxx);
+        oy = py * 8 + (q >> 3); ox = pxx * 8 + (q & 7u);
+    } else fd_divmod(pix, g.OB, oy, ox);
     float sc[VE], sh[VE];
     load_coeffs<VE>(pr.scale, kq * VE, 1.0f, sc);
     load_coeffs<VE>(pr.shift, kq * VE, 0.0f, sh);
@@ -1510,7 +1518,7 @@ __global__ __launch_bounds__(WG) void k_maxpool3x3s2_nhwc(typename VecOf<sizeof(
     T *r = reinterpret_cast<T *>(&res);
 #pragma unroll
     for (int j = 0; j < VE; ++j) r[j] = Cvt<T>::st(best[j]);
-    out[(size_t)b * g.per_tile + f] = res;
+    out[(size_t)b * g.per_tile + ((size_t)oy * g.OB.d + ox) * K + kq] = res;
     }
 }
 
@@ -4187,6 +4195,8 @@ BC_EXPORT int bc_maxpool3x3s2_ring_nhwc(void *out, const void *features, void *r
     const uint32_t K = (uint32_t)((size_t)C * E / 16), OB = bs / 2;
     g.K = make_fd(K); g.OB = make_fd(OB); g.GW = make_fd(GW); g.GH = make_fd(GH);
     g.bs = bs; g.n_total = (uint32_t)N * GH * GW; g.per_tile = OB * OB * K;
+    g.OBP = make_fd(OB / 8);
+    if (OB % 8 != 0) g.OBP.d = 0;
     if (!dyn_tiles(arm, n_exec, 1, g.dyn)) return BC_ERR_SHAPE;
     const dim3 grid((g.per_tile + WG * MP_U - 1) / (WG * MP_U), (unsigned)n_exec);
     const long long delta = ((const char *)ring - (const char *)features) / 16;
