@@ -123,6 +123,22 @@ def main():
         wpk = be.pack_conv3x3_weights(torch.randn((Cout, Cin, 3, 3), device="cuda") * 0.05)
         alg = 4.0 * (nn * Cin * ((bs + 2) ** 2 + 4 * bs) + nn * Cout * bs * bs + 9 * Cin * Cout)
         run(f"{name} ({nn},{Cin}->{Cout},{bs}x{bs})", alg, lambda: be.conv3x3_ring(feats, ring, wpk, Cout, gi2, m2, None, None, cfg=code))
+    # Winograd F(4x4,3x3) (round 5, codes 0x1000 | c) at the shapes the plan table runs it: the 36/9 larger weight stream is extra reads
+    for (nn, Cin, Cout, bs, code, name) in [(64, 64, 64, 32, 0x1000, "F(4x4) winograd layer1"), (64, 128, 128, 32, 0x1000, "F(4x4) winograd up 1/4"),
+                                            (72, 128, 128, 16, 0x1000, "F(4x4) winograd layer2 (72 tiles)"), (38, 768, 256, 32, 0x1000, "F(4x4) winograd CSP head")]:
+        gi2, m2 = grid_tables(1, 8, 16, nn)
+        feats = cl(torch.randn((nn, Cin, bs, bs), device="cuda"))
+        ring = torch.randn((128, Cin, 4 * bs), device="cuda")
+        wpk = be.pack_conv3x3_weights(torch.randn((Cout, Cin, 3, 3), device="cuda") * 0.05)
+        alg = 4.0 * (nn * Cin * ((bs + 2) ** 2 + 4 * bs) + nn * Cout * bs * bs + 9 * Cin * Cout)
+        run(f"{name} ({nn},{Cin}->{Cout},{bs}x{bs})", alg, lambda: be.conv3x3_ring(feats, ring, wpk, Cout, gi2, m2, None, None, cfg=code))
+    # the decoder's lateral 1x1 conv with the upsample term in its epilogue (round 5): skip + coarser map in, sum out
+    for (nn, Cin, Cout, bs) in [(64, 64, 128, 32), (64, 128, 128, 16)]:
+        x = cl(torch.randn((nn, Cin, bs, bs), device="cuda"))
+        low = cl(torch.randn((nn, Cout, bs // 2, bs // 2), device="cuda"))
+        wpk = be.pack_conv3x3_weights(torch.randn((Cout, Cin, 1, 1), device="cuda") * 0.05)
+        alg = 4.0 * (nn * bs * bs * (Cin + Cout) + nn * (bs // 2) ** 2 * Cout + Cin * Cout)
+        run(f"conv1x1 + upsample epilogue ({nn},{Cin}->{Cout},{bs}x{bs})", alg, lambda: be.conv1x1(x, wpk, Cout, None, None, upsample=(low, bs, False, 0.5, 0.5)))
     # dilation-2 form of the direct kernel (C5 backbone stage 4) and the dense prediction convs of the CSP head
     gi2, m2 = grid_tables(1, 8, 16, 38)
     feats = cl(torch.randn((38, 512, 8, 8), device="cuda"))
