@@ -741,7 +741,7 @@ class HipBackend:
         B, C, h, w = data.shape
         return (launch_kw.get("stride", 1) == 1 and data.is_cuda and src.is_cuda and src.dtype == data.dtype and src.dim() == 4
                 and is_nhwc(src) and src.shape[0] == B and src.shape[1] == cout and src.shape[2] == src.shape[3]
-                and (h, w) == (H, W) and H == W and H >= 8 and (H & (H - 1)) == 0 and self.conv1x1_geometry(data, 1) is not None)
+                and (h, w) == (H, W) and H == W and H >= 2 and (H & (H - 1)) == 0 and self.conv1x1_geometry(data, 1) is not None)
 
     def conv1x1(self, data, wpk, cout, prologue=None, epilogue=None, cfg=None, stride=1, dyn=None, upsample=None):
         """relu?(conv1x1(prologue(data)) * scale + shift + add) of a channels-last tensor in one launch (bc_conv1x1_nhwc).

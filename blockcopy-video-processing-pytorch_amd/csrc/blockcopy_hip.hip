@@ -3872,7 +3872,7 @@ BC_EXPORT int bc_conv1x1_nhwc(void *out, const void *features, const void *weigh
         if (!aligned(up.src, dtype == BC_F32 ? 16 : 8)) return BC_ERR_ALIGN;
         int lg = 0;
         while ((1 << lg) < up.out_bs) ++lg;
-        if ((1 << lg) != up.out_bs || up.out_bs < 8 || ((long long)n_tiles * 64) % ((long long)up.out_bs * up.out_bs) != 0) return BC_ERR_SHAPE;
+        if ((1 << lg) != up.out_bs || up.out_bs < 2 || ((long long)n_tiles * 64) % ((long long)up.out_bs * up.out_bs) != 0) return BC_ERR_SHAPE;
         ept.up_src = up.src; ept.up_bs = (uint32_t)up.src_bs; ept.up_obs_log2 = (uint32_t)lg;
         ept.up_rh = up.rh; ept.up_rw = up.rw; ept.up_align = up.align;
     }

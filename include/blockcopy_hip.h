@@ -298,7 +298,7 @@ int bc_conv1x1_candidates(int dtype, int stride, int n_tiles, int Cin, int Cout,
  * reference resamples the packed tiles, every tile by itself, then adds) as the EPILOGUE of the 1x1 conv: arms the NEXT bc_conv1x1_nhwc
  * (consumed at its entry, like bc_dyn_set) with "+ bilinear(src)":  out[t][y][x][c] = conv(...)*out_scale + out_shift + bilinear(src[t])[y][x][c]
  * (+ out_add, ReLU), src = the coarser packed map (n_exec, src_bs, src_bs, Cout) in the tensor dtype, out_bs = the real tile size of
- * `out` (a power of two >= 8; the armed call itself sees 8x8 re-tiles: bs = 8, stride 1, the direct one-tap form), rh / rw / align_corners =
+ * `out` (a power of two >= 2; the armed call itself sees 8x8 re-tiles: bs = 8, stride 1, the direct one-tap form), rh / rw / align_corners =
  * the source-index scale of F.interpolate (in / out for align_corners = 0).  Index arithmetic, clamping at the TILE border and rounding
  * are those of bc_interp_bilinear_nhwc on the packed batch.  No resampling launch, no round trip of the sum through memory.
  * BC_ERR_SHAPE from the armed call when it cannot carry the term (stride 2, a GEMM-form decomposition forced, tile size not 2^k). */

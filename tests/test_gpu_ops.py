@@ -1210,7 +1210,7 @@ def test_pointwise_conv_with_upsample_epilogue(be, dtype):
     pixels from coarser tiles of half the size (and a 4x step), with and without prologue / bias / trailing residual + ReLU; the arm is
     consumed by one call; shapes the epilogue cannot carry are refused loudly."""
     gen = torch.Generator().manual_seed(29)
-    for (B, Cin, Cout, bs, sbs, align) in [(6, 64, 128, 16, 8, False), (3, 128, 128, 32, 16, False), (5, 256, 128, 8, 4, False), (2, 64, 64, 32, 8, True),
+    for (B, Cin, Cout, bs, sbs, align) in [(6, 64, 128, 16, 8, False), (3, 128, 128, 32, 16, False), (5, 256, 128, 8, 4, False), (8, 256, 128, 4, 2, False), (2, 64, 64, 32, 8, True),
                                            (7, 64, 128, 16, 8, True)]:
         x = _cl(torch.randn((B, Cin, bs, bs), generator=gen).cuda().to(dtype))
         low = _cl(torch.randn((B, Cout, sbs, sbs), generator=gen).cuda().to(dtype))
