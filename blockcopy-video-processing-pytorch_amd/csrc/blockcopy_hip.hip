@@ -2526,6 +2526,9 @@ int check_halo(const void *out, const void *features, const int32_t *grid_idx, c
     return BC_OK;
 }
 
+#ifndef BC_NBR_KO
+#define BC_NBR_KO 0
+#endif
 #include "conv3x3_mfma.inc"
 #include "conv3x3_v2.inc"
 #include "conv3x3_wino.inc"
