@@ -127,6 +127,9 @@ class CSPNeck(nn.Module):
 
         be = get_backend()
         raws = [u._materialize()._raw() if hasattr(u, "_raw") else u for u in ups]
+        weights = (self.p3_l2.weight, self.p4_l2.weight, self.p5_l2.weight)
+        if torch.is_grad_enabled() and any(t.requires_grad for t in (*raws, *weights)):
+            return None      # (the fused pass detaches: a caller that wants gradients -- fine-tuning the detector -- takes the stock ops)
         if not (hasattr(be, "l2norm_cat") and all(be.l2norm_cat_supported(r) and r.shape[0] == raws[0].shape[0] and r.shape[2:] == raws[0].shape[2:]
                                                    and r.dtype == raws[0].dtype for r in raws)):
             return None
@@ -197,7 +200,8 @@ class CSPHead(nn.Module):
         Returns (det_bboxes (k,5), det_labels (k,))."""
         h, w = cls_score.shape[-2:]
         dev, s = cls_score.device, self.stride
-        if cls_score.is_cuda and os.environ.get("BLOCKCOPY_FUSED_DECODE", "1") != "0" and 0 < nms_pre < h * w and nms_pre <= 4096:
+        if (cls_score.is_cuda and os.environ.get("BLOCKCOPY_FUSED_DECODE", "1") != "0" and 0 < nms_pre < h * w and nms_pre <= 4096
+                and cls_score.shape[1] == 1 and bbox_pred.shape[1] == 1 and offset_pred.shape[1] == 2):      # (the fused decode flattens 1-channel maps)
             # MI355X-first: top-k on the score map, then ONE decode launch and ONE NMS launch that reads the candidate count from the
             # device -- the reference's ~40 elementwise / indexing launches and its two host round trips (score mask, NMS sweep)
             # become five launches and the one read of the kept count (bc_csp_decode, bc_nms_sorted_dev; same boxes bit for bit)

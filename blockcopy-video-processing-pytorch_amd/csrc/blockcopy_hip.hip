@@ -2305,7 +2305,7 @@ struct ProfScope {
 // ---- executed-tile count on the device: bc_dyn_set ARMS the next launch only (the capable launchers take it at their first line,
 // armed or not, so an armed state can never leak into a later, unrelated launch of theirs)
 struct DynArm { const int32_t *ptr = nullptr; int ceiling = 0; };
-DynArm g_dyn_arm;
+thread_local DynArm g_dyn_arm;      // per host thread: an arm set by one thread is only ever consumed by that thread's next launch
 
 DynArm dyn_take()
 {
@@ -2316,7 +2316,7 @@ DynArm dyn_take()
 
 // ---- bc_conv_upsample_arm: "+ bilinear(src)" term for the epilogue of the NEXT bc_conv1x1_nhwc (taken and cleared at its first lines)
 struct UpsampleArm { const void *src = nullptr; int src_bs = 0, out_bs = 0, align = 0; float rh = 0.0f, rw = 0.0f; };
-UpsampleArm g_up_arm;
+thread_local UpsampleArm g_up_arm;
 
 // tile-indexed launch (units = executed tiles x per_tile): the launch must have been sized for the ceiling
 bool dyn_tiles(const DynArm &a, int n_exec, uint32_t per_tile, DynCount &d)
@@ -2953,7 +2953,7 @@ extern "C" int bc_part_conv_wino32(void *p) { return conv_wino32_run(*static_cas
 // ---- host side of conv3x3_wino4.inc (Winograd F(4x4,3x3), fp32 / stride 1, tiles of a multiple of 16 pixels or 8x8 tiles):
 // decompositions (WNW, WFW, NB) of 8 waves; code 0x1000 | index
 struct Wino4Cfg { int WNW, WFW, NB; };
-static const Wino4Cfg WINO4_CFGS[] = {{4, 2, 1}, {2, 4, 1}, {2, 4, 2}, {4, 2, 2}};
+static const Wino4Cfg WINO4_CFGS[] = {{4, 2, 1}, {2, 4, 1}, {2, 4, 2}};      // ((4,2,2): 144 accumulators per lane, 327 spilled registers -- removed)
 constexpr int WINO4_N = (int)(sizeof(WINO4_CFGS) / sizeof(WINO4_CFGS[0]));
 
 struct Wino4Plan { long long wgs; size_t lds_bytes; uint32_t n_rows; };
@@ -3016,7 +3016,7 @@ static int conv_wino4_run(ConvV2Args &a)
     case 0: launch_wino4_cfg<4, 2, 1>(ps, grid, plan.lds_bytes, a, g); break;
     case 1: launch_wino4_cfg<2, 4, 1>(ps, grid, plan.lds_bytes, a, g); break;
     case 2: launch_wino4_cfg<2, 4, 2>(ps, grid, plan.lds_bytes, a, g); break;
-    default: launch_wino4_cfg<4, 2, 2>(ps, grid, plan.lds_bytes, a, g); break;
+    default: return BC_ERR_SHAPE;
     }
     a.chosen = a.force_cfg & 0x10ff;
     return launch_status();
@@ -3069,7 +3069,7 @@ int bc_part_conv_v2_dil(void *);
 }
 #endif
 
-static DynCount g_conv_dyn;      // set by the exported conv launchers for the ONE launch_conv3x3_v2 call they make (bc_dyn_set)
+static thread_local DynCount g_conv_dyn;      // set by the exported conv launchers for the ONE launch_conv3x3_v2 call they make (bc_dyn_set)
 
 template <int DT, int S, int KS = 3>
 static int launch_conv3x3_v2(ProfScope &ps, void *out, const void *features, void *ring, const void *wpk, const int32_t *grid_idx,
@@ -3651,20 +3651,32 @@ static int nms_launch(const float *boxes, int n, const int32_t *n_dev, float iou
     if (!count || (n > 0 && (!boxes || !mask_ws || !keep))) return BC_ERR_NULL;
     hipStream_t st = (hipStream_t)stream;
     if (n == 0) { (void)hipMemsetAsync(count, 0, sizeof(int32_t), st); return launch_status(); }
+    // ticket slot = (device, stream): the symbol lives once per device, and two devices' null streams must not share a word
     static std::mutex mu;
-    static void *slot_of[64];
-    static int n_slots = 0;
-    static unsigned int *tickets = nullptr;
+    struct Slot { int dev; void *stream; };
+    static Slot slot_of[8][64];
+    static int n_slots[8];
+    static unsigned int *tickets_of[8];
+    static bool attr_set[8];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return launch_status();
+    if (dev < 0 || dev >= 8) return BC_ERR_SHAPE;
+    unsigned int *tickets = nullptr;
     int slot = -1;
     {
         std::lock_guard<std::mutex> lk(mu);
-        if (!tickets && hipGetSymbolAddress((void **)&tickets, HIP_SYMBOL(g_nms_tickets)) != hipSuccess) return launch_status();
-        for (int i = 0; i < n_slots; ++i)
-            if (slot_of[i] == stream) slot = i;
+        if (!tickets_of[dev] && hipGetSymbolAddress((void **)&tickets_of[dev], HIP_SYMBOL(g_nms_tickets)) != hipSuccess) return launch_status();
+        tickets = tickets_of[dev];
+        for (int i = 0; i < n_slots[dev]; ++i)
+            if (slot_of[dev][i].stream == stream) slot = i;
         if (slot < 0) {
-            if (n_slots == 64) return BC_ERR_SHAPE;      // (more than 64 streams running detectors in one process)
-            slot_of[n_slots] = stream;
-            slot = n_slots++;
+            if (n_slots[dev] == 64) return BC_ERR_SHAPE;      // (more than 64 streams of one device running detectors in one process)
+            slot_of[dev][n_slots[dev]] = Slot{dev, stream};
+            slot = n_slots[dev]++;
+        }
+        if (!attr_set[dev]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nms), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            attr_set[dev] = true;
         }
     }
     NmsGeom g;
@@ -3675,11 +3687,6 @@ static int nms_launch(const float *boxes, int n, const int32_t *n_dev, float iou
     const size_t all = ((size_t)n * (g.words | 1) + n + 17) * sizeof(unsigned long long);     // (odd row stride, 17 spare words: see the kernel)
     g.lds_rows = (all <= (size_t)150 * 1024 && n <= 1024) ? n : 0;
     const size_t lds_bytes = g.lds_rows ? all : 0;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nms), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        attr_set = true;
-    }
     ProfScope ps(BC_OP_NMS, 20.0 * n);
     BC_LAUNCH(ps, k_nms, dim3(g.tiles), dim3(1024), lds_bytes, st, g, iou_thr, boxes, mask_ws, keep, count, tickets + slot, g_tune.conv_stamps, n_dev);
     return launch_status();

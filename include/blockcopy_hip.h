@@ -103,7 +103,9 @@ int bc_combine_copy_indirect(const void *blocks, const void *slots, const int32_
  * bc_pad_ring_add_nhwc, bc_maxpool3x3s2_ring_nhwc, bc_conv3x3_ring_nhwc, bc_conv3x3s2_ring_nhwc, bc_conv3x3_dil_ring_nhwc,
  * bc_conv1x1_nhwc, bc_stem7x7s2_nhwc, bc_head1x1_scatter_nhwc (the copy half then always runs), bc_affine_act_nhwc,
  * bc_interp_bilinear(_act)_nhwc; bc_tile_copy_indirect takes the pointer as an argument.  Tile-indexed launches must be sized exactly
- * for `ceiling` (BC_ERR_SHAPE otherwise); pointwise ones (affine, interp, conv1x1) scale their unit count by *n_exec_dev / ceiling. */
+ * for `ceiling` (BC_ERR_SHAPE otherwise); pointwise ones (affine, interp, conv1x1) scale their unit count by *n_exec_dev / ceiling.
+ * The armed state is PER HOST THREAD (thread_local): an arm is consumed by the next capable launch of the thread that set it, so two
+ * threads (or two engines driven from two threads) of one process never take each other's arm. */
 int bc_dyn_set(const void *n_exec_dev, int ceiling);
 
 /* The network-INPUT stage of a graph-replayed frame: dst[tile] = src[tile] for every executed tile (mapping_exec) of two dense maps of
@@ -301,7 +303,8 @@ int bc_conv1x1_candidates(int dtype, int stride, int n_tiles, int Cin, int Cout,
  * `out` (a power of two >= 2; the armed call itself sees 8x8 re-tiles: bs = 8, stride 1, the direct one-tap form), rh / rw / align_corners =
  * the source-index scale of F.interpolate (in / out for align_corners = 0).  Index arithmetic, clamping at the TILE border and rounding
  * are those of bc_interp_bilinear_nhwc on the packed batch.  No resampling launch, no round trip of the sum through memory.
- * BC_ERR_SHAPE from the armed call when it cannot carry the term (stride 2, a GEMM-form decomposition forced, tile size not 2^k). */
+ * BC_ERR_SHAPE from the armed call when it cannot carry the term (stride 2, a GEMM-form decomposition forced, tile size not 2^k).
+ * Per host thread, like bc_dyn_set: only the arming thread's next bc_conv1x1_nhwc takes the term. */
 int bc_conv_upsample_arm(const void *src, int src_bs, int out_bs, int align_corners, float rh, float rw);
 
 /* network-input stage in ONE launch: (bs+6)^2 window gather from the frame-state map + the 7x7 / stride 2 / pad 3 conv of the
