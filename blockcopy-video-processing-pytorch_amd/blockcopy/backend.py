@@ -153,6 +153,19 @@ def load_library(path: str = None) -> ctypes.CDLL:
         "bc_l2norm_cat_nhwc": [p, p, p, ctypes.c_longlong, i, i, i, ctypes.c_float, i, p],
         "bc_policy_step": [p, i, ctypes.c_ulonglong, ctypes.c_ulonglong, i, i, p, p, p, p, p, p],
         "bc_policy_features": [p, i, i, i, p, p, p, p, p],
+        "bc_pn_conv_nhwc": [p, p, p] + [i] * 10 + [p, p, i, p, p, i, p, ctypes.c_longlong, p],
+        "bc_pn_wgrad_nhwc": [p, p, ctypes.c_longlong, p, p] + [i] * 9 + [p, p, i, p],
+        "bc_pn_bn_finalize": [p, ctypes.c_longlong, i, ctypes.c_double, p, p, ctypes.c_float, ctypes.c_float, p, p, p, p, p, p, p, p],
+        "bc_pn_join": [p, p, p, p, p, p, p, i, i, ctypes.c_longlong, p],
+        "bc_pn_bn_bwd": [p, p, p, p, p, p, p, p, i, p, p, p, p, p, i, ctypes.c_longlong, p],
+        "bc_pn_head_fwd": [p, p, p, p, p, p, i, i, i, i, p],
+        "bc_pn_head_bwd": [p, p, p, p, p, p, p, p, i, i, i, i, p],
+        "bc_pn_infogain": [p, p, p, i, i, i, i, i] + [ctypes.c_longlong] * 4 + [i, i, ctypes.c_float, ctypes.c_float, p],
+        "bc_pn_reward_seed": [p, p, p, p, p, p, p, ctypes.c_double, ctypes.c_double, ctypes.c_double, i, i, i, i, i, p],
+        "bc_pn_rmsprop": [p, p, p, p, ctypes.c_longlong] + [ctypes.c_float] * 5 + [p],
+        "bc_pn_sync_params": [p, p, p, i, i, p],
+        "bc_pn_seg_bytes": [],
+        "bc_pn_features_nhwc": [p, i, i, i, i, p, p, p, p, p],
         "bc_dyn_set": [p, i],
         "bc_tune_set": [ctypes.c_char_p, i],
         "bc_tune_get": [ctypes.c_char_p, ctypes.POINTER(i)],
@@ -167,6 +180,10 @@ def load_library(path: str = None) -> ctypes.CDLL:
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = i
+    for name, argtypes in {"bc_pn_conv_partials": [i, i, i], "bc_pn_wgrad_workspace": [i] * 6, "bc_pn_bn_bwd_partials": [ctypes.c_longlong]}.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_longlong
     lib.bc_error_string.argtypes = [i]
     lib.bc_error_string.restype = ctypes.c_char_p
     lib.bc_op_name.argtypes = [i]

@@ -71,17 +71,12 @@ class PolicyNet(nn.Module):
                  at_policy_resolution(policy_meta.get("grid"), centre=True)]
         return torch.cat(parts, dim=1).detach()
 
-    def _build_features_fused(self, policy_meta: Dict):
-        """The same tensor from ONE gather kernel (bc_policy_features) instead of 4 resamplings + casts + 2 subtractions +
-        concat; index arithmetic identical to F.interpolate(mode='nearest') (float32 scale: 1/scale_factor where a factor is
-        given, in/out where a size is given), so the result is bit-identical."""
+    def feature_sources(self, policy_meta: Dict):
+        """([(tensor, scale_h, scale_w, offset)] * 4, h, w): the four sources of the policy input with the float32 source-index scales
+        of F.interpolate(mode='nearest') (1/scale_factor where a factor is given, in/out where a size is given); None when a source
+        is missing or not a GPU tensor the gather kernels read."""
         import numpy as np
 
-        from blockcopy.backend import get_backend
-
-        be = get_backend()
-        if not hasattr(be, "policy_features"):
-            return None
         frame, state, rep, grid = (policy_meta["inputs"], policy_meta["frame_state"], policy_meta.get("output_repr"), policy_meta.get("grid"))
         ok = lambda t: t is not None and t.is_cuda and t.dim() == 4 and t.dtype in (torch.float32, torch.float16, torch.bfloat16, torch.bool, torch.uint8)
         if not all(ok(t) for t in (frame, state, rep, grid)):
@@ -91,6 +86,20 @@ class PolicyNet(nn.Module):
         by_factor = float(np.float32(1.0 / self.scale_factor))
         by_size = lambda t: (float(np.float32(t.shape[2]) / np.float32(h)), float(np.float32(t.shape[3]) / np.float32(w)))
         srcs = [(frame, by_factor, by_factor, 0.0), (state,) + by_size(state) + (0.0,), (rep,) + by_size(rep) + (-0.5,), (grid,) + by_size(grid) + (-0.5,)]
+        return srcs, h, w
+
+    def _build_features_fused(self, policy_meta: Dict):
+        """The same tensor from ONE gather kernel (bc_policy_features) instead of 4 resamplings + casts + 2 subtractions +
+        concat; index arithmetic identical to F.interpolate(mode='nearest'), so the result is bit-identical."""
+        from blockcopy.backend import get_backend
+
+        be = get_backend()
+        if not hasattr(be, "policy_features"):
+            return None
+        srcs = self.feature_sources(policy_meta)
+        if srcs is None:
+            return None
+        srcs, h, w = srcs
         with torch.no_grad():
             return be.policy_features(srcs, h, w)
 

@@ -331,6 +331,7 @@ class PolicyTrainRL(Policy, metaclass=abc.ABCMeta):
         self.rng_seed = None          # counter-based RNG of the device step: drawn from torch's generator at first use
         self.rng_counter = 0
         self._step_bufs = {}
+        self._natives = {}            # frame geometry -> own-kernel forward / backward / optimizer of the policy net (policy/native.py) or None
         assert 0 <= block_target <= 1
         self.block_target = block_target
         self.information_gain = information_gain
@@ -383,7 +384,12 @@ class PolicyTrainRL(Policy, metaclass=abc.ABCMeta):
                 with timings.env("policy/net", 3):
                     assert self.net.training
                     on_gpu = policy_meta["inputs"].is_cuda
-                    if self.graph_forward and on_gpu and not will_train:
+                    native = self._native_for(policy_meta) if on_gpu else None
+                    grid_logits = native.forward(policy_meta) if native is not None else None
+                    if grid_logits is not None:
+                        # own kernels, no autograd graph: optim() runs the backward of THIS forward from the buffers it left (native.py)
+                        policy_meta["_native"] = native
+                    elif self.graph_forward and on_gpu and not will_train:
                         grid_logits = self._forward_nograd_graph(policy_meta)
                     else:
                         grid_logits = self.net(policy_meta)
@@ -406,6 +412,36 @@ class PolicyTrainRL(Policy, metaclass=abc.ABCMeta):
                 policy_meta["grid_log_probs"] = m.log_prob(grid_f) if grid_logits.requires_grad or not self.graph_forward else None
                 policy_meta["grid_probs"] = m.probs
         return self.stats.add_policy_meta(policy_meta)
+
+    def _native_for(self, policy_meta: dict):
+        """blockcopy.policy.native.NativePolicyNet for this frame geometry (built once per geometry; None where it does not apply)."""
+        frame = policy_meta["inputs"]
+        key = (tuple(frame.shape), frame.device)
+        if key not in self._natives:
+            from blockcopy.policy import native
+
+            self._natives[key] = native.try_build(self.net, self.optimizer, frame.shape, frame.device) if frame.dim() == 4 else None
+        return self._natives[key]
+
+    def _native_step(self, native, policy_meta: dict):
+        """REINFORCE update on own kernels (information gain, seed, backward, RMSprop, parameter export: native.NativePolicyNet.step)."""
+        grid = policy_meta["grid"]
+        if self.wait_free and (self._rc_dev is not None or self._pending_dev):
+            cost = self._running_cost_dev(grid.device)
+        else:
+            cost = float(self.running_cost)
+        out, prev = policy_meta["outputs"], policy_meta["outputs_prev"]
+        ig = None
+        direct = (isinstance(self.information_gain, InformationGainSemSeg) and torch.is_tensor(out) and torch.is_tensor(prev) and out.is_cuda and out.dim() == 4
+                  and out.shape == prev.shape and out.dtype == prev.dtype and out.stride() == prev.stride()
+                  and out.dtype in (torch.float32, torch.float16, torch.bfloat16))
+        if not direct:
+            with torch.no_grad():
+                ig = self._get_information_gain(policy_meta)
+        ig, loss = native.step(grid, out, prev, cost, self.block_target, self.complexity_weight_gamma,
+                               scale_factor=getattr(self.information_gain, "scale_factor", 0.25), ig=ig)
+        policy_meta["information_gain"] = ig
+        policy_meta["loss_policy"] = loss
 
     MAILBOX_ROWS = 64      # pinned rows the device step reports its counts into, one per frame, reused round robin
 
@@ -503,7 +539,12 @@ class PolicyTrainRL(Policy, metaclass=abc.ABCMeta):
 
     def optim(self, policy_meta: dict, train=True) -> dict:
         logits = policy_meta.pop("_decision_logits", None)
-        if logits is not None:          # (device step: see _device_step)
+        native = policy_meta.pop("_native", None)
+        if logits is not None and native is not None:
+            with torch.no_grad():       # (no autograd graph on the native route: the backward runs from the forward's own buffers)
+                policy_meta["grid_log_probs"] = -F.binary_cross_entropy_with_logits(logits, policy_meta["grid"].to(logits.dtype), reduction="none")
+                policy_meta["grid_probs"] = torch.sigmoid(logits)
+        elif logits is not None:        # (device step: see _device_step)
             with torch.enable_grad():   # (the log-probabilities of a frame that will be trained on carry the policy net's autograd graph)
                 # Bernoulli(logits).probs / .log_prob(grid) written out (torch/distributions/bernoulli.py: sigmoid; minus the binary cross
                 # entropy with logits): the distribution object VALIDATES its arguments with `.all()` -- a device synchronisation in the
@@ -529,7 +570,9 @@ class PolicyTrainRL(Policy, metaclass=abc.ABCMeta):
             self._rc_dev = None
             del self._pending_dev[:]
 
-        if policy_meta["outputs_prev"] is not None and train:
+        if policy_meta["outputs_prev"] is not None and train and native is not None:
+            self._native_step(native, policy_meta)
+        elif policy_meta["outputs_prev"] is not None and train:
             with torch.enable_grad():
                 ig = self._get_information_gain(policy_meta)
                 policy_meta["information_gain"] = ig

@@ -8,6 +8,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = [os.path.join(HERE, "csrc", "blockcopy_hip.hip")]
+EXTRA_SRC = [os.path.join(HERE, "csrc", "policy_net.hip")]      # translation units of their own (the RL policy's CNN: forward / backward / optimizer)
 HDR = [os.path.join(os.path.dirname(HERE), "include", "blockcopy_hip.h")] + [os.path.join(HERE, "csrc", f) for f in
                                                                              ("conv3x3_mfma.inc", "conv3x3_v2.inc", "conv3x3_wino.inc", "conv3x3_wino32.inc", "conv3x3_wino4.inc", "stem7x7.inc", "head1x1.inc", "pred3x3.inc", "gemm1x1.inc", "spp.inc")]
 OUT = os.path.join(HERE, "lib", "libblockcopy_hip.so")
@@ -30,7 +31,7 @@ def needs_build() -> bool:
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(f) > t for f in SRC + HDR)
+    return any(os.path.getmtime(f) > t for f in SRC + EXTRA_SRC + HDR)
 
 
 def build_hip_library(force: bool = False, verbose: bool = False) -> str:
@@ -42,14 +43,23 @@ def build_hip_library(force: bool = False, verbose: bool = False) -> str:
     flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-result", "-Wno-unused-function"]
     if verbose:
         flags.append("-Rpass-analysis=kernel-resource-usage")
-    objs = [os.path.join(OBJ_DIR, f"part{n}.o") for n in PARTS]
+    objs = [os.path.join(OBJ_DIR, f"part{n}.o") for n in PARTS] + [os.path.join(OBJ_DIR, os.path.basename(f)[:-4] + ".o") for f in EXTRA_SRC]
+
+    def fresh(obj, deps):
+        return not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(d) for d in deps)
 
     def compile_part(n):
-        subprocess.check_call([hipcc()] + flags + [f"-DBC_PART={n}", "-c", "-o", objs[n]] + SRC)
+        # (an object is rebuilt when its own source -- or a header it includes -- is newer: editing policy_net.hip costs one unit, not twelve)
+        if fresh(objs[n], ([EXTRA_SRC[n - len(PARTS)], HDR[0]] if n >= len(PARTS) else SRC + HDR) + [os.path.abspath(__file__)]):
+            return
+        if n >= len(PARTS):
+            subprocess.check_call([hipcc()] + flags + ["-c", "-o", objs[n], EXTRA_SRC[n - len(PARTS)]])
+        else:
+            subprocess.check_call([hipcc()] + flags + [f"-DBC_PART={n}", "-c", "-o", objs[n]] + SRC)
 
-    jobs = int(os.environ.get("BC_BUILD_JOBS", "0")) or max(1, min(len(PARTS), os.cpu_count() or 1))
+    jobs = int(os.environ.get("BC_BUILD_JOBS", "0")) or max(1, min(len(objs), os.cpu_count() or 1))
     with ThreadPoolExecutor(max_workers=jobs) as pool:
-        list(pool.map(compile_part, PARTS))
+        list(pool.map(compile_part, range(len(objs))))
     subprocess.check_call([hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-fvisibility=hidden", "-o", OUT + ".tmp"] + objs)
     os.replace(OUT + ".tmp", OUT)
     return OUT

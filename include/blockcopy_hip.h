@@ -455,6 +455,75 @@ int bc_policy_step(const float *logits, int n_total, unsigned long long seed, un
 int bc_policy_features(float *out, int N, int h, int w, const void *const *ptrs, const long long *strides, const int *dims,
                        const float *scales, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * B2. The online-RL policy's CNN on own kernels (csrc/policy_net.hip): forward, backward and optimizer step of the reference's
+ * PolicyNet (policy/net.py:17-125: resnet8 trunk policy/resnet.py:60-115 + three stride-2 head stages) and of PolicyTrainRL.optim
+ * (policy/policy.py:319-370: information gain policy/information_gain.py:22-41, REINFORCE loss, backward, RMSprop), which the
+ * reference runs as ~45 + ~120 PyTorch/cuDNN launches per frame / training step.  All maps are DENSE channels-last fp32
+ * [N][H][W][C], C a multiple of 32; weights W[tap = 3 ky + kx][Cin][Cout], transposed copy WT[tap][Cout][Cin] for the data gradient.
+ * Stateless entry points (the host sequences them and captures the sequence in a hipGraph: blockcopy/policy/native.py).
+ * ------------------------------------------------------------------------------------------- */
+
+/* implicit-GEMM conv on the fp32 matrix cores (exact fp32: a k-ordered fmaf chain).  ks 3 (pad 1) or 1 (pad 0, stride 2), stride 1 / 2.
+ *   direction 0 (forward):        out (N,Hy,Wy,Cy) = conv(prologue(x (N,Hx,Wx,Cx)), w = W[tap][Cx][Cy])
+ *   direction 1 (data gradient):  out (N,Hx,Wx,Cx) = conv_transpose(x = gz (N,Hy,Wy,Cy), w = WT[tap][Cy][Cx]); stride 2 runs as the four
+ *                                 output-parity classes (1 / 2 / 2 / 4 taps, no multiplications by inserted zeros)
+ *   prologue: relu?(x * in_scale[c] + in_shift[c]) applied while the patch is staged (the producer's BatchNorm + ReLU), zero padding after it;
+ *   epilogue: out = acc (+ add, or add where add_mask > 0: the residual branch's gradient behind a ReLU) (+ out if accumulate);
+ *   stats (forward only): per-workgroup partial sums [bc_pn_conv_partials(N,Hy,Wy)][2][Cy] of out and out^2 (training-mode BatchNorm
+ *   statistics of the OUTPUT, finished by bc_pn_bn_finalize). */
+int bc_pn_conv_nhwc(float *out, const float *x, const float *w, int N, int Hx, int Wx, int Cx, int Hy, int Wy, int Cy, int ks, int stride,
+                    int direction, const float *in_scale, const float *in_shift, int in_relu, const float *add, const float *add_mask,
+                    int accumulate, float *stats, long long stats_capacity, void *stream);
+long long bc_pn_conv_partials(int N, int Hy, int Wy);
+/* weight gradient dw[tap][Cx][Cy] = sum over output pixels of prologue(x)[pixel * stride + tap - pad][ci] * gz[pixel][co] as a GEMM over
+ * pixels, split over pixel-tile groups and summed in a FIXED order (two launches, no atomics): part = workspace of
+ * bc_pn_wgrad_workspace(...) floats. */
+int bc_pn_wgrad_nhwc(float *dw, float *part, long long part_capacity, const float *x, const float *gz, int N, int Hx, int Wx, int Cx, int Hy, int Wy,
+                     int Cy, int ks, int stride, const float *in_scale, const float *in_shift, int in_relu, void *stream);
+long long bc_pn_wgrad_workspace(int N, int Hy, int Wy, int Cx, int Cy, int ks);
+/* training-mode BatchNorm from the conv's partial sums: scale / shift (the consumers' prologue), save_mean / save_invstd (backward), running
+ * statistics (momentum, unbiased variance) and the batch counter updated in place (F.batch_norm(training=True) semantics). */
+int bc_pn_bn_finalize(const float *part, long long n_part, int C, double count, const float *gamma, const float *beta, float eps, float momentum,
+                      float *running_mean, float *running_var, long long *batches, float *scale, float *shift, float *save_mean, float *save_invstd,
+                      void *stream);
+/* residual join: out = relu(za * sa + ta + B), B = zb (mode 0) | zb * sb + tb (mode 1: projection shortcut) | relu(zb * sb + tb) (mode 2) */
+int bc_pn_join(float *out, const float *za, const float *sa, const float *ta, const float *zb, const float *sb, const float *tb, int mode, int C,
+               long long pixels, void *stream);
+/* backward of BatchNorm (+ the ReLU behind it) in three launches: gz = d loss / d conv output, dgamma, dbeta.  g = gradient w.r.t. the activation;
+ * mask_mode 0 none | 1 own output (z * scale + shift > 0) | 2 external map (mask > 0: the block output behind the residual join);
+ * part = bc_pn_bn_bwd_partials(pixels) * 2 * C floats, coef = 3 * C floats (workspaces). */
+long long bc_pn_bn_bwd_partials(long long pixels);
+int bc_pn_bn_bwd(float *gz, float *dgamma, float *dbeta, float *part, float *coef, const float *g, const float *z, const float *mask, int mask_mode,
+                 const float *scale, const float *shift, const float *mean, const float *invstd, const float *gamma, int C, long long pixels,
+                 void *stream);
+/* the last head stage (3x3 / stride 2 / pad 1 to ONE channel + bias = the tile logits) on relu(z * scale + shift), and its backward */
+int bc_pn_head_fwd(float *logits, const float *z, const float *scale, const float *shift, const float *w, const float *bias, int N, int Hi, int Wi,
+                   int C, void *stream);
+int bc_pn_head_bwd(float *ga, float *dw, float *db, const float *gl, const float *z, const float *scale, const float *shift, const float *w, int N,
+                   int Hi, int Wi, int C, void *stream);
+/* information gain of a segmentation output (information_gain.py:22-41): KL(prev || cur) of the bilinearly resampled (ATen upsample_bilinear2d,
+ * align_corners = False, rh / rw = 1 / scale_factor), log-softmaxed logit maps, mean over the classes; cur / prev share the element strides
+ * and the element type `dtype` (BC_F32 / BC_F16 / BC_BF16; arithmetic in fp32). */
+int bc_pn_infogain(float *ig, const void *cur, const void *prev, int dtype, int N, int C, int H, int W, long long sn, long long sc, long long sh,
+                   long long sw, int h, int w, float rh, float rw, void *stream);
+/* REINFORCE seed (policy.py:334-349): reward = adaptive_max_pool2d(ig + rc) per tile, rc = -(cost - target) |cost - target| gamma, negated on
+ * skipped tiles; gl = d mean(-log_prob * reward) / d logits = (sigmoid(l) - grid) * reward / n; loss and reward are optional outputs;
+ * cost: *cost_dev (device float64) when given, else cost_host. */
+int bc_pn_reward_seed(float *gl, float *loss, float *reward, const float *logits, const uint8_t *grid, const float *ig, const double *cost_dev,
+                      double cost_host, double target, double gamma, int N, int h, int w, int GH, int GW, void *stream);
+/* torch.optim.RMSprop (centered = False) over a flat buffer, torch's operation order */
+int bc_pn_rmsprop(float *p, const float *g, float *sq, float *mom, long long n, float lr, float alpha, float eps, float wd, float momentum,
+                  void *stream);
+/* flat buffer <-> torch parameters in one launch (dir 0: flat -> parameters + transposed copies, 1: parameters -> flat + transposed copies);
+ * segs = DEVICE array of bc_pn_seg_bytes()-byte records: int64 off, off_t, param address, s_co, s_ci, s_ky, s_kx; int32 taps (0 = plain
+ * vector), kw, cin, cin_pad, cout, numel. */
+int bc_pn_sync_params(float *flat, float *flat_t, const void *segs, int n_segs, int dir, void *stream);
+int bc_pn_seg_bytes(void);
+/* the policy input (bc_policy_features) straight into the channels-last layout, channels sum C_k .. Cpad - 1 zero */
+int bc_pn_features_nhwc(float *out, int N, int h, int w, int Cpad, const void *const *ptrs, const long long *strides, const int *dims,
+                        const float *scales, void *stream);
+
 /* tuning / A-B knob (measurement infrastructure; defaults are the shipped behaviour): key in
  *   "conv_impl"      1 = first-generation fused conv kernel, 2 = CU-balanced kernel (default)
  *   "conv2_cfg"      -1 = choose the decomposition per launch (default), 0..15 = force one (BC_ERR_SHAPE at launch if it does not fit)
