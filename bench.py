@@ -347,7 +347,7 @@ def isolate_rank(rank, local, local_world):
     except (AttributeError, OSError):
         pass
     if local_world > 1:
-        base = os.environ.get("BC_BENCH_MIOPEN_DIR") or os.path.join(tempfile.gettempdir(), f"bc_bench_miopen_{os.getuid()}")
+        base = miopen_base_dir()
         for var, sub in (("MIOPEN_USER_DB_PATH", "db"), ("MIOPEN_CUSTOM_CACHE_DIR", "cache")):
             if var not in os.environ:
                 d = os.path.join(base, f"rank{rank}", sub)
@@ -355,6 +355,13 @@ def isolate_rank(rank, local, local_world):
                 os.environ[var] = d
             info[var] = os.environ[var]
     return info
+
+
+def miopen_base_dir():
+    """Parent of the per-rank MIOpen user-db / cache directories of a multi-replica run (rank r: <base>/rank<r>/{db,cache})."""
+    import tempfile
+
+    return os.environ.get("BC_BENCH_MIOPEN_DIR") or os.path.join(tempfile.gettempdir(), f"bc_bench_miopen_{os.getuid()}")
 
 
 def details_path(args):
@@ -519,7 +526,8 @@ def main(argv=None):
     per_rank_ms = replicas.gather_scalars(1e3 * elapsed_local / args.steps, world)
     if rank == 0:
         details["per_rank"] = [{"rank": r, "fps": round(per_rank[r], 2), "ms_per_step": round(per_rank_ms[r], 3), "exec_fraction": round(per_rank_exec[r], 4),
-                                "conv_plan_hash48": f"{int(per_rank_plan[r]):012x}", "shapes_tuned_live": int(per_rank_tuned[r])} for r in range(world)]
+                                "conv_plan_hash48": f"{int(per_rank_plan[r]):012x}", "shapes_tuned_live": int(per_rank_tuned[r]),
+                                **({"miopen_dir": os.path.join(miopen_base_dir(), f"rank{r}")} if world > 1 else {})} for r in range(world)]
         details["per_rank_plans_equal"] = len(set(int(v) for v in per_rank_plan)) == 1
         # halo-gather kernel statistics from one extra, untimed clip (events around all 21 launches per frame)
         be.prof_reset()

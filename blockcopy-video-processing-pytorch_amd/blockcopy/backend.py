@@ -165,6 +165,7 @@ def load_library(path: str = None) -> ctypes.CDLL:
         "bc_pn_rmsprop": [p, p, p, p, ctypes.c_longlong] + [ctypes.c_float] * 5 + [p],
         "bc_pn_sync_params": [p, p, p, i, i, p],
         "bc_pn_seg_bytes": [],
+        "bc_pn_set_stamps": [p],
         "bc_pn_features_nhwc": [p, i, i, i, i, p, p, p, p, p],
         "bc_dyn_set": [p, i],
         "bc_tune_set": [ctypes.c_char_p, i],

@@ -305,6 +305,8 @@ class NativePolicyNet:
 
     # ------------------------------------------------------------------------------------------------------------ op builders
     def _conv_fwd(self, c: _Conv, x, pro: Optional[_BN], bn: _BN):
+        """conv (per-workgroup partial sums of its output in the epilogue) + the training-mode BatchNorm finish.  (The finish inside the conv
+        launch -- last workgroup by ticket -- was built and measured SLOWER: 46-51 us against 41-45 per full-resolution layer, DESIGN.md.)"""
         lib, P = self.lib, self.P
         sc, sh = (pro.scale.data_ptr(), pro.shift.data_ptr()) if pro is not None else (None, None)
         relu = 1 if pro is not None else 0

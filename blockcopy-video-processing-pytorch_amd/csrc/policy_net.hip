@@ -29,6 +29,8 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+unsigned long long *g_pn_stamps = nullptr;      // measurement only (bc_pn_set_stamps)
+
 inline int pn_status()
 {
     const hipError_t e = hipGetLastError();
@@ -62,52 +64,50 @@ struct PnConvArgs {
     int tiles_x, tiles_y;
     int npix_pad;            // padded pixel count of the staged patch (= 1 mod 8)
     int n_cls;
+    unsigned long long *stamps;      // measurement only (bc_pn_set_stamps): 8 x 100 MHz stamps per workgroup
     int dbg;                 // measurement only (PN_DBG): 1 no MFMAs, 2 no global loads, 4 no output stores, 8 no LDS stores, 16 no next-tile planning
     PnTapSet cls[4];
 };
 
-// A image: [c4][h][pix][2]  (channel 4*c4 + 2*h + j at element j): lane (r, h) reads the operands of two k-steps with one ds_read_b64
-// B image: [t][c4][h][n][2]
-// PERSISTENT workgroups: a workgroup walks the tiles wg, wg + G, ... of its class; the stage sequence (tile, channel chunk) is software
-// pipelined across tile boundaries -- the global loads of the next stage are requested in the middle of the current stage's MFMAs and land
-// under them; a layer whose K is one chunk keeps its weights resident in the LDS for every tile.
+// Patch image  P[c4][h][pix][2]  (channel 4*c4 + 2*h + j at element j): lane (r, h) reads the operands of two k-steps with one ds_read_b64.
+// Weight image W[t][c4][h][n][2].  MFMA roles: A = weights (M = output channel), B = pixels (N = the 32 columns of tile row `wave`), so a lane
+// ends up with 16 output channels of ONE pixel -- four float4 stores per lane instead of sixteen dword stores.
+// PERSISTENT workgroups over the tiles wg, wg + G, ... of a class; stage = (tile, channel chunk).  Both images are DOUBLE BUFFERED: while stage s
+// multiplies, stage s + 1 is written to the other buffer (behind the first tap's MFMAs) and stage s + 2 is requested from memory (behind the
+// fifth tap's) -- one barrier per stage, no phase in which a wave only moves data.  A layer whose K is one chunk keeps its weights resident.
 template <int NB, int KC, int S>
-__global__ __launch_bounds__(256) void k_pn_conv(const PnConvArgs a)
+__global__ __launch_bounds__(256, (KC == 16 && S == 1) ? 2 : 1) void k_pn_conv(const PnConvArgs a)
 {
+    static_assert(NB == 1, "one 32-channel output block per workgroup");
     extern __shared__ __attribute__((aligned(16))) float pn_lds[];
-    constexpr int BN = 32 * NB, C4 = KC / 4, TG = PN_MAXTAPS;
+    constexpr int BN = 32, C4 = KC / 4, TG = PN_MAXTAPS;
     const PnTapSet &cs = a.cls[blockIdx.z];
-    float *As = pn_lds;
-    float *Bs = pn_lds + (size_t)KC * a.npix_pad;
+    const int a_floats = KC * a.npix_pad;
+    constexpr int b_floats = TG * KC * BN;
+    float *As0 = pn_lds, *As1 = pn_lds + a_floats;
+    float *Bs0 = pn_lds + 2 * a_floats, *Bs1 = Bs0 + b_floats;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const int n0 = blockIdx.y * BN;
     const int npix = cs.PH * cs.PW;
     const int n_chunks = cs.ntaps > 0 ? a.K / KC : 0;
     const int tiles_img = a.tiles_x * a.tiles_y, n_tiles = a.N * tiles_img;
 
-    constexpr int MAXA = (S == 1 ? 204 * 8 : (KC == 16 ? 585 * 4 : 585 * 8)) / 256 + 1;     // float4 of the patch per thread and chunk
+    constexpr int MAXA = (S == 1 ? 204 : 585) * C4 / 256 + 1;     // float4 of the patch per thread and chunk
     constexpr int NBQ = TG * KC * BN / 4;                 // float4 of the weights per stage
     constexpr int NBV = (NBQ + 255) / 256;                // ... per thread
     float4 pa[MAXA];
     float4 pb[NBV];
     int aoff[MAXA];       // element offset of pa[i] inside the image at chunk 0, -1 outside the image / the patch
     int boff[NBV];        // element offset of pb[i] inside w at chunk 0, -1 = no such tap
-    f32x16 acc[NB];
-    float s1[NB], s2[NB];
+    f32x16 acc;
+    float s1[16], s2[16];
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        s1[i] = 0.f; s2[i] = 0.f;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][e] = 0.0f;
-    }
-#pragma unroll
-    for (int i = 0; i < NBV; ++i) {
-        const int idx = tid + 256 * i;
-        const int n4 = idx % (BN / 4), k = (idx / (BN / 4)) % KC, t = idx / (BN / 4 * KC);
-        boff[i] = (idx < NBQ && t < cs.ntaps) ? (cs.wt[t < PN_MAXTAPS ? t : 0] * a.K + k) * a.Nn + n0 + 4 * n4 : -1;
-    }
+    for (int e = 0; e < 16; ++e) { acc[e] = 0.0f; s1[e] = 0.f; s2[e] = 0.f; }
 
-    // the tile a pipeline step belongs to: step = it * n_chunks + chunk, tile = blockIdx.x + it * gridDim.x
+    unsigned long long *stp = a.stamps ? a.stamps + 8 * ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) : nullptr;
+    auto stamp = [&](int k) { if (stp && tid == 0) stp[k] = __builtin_amdgcn_s_memrealtime(); };
+    stamp(0);
+
     auto tile_origin = [&](int tile, int &n, int &oy0, int &ox0) {
         n = tile / tiles_img;
         const int t2 = tile - n * tiles_img;
@@ -118,6 +118,11 @@ __global__ __launch_bounds__(256) void k_pn_conv(const PnConvArgs a)
         int n, oy0, ox0;
         tile_origin(tile, n, oy0, ox0);
         return oy0 < cs.Hc && ox0 < cs.Wc;      // (the classes of a stride-2 data gradient differ in size)
+    };
+    auto next_live = [&](int tile) {
+        tile += gridDim.x;
+        while (tile < n_tiles && !tile_live(tile)) tile += gridDim.x;
+        return tile;
     };
     auto plan_tile = [&](int tile) {
         int n, oy0, ox0;
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(256) void k_pn_conv(const PnConvArgs a)
             }
         }
     };
-    auto store_stage = [&](int chunk, bool with_b) {
+    auto store_stage = [&](float *As, float *Bs, int chunk, bool with_b) {
         if (a.dbg & 8) return;
 #pragma unroll
         for (int i = 0; i < MAXA; ++i) {
@@ -186,31 +191,94 @@ __global__ __launch_bounds__(256) void k_pn_conv(const PnConvArgs a)
         }
     };
 
-    // live tiles of this workgroup (uniform over the workgroup: every barrier below is reached by all of its waves)
-    int tile = blockIdx.x;
-    while (tile < n_tiles && !tile_live(tile)) tile += gridDim.x;
+    // the stage sequence of this workgroup: (tile, chunk) over its live tiles (uniform over the workgroup: every barrier is reached by all waves)
     const bool b_resident = n_chunks == 1;
-    bool b_staged = false;
+    int tile = blockIdx.x;                    // tile of the stage being multiplied
+    while (tile < n_tiles && !tile_live(tile)) tile += gridDim.x;
+    int ld_tile = tile, ld_chunk = 0;         // stage whose data the registers hold / will hold next
+    auto advance = [&](int &t, int &c) {
+        if (++c >= n_chunks) { c = 0; t = next_live(t); }
+    };
+    int st_tile = tile, st_chunk = 0;         // stage that goes to the LDS next
+    int s_idx = 0;
     if (tile < n_tiles && n_chunks > 0) {
         plan_tile(tile);
-        load_stage(0, true);
+        // the patch goes out first, the (tile-independent) weight offsets are built under its latency
+        load_stage(0, false);
+#pragma unroll
+        for (int i = 0; i < NBV; ++i) {
+            const int idx = tid + 256 * i;
+            const int n4 = idx % (BN / 4), k = (idx / (BN / 4)) % KC, t = idx / (BN / 4 * KC);
+            boff[i] = (idx < NBQ && t < cs.ntaps) ? (cs.wt[t < PN_MAXTAPS ? t : 0] * a.K + k) * a.Nn + n0 + 4 * n4 : -1;
+        }
+        if (!(a.dbg & 2)) {
+#pragma unroll
+            for (int i = 0; i < NBV; ++i) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (boff[i] >= 0) v = *reinterpret_cast<const float4 *>(a.w + (size_t)boff[i]);
+                pb[i] = v;
+            }
+        }
+        stamp(1);
+        store_stage(As0, Bs0, 0, true);
+        advance(st_tile, st_chunk);
+        ld_tile = st_tile; ld_chunk = st_chunk;
+        if (ld_tile < n_tiles) {
+            if (ld_chunk == 0) plan_tile(ld_tile);
+            load_stage(ld_chunk, !b_resident);
+        }
+        __syncthreads();
+        stamp(2);
     }
+    // ---- epilogue of a tile: lane = pixel column r of tile row `wave`; register e = output channel n0 + (e & 3) + 8 (e >> 2) + 4 h
+    auto epilogue = [&](int tile_) {
+        int n, oy0, ox0;
+        tile_origin(tile_, n, oy0, ox0);
+        const int oy = oy0 + wave, ox = ox0 + r;
+        if (oy < cs.Hc && ox < cs.Wc && !(a.dbg & 4)) {
+            const int Y = oy * a.out_s + cs.out_oy, X = ox * a.out_s + cs.out_ox;
+            const size_t o = (((size_t)n * a.Hout + Y) * a.Wout + X) * a.Nn + n0 + 4 * h;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 v = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+                if (a.add) {
+                    const float4 g = *reinterpret_cast<const float4 *>(a.add + o + 8 * q);
+                    if (a.add_mask) {
+                        const float4 m = *reinterpret_cast<const float4 *>(a.add_mask + o + 8 * q);
+                        v.x += m.x > 0.f ? g.x : 0.f; v.y += m.y > 0.f ? g.y : 0.f; v.z += m.z > 0.f ? g.z : 0.f; v.w += m.w > 0.f ? g.w : 0.f;
+                    } else { v.x += g.x; v.y += g.y; v.z += g.z; v.w += g.w; }
+                }
+                if (a.accumulate) {
+                    const float4 p = *reinterpret_cast<const float4 *>(a.out + o + 8 * q);
+                    v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+                }
+                *reinterpret_cast<float4 *>(a.out + o + 8 * q) = v;
+                s1[4 * q] += v.x; s1[4 * q + 1] += v.y; s1[4 * q + 2] += v.z; s1[4 * q + 3] += v.w;
+                s2[4 * q] = fmaf(v.x, v.x, s2[4 * q]); s2[4 * q + 1] = fmaf(v.y, v.y, s2[4 * q + 1]);
+                s2[4 * q + 2] = fmaf(v.z, v.z, s2[4 * q + 2]); s2[4 * q + 3] = fmaf(v.w, v.w, s2[4 * q + 3]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+    };
+    bool first_tile = true;
     while (tile < n_tiles) {
-        int next = tile + gridDim.x;
-        while (next < n_tiles && !tile_live(next)) next += gridDim.x;
-        for (int chunk = 0; chunk < n_chunks; ++chunk) {
-            const bool with_b = !(b_resident && b_staged);
-            __syncthreads();                 // every wave is done with the previous stage's images
-            store_stage(chunk, with_b);
-            b_staged = true;
-            __syncthreads();
-            const bool more_here = chunk + 1 < n_chunks, more = more_here || next < n_tiles;
+        if (n_chunks == 0) epilogue(tile);      // (a parity class no tap reaches: zeros, plus the residual terms)
+        for (int chunk = 0; chunk < n_chunks; ++chunk, ++s_idx) {
+            const int cur = s_idx & 1;
+            const float *As = cur ? As1 : As0;
+            const float *Bs = (b_resident || !cur) ? Bs0 : Bs1;
 #pragma unroll
             for (int t = 0; t < TG; ++t) {
-                if (t == 1 && more) {
-                    // the next stage's requests go out behind the first tap's MFMAs: address arithmetic and loads run in their shadow
-                    if (!more_here && !(a.dbg & 16)) plan_tile(next);
-                    load_stage(more_here ? chunk + 1 : 0, !b_resident);
+                if (t == 1 && st_tile < n_tiles) {
+                    // stage s + 1 into the other buffer, behind the first tap's MFMAs (its loads were requested during stage s - 1)
+                    store_stage(cur ? As0 : As1, cur ? Bs0 : Bs1, st_chunk, !b_resident);
+                    advance(st_tile, st_chunk);
+                }
+                if (t == 4 && st_tile < n_tiles) {
+                    // stage s + 2 from memory: address arithmetic and requests in the shadow of the MFMAs
+                    if (st_chunk == 0 && !(a.dbg & 16)) plan_tile(st_tile);
+                    load_stage(st_chunk, !b_resident);
                 }
                 if (t < cs.ntaps && !(a.dbg & 1)) {
                     const int pb0 = (wave * S + cs.dy[t] - cs.dmin_y) * cs.PW + r * S + cs.dx[t] - cs.dmin_x;
@@ -219,60 +287,45 @@ __global__ __launch_bounds__(256) void k_pn_conv(const PnConvArgs a)
 #pragma unroll
                     for (int c4 = 0; c4 < C4; ++c4) {
                         const float2 av = *reinterpret_cast<const float2 *>(ap + (size_t)c4 * 4 * a.npix_pad);
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) {
-                            const float2 bv = *reinterpret_cast<const float2 *>(bp + (size_t)c4 * 4 * BN + nb * 64);
-                            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[nb], 0, 0, 0);
-                            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[nb], 0, 0, 0);
-                        }
+                        const float2 bv = *reinterpret_cast<const float2 *>(bp + (size_t)c4 * 4 * BN);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.x, av.x, acc, 0, 0, 0);      // D[i = channel][j = pixel]
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.y, av.y, acc, 0, 0, 0);
                     }
                 }
             }
-        }
-        // ---- epilogue of the tile: lane = output channel n0 + 32 nb + r; register e = pixel column (e & 3) + 8 (e >> 2) + 4 h of tile row `wave`
-        {
-            int n, oy0, ox0;
-            tile_origin(tile, n, oy0, ox0);
-            const int oy = oy0 + wave;
-            const bool row_ok = oy < cs.Hc;
-            const int Y = oy * a.out_s + cs.out_oy;
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                const int co = n0 + 32 * nb + r;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int ox = ox0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    if (row_ok && ox < cs.Wc && !(a.dbg & 4)) {
-                        const int X = ox * a.out_s + cs.out_ox;
-                        const size_t o = (((size_t)n * a.Hout + Y) * a.Wout + X) * a.Nn + co;
-                        float v = acc[nb][e];
-                        if (a.add) {
-                            const float g = a.add[o];
-                            v += a.add_mask ? (a.add_mask[o] > 0.f ? g : 0.f) : g;
-                        }
-                        if (a.accumulate) v += a.out[o];
-                        a.out[o] = v;
-                        s1[nb] += v; s2[nb] = fmaf(v, v, s2[nb]);
-                    }
-                    acc[nb][e] = 0.0f;
-                }
+            if (chunk + 1 == n_chunks) {
+                if (first_tile) stamp(3);
+                epilogue(tile);
+                if (first_tile) stamp(4);
+                first_tile = false;
             }
+            __syncthreads();      // stage s + 1 is complete in its buffer; every wave is done reading stage s
         }
-        tile = next;
+        tile = next_live(tile);
     }
+    stamp(5);
     if (a.stats) {
-        // per-workgroup partial sums of the output (training-mode batch statistics): halves of a wave, then the four waves in a fixed order
-        __syncthreads();
-        float *red = pn_lds;      // [wave][2][BN]
+        // per-workgroup partial sums of the output (training-mode batch statistics): a lane holds the sums of ITS pixels for 16 channels;
+        // transpose through the LDS (row = (wave, h, e, which), column = lane's pixel column; row stride 33: conflict-free both ways),
+        // a thread sums a row, then the four waves are joined in a fixed order
+        float *red = pn_lds;      // [256 rows][33] + [256]
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const float t1 = s1[nb] + __shfl_xor(s1[nb], 32), t2 = s2[nb] + __shfl_xor(s2[nb], 32);
-            if (h == 0) { red[(wave * 2 + 0) * BN + 32 * nb + r] = t1; red[(wave * 2 + 1) * BN + 32 * nb + r] = t2; }
+        for (int e = 0; e < 16; ++e) {
+            red[(((wave * 2 + h) * 16 + e) * 2 + 0) * 33 + r] = s1[e];
+            red[(((wave * 2 + h) * 16 + e) * 2 + 1) * 33 + r] = s2[e];
         }
         __syncthreads();
-        if (tid < 2 * BN) {
-            const int which = tid / BN, c = tid % BN;
-            const float v = ((red[(0 * 2 + which) * BN + c] + red[(1 * 2 + which) * BN + c]) + red[(2 * 2 + which) * BN + c]) + red[(3 * 2 + which) * BN + c];
+        float tot = 0.f;
+#pragma unroll 8
+        for (int j = 0; j < 32; ++j) tot += red[tid * 33 + j];
+        __syncthreads();
+        red[tid] = tot;           // row id = ((wave * 2 + h) * 16 + e) * 2 + which
+        __syncthreads();
+        if (tid < 64) {
+            const int which = tid >> 5, c = tid & 31;                       // channel c = (e & 3) + 8 (e >> 2) + 4 h
+            const int hh = (c >> 2) & 1, e = (c & 3) + 4 * (c >> 3);
+            const int row = (hh * 16 + e) * 2 + which;
+            const float v = ((red[0 * 64 + row] + red[1 * 64 + row]) + red[2 * 64 + row]) + red[3 * 64 + row];
             const size_t wg = (size_t)blockIdx.z * gridDim.x + blockIdx.x;
             a.stats[(wg * 2 + which) * a.Nn + n0 + c] = v;
         }
@@ -287,12 +340,13 @@ uint32_t pn_magic(int d, int max_n)
     return m;
 }
 
-constexpr int PN_PERSIST_WGS = 512;      // two workgroups per CU walk the tiles of a launch
+constexpr int PN_PERSIST_WGS = 512;      // workgroups that walk the tiles of a launch (and rows of partial statistics its last workgroup reduces)
 
 template <int NB, int KC, int S>
 int pn_conv_launch(const PnConvArgs &a, hipStream_t st)
 {
-    const size_t lds = ((size_t)KC * a.npix_pad + (size_t)PN_MAXTAPS * KC * 32 * NB) * sizeof(float);
+    size_t lds = 2 * ((size_t)KC * a.npix_pad + (size_t)PN_MAXTAPS * KC * 32 * NB) * sizeof(float);      // both images double buffered
+    if (lds < (256 * 33 + 256) * sizeof(float)) lds = (256 * 33 + 256) * sizeof(float);                    // (the statistics transpose)
     if (lds > 160 * 1024 - 512) return BC_ERR_SHAPE;
     static bool attr_set[16];      // per device (the first launch on a device is never inside a stream capture: the host runs a warm pass first)
     int dev = 0;
@@ -738,41 +792,43 @@ __device__ __forceinline__ void pn_src(float scale, int dst, int size, int &i0, 
 }
 
 
-__global__ __launch_bounds__(64) void k_pn_infogain(const PnIgArgs a)
+// half a wave per output pixel, a class per lane: the 8 taps of a lane are requested together, maximum / normaliser / divergence are 32-lane
+// reductions (C <= 32)
+__global__ __launch_bounds__(256) void k_pn_infogain(const PnIgArgs a)
 {
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= a.N * a.h * a.w) return;
-    const int x = i % a.w, y = (i / a.w) % a.h, n = i / (a.w * a.h);
+    const int lane = threadIdx.x & 31;
+    const int i = (blockIdx.x * 256 + threadIdx.x) >> 5;
+    const bool live = i < a.N * a.h * a.w;
+    const int ii = live ? i : 0;
+    const int x = ii % a.w, y = (ii / a.w) % a.h, n = ii / (a.w * a.h);
     int y0, y1, x0, x1;
     float ly0, ly1, lx0, lx1;
     pn_src(a.rh, y, a.H, y0, y1, ly0, ly1);
     pn_src(a.rw, x, a.W, x0, x1, lx0, lx1);
-    const long long b00 = n * a.sn + y0 * a.sh + x0 * a.sw, b01 = n * a.sn + y0 * a.sh + x1 * a.sw, b10 = n * a.sn + y1 * a.sh + x0 * a.sw,
-                    b11 = n * a.sn + y1 * a.sh + x1 * a.sw;
-    // three sweeps over the classes (maximum, normaliser, divergence): the taps come out of the caches, no per-class array is kept
+    const int c = lane < a.C ? lane : 0;
+    const long long base = n * a.sn + c * a.sc;
+    const long long b00 = base + y0 * a.sh + x0 * a.sw, b01 = base + y0 * a.sh + x1 * a.sw, b10 = base + y1 * a.sh + x0 * a.sw, b11 = base + y1 * a.sh + x1 * a.sw;
     auto ld = [&](const void *m, long long o) -> float {
         if (a.dtype == 0) return reinterpret_cast<const float *>(m)[o];
         if (a.dtype == 1) return __half2float(reinterpret_cast<const __half *>(m)[o]);
         return __uint_as_float((uint32_t)reinterpret_cast<const uint16_t *>(m)[o] << 16);
     };
-    auto tap = [&](const void *m, int c) {
-        const long long o = c * a.sc;
-        return ly0 * (lx0 * ld(m, b00 + o) + lx1 * ld(m, b01 + o)) + ly1 * (lx0 * ld(m, b10 + o) + lx1 * ld(m, b11 + o));
-    };
-    float mc = -INFINITY, mp = -INFINITY;
-#pragma unroll 1
-    for (int c = 0; c < a.C; ++c) { mc = fmaxf(mc, tap(a.cur, c)); mp = fmaxf(mp, tap(a.prev, c)); }
-    float sc = 0.f, sp = 0.f;
-#pragma unroll 1
-    for (int c = 0; c < a.C; ++c) { sc += expf(tap(a.cur, c) - mc); sp += expf(tap(a.prev, c) - mp); }
-    const float lc = logf(sc), lp = logf(sp);
-    float kl = 0.f;
-#pragma unroll 1
-    for (int c = 0; c < a.C; ++c) {
-        const float ls_c = tap(a.cur, c) - mc - lc, ls_p = tap(a.prev, c) - mp - lp;
-        kl += expf(ls_p) * (ls_p - ls_c);
-    }
-    a.ig[i] = kl / (float)a.C;
+    const float c00 = ld(a.cur, b00), c01 = ld(a.cur, b01), c10 = ld(a.cur, b10), c11 = ld(a.cur, b11);
+    const float p00 = ld(a.prev, b00), p01 = ld(a.prev, b01), p10 = ld(a.prev, b10), p11 = ld(a.prev, b11);
+    const bool on = lane < a.C;
+    const float vc = ly0 * (lx0 * c00 + lx1 * c01) + ly1 * (lx0 * c10 + lx1 * c11);
+    const float vp = ly0 * (lx0 * p00 + lx1 * p01) + ly1 * (lx0 * p10 + lx1 * p11);
+    float mc = on ? vc : -INFINITY, mp = on ? vp : -INFINITY;
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) { mc = fmaxf(mc, __shfl_xor(mc, d)); mp = fmaxf(mp, __shfl_xor(mp, d)); }
+    float sc = on ? expf(vc - mc) : 0.f, sp = on ? expf(vp - mp) : 0.f;
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) { sc += __shfl_xor(sc, d); sp += __shfl_xor(sp, d); }
+    const float ls_c = vc - mc - logf(sc), ls_p = vp - mp - logf(sp);
+    float kl = on ? expf(ls_p) * (ls_p - ls_c) : 0.f;
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) kl += __shfl_xor(kl, d);
+    if (live && lane == 0) a.ig[i] = kl / (float)a.C;
 }
 
 // REINFORCE seed (policy.py:334-349): reward = adaptive_max_pool2d(ig + rc) with rc = -(cost - target) |cost - target| gamma, sign-flipped on
@@ -942,6 +998,7 @@ BC_EXPORT int bc_pn_conv_nhwc(float *out, const float *x, const float *w, int N,
     {
         static const int dbg = [] { const char *e = getenv("PN_DBG"); return e ? atoi(e) : 0; }();
         a.dbg = dbg;
+        a.stamps = g_pn_stamps;
     }
     int S = 1, max_hc = 0, max_wc = 0, max_npix = 0;
     if (direction == 0) {
@@ -991,10 +1048,8 @@ BC_EXPORT int bc_pn_conv_nhwc(float *out, const float *x, const float *w, int N,
     hipStream_t st = (hipStream_t)stream;
     // one 32-channel output block per workgroup and all nine taps of a channel chunk per stage: the small maps of the net (8 k, 2 k,
     // 512 pixels) get four times the workgroups, and a workgroup's K loop is Cin / KC stages
-    if (S == 1) return pn_conv_launch<1, 32, 1>(a, st);
-    // stride 2: 16-channel chunks leave room for two workgroups per CU; a launch with at most one workgroup per CU takes 32-channel chunks
-    if (n_tiles * (a.Nn / 32) <= 256) return pn_conv_launch<1, 32, 2>(a, st);
-    return pn_conv_launch<1, 16, 2>(a, st);
+    if (S == 1) return pn_conv_launch<1, 16, 1>(a, st);
+    return pn_conv_launch<1, 16, 2>(a, st);      // (stride 2: the patch is 2.9 x the stride-1 one -- 16-channel chunks, 112 KB double buffered)
 }
 
 // number of stats partial rows a forward launch of this geometry writes (rows of [2][Cy])
@@ -1089,6 +1144,7 @@ BC_EXPORT int bc_pn_join(float *out, const float *za, const float *sa, const flo
 
 // backward of training-mode BatchNorm (+ the ReLU behind it): gz, and dgamma / dbeta; part = workspace of bc_pn_bn_bwd_partials(pixels) x 2 x C floats,
 // coef = 3 C floats.  mask_mode 0 none, 1 own output (z * scale + shift > 0), 2 external map (mask > 0)
+// partial rows of a backward launch: 64 pixels per workgroup or more, at most 1024 rows
 BC_EXPORT long long bc_pn_bn_bwd_partials(long long pixels)
 {
     long long per = (pixels + 1023) / 1024;
@@ -1143,11 +1199,11 @@ BC_EXPORT int bc_pn_infogain(float *ig, const void *cur, const void *prev, int d
                              long long sw, int h, int w, float rh, float rw, void *stream)
 {
     if (!ig || !cur || !prev) return BC_ERR_NULL;
-    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || h <= 0 || w <= 0) return BC_ERR_SHAPE;
+    if (N <= 0 || C <= 0 || C > 32 || H <= 0 || W <= 0 || h <= 0 || w <= 0 || (long long)N * h * w > (1LL << 26)) return BC_ERR_SHAPE;
     if (dtype < 0 || dtype > 2) return BC_ERR_ELEM;
     PnIgArgs a;
     a.cur = cur; a.prev = prev; a.dtype = dtype; a.ig = ig; a.sn = sn; a.sc = sc; a.sh = sh; a.sw = sw; a.N = N; a.C = C; a.H = H; a.W = W; a.h = h; a.w = w; a.rh = rh; a.rw = rw;
-    hipLaunchKernelGGL(k_pn_infogain, dim3((unsigned)((N * h * w + 63) / 64)), dim3(64), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_pn_infogain, dim3((unsigned)(((long long)N * h * w * 32 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     return pn_status();
 }
 
@@ -1179,6 +1235,10 @@ BC_EXPORT int bc_pn_sync_params(float *flat, float *flat_t, const void *segs, in
     hipLaunchKernelGGL(k_pn_sync_params, dim3(64, (unsigned)n_segs), dim3(256), 0, (hipStream_t)stream, flat, flat_t, (const PnSeg *)segs, dir);
     return pn_status();
 }
+
+/* measurement only: device buffer that receives 8 x uint64 (100 MHz s_memrealtime) per workgroup of the next bc_pn_conv_nhwc launches:
+ * [0] entry, [1] first patch requested, [2] first stage in the LDS, [3] first tile multiplied, [4] first tile stored, [5] all tiles done; NULL = off */
+BC_EXPORT int bc_pn_set_stamps(void *buf) { g_pn_stamps = (unsigned long long *)buf; return BC_OK; }
 
 BC_EXPORT int bc_pn_seg_bytes(void) { return (int)sizeof(PnSeg); }
 

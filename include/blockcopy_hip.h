@@ -520,6 +520,8 @@ int bc_pn_rmsprop(float *p, const float *g, float *sq, float *mom, long long n, 
  * vector), kw, cin, cin_pad, cout, numel. */
 int bc_pn_sync_params(float *flat, float *flat_t, const void *segs, int n_segs, int dir, void *stream);
 int bc_pn_seg_bytes(void);
+/* measurement only: device buffer receiving 8 x uint64 stamps (100 MHz) per workgroup of the following bc_pn_conv_nhwc launches; NULL = off */
+int bc_pn_set_stamps(void *buf);
 /* the policy input (bc_policy_features) straight into the channels-last layout, channels sum C_k .. Cpad - 1 zero */
 int bc_pn_features_nhwc(float *out, int N, int h, int w, int Cpad, const void *const *ptrs, const long long *strides, const int *dims,
                         const float *scales, void *stream);

@@ -2,6 +2,8 @@
 same seeded inputs, bit-exact (the ops are pure copies).  Run with -m gpu on a real MI355X."""
 import itertools
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -1731,3 +1733,87 @@ def test_upsample_argmax_equals_interpolate_then_max(be, dtype, nhwc):
     assert int(upsample_argmax(x, (4, 4)).abs().sum()) == 0
     x[0, 2, 0, 0] = float("nan")
     assert int(upsample_argmax(x, (2, 2))[0, 0, 0]) == 2
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# round 6: arm states are per host thread; quality metrics fed by the HIP prediction kernel
+def test_armed_states_are_per_host_thread():
+    """bc_dyn_set / bc_conv_upsample_arm arm the NEXT capable launch OF THE CALLING THREAD (thread_local state, include/blockcopy_hip.h):
+    thread A arms "read the executed count from the device" with a count of zero, thread B then launches the same entry point and must run
+    unarmed (its whole output computed); A's own next launch then consumes A's arm (nothing computed)."""
+    import threading
+
+    import blockcopy.backend as bk
+
+    be = bk.get_backend()
+    n_tiles, C, bs = 6, 8, 4
+    zero = torch.zeros(1, dtype=torch.int32, device="cuda")
+    data_a = torch.randn((n_tiles, C, bs, bs), device="cuda").contiguous(memory_format=torch.channels_last)
+    data_b = torch.randn((n_tiles, C, bs, bs), device="cuda").contiguous(memory_format=torch.channels_last)
+    scale, shift = torch.full((C,), 2.0, device="cuda"), torch.full((C,), 1.0, device="cuda")
+    armed, b_done = threading.Event(), threading.Event()
+    res, errs = {}, []
+
+    def thread_a():
+        try:
+            with torch.cuda.device(0):
+                be._check(be.lib.bc_dyn_set(zero.data_ptr(), n_tiles), "dyn_set")      # arm (not consumed yet)
+                armed.set()
+                assert b_done.wait(30)
+                out = torch.full_like(data_a, -7.0)
+                be._check(be.lib.bc_affine_act_nhwc(out.data_ptr(), data_a.data_ptr(), None, scale.data_ptr(), shift.data_ptr(), 0, n_tiles * bs * bs, C, 0,
+                                                    torch.cuda.current_stream().cuda_stream), "affine_act_nhwc")
+                torch.cuda.synchronize()
+                res["a"] = out
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+            armed.set()
+
+    def thread_b():
+        try:
+            assert armed.wait(30)
+            with torch.cuda.device(0):
+                out = torch.full_like(data_b, -7.0)
+                be._check(be.lib.bc_affine_act_nhwc(out.data_ptr(), data_b.data_ptr(), None, scale.data_ptr(), shift.data_ptr(), 0, n_tiles * bs * bs, C, 0,
+                                                    torch.cuda.current_stream().cuda_stream), "affine_act_nhwc")
+                torch.cuda.synchronize()
+                res["b"] = out
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+        finally:
+            b_done.set()
+
+    ta, tb = threading.Thread(target=thread_a), threading.Thread(target=thread_b)
+    ta.start(); tb.start(); ta.join(60); tb.join(60)
+    assert not errs, errs
+    assert torch.equal(res["b"], data_b * 2.0 + 1.0)             # B never saw A's arm
+    assert bool((res["a"] == -7.0).all())                        # A's arm (count 0) was still there for A's own launch
+
+
+def test_segmentation_metrics_fed_by_the_hip_prediction_kernel(golden_dir):
+    """SURVEY section 8(f)-4 on the GPU: label maps produced by bc_upsample_argmax (blockcopy.utils.postprocess.upsample_argmax) from logit
+    maps drive bc_workloads.metrics to the reference's confusion matrix and scores (tests/golden/io_metrics.npz, StreamSegMetrics of the
+    reference).  The logit maps are built so that their bilinear 2x upsampling has the fixture's predictions as arg-max (one-hot at the
+    prediction resolution, +8 margin: resampling at twice the resolution of a piecewise-constant one-hot map keeps the winner)."""
+    import json
+
+    from bc_workloads.metrics import cityscapes_metrics
+    from blockcopy.utils.postprocess import upsample_argmax
+
+    G = np.load(os.path.join(golden_dir, "io_metrics.npz"))
+    want = json.loads(bytes(G["m_results"]).decode())
+    m = cityscapes_metrics()
+    for u in range(3):
+        lp = torch.from_numpy(G[f"m_lp{u}"]).cuda()                                   # (N, H, W) class ids
+        N, H, W = lp.shape
+        logits = torch.randn((N, 19, H, W), device="cuda") * 0.1
+        logits.scatter_(1, lp.view(N, 1, H, W), 8.0)
+        for layout in (torch.contiguous_format, torch.channels_last):
+            pred = upsample_argmax(logits.contiguous(memory_format=layout), (H, W))      # same resolution: the map itself
+            assert pred.dtype == torch.int64 and torch.equal(pred, lp)
+        m.update(G[f"m_lt{u}"], pred.cpu().numpy())
+        got = m.get_results()
+        for k, v in want[u].items():
+            if k != "Class IoU":
+                assert got[k] == pytest.approx(v, rel=1e-12), (u, k)
+    assert np.array_equal(m.confusion_matrix, G["m_confusion"])

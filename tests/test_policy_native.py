@@ -319,11 +319,34 @@ def test_native_policy_forward_and_gradients_match_autograd(N, H, W, open_gates)
         print(f"N={N} {H}x{W} rep {rep}: worst relative gradient error (native, torch fp32, layer) = {worst}")
 
 
-def test_native_policy_step_matches_torch_rmsprop():
-    """REINFORCE updates with a real learning rate, momentum and weight decay on: after ONE step from identical parameters the module's
-    parameters (exported by the native step) equal autograd + torch.optim.RMSprop on a copy, element for element, except where a gradient
-    is zero to rounding (RMSprop's first steps are sign-like: lr * g / sqrt(0.01 g^2)).  A second step from re-synchronised parameters
-    exercises the carried state (square average, momentum buffer)."""
+@pytest.mark.parametrize("momentum,wd", [(0.0, 0.0), (0.5, 1e-3)])
+def test_pn_rmsprop_kernel_matches_torch(momentum, wd):
+    """bc_pn_rmsprop == torch.optim.RMSprop (uncentred) on the same gradients, three steps with carried state."""
+    be, lib = _lib()
+    g = torch.Generator().manual_seed(17)
+    n = 10007
+    p0 = torch.randn(n, generator=g).cuda()
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.RMSprop([ref], lr=1e-3, alpha=0.99, eps=1e-8, weight_decay=wd, momentum=momentum)
+    p, sq, mom = p0.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    for it in range(3):
+        grad = (torch.randn(n, generator=g) * 10 ** float(torch.randint(-6, 0, (1,), generator=g))).cuda()
+        ref.grad = grad.clone()
+        opt.step()
+        assert lib.bc_pn_rmsprop(p.data_ptr(), grad.data_ptr(), sq.data_ptr(), mom.data_ptr(), n, 1e-3, 0.99, 1e-8, wd, momentum, _st()) == 0
+        assert torch.allclose(p, ref.detach(), rtol=1e-5, atol=1e-7), (it, float((p - ref).abs().max()))
+        assert torch.allclose(sq, opt.state[ref]["square_avg"], rtol=1e-5, atol=1e-12)
+        if momentum > 0:
+            want = opt.state[ref]["momentum_buffer"]
+            assert torch.allclose(mom, want, rtol=1e-5, atol=1e-6), (it, float((mom - want).abs().max()), float(((mom - want).abs() / want.abs().clamp_min(1e-3)).max()))
+
+
+def test_native_policy_step_moves_the_module_like_torch_rmsprop():
+    """REINFORCE updates with a real learning rate, momentum and weight decay on: the module's parameters (exported by the native step) move
+    the way autograd + torch.optim.RMSprop moves a copy.  RMSprop's first steps are sign-like (lr * g / sqrt(0.01 g^2)) and the library's
+    gradients carry their own rounding (measured here: up to 1e-3 of a tensor's largest element on a first call), so elements whose gradient is
+    near zero step the other way in either implementation: the comparison is by direction and sign agreement, per tensor; the arithmetic of the
+    update itself is compared exactly in test_pn_rmsprop_kernel_matches_torch and the gradients in the test above."""
     N, H, W = 1, 128, 256
     pol = _small_policy(H=H, W=W, lr=1e-3, momentum=0.5, wd=1e-3)
     net = pol.net
@@ -354,15 +377,13 @@ def test_native_policy_step_matches_torch_rmsprop():
         before = {k: v.detach().clone() for k, v in ref.named_parameters()}
         opt.step()
         nat.step(grid, outputs, outputs_prev, torch.tensor(cost, dtype=torch.float64, device="cuda"), target, gamma)
-        moved = 0.0
         for (name, p_ref), (_, p) in zip(ref.named_parameters(), net.named_parameters()):
             if name.startswith("backbone.fc"):
                 continue
-            step = float((p_ref - before[name]).abs().max())
-            moved = max(moved, step)
-            differs = ((p - p_ref).abs() > 1e-3 * max(step, 1e-12)).float().mean()
-            assert float(differs) <= 0.02, (it, name, float(differs), step)
-        assert moved > 1e-3      # (the step is not a no-op)
+            d_ref, d = (p_ref - before[name]).flatten(), (p.detach() - before[name]).flatten()
+            assert float(d_ref.abs().max()) > 1e-4, name      # (the step is not a no-op)
+            assert float((d * d_ref).sum() / d.norm() / d_ref.norm()) > 0.95, (it, name)
+            assert float((torch.sign(d) == torch.sign(d_ref)).float().mean()) > 0.9, (it, name)
         # same parameters again for the next round (the native side imports them: version counters), its own optimizer state carried on
         with torch.no_grad():
             for (_, p_ref), (_, p) in zip(ref.named_parameters(), net.named_parameters()):
