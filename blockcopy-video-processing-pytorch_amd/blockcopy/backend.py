@@ -166,6 +166,7 @@ def load_library(path: str = None) -> ctypes.CDLL:
         "bc_pn_sync_params": [p, p, p, i, i, p],
         "bc_pn_seg_bytes": [],
         "bc_pn_set_stamps": [p],
+        "bc_pn_probs": [p, p, p, p, i, p],
         "bc_pn_features_nhwc": [p, i, i, i, i, p, p, p, p, p],
         "bc_dyn_set": [p, i],
         "bc_tune_set": [ctypes.c_char_p, i],
@@ -181,7 +182,7 @@ def load_library(path: str = None) -> ctypes.CDLL:
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = i
-    for name, argtypes in {"bc_pn_conv_partials": [i, i, i], "bc_pn_wgrad_workspace": [i] * 6, "bc_pn_bn_bwd_partials": [ctypes.c_longlong]}.items():
+    for name, argtypes in {"bc_pn_conv_partials": [i, i, i, i], "bc_pn_wgrad_workspace": [i] * 6, "bc_pn_bn_bwd_partials": [ctypes.c_longlong]}.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = ctypes.c_longlong

@@ -127,6 +127,8 @@ class NativePolicyNet:
         self.h, self.w = int(np.floor(H * net.scale_factor)), int(np.floor(W * net.scale_factor))
         self.GH, self.GW = H // net.block_size, W // net.block_size
         self.n_total = N * self.GH * self.GW
+        self._plist = self._blist = None      # cached parameter / buffer object lists (the module's structure is fixed once validated)
+        self._feat_desc = {}
         self._build_topology()
         self._alloc()
         self._segs_key = None
@@ -194,7 +196,7 @@ class NativePolicyNet:
         for c in self.convs:
             c.z = f(N, c.Hy, c.Wy, c.Cy)
             max_act = max(max_act, c.z.numel())
-            stats_cap = max(stats_cap, lib.bc_pn_conv_partials(N, c.Hy, c.Wy) * 2 * c.Cy)
+            stats_cap = max(stats_cap, lib.bc_pn_conv_partials(N, c.Hy, c.Wy, c.Cy) * 2 * c.Cy)
             wg_cap = max(wg_cap, lib.bc_pn_wgrad_workspace(N, c.Hy, c.Wy, c.Cxp, c.Cy, c.ks))
             bwd_cap = max(bwd_cap, lib.bc_pn_bn_bwd_partials(N * c.Hy * c.Wy) * 2 * c.Cy)
         for b in self.blocks:
@@ -262,10 +264,14 @@ class NativePolicyNet:
         self._segs_key = self._ptr_key()
 
     def _ptr_key(self):
-        return tuple(p.data_ptr() for p in self._param_list()) + tuple(b.data_ptr() for b in self._buffer_list())
+        if self._plist is None:
+            self._plist, self._blist = self._param_list(), self._buffer_list()
+        return tuple([p.data_ptr() for p in self._plist] + [b.data_ptr() for b in self._blist])
 
     def _versions(self):
-        return tuple(p._version for p in self._param_list())
+        if self._plist is None:
+            self._plist, self._blist = self._param_list(), self._buffer_list()
+        return tuple([p._version for p in self._plist])
 
     def _check(self, rc, what):
         if rc != 0:
@@ -310,7 +316,7 @@ class NativePolicyNet:
         lib, P = self.lib, self.P
         sc, sh = (pro.scale.data_ptr(), pro.shift.data_ptr()) if pro is not None else (None, None)
         relu = 1 if pro is not None else 0
-        n_part = lib.bc_pn_conv_partials(c.N, c.Hy, c.Wy)
+        n_part = lib.bc_pn_conv_partials(c.N, c.Hy, c.Wy, c.Cy)
         args = (c.z.data_ptr(), x.data_ptr(), P.data_ptr() + 4 * c.off, c.N, c.Hx, c.Wx, c.Cxp, c.Hy, c.Wy, c.Cy, c.ks, c.stride, 0, sc, sh, relu, None, None, 0,
                 self.stats.data_ptr(), self.stats.numel())
         m = bn.mod
@@ -491,25 +497,48 @@ class NativePolicyNet:
 
     def features(self, policy_meta: Dict) -> bool:
         """Gather the policy input into ``self.feat`` (channels-last, 32 channels); False when a source is not usable."""
-        srcs = self.net.feature_sources(policy_meta)
-        if srcs is None:
+        frame, state, rep, grid = (policy_meta["inputs"], policy_meta["frame_state"], policy_meta.get("output_repr"), policy_meta.get("grid"))
+        srcs_t = (frame, state, rep, grid)
+        if any(t is None for t in srcs_t):
             return False
-        srcs, h, w = srcs
-        assert (h, w) == (self.h, self.w)
-        from blockcopy.backend import _DTYPE_CODE
+        key = tuple((t.shape, t.stride(), t.dtype) for t in srcs_t)
+        desc = self._feat_desc.get(key)
+        if desc is None:
+            # geometry of the four sources (element strides, sizes, dtype codes, source-index scales): built once per layout, only the addresses
+            # change from frame to frame
+            srcs = self.net.feature_sources(policy_meta)
+            if srcs is None:
+                return False
+            srcs, h, w = srcs
+            assert (h, w) == (self.h, self.w)
+            from blockcopy.backend import _DTYPE_CODE
 
-        ptrs = (ctypes.c_void_p * 4)()
-        strides = (ctypes.c_longlong * 16)()
-        dims = (ctypes.c_int * 16)()
-        scales = (ctypes.c_float * 12)()
-        for k, (t, sh, sw, off) in enumerate(srcs):
-            code = 3 if t.dtype in (torch.bool, torch.uint8) else _DTYPE_CODE[t.dtype]
+            strides = (ctypes.c_longlong * 16)()
+            dims = (ctypes.c_int * 16)()
+            scales = (ctypes.c_float * 12)()
+            for k, (t, sh, sw, off) in enumerate(srcs):
+                code = 3 if t.dtype in (torch.bool, torch.uint8) else _DTYPE_CODE[t.dtype]
+                strides[4 * k:4 * k + 4] = list(t.stride())
+                dims[4 * k:4 * k + 4] = [t.shape[1], t.shape[2], t.shape[3], code]
+                scales[3 * k:3 * k + 3] = [float(sh), float(sw), float(off)]
+            desc = self._feat_desc[key] = ((ctypes.c_void_p * 4)(), strides, dims, scales)
+        ptrs, strides, dims, scales = desc
+        if not all(t.is_cuda for t in srcs_t):
+            return False
+        for k, t in enumerate(srcs_t):
             ptrs[k] = t.data_ptr()
-            strides[4 * k:4 * k + 4] = list(t.stride())
-            dims[4 * k:4 * k + 4] = [t.shape[1], t.shape[2], t.shape[3], code]
-            scales[3 * k:3 * k + 3] = [float(sh), float(sw), float(off)]
         self._check(self.lib.bc_pn_features_nhwc(self.feat.data_ptr(), self.N, self.h, self.w, CPAD, ptrs, strides, dims, scales, self._stream()), "pn_features_nhwc")
         return True
+
+    def decision_probs(self, grid: torch.Tensor):
+        """(probs, log_probs) (N,1,GH,GW) of the decided grid under Bernoulli(logits of the LAST forward): one launch (bc_pn_probs)."""
+        probs = torch.empty((self.N, 1, self.GH, self.GW), dtype=torch.float32, device=self.dev)
+        logp = torch.empty_like(probs)
+        g = grid.reshape(-1)
+        g = g.view(torch.uint8) if g.dtype == torch.bool else g.to(torch.uint8)
+        with torch.cuda.device(self.dev):
+            self._check(self.lib.bc_pn_probs(probs.data_ptr(), logp.data_ptr(), self.logits.data_ptr(), g.data_ptr(), self.n_total, self._stream()), "pn_probs")
+        return probs, logp
 
     @torch.no_grad()
     def forward(self, policy_meta: Dict) -> Optional[torch.Tensor]:

@@ -541,9 +541,8 @@ class PolicyTrainRL(Policy, metaclass=abc.ABCMeta):
         logits = policy_meta.pop("_decision_logits", None)
         native = policy_meta.pop("_native", None)
         if logits is not None and native is not None:
-            with torch.no_grad():       # (no autograd graph on the native route: the backward runs from the forward's own buffers)
-                policy_meta["grid_log_probs"] = -F.binary_cross_entropy_with_logits(logits, policy_meta["grid"].to(logits.dtype), reduction="none")
-                policy_meta["grid_probs"] = torch.sigmoid(logits)
+            # (no autograd graph on the native route: the backward runs from the forward's own buffers; one launch for both maps)
+            policy_meta["grid_probs"], policy_meta["grid_log_probs"] = native.decision_probs(policy_meta["grid"])
         elif logits is not None:        # (device step: see _device_step)
             with torch.enable_grad():   # (the log-probabilities of a frame that will be trained on carry the policy net's autograd graph)
                 # Bernoulli(logits).probs / .log_prob(grid) written out (torch/distributions/bernoulli.py: sigmoid; minus the binary cross

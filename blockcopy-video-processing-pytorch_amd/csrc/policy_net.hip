@@ -75,10 +75,14 @@ struct PnConvArgs {
 // PERSISTENT workgroups over the tiles wg, wg + G, ... of a class; stage = (tile, channel chunk).  Both images are DOUBLE BUFFERED: while stage s
 // multiplies, stage s + 1 is written to the other buffer (behind the first tap's MFMAs) and stage s + 2 is requested from memory (behind the
 // fifth tap's) -- one barrier per stage, no phase in which a wave only moves data.  A layer whose K is one chunk keeps its weights resident.
-template <int NB, int KC, int S>
-__global__ __launch_bounds__(256, (KC == 16 && S == 1) ? 2 : 1) void k_pn_conv(const PnConvArgs a)
+// TS (small maps: too few 4-row tiles to fill the chip): the tile is ONE row, the four waves split the TAPS of every stage (tap t -> wave t mod 4)
+// and their accumulators are joined through the LDS in a fixed order before wave 0 runs the epilogue -- four times the workgroups, a third of the
+// serial MFMA chain per workgroup.
+template <int NB, int KC, int S, bool TS>
+__global__ __launch_bounds__(256, (KC == 16 && S == 1 && !TS) ? 2 : 1) void k_pn_conv(const PnConvArgs a)
 {
     static_assert(NB == 1, "one 32-channel output block per workgroup");
+    constexpr int TH = TS ? 1 : PN_TH;
     extern __shared__ __attribute__((aligned(16))) float pn_lds[];
     constexpr int BN = 32, C4 = KC / 4, TG = PN_MAXTAPS;
     const PnTapSet &cs = a.cls[blockIdx.z];
@@ -86,13 +90,14 @@ __global__ __launch_bounds__(256, (KC == 16 && S == 1) ? 2 : 1) void k_pn_conv(c
     constexpr int b_floats = TG * KC * BN;
     float *As0 = pn_lds, *As1 = pn_lds + a_floats;
     float *Bs0 = pn_lds + 2 * a_floats, *Bs1 = Bs0 + b_floats;
+    float *join = Bs1 + b_floats;      // TS: [wave][16][64] accumulators
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const int n0 = blockIdx.y * BN;
     const int npix = cs.PH * cs.PW;
     const int n_chunks = cs.ntaps > 0 ? a.K / KC : 0;
     const int tiles_img = a.tiles_x * a.tiles_y, n_tiles = a.N * tiles_img;
 
-    constexpr int MAXA = (S == 1 ? 204 : 585) * C4 / 256 + 1;     // float4 of the patch per thread and chunk
+    constexpr int MAXA = (TS ? (S == 1 ? 102 : 195) : (S == 1 ? 204 : 585)) * C4 / 256 + 1;     // float4 of the patch per thread and chunk
     constexpr int NBQ = TG * KC * BN / 4;                 // float4 of the weights per stage
     constexpr int NBV = (NBQ + 255) / 256;                // ... per thread
     float4 pa[MAXA];
@@ -112,7 +117,7 @@ __global__ __launch_bounds__(256, (KC == 16 && S == 1) ? 2 : 1) void k_pn_conv(c
         n = tile / tiles_img;
         const int t2 = tile - n * tiles_img;
         const int ty = t2 / a.tiles_x;
-        oy0 = ty * PN_TH; ox0 = (t2 - ty * a.tiles_x) * PN_TW;
+        oy0 = ty * TH; ox0 = (t2 - ty * a.tiles_x) * PN_TW;
     };
     auto tile_live = [&](int tile) {
         int n, oy0, ox0;
@@ -234,8 +239,8 @@ __global__ __launch_bounds__(256, (KC == 16 && S == 1) ? 2 : 1) void k_pn_conv(c
     auto epilogue = [&](int tile_) {
         int n, oy0, ox0;
         tile_origin(tile_, n, oy0, ox0);
-        const int oy = oy0 + wave, ox = ox0 + r;
-        if (oy < cs.Hc && ox < cs.Wc && !(a.dbg & 4)) {
+        const int oy = oy0 + (TS ? 0 : wave), ox = ox0 + r;
+        if ((!TS || wave == 0) && oy < cs.Hc && ox < cs.Wc && !(a.dbg & 4)) {
             const int Y = oy * a.out_s + cs.out_oy, X = ox * a.out_s + cs.out_ox;
             const size_t o = (((size_t)n * a.Hout + Y) * a.Wout + X) * a.Nn + n0 + 4 * h;
 #pragma unroll
@@ -263,7 +268,7 @@ __global__ __launch_bounds__(256, (KC == 16 && S == 1) ? 2 : 1) void k_pn_conv(c
     };
     bool first_tile = true;
     while (tile < n_tiles) {
-        if (n_chunks == 0) epilogue(tile);      // (a parity class no tap reaches: zeros, plus the residual terms)
+        if (n_chunks == 0) epilogue(tile);      // (a parity class no tap reaches: zeros, plus the residual terms; TS: wave 0 stores)
         for (int chunk = 0; chunk < n_chunks; ++chunk, ++s_idx) {
             const int cur = s_idx & 1;
             const float *As = cur ? As1 : As0;
@@ -280,8 +285,8 @@ __global__ __launch_bounds__(256, (KC == 16 && S == 1) ? 2 : 1) void k_pn_conv(c
                     if (st_chunk == 0 && !(a.dbg & 16)) plan_tile(st_tile);
                     load_stage(st_chunk, !b_resident);
                 }
-                if (t < cs.ntaps && !(a.dbg & 1)) {
-                    const int pb0 = (wave * S + cs.dy[t] - cs.dmin_y) * cs.PW + r * S + cs.dx[t] - cs.dmin_x;
+                if (t < cs.ntaps && !(a.dbg & 1) && (!TS || (t & 3) == wave)) {
+                    const int pb0 = ((TS ? 0 : wave * S) + cs.dy[t] - cs.dmin_y) * cs.PW + r * S + cs.dx[t] - cs.dmin_x;
                     const float *ap = As + ((size_t)h * a.npix_pad + pb0) * 2;
                     const float *bp = Bs + ((size_t)(t * C4 * 2 + h) * BN + r) * 2;
 #pragma unroll
@@ -295,6 +300,17 @@ __global__ __launch_bounds__(256, (KC == 16 && S == 1) ? 2 : 1) void k_pn_conv(c
             }
             if (chunk + 1 == n_chunks) {
                 if (first_tile) stamp(3);
+                if (TS) {
+                    // join the four waves' partial sums (fixed order 0..3) in wave 0; the region is not touched by the staging of later stages
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) join[(wave * 16 + e) * 64 + lane] = acc[e];
+                    __syncthreads();
+                    if (wave == 0) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e)
+                            acc[e] = ((join[(0 * 16 + e) * 64 + lane] + join[(1 * 16 + e) * 64 + lane]) + join[(2 * 16 + e) * 64 + lane]) + join[(3 * 16 + e) * 64 + lane];
+                    }
+                }
                 epilogue(tile);
                 if (first_tile) stamp(4);
                 first_tile = false;
@@ -342,23 +358,31 @@ uint32_t pn_magic(int d, int max_n)
 
 constexpr int PN_PERSIST_WGS = 512;      // workgroups that walk the tiles of a launch (and rows of partial statistics its last workgroup reduces)
 
-template <int NB, int KC, int S>
+template <int NB, int KC, int S, bool TS>
 int pn_conv_launch(const PnConvArgs &a, hipStream_t st)
 {
     size_t lds = 2 * ((size_t)KC * a.npix_pad + (size_t)PN_MAXTAPS * KC * 32 * NB) * sizeof(float);      // both images double buffered
+    if (TS) lds += 4 * 16 * 64 * sizeof(float);                                                            // + the accumulator join
     if (lds < (256 * 33 + 256) * sizeof(float)) lds = (256 * 33 + 256) * sizeof(float);                    // (the statistics transpose)
     if (lds > 160 * 1024 - 512) return BC_ERR_SHAPE;
     static bool attr_set[16];      // per device (the first launch on a device is never inside a stream capture: the host runs a warm pass first)
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pn_conv<NB, KC, S>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pn_conv<NB, KC, S, TS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
         attr_set[dev] = true;
     }
     const long long n_tiles = (long long)a.N * a.tiles_y * a.tiles_x;
     const dim3 grid((unsigned)(n_tiles < PN_PERSIST_WGS ? n_tiles : PN_PERSIST_WGS), (unsigned)(a.Nn / (32 * NB)), (unsigned)a.n_cls);
-    hipLaunchKernelGGL((k_pn_conv<NB, KC, S>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((k_pn_conv<NB, KC, S, TS>), grid, dim3(256), lds, st, a);
     return pn_status();
+}
+
+// one-row tiles with the taps split over the waves where four-row tiles would leave most of the chip idle
+static bool pn_tap_split(int N, int Hc_max, int Wc_max, int Nn, int n_cls)
+{
+    const long long wgs = (long long)N * ((Hc_max + PN_TH - 1) / PN_TH) * ((Wc_max + PN_TW - 1) / PN_TW) * (Nn / 32) * n_cls;
+    return wgs < 160;
 }
 
 // ------------------------------------------------------------------------------------------------------------------ wgrad
@@ -946,30 +970,46 @@ __device__ __forceinline__ float pn_feat_load(const PnFeatSrc &s, long long off)
     }
 }
 
+// a lane per output pixel (consecutive lanes = consecutive columns: every source row is read in order), the channels of the pixel in a loop,
+// 16-byte stores of its Cpad-channel run
 __global__ __launch_bounds__(256) void k_pn_features(float *__restrict__ out, const PnFeatGeom g)
 {
-    const int C4 = g.Cpad / 4;
-    const long long total = (long long)g.N * g.h * g.w * C4;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int q = (int)(i % C4);
-        long long p = i / C4;
-        const int x = (int)(p % g.w);
-        p /= g.w;
-        const int y = (int)(p % g.h), n = (int)(p / g.h);
-        float v[4];
+    const long long total = (long long)g.N * g.h * g.w;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int x = (int)(i % g.w);
+    const long long p = i / g.w;
+    const int y = (int)(p % g.h), n = (int)(p / g.h);
+    float4 *o = reinterpret_cast<float4 *>(out + i * g.Cpad);
+    float v[4];
+    int c = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int cc = 4 * q + j, k = 0;
-            while (k < 4 && cc >= g.src[k].C) { cc -= g.src[k].C; ++k; }
-            if (k == 4) { v[j] = 0.f; continue; }
-            const PnFeatSrc &s = g.src[k];
-            int sy = (int)floorf((float)y * s.scale_h), sx = (int)floorf((float)x * s.scale_w);
-            sy = sy < s.H - 1 ? sy : s.H - 1;
-            sx = sx < s.W - 1 ? sx : s.W - 1;
-            v[j] = pn_feat_load(s, n * s.sn + cc * s.sc + sy * s.sh + sx * s.sw) + s.offset;
+    for (int k = 0; k < 4; ++k) {
+        const PnFeatSrc &s = g.src[k];
+        int sy = (int)floorf((float)y * s.scale_h), sx = (int)floorf((float)x * s.scale_w);
+        sy = sy < s.H - 1 ? sy : s.H - 1;
+        sx = sx < s.W - 1 ? sx : s.W - 1;
+        const long long base = n * s.sn + sy * s.sh + sx * s.sw;
+        for (int cc = 0; cc < s.C; ++cc, ++c) {
+            v[c & 3] = pn_feat_load(s, base + cc * s.sc) + s.offset;
+            if ((c & 3) == 3) o[c >> 2] = make_float4(v[0], v[1], v[2], v[3]);
         }
-        *reinterpret_cast<float4 *>(out + i * 4) = make_float4(v[0], v[1], v[2], v[3]);
     }
+    for (; c < g.Cpad; ++c) {
+        v[c & 3] = 0.f;
+        if ((c & 3) == 3) o[c >> 2] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// decision bookkeeping of a frame (policy.py:283-288 via torch.distributions.Bernoulli): probs = sigmoid(l), log_prob(grid) = -BCE-with-logits
+__global__ __launch_bounds__(256) void k_pn_probs(float *__restrict__ probs, float *__restrict__ log_probs, const float *__restrict__ logits,
+                                                  const uint8_t *__restrict__ grid, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float l = logits[i], g = grid[i] ? 1.f : 0.f;
+    probs[i] = 1.0f / (1.0f + expf(-l));
+    log_probs[i] = -(fmaxf(l, 0.f) - l * g + log1pf(expf(-fabsf(l))));
 }
 
 bool pn_aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -1026,6 +1066,12 @@ BC_EXPORT int bc_pn_conv_nhwc(float *out, const float *x, const float *w, int N,
     }
     if (a.K % 32 != 0 || a.Nn % 32 != 0) return BC_ERR_SHAPE;
     for (int k = 0; k < a.n_cls; ++k) {
+        max_hc = a.cls[k].Hc > max_hc ? a.cls[k].Hc : max_hc;
+        max_wc = a.cls[k].Wc > max_wc ? a.cls[k].Wc : max_wc;
+    }
+    const bool ts = pn_tap_split(N, max_hc, max_wc, a.Nn, a.n_cls);
+    const int TH = ts ? 1 : PN_TH;
+    for (int k = 0; k < a.n_cls; ++k) {
         PnTapSet &c = a.cls[k];
         int ymin = 0, ymax = 0, xmin = 0, xmax = 0;
         for (int t = 0; t < c.ntaps; ++t) {
@@ -1033,13 +1079,12 @@ BC_EXPORT int bc_pn_conv_nhwc(float *out, const float *x, const float *w, int N,
             xmin = t == 0 ? c.dx[t] : (c.dx[t] < xmin ? c.dx[t] : xmin); xmax = t == 0 ? c.dx[t] : (c.dx[t] > xmax ? c.dx[t] : xmax);
         }
         c.dmin_y = ymin; c.dmin_x = xmin;
-        c.PH = (PN_TH - 1) * S + (ymax - ymin) + 1; c.PW = (PN_TW - 1) * S + (xmax - xmin) + 1;
+        c.PH = (TH - 1) * S + (ymax - ymin) + 1; c.PW = (PN_TW - 1) * S + (xmax - xmin) + 1;
         c.pw_magic = pn_magic(c.PW, c.PH * c.PW + 8);
         if (!c.pw_magic) return BC_ERR_SHAPE;
-        max_hc = c.Hc > max_hc ? c.Hc : max_hc; max_wc = c.Wc > max_wc ? c.Wc : max_wc;
         max_npix = c.PH * c.PW > max_npix ? c.PH * c.PW : max_npix;
     }
-    a.tiles_y = (max_hc + PN_TH - 1) / PN_TH; a.tiles_x = (max_wc + PN_TW - 1) / PN_TW;
+    a.tiles_y = (max_hc + TH - 1) / TH; a.tiles_x = (max_wc + PN_TW - 1) / PN_TW;
     a.npix_pad = (max_npix + 7) / 8 * 8 + 1;
     const long long n_tiles = (long long)N * a.tiles_y * a.tiles_x;
     if (n_tiles > 0x7fffffffLL || (long long)N * a.Hi * a.Wi * a.K > 0x7fffffffLL || (long long)9 * a.K * a.Nn > 0x7fffffffLL) return BC_ERR_RANGE;     // (32-bit staging offsets)
@@ -1048,14 +1093,18 @@ BC_EXPORT int bc_pn_conv_nhwc(float *out, const float *x, const float *w, int N,
     hipStream_t st = (hipStream_t)stream;
     // one 32-channel output block per workgroup and all nine taps of a channel chunk per stage: the small maps of the net (8 k, 2 k,
     // 512 pixels) get four times the workgroups, and a workgroup's K loop is Cin / KC stages
-    if (S == 1) return pn_conv_launch<1, 16, 1>(a, st);
-    return pn_conv_launch<1, 16, 2>(a, st);      // (stride 2: the patch is 2.9 x the stride-1 one -- 16-channel chunks, 112 KB double buffered)
+    // one-row tiles (small maps) take 32-channel chunks: their patch is small, and half as many stages means half as many exposed memory
+    // round trips (a stage of a tap-split workgroup is shorter than the latency of its successor's loads)
+    if (S == 1) return ts ? pn_conv_launch<1, 32, 1, true>(a, st) : pn_conv_launch<1, 16, 1, false>(a, st);
+    // (stride 2, four-row tiles: the patch is 2.9 x the stride-1 one -- 16-channel chunks, 112 KB double buffered)
+    return ts ? pn_conv_launch<1, 32, 2, true>(a, st) : pn_conv_launch<1, 16, 2, false>(a, st);
 }
 
-// number of stats partial rows a forward launch of this geometry writes (rows of [2][Cy])
-BC_EXPORT long long bc_pn_conv_partials(int N, int Hy, int Wy)
+// number of stats partial rows a forward launch of this geometry writes (rows of [2][Cy]; small maps run one-row tiles)
+BC_EXPORT long long bc_pn_conv_partials(int N, int Hy, int Wy, int Cy)
 {
-    const long long n_tiles = (long long)N * ((Hy + PN_TH - 1) / PN_TH) * ((Wy + PN_TW - 1) / PN_TW);
+    const int TH = pn_tap_split(N, Hy, Wy, Cy, 1) ? 1 : PN_TH;
+    const long long n_tiles = (long long)N * ((Hy + TH - 1) / TH) * ((Wy + PN_TW - 1) / PN_TW);
     return n_tiles < PN_PERSIST_WGS ? n_tiles : PN_PERSIST_WGS;
 }
 
@@ -1079,9 +1128,10 @@ BC_EXPORT int bc_pn_wgrad_nhwc(float *dw, float *part, long long part_capacity, 
     a.PH = (PN_TH - 1) * stride + ks; a.PW = (PN_TW - 1) * stride + ks; a.npix = a.PH * a.PW;
     a.pw_magic = pn_magic(a.PW, a.npix + 8);
     if (!a.pw_magic) return BC_ERR_SHAPE;
-    // groups: about two workgroups per CU over all (ci, co) blocks
+    // groups: about one workgroup per CU over all (ci, co) blocks (more tiles per workgroup: the final reduction and the partials are paid once)
     const int blocks = (Cx / 32) * (Cy / 32);
-    int groups = (512 + blocks - 1) / blocks;
+    static const int wg_target = [] { const char *e = getenv("PN_WGRAD_WGS"); return e ? atoi(e) : 256; }();      // (measurement knob)
+    int groups = (wg_target + blocks - 1) / blocks;
     groups = groups < 1 ? 1 : (groups > a.n_tiles ? a.n_tiles : groups);
     a.tiles_per_group = (a.n_tiles + groups - 1) / groups;
     groups = (a.n_tiles + a.tiles_per_group - 1) / a.tiles_per_group;
@@ -1113,7 +1163,7 @@ BC_EXPORT int bc_pn_wgrad_nhwc(float *dw, float *part, long long part_capacity, 
 BC_EXPORT long long bc_pn_wgrad_workspace(int N, int Hy, int Wy, int Cx, int Cy, int ks)
 {
     const int n_tiles = N * ((Hy + PN_TH - 1) / PN_TH) * ((Wy + PN_TW - 1) / PN_TW), blocks = (Cx / 32) * (Cy / 32);
-    int groups = (512 + blocks - 1) / blocks;
+    int groups = (512 + blocks - 1) / blocks;      // (upper bound of what bc_pn_wgrad_nhwc uses)
     groups = groups < 1 ? 1 : (groups > n_tiles ? n_tiles : groups);
     const int per = (n_tiles + groups - 1) / groups;
     groups = (n_tiles + per - 1) / per;
@@ -1261,8 +1311,16 @@ BC_EXPORT int bc_pn_features_nhwc(float *out, int N, int h, int w, int Cpad, con
         ctot += s.C;
     }
     if (ctot > Cpad) return BC_ERR_SHAPE;
-    const long long total = (long long)N * h * w * (Cpad / 4);
-    const long long blocks = (total + 255) / 256;
-    hipLaunchKernelGGL(k_pn_features, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream, out, g);
+    const long long total = (long long)N * h * w;
+    if (total > 0x7fffffffLL) return BC_ERR_RANGE;
+    hipLaunchKernelGGL(k_pn_features, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, g);
+    return pn_status();
+}
+
+BC_EXPORT int bc_pn_probs(float *probs, float *log_probs, const float *logits, const uint8_t *grid, int n, void *stream)
+{
+    if (!probs || !log_probs || !logits || !grid) return BC_ERR_NULL;
+    if (n <= 0) return BC_ERR_SHAPE;
+    hipLaunchKernelGGL(k_pn_probs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, probs, log_probs, logits, grid, n);
     return pn_status();
 }

@@ -470,12 +470,12 @@ int bc_policy_features(float *out, int N, int h, int w, const void *const *ptrs,
  *                                 output-parity classes (1 / 2 / 2 / 4 taps, no multiplications by inserted zeros)
  *   prologue: relu?(x * in_scale[c] + in_shift[c]) applied while the patch is staged (the producer's BatchNorm + ReLU), zero padding after it;
  *   epilogue: out = acc (+ add, or add where add_mask > 0: the residual branch's gradient behind a ReLU) (+ out if accumulate);
- *   stats (forward only): per-workgroup partial sums [bc_pn_conv_partials(N,Hy,Wy)][2][Cy] of out and out^2 (training-mode BatchNorm
+ *   stats (forward only): per-workgroup partial sums [bc_pn_conv_partials(N,Hy,Wy,Cy)][2][Cy] of out and out^2 (training-mode BatchNorm
  *   statistics of the OUTPUT, finished by bc_pn_bn_finalize). */
 int bc_pn_conv_nhwc(float *out, const float *x, const float *w, int N, int Hx, int Wx, int Cx, int Hy, int Wy, int Cy, int ks, int stride,
                     int direction, const float *in_scale, const float *in_shift, int in_relu, const float *add, const float *add_mask,
                     int accumulate, float *stats, long long stats_capacity, void *stream);
-long long bc_pn_conv_partials(int N, int Hy, int Wy);
+long long bc_pn_conv_partials(int N, int Hy, int Wy, int Cy);
 /* weight gradient dw[tap][Cx][Cy] = sum over output pixels of prologue(x)[pixel * stride + tap - pad][ci] * gz[pixel][co] as a GEMM over
  * pixels, split over pixel-tile groups and summed in a FIXED order (two launches, no atomics): part = workspace of
  * bc_pn_wgrad_workspace(...) floats. */
@@ -520,6 +520,9 @@ int bc_pn_rmsprop(float *p, const float *g, float *sq, float *mom, long long n, 
  * vector), kw, cin, cin_pad, cout, numel. */
 int bc_pn_sync_params(float *flat, float *flat_t, const void *segs, int n_segs, int dir, void *stream);
 int bc_pn_seg_bytes(void);
+/* decision bookkeeping of a frame: probs = sigmoid(logits), log_probs = log-probability of the decided grid under Bernoulli(logits)
+ * (= -binary_cross_entropy_with_logits; torch.distributions.Bernoulli's own formulas, policy/policy.py:283-288) in one launch */
+int bc_pn_probs(float *probs, float *log_probs, const float *logits, const uint8_t *grid, int n, void *stream);
 /* measurement only: device buffer receiving 8 x uint64 stamps (100 MHz) per workgroup of the following bc_pn_conv_nhwc launches; NULL = off */
 int bc_pn_set_stamps(void *buf);
 /* the policy input (bc_policy_features) straight into the channels-last layout, channels sum C_k .. Cpad - 1 zero */

@@ -82,7 +82,7 @@ def test_pn_conv_forward_and_statistics(case, prologue):
     want, _ = _conv_ref(x, w, ks, s, sc, sh, prologue)
     Hy, Wy = want.shape[2:]
     out = torch.full((N, Hy, Wy, Co), float("nan"), device="cuda")
-    n_part = lib.bc_pn_conv_partials(N, Hy, Wy)
+    n_part = lib.bc_pn_conv_partials(N, Hy, Wy, Co)
     stats = torch.full((n_part * 2 * Co,), float("nan"), device="cuda")
     xg, wg = _nhwc(x), _wk(w)
     scg, shg = (sc.cuda(), sh.cuda()) if prologue else (None, None)
@@ -479,3 +479,34 @@ def test_native_route_in_the_rl_loop_matches_the_autograd_route(monkeypatch):
             assert torch.allclose(i1, i2, rtol=1e-3, atol=1e-5), t
     cos = float((d_n * d_a).sum() / d_n.norm() / d_a.norm())
     assert cos > 0.9, cos
+
+
+@pytest.mark.parametrize("dtype,cl", [(torch.float32, False), (torch.float16, True)])
+def test_pn_features_and_probs(dtype, cl):
+    """The channels-last, channel-padded policy input (bc_pn_features_nhwc) == the reference recipe (4 x F.interpolate(nearest) + casts +
+    centring + concat, policy/net.py:82-113), bit for bit; bc_pn_probs == sigmoid / -BCE-with-logits."""
+    pol = _small_policy(H=128, W=256, block=64)           # block 64: the policy input is half the frame's resolution
+    nat = _native(pol, (1, 3, 128, 256))
+    g = torch.Generator().manual_seed(4)
+    mf = torch.channels_last if cl else torch.contiguous_format
+    meta = {"inputs": torch.randn((1, 3, 128, 256), generator=g).cuda().to(dtype).contiguous(memory_format=mf),
+            "frame_state": torch.randn((1, 3, 128, 256), generator=g).cuda().to(dtype).contiguous(memory_format=mf),
+            "output_repr": torch.randn((1, 19, 32, 64), generator=g).cuda().to(dtype).contiguous(memory_format=mf),
+            "grid": (torch.rand((1, 1, 2, 4), generator=g) > 0.5).cuda()}
+    import blockcopy.policy.net as pnet
+
+    old = pnet.FUSED_FEATURES
+    pnet.FUSED_FEATURES = False
+    try:
+        want = pol.net.build_features(meta)             # the stock ops
+    finally:
+        pnet.FUSED_FEATURES = old
+    assert nat.features(meta)
+    got = nat.feat
+    assert got.shape == (1, 64, 128, 32) and torch.equal(got[..., :26], want.permute(0, 2, 3, 1).float()) and float(got[..., 26:].abs().max()) == 0.0
+    # decision bookkeeping
+    nat.logits.copy_(torch.randn(nat.n_total, generator=g).cuda() * 3)
+    probs, logp = nat.decision_probs(meta["grid"])
+    lg = nat.logits.view(1, 1, 2, 4)
+    assert torch.allclose(probs, torch.sigmoid(lg), rtol=1e-6, atol=1e-7)
+    assert torch.allclose(logp, -F.binary_cross_entropy_with_logits(lg, meta["grid"].float(), reduction="none"), rtol=1e-5, atol=1e-6)

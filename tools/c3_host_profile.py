@@ -54,7 +54,9 @@ def main():
         pr.disable()
         torch.cuda.synchronize()
         st = pstats.Stats(pr, stream=sys.stdout)
-        st.sort_stats("cumulative").print_stats(45)
+        st.strip_dirs()
+        st.sort_stats("tottime").print_stats(40)
+        st.sort_stats("cumulative").print_stats(60)
 
 
 if __name__ == "__main__":

@@ -26,7 +26,7 @@ def main():
     x = torch.randn((N, H, W, Ci), device="cuda")
     w = torch.randn((9, Ci, Co), device="cuda") * 0.1
     out = torch.empty((N, Hy, Wy, Co), device="cuda")
-    n_part = lib.bc_pn_conv_partials(N, Hy, Wy)
+    n_part = lib.bc_pn_conv_partials(N, Hy, Wy, Co)
     stats = torch.zeros(n_part * 2 * Co, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
     n_wg = n_part * (Co // 32)
