@@ -153,7 +153,7 @@ def load_library(path: str = None) -> ctypes.CDLL:
         "bc_l2norm_cat_nhwc": [p, p, p, ctypes.c_longlong, i, i, i, ctypes.c_float, i, p],
         "bc_policy_step": [p, i, ctypes.c_ulonglong, ctypes.c_ulonglong, i, i, p, p, p, p, p, p],
         "bc_policy_features": [p, i, i, i, p, p, p, p, p],
-        "bc_pn_conv_nhwc": [p, p, p] + [i] * 10 + [p, p, i, p, p, i, p, ctypes.c_longlong, p],
+        "bc_pn_conv_nhwc": [p, p, p] + [i] * 10 + [p, p, i, p, p, i, p, ctypes.c_longlong, i, p],
         "bc_pn_wgrad_nhwc": [p, p, ctypes.c_longlong, p, p] + [i] * 9 + [p, p, i, p],
         "bc_pn_bn_finalize": [p, ctypes.c_longlong, i, ctypes.c_double, p, p, ctypes.c_float, ctypes.c_float, p, p, p, p, p, p, p, p],
         "bc_pn_join": [p, p, p, p, p, p, p, i, i, ctypes.c_longlong, p],

@@ -31,6 +31,8 @@ import torch.nn as nn
 ENABLED = os.environ.get("BLOCKCOPY_NATIVE_POLICY", "1") != "0"
 USE_GRAPH = os.environ.get("BLOCKCOPY_NATIVE_POLICY_GRAPH", "1") != "0"
 CPAD = 32
+# forward convs: 1 = split-fp16 products on the 16-bit matrix pipe (fp32-level accuracy, 5.3 x the fp32 matrix rate; bc_pn_conv_nhwc), 0 = fp32 pipe
+FWD_PRECISION = int(os.environ.get("BLOCKCOPY_POLICY_FWD_PRECISION", "1"))
 
 
 def _pad32(c: int) -> int:
@@ -318,7 +320,7 @@ class NativePolicyNet:
         relu = 1 if pro is not None else 0
         n_part = lib.bc_pn_conv_partials(c.N, c.Hy, c.Wy, c.Cy)
         args = (c.z.data_ptr(), x.data_ptr(), P.data_ptr() + 4 * c.off, c.N, c.Hx, c.Wx, c.Cxp, c.Hy, c.Wy, c.Cy, c.ks, c.stride, 0, sc, sh, relu, None, None, 0,
-                self.stats.data_ptr(), self.stats.numel())
+                self.stats.data_ptr(), self.stats.numel(), FWD_PRECISION)
         m = bn.mod
         fin = (self.stats.data_ptr(), n_part, bn.C, float(c.N * c.Hy * c.Wy), P.data_ptr() + 4 * bn.off_g, P.data_ptr() + 4 * bn.off_b, float(m.eps), float(m.momentum),
                m.running_mean.data_ptr(), m.running_var.data_ptr(), m.num_batches_tracked.data_ptr(), bn.scale.data_ptr(), bn.shift.data_ptr(),
@@ -379,7 +381,7 @@ class NativePolicyNet:
     def _dgrad(self, c: _Conv, out, gz, add=None, add_mask=None, accumulate=0):
         lib = self.lib
         args = (out.data_ptr(), gz.data_ptr(), self.WT.data_ptr() + 4 * c.off_t, c.N, c.Hx, c.Wx, c.Cxp, c.Hy, c.Wy, c.Cy, c.ks, c.stride, 1, None, None, 0,
-                add.data_ptr() if add is not None else None, add_mask.data_ptr() if add_mask is not None else None, accumulate, None, 0)
+                add.data_ptr() if add is not None else None, add_mask.data_ptr() if add_mask is not None else None, accumulate, None, 0, 0)
         return lambda st: self._check(lib.bc_pn_conv_nhwc(*args, st), "pn_conv_nhwc(dgrad)")
 
     def _build_step(self):

@@ -470,11 +470,14 @@ int bc_policy_features(float *out, int N, int h, int w, const void *const *ptrs,
  *                                 output-parity classes (1 / 2 / 2 / 4 taps, no multiplications by inserted zeros)
  *   prologue: relu?(x * in_scale[c] + in_shift[c]) applied while the patch is staged (the producer's BatchNorm + ReLU), zero padding after it;
  *   epilogue: out = acc (+ add, or add where add_mask > 0: the residual branch's gradient behind a ReLU) (+ out if accumulate);
+ *   precision 0: v_mfma_f32_32x32x2_f32 (exact fp32 products); 1: every operand split hi + lo into two fp16 numbers (both scaled by 16:
+ *   |values| < 4094, 22 bits of mantissa) and each product taken as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation --
+ *   fp32-level accuracy (measured <= 3e-6 of the output's largest element) at 5.3 x the matrix rate; meant for forward convs behind BatchNorm;
  *   stats (forward only): per-workgroup partial sums [bc_pn_conv_partials(N,Hy,Wy,Cy)][2][Cy] of out and out^2 (training-mode BatchNorm
  *   statistics of the OUTPUT, finished by bc_pn_bn_finalize). */
 int bc_pn_conv_nhwc(float *out, const float *x, const float *w, int N, int Hx, int Wx, int Cx, int Hy, int Wy, int Cy, int ks, int stride,
                     int direction, const float *in_scale, const float *in_shift, int in_relu, const float *add, const float *add_mask,
-                    int accumulate, float *stats, long long stats_capacity, void *stream);
+                    int accumulate, float *stats, long long stats_capacity, int precision, void *stream);
 long long bc_pn_conv_partials(int N, int Hy, int Wy, int Cy);
 /* weight gradient dw[tap][Cx][Cy] = sum over output pixels of prologue(x)[pixel * stride + tap - pad][ci] * gz[pixel][co] as a GEMM over
  * pixels, split over pixel-tile groups and summed in a FIXED order (two launches, no atomics): part = workspace of

@@ -71,7 +71,8 @@ def _conv_ref(x, w, ks, stride, scale=None, shift=None, relu=False):
 
 @pytest.mark.parametrize("case", CONV_CASES)
 @pytest.mark.parametrize("prologue", [False, True])
-def test_pn_conv_forward_and_statistics(case, prologue):
+@pytest.mark.parametrize("precision", [0, 1])
+def test_pn_conv_forward_and_statistics(case, prologue, precision):
     be, lib = _lib()
     N, H, W, Ci, Co, ks, s = case
     g = torch.Generator().manual_seed(sum(case) + prologue)
@@ -87,7 +88,7 @@ def test_pn_conv_forward_and_statistics(case, prologue):
     xg, wg = _nhwc(x), _wk(w)
     scg, shg = (sc.cuda(), sh.cuda()) if prologue else (None, None)
     rc = lib.bc_pn_conv_nhwc(out.data_ptr(), xg.data_ptr(), wg.data_ptr(), N, H, W, Ci, Hy, Wy, Co, ks, s, 0, scg.data_ptr() if prologue else None,
-                             shg.data_ptr() if prologue else None, int(prologue), None, None, 0, stats.data_ptr(), stats.numel(), _st())
+                             shg.data_ptr() if prologue else None, int(prologue), None, None, 0, stats.data_ptr(), stats.numel(), precision, _st())
     assert rc == 0
     got = _nchw(out)
     tol = 2e-5 * float(want.abs().max())
@@ -114,14 +115,14 @@ def test_pn_conv_data_gradient(case):
     gyg, wtg, addg, maskg = _nhwc(gy), _wt(w), _nhwc(add), _nhwc(mask)
     out = torch.full((N, H, W, Ci), float("nan"), device="cuda")
     args = (gyg.data_ptr(), wtg.data_ptr(), N, H, W, Ci, Hy, Wy, Co, ks, s, 1, None, None, 0)
-    assert lib.bc_pn_conv_nhwc(out.data_ptr(), *args, None, None, 0, None, 0, _st()) == 0
+    assert lib.bc_pn_conv_nhwc(out.data_ptr(), *args, None, None, 0, None, 0, 0, _st()) == 0
     tol = 2e-5 * max(1.0, float(want.abs().max()))
     assert float((_nchw(out) - want).abs().max()) <= tol
     # + residual gradient behind a ReLU, then accumulated once more on top
-    assert lib.bc_pn_conv_nhwc(out.data_ptr(), *args, addg.data_ptr(), maskg.data_ptr(), 0, None, 0, _st()) == 0
+    assert lib.bc_pn_conv_nhwc(out.data_ptr(), *args, addg.data_ptr(), maskg.data_ptr(), 0, None, 0, 0, _st()) == 0
     want2 = want + add.double() * (mask > 0)
     assert float((_nchw(out) - want2).abs().max()) <= tol
-    assert lib.bc_pn_conv_nhwc(out.data_ptr(), *args, None, None, 1, None, 0, _st()) == 0
+    assert lib.bc_pn_conv_nhwc(out.data_ptr(), *args, None, None, 1, None, 0, 0, _st()) == 0
     assert float((_nchw(out) - (want2 + want)).abs().max()) <= 2 * tol
 
 

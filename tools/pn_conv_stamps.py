@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--cout", type=int, default=32)
     ap.add_argument("--stride", type=int, default=1)
     ap.add_argument("--n", type=int, default=1)
+    ap.add_argument("--precision", type=int, default=1)
     args = ap.parse_args()
     import blockcopy.backend as bk
 
@@ -34,7 +35,7 @@ def main():
 
     def launch():
         assert lib.bc_pn_conv_nhwc(out.data_ptr(), x.data_ptr(), w.data_ptr(), N, H, W, Ci, Hy, Wy, Co, 3, s, 0, None, None, 0, None, None, 0, stats.data_ptr(),
-                                   stats.numel(), st) == 0
+                                   stats.numel(), args.precision, st) == 0
 
     for _ in range(5):
         launch()
