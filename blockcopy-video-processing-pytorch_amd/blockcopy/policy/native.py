@@ -33,6 +33,9 @@ USE_GRAPH = os.environ.get("BLOCKCOPY_NATIVE_POLICY_GRAPH", "1") != "0"
 CPAD = 32
 # forward convs: 1 = split-fp16 products on the 16-bit matrix pipe (fp32-level accuracy, 5.3 x the fp32 matrix rate; bc_pn_conv_nhwc), 0 = fp32 pipe
 FWD_PRECISION = int(os.environ.get("BLOCKCOPY_POLICY_FWD_PRECISION", "1"))
+# data gradients: 2 = split-bf16 products (no scaling needed over the gradients' range; ~2e-5 relative, against the 1e-3 the REINFORCE step is
+# tested to and an RMSprop update that is sign-like), 0 = fp32 pipe
+BWD_PRECISION = int(os.environ.get("BLOCKCOPY_POLICY_BWD_PRECISION", "2"))
 
 
 def _pad32(c: int) -> int:
@@ -381,7 +384,7 @@ class NativePolicyNet:
     def _dgrad(self, c: _Conv, out, gz, add=None, add_mask=None, accumulate=0):
         lib = self.lib
         args = (out.data_ptr(), gz.data_ptr(), self.WT.data_ptr() + 4 * c.off_t, c.N, c.Hx, c.Wx, c.Cxp, c.Hy, c.Wy, c.Cy, c.ks, c.stride, 1, None, None, 0,
-                add.data_ptr() if add is not None else None, add_mask.data_ptr() if add_mask is not None else None, accumulate, None, 0, 0)
+                add.data_ptr() if add is not None else None, add_mask.data_ptr() if add_mask is not None else None, accumulate, None, 0, BWD_PRECISION)
         return lambda st: self._check(lib.bc_pn_conv_nhwc(*args, st), "pn_conv_nhwc(dgrad)")
 
     def _build_step(self):

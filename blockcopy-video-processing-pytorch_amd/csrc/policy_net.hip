@@ -30,6 +30,11 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+template <int PREC> struct PnHalf { typedef _Float16 T; typedef f16x4 V4; typedef f16x8 V8; static constexpr float scale = 16.f; };
+template <> struct PnHalf<2> { typedef __bf16 T; typedef bf16x4 V4; typedef bf16x8 V8; static constexpr float scale = 1.f; };
 
 unsigned long long *g_pn_stamps = nullptr;      // measurement only (bc_pn_set_stamps)
 
@@ -80,16 +85,23 @@ struct PnConvArgs {
 // TS (small maps: too few 4-row tiles to fill the chip): the tile is ONE row, the four waves split the TAPS of every stage (tap t -> wave t mod 4)
 // and their accumulators are joined through the LDS in a fixed order before wave 0 runs the epilogue -- four times the workgroups, a third of the
 // serial MFMA chain per workgroup.
-// F16: the same sums on the 16-bit matrix pipe at fp32 accuracy -- every operand is split  x = hi + lo  into two fp16 numbers (22 bits of mantissa
+// PREC 1 / 2: the same sums on the 16-bit matrix pipe.  PREC 1, fp32 accuracy -- every operand is split  x = hi + lo  into two fp16 numbers (22 bits of mantissa
 // together; both operands scaled by 16 so that lo stays a normal number down to 4e-6, |x| < 4094) and a product is the three MFMAs
 // hi*hi + hi*lo + lo*hi into the fp32 accumulator (lo*lo, 2^-22 of the product, is dropped): v_mfma_f32_32x32x16_f16 multiplies 16 channels in
 // 32 cycles where v_mfma_f32_32x32x2_f32 needs 8 x 64, so three of them are 5.3 x faster than the fp32 pipe.  Used for the FORWARD convs
-// (activations and weights are O(1) numbers behind BatchNorm); gradients (1e-6 .. 1e-3, no fixed scale) stay on the fp32 pipe.
-template <int NB, int KC, int S, bool TS, bool F16>
+// (activations and weights are O(1) numbers behind BatchNorm).  PREC 2: hi + lo in bf16 (fp32's exponent range: no scale, nothing under- or
+// overflows; 16 bits of mantissa together, products good to 2^-16) -- for the DATA GRADIENT, whose operand (1e-7 .. 1e-3) has no fixed scale
+// and whose consumer is an RMSprop step.
+template <int NB, int KC, int S, bool TS, int PREC>
 __global__ __launch_bounds__(256, (KC == 16 && S == 1 && !TS) ? 2 : 1) void k_pn_conv(const PnConvArgs a)
 {
     static_assert(NB == 1, "one 32-channel output block per workgroup");
     constexpr int TH = TS ? 1 : PN_TH;
+    constexpr bool F16 = PREC != 0;      // 16-bit matrix pipe, operands split hi + lo (PREC 1: fp16 scaled by 16, 2: bf16)
+    typedef typename PnHalf<PREC>::T HT;
+    typedef typename PnHalf<PREC>::V4 HV4;
+    typedef typename PnHalf<PREC>::V8 HV8;
+    constexpr float HS = PnHalf<PREC>::scale;
     extern __shared__ __attribute__((aligned(16))) float pn_lds[];
     constexpr int BN = 32, C4 = KC / 4, TG = PN_MAXTAPS;
     const PnTapSet &cs = a.cls[blockIdx.z];
@@ -97,7 +109,7 @@ __global__ __launch_bounds__(256, (KC == 16 && S == 1 && !TS) ? 2 : 1) void k_pn
     constexpr int b_floats = TG * KC * BN;
     float *As0 = pn_lds, *As1 = pn_lds + a_floats;
     float *Bs0 = pn_lds + 2 * a_floats, *Bs1 = Bs0 + b_floats;
-    float *join = Bs1 + b_floats;      // TS: [wave][16][64] accumulators
+    float *join = Bs0 + (a.K == KC ? 1 : 2) * b_floats;      // TS: [wave][16][64] accumulators (behind the one or two weight images)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const int n0 = blockIdx.y * BN;
     const int npix = cs.PH * cs.PW;
@@ -188,17 +200,17 @@ __global__ __launch_bounds__(256, (KC == 16 && S == 1 && !TS) ? 2 : 1) void k_pn
                 }
                 if constexpr (F16) {
                     // halves: [part hi | lo][kg = channel / 8][pix][8]
-                    _Float16 *Ah = reinterpret_cast<_Float16 *>(As);
-                    const float x4[4] = {v.x * 16.f, v.y * 16.f, v.z * 16.f, v.w * 16.f};
-                    f16x4 hi, lo;
+                    HT *Ah = reinterpret_cast<HT *>(As);
+                    const float x4[4] = {v.x * HS, v.y * HS, v.z * HS, v.w * HS};
+                    HV4 hi, lo;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        hi[j] = (_Float16)x4[j];
-                        lo[j] = (_Float16)(x4[j] - (float)hi[j]);
+                        hi[j] = (HT)x4[j];
+                        lo[j] = (HT)(x4[j] - (float)hi[j]);
                     }
                     const size_t o = ((size_t)(c4 >> 1) * a.npix_pad + pix) * 8 + (c4 & 1) * 4;
-                    *reinterpret_cast<f16x4 *>(Ah + o) = hi;
-                    *reinterpret_cast<f16x4 *>(Ah + (size_t)KC * a.npix_pad + o) = lo;
+                    *reinterpret_cast<HV4 *>(Ah + o) = hi;
+                    *reinterpret_cast<HV4 *>(Ah + (size_t)KC * a.npix_pad + o) = lo;
                 } else {
                     *reinterpret_cast<float2 *>(As + ((size_t)(c4 * 2 + 0) * a.npix_pad + pix) * 2) = make_float2(v.x, v.y);
                     *reinterpret_cast<float2 *>(As + ((size_t)(c4 * 2 + 1) * a.npix_pad + pix) * 2) = make_float2(v.z, v.w);
@@ -213,14 +225,14 @@ __global__ __launch_bounds__(256, (KC == 16 && S == 1 && !TS) ? 2 : 1) void k_pn
                 if (idx < NBQ) {
                     if constexpr (F16) {
                         // halves: [part hi | lo][t][kg = k / 8][n][8]
-                        _Float16 *Bh = reinterpret_cast<_Float16 *>(Bs);
-                        const float w4[4] = {pb[i].x * 16.f, pb[i].y * 16.f, pb[i].z * 16.f, pb[i].w * 16.f};
+                        HT *Bh = reinterpret_cast<HT *>(Bs);
+                        const float w4[4] = {pb[i].x * HS, pb[i].y * HS, pb[i].z * HS, pb[i].w * HS};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const _Float16 hi = (_Float16)w4[e];
+                            const HT hi = (HT)w4[e];
                             const size_t o = ((size_t)(t * (KC / 8) + (k >> 3)) * BN + 4 * n4 + e) * 8 + (k & 7);
                             Bh[o] = hi;
-                            Bh[(size_t)TG * KC * BN + o] = (_Float16)(w4[e] - (float)hi);
+                            Bh[(size_t)TG * KC * BN + o] = (HT)(w4[e] - (float)hi);
                         }
                     } else {
                         float *dst = Bs + ((size_t)((t * C4 + k / 4) * 2 + ((k >> 1) & 1)) * BN + 4 * n4) * 2 + (k & 1);
@@ -281,7 +293,7 @@ __global__ __launch_bounds__(256, (KC == 16 && S == 1 && !TS) ? 2 : 1) void k_pn
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float4 v = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
-                if constexpr (F16) { v.x *= 1.0f / 256.f; v.y *= 1.0f / 256.f; v.z *= 1.0f / 256.f; v.w *= 1.0f / 256.f; }      // (both operands carried a factor 16)
+                if constexpr (PREC == 1) { v.x *= 1.0f / 256.f; v.y *= 1.0f / 256.f; v.z *= 1.0f / 256.f; v.w *= 1.0f / 256.f; }      // (both operands carried a factor 16)
                 if (a.add) {
                     const float4 g = *reinterpret_cast<const float4 *>(a.add + o + 8 * q);
                     if (a.add_mask) {
@@ -324,16 +336,22 @@ __global__ __launch_bounds__(256, (KC == 16 && S == 1 && !TS) ? 2 : 1) void k_pn
                 if (t < cs.ntaps && !(a.dbg & 1) && (!TS || (t & 3) == wave)) {
                     const int pb0 = ((TS ? 0 : wave * S) + cs.dy[t] - cs.dmin_y) * cs.PW + r * S + cs.dx[t] - cs.dmin_x;
                     if constexpr (F16) {
-                        const _Float16 *Ah = reinterpret_cast<const _Float16 *>(As), *Bh = reinterpret_cast<const _Float16 *>(Bs);
+                        const HT *Ah = reinterpret_cast<const HT *>(As), *Bh = reinterpret_cast<const HT *>(Bs);
 #pragma unroll
                         for (int m = 0; m < KC / 16; ++m) {      // lane half h takes channels 8 (2 m + h) .. + 7 of the 16 an MFMA multiplies
                             const size_t po = ((size_t)(2 * m + h) * a.npix_pad + pb0) * 8;
                             const size_t wo = ((size_t)(t * (KC / 8) + 2 * m + h) * BN + r) * 8;
-                            const f16x8 ph = *reinterpret_cast<const f16x8 *>(Ah + po), pl = *reinterpret_cast<const f16x8 *>(Ah + (size_t)KC * a.npix_pad + po);
-                            const f16x8 wh = *reinterpret_cast<const f16x8 *>(Bh + wo), wl = *reinterpret_cast<const f16x8 *>(Bh + (size_t)TG * KC * BN + wo);
-                            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, ph, acc, 0, 0, 0);      // D[i = channel][j = pixel]
-                            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, pl, acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, ph, acc, 0, 0, 0);
+                            const HV8 ph = *reinterpret_cast<const HV8 *>(Ah + po), pl = *reinterpret_cast<const HV8 *>(Ah + (size_t)KC * a.npix_pad + po);
+                            const HV8 wh = *reinterpret_cast<const HV8 *>(Bh + wo), wl = *reinterpret_cast<const HV8 *>(Bh + (size_t)TG * KC * BN + wo);
+                            if constexpr (PREC == 2) {
+                                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, ph, acc, 0, 0, 0);      // D[i = channel][j = pixel]
+                                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, pl, acc, 0, 0, 0);
+                                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, ph, acc, 0, 0, 0);
+                            } else {
+                                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, ph, acc, 0, 0, 0);
+                                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, pl, acc, 0, 0, 0);
+                                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, ph, acc, 0, 0, 0);
+                            }
                         }
                     } else {
                         const float *ap = As + ((size_t)h * a.npix_pad + pb0) * 2;
@@ -408,10 +426,11 @@ uint32_t pn_magic(int d, int max_n)
 
 constexpr int PN_PERSIST_WGS = 512;      // workgroups that walk the tiles of a launch (and rows of partial statistics its last workgroup reduces)
 
-template <int NB, int KC, int S, bool TS, bool F16>
+template <int NB, int KC, int S, bool TS, int PREC>
 int pn_conv_launch(const PnConvArgs &a, hipStream_t st)
 {
-    size_t lds = 2 * ((size_t)KC * a.npix_pad + (size_t)PN_MAXTAPS * KC * 32 * NB) * sizeof(float);      // both images double buffered
+    const int n_b = a.K == KC ? 1 : 2;      // (a layer whose K is one chunk keeps its weights resident: one weight image)
+    size_t lds = (2 * (size_t)KC * a.npix_pad + n_b * (size_t)PN_MAXTAPS * KC * 32 * NB) * sizeof(float);      // images double buffered
     if (TS) lds += 4 * 16 * 64 * sizeof(float);                                                            // + the accumulator join
     if (lds < (256 * 33 + 256) * sizeof(float)) lds = (256 * 33 + 256) * sizeof(float);                    // (the statistics transpose)
     if (lds > 160 * 1024 - 512) return BC_ERR_SHAPE;
@@ -419,12 +438,12 @@ int pn_conv_launch(const PnConvArgs &a, hipStream_t st)
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pn_conv<NB, KC, S, TS, F16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pn_conv<NB, KC, S, TS, PREC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
         attr_set[dev] = true;
     }
     const long long n_tiles = (long long)a.N * a.tiles_y * a.tiles_x;
     const dim3 grid((unsigned)(n_tiles < PN_PERSIST_WGS ? n_tiles : PN_PERSIST_WGS), (unsigned)(a.Nn / (32 * NB)), (unsigned)a.n_cls);
-    hipLaunchKernelGGL((k_pn_conv<NB, KC, S, TS, F16>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((k_pn_conv<NB, KC, S, TS, PREC>), grid, dim3(256), lds, st, a);
     return pn_status();
 }
 
@@ -1073,7 +1092,7 @@ BC_EXPORT int bc_pn_conv_nhwc(float *out, const float *x, const float *w, int N,
                               int direction, const float *in_scale, const float *in_shift, int in_relu, const float *add, const float *add_mask,
                               int accumulate, float *stats, long long stats_capacity, int precision, void *stream)
 {
-    if (!(precision == 0 || precision == 1)) return BC_ERR_SHAPE;
+    if (precision < 0 || precision > 2) return BC_ERR_SHAPE;
     if (!out || !x || !w) return BC_ERR_NULL;
     if (N <= 0 || Hx <= 0 || Wx <= 0 || Hy <= 0 || Wy <= 0 || Cx <= 0 || Cy <= 0) return BC_ERR_SHAPE;
     if (!(ks == 3 || ks == 1) || !(stride == 1 || stride == 2) || !(direction == 0 || direction == 1)) return BC_ERR_SHAPE;
@@ -1147,8 +1166,11 @@ BC_EXPORT int bc_pn_conv_nhwc(float *out, const float *x, const float *w, int N,
     // one-row tiles (small maps) take 32-channel chunks: their patch is small, and half as many stages means half as many exposed memory
     // round trips (a stage of a tap-split workgroup is shorter than the latency of its successor's loads); stride 2 with four-row tiles: the
     // patch is 2.9 x the stride-1 one -- 16-channel chunks, 112 KB double buffered
-    const bool f16 = precision == 1;
-#define PN_GO(KC_, S_, TS_) (f16 ? pn_conv_launch<1, KC_, S_, TS_, true>(a, st) : pn_conv_launch<1, KC_, S_, TS_, false>(a, st))
+#define PN_GO(KC_, S_, TS_)                                                          \
+    (precision == 1 ? pn_conv_launch<1, KC_, S_, TS_, 1>(a, st)                      \
+                    : (precision == 2 ? pn_conv_launch<1, KC_, S_, TS_, 2>(a, st) : pn_conv_launch<1, KC_, S_, TS_, 0>(a, st)))
+    // (32-input-channel layers as ONE 32-channel chunk with resident weights -- 90 KB, one workgroup per CU -- measured slower: 40-43 us against
+    //  31-33 with two 16-channel chunks and two workgroups per CU)
     if (S == 1) return ts ? PN_GO(32, 1, true) : PN_GO(16, 1, false);
     return ts ? PN_GO(32, 2, true) : PN_GO(16, 2, false);
 #undef PN_GO

@@ -473,6 +473,8 @@ int bc_policy_features(float *out, int N, int h, int w, const void *const *ptrs,
  *   precision 0: v_mfma_f32_32x32x2_f32 (exact fp32 products); 1: every operand split hi + lo into two fp16 numbers (both scaled by 16:
  *   |values| < 4094, 22 bits of mantissa) and each product taken as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation --
  *   fp32-level accuracy (measured <= 3e-6 of the output's largest element) at 5.3 x the matrix rate; meant for forward convs behind BatchNorm;
+ *   2: the same with bf16 halves (fp32's exponent range: no scale, no under- / overflow; 16 bits of mantissa, ~2e-5 relative) -- meant for the
+ *   data gradient, whose operand spans 1e-7 .. 1e-3;
  *   stats (forward only): per-workgroup partial sums [bc_pn_conv_partials(N,Hy,Wy,Cy)][2][Cy] of out and out^2 (training-mode BatchNorm
  *   statistics of the OUTPUT, finished by bc_pn_bn_finalize). */
 int bc_pn_conv_nhwc(float *out, const float *x, const float *w, int N, int Hx, int Wx, int Cx, int Hy, int Wy, int Cy, int ks, int stride,

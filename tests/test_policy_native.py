@@ -99,7 +99,8 @@ def test_pn_conv_forward_and_statistics(case, prologue, precision):
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_pn_conv_data_gradient(case):
+@pytest.mark.parametrize("precision", [0, 2])
+def test_pn_conv_data_gradient(case, precision):
     """direction 1 == autograd's gradient of the input (stride 2: four parity classes), with the masked residual term and accumulation."""
     be, lib = _lib()
     N, H, W, Ci, Co, ks, s = case
@@ -115,14 +116,14 @@ def test_pn_conv_data_gradient(case):
     gyg, wtg, addg, maskg = _nhwc(gy), _wt(w), _nhwc(add), _nhwc(mask)
     out = torch.full((N, H, W, Ci), float("nan"), device="cuda")
     args = (gyg.data_ptr(), wtg.data_ptr(), N, H, W, Ci, Hy, Wy, Co, ks, s, 1, None, None, 0)
-    assert lib.bc_pn_conv_nhwc(out.data_ptr(), *args, None, None, 0, None, 0, 0, _st()) == 0
-    tol = 2e-5 * max(1.0, float(want.abs().max()))
+    assert lib.bc_pn_conv_nhwc(out.data_ptr(), *args, None, None, 0, None, 0, precision, _st()) == 0
+    tol = (2e-5 if precision == 0 else 1e-4) * max(1.0, float(want.abs().max()))      # (split bf16: 16 bits of mantissa per operand)
     assert float((_nchw(out) - want).abs().max()) <= tol
     # + residual gradient behind a ReLU, then accumulated once more on top
-    assert lib.bc_pn_conv_nhwc(out.data_ptr(), *args, addg.data_ptr(), maskg.data_ptr(), 0, None, 0, 0, _st()) == 0
+    assert lib.bc_pn_conv_nhwc(out.data_ptr(), *args, addg.data_ptr(), maskg.data_ptr(), 0, None, 0, precision, _st()) == 0
     want2 = want + add.double() * (mask > 0)
     assert float((_nchw(out) - want2).abs().max()) <= tol
-    assert lib.bc_pn_conv_nhwc(out.data_ptr(), *args, None, None, 1, None, 0, 0, _st()) == 0
+    assert lib.bc_pn_conv_nhwc(out.data_ptr(), *args, None, None, 1, None, 0, precision, _st()) == 0
     assert float((_nchw(out) - (want2 + want)).abs().max()) <= 2 * tol
 
 
