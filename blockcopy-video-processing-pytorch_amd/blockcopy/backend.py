@@ -165,6 +165,8 @@ def load_library(path: str = None) -> ctypes.CDLL:
         "bc_pn_rmsprop": [p, p, p, p, ctypes.c_longlong] + [ctypes.c_float] * 5 + [p],
         "bc_pn_sync_params": [p, p, p, i, i, p],
         "bc_pn_seg_bytes": [],
+        "bc_pn_wgrad_groups": [i, i, i, i, i],
+        "bc_pn_update": [p, p, p, p, p, p, p, i] + [ctypes.c_float] * 5 + [p],
         "bc_pn_set_stamps": [p],
         "bc_pn_probs": [p, p, p, p, i, p],
         "bc_pn_features_nhwc": [p, i, i, i, i, p, p, p, p, p],

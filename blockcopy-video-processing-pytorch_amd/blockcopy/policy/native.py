@@ -202,7 +202,8 @@ class NativePolicyNet:
             c.z = f(N, c.Hy, c.Wy, c.Cy)
             max_act = max(max_act, c.z.numel())
             stats_cap = max(stats_cap, lib.bc_pn_conv_partials(N, c.Hy, c.Wy, c.Cy) * 2 * c.Cy)
-            wg_cap = max(wg_cap, lib.bc_pn_wgrad_workspace(N, c.Hy, c.Wy, c.Cxp, c.Cy, c.ks))
+            c.groups = lib.bc_pn_wgrad_groups(N, c.Hy, c.Wy, c.Cxp, c.Cy)
+            c.ws_off, wg_cap = wg_cap, wg_cap + (c.groups * c.numel + 3) // 4 * 4      # every conv keeps its partial copies until the step's last launch sums them
             bwd_cap = max(bwd_cap, lib.bc_pn_bn_bwd_partials(N * c.Hy * c.Wy) * 2 * c.Cy)
         for b in self.blocks:
             b.out = f(N, b.c2.Hy, b.c2.Wy, b.c2.Cy)
@@ -249,20 +250,22 @@ class NativePolicyNet:
 
     def _build_segs(self):
         rec = np.zeros(0, dtype=np.uint8)
-        assert self.lib.bc_pn_seg_bytes() == 80
+        assert self.lib.bc_pn_seg_bytes() == 96
         dt = np.dtype([("off", "<i8"), ("off_t", "<i8"), ("ptr", "<u8"), ("s_co", "<i8"), ("s_ci", "<i8"), ("s_ky", "<i8"), ("s_kx", "<i8"),
-                       ("taps", "<i4"), ("kw", "<i4"), ("cin", "<i4"), ("cin_pad", "<i4"), ("cout", "<i4"), ("numel", "<i4")])
+                       ("taps", "<i4"), ("kw", "<i4"), ("cin", "<i4"), ("cin_pad", "<i4"), ("cout", "<i4"), ("numel", "<i4"),
+                       ("ws_off", "<i8"), ("groups", "<i4"), ("pad", "<i4")])
         rows = []
         for c in self.convs:
             w = c.mod.weight
-            rows.append((c.off, c.off_t, w.data_ptr(), w.stride(0), w.stride(1), w.stride(2), w.stride(3), c.ks * c.ks, c.ks, c.Cx, c.Cxp, c.Cy, c.numel))
+            rows.append((c.off, c.off_t, w.data_ptr(), w.stride(0), w.stride(1), w.stride(2), w.stride(3), c.ks * c.ks, c.ks, c.Cx, c.Cxp, c.Cy, c.numel,
+                         c.ws_off, c.groups, 0))
         for b in self.bns:
             for off, p in ((b.off_g, b.mod.weight), (b.off_b, b.mod.bias)):
                 assert p.is_contiguous()
-                rows.append((off, -1, p.data_ptr(), 0, 0, 0, 0, 0, 1, 0, 0, 0, b.C))
+                rows.append((off, -1, p.data_ptr(), 0, 0, 0, 0, 0, 1, 0, 0, 0, b.C, 0, 0, 0))
         w = self.last.weight
-        rows.append((self.off_last_w, -1, w.data_ptr(), w.stride(0), w.stride(1), w.stride(2), w.stride(3), 9, 3, self.last_C, self.last_C, 1, 9 * self.last_C))
-        rows.append((self.off_last_b, -1, self.last.bias.data_ptr(), 0, 0, 0, 0, 0, 1, 0, 0, 0, 1))
+        rows.append((self.off_last_w, -1, w.data_ptr(), w.stride(0), w.stride(1), w.stride(2), w.stride(3), 9, 3, self.last_C, self.last_C, 1, 9 * self.last_C, 0, 0, 0))
+        rows.append((self.off_last_b, -1, self.last.bias.data_ptr(), 0, 0, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0))
         rec = np.array(rows, dtype=dt)
         self.n_segs = len(rows)
         self.segs = torch.from_numpy(rec.view(np.uint8).reshape(-1).copy()).to(self.dev)
@@ -377,7 +380,8 @@ class NativePolicyNet:
     def _wgrad(self, c: _Conv, x, pro: Optional[_BN], gz):
         lib = self.lib
         sc, sh = (pro.scale.data_ptr(), pro.shift.data_ptr()) if pro is not None else (None, None)
-        args = (self.G.data_ptr() + 4 * c.off, self.wg_ws.data_ptr(), self.wg_ws.numel(), x.data_ptr(), gz.data_ptr(), c.N, c.Hx, c.Wx, c.Cxp, c.Hy, c.Wy, c.Cy,
+        # (dw = None: the partial copies stay in this conv's slice of the workspace; the step's last launch sums them, bc_pn_update)
+        args = (None, self.wg_ws.data_ptr() + 4 * c.ws_off, c.groups * c.numel, x.data_ptr(), gz.data_ptr(), c.N, c.Hx, c.Wx, c.Cxp, c.Hy, c.Wy, c.Cy,
                 c.ks, c.stride, sc, sh, 1 if pro is not None else 0)
         return lambda st: self._check(lib.bc_pn_wgrad_nhwc(*args, st), "pn_wgrad_nhwc")
 
@@ -449,16 +453,17 @@ class NativePolicyNet:
         ops.append(self._wgrad(self.stem, self.feat, None, gZ))
         release(gZ)
         self._opt_slot = len(ops)
-        ops.append(None)      # RMSprop with the optimizer's current hyper-parameters (_bind_optimizer)
-        ops.append(lambda st: self._check(lib.bc_pn_sync_params(self.P.data_ptr(), self.WT.data_ptr(), self.segs.data_ptr(), self.n_segs, 0, st), "pn_sync_params"))
+        ops.append(None)      # gradient sums + RMSprop with the optimizer's current hyper-parameters + export, one launch (_bind_optimizer)
         return ops
 
     def _bind_optimizer(self):
         g = self.optimizer.param_groups[0]
         hyper = (float(g["lr"]), float(g["alpha"]), float(g["eps"]), float(g["weight_decay"]), float(g["momentum"]))
         if hyper != self._hyper:
-            a = (self.P.data_ptr(), self.G.data_ptr(), self.SQ.data_ptr(), self.MOM.data_ptr(), self.n_flat) + hyper
-            self._step_ops[self._opt_slot] = lambda st, a=a: self._check(self.lib.bc_pn_rmsprop(*a, st), "pn_rmsprop")
+            def update(st, hyper=hyper):      # (the segment table is looked up at run time: it is rebuilt when the module's tensors move)
+                self._check(self.lib.bc_pn_update(self.P.data_ptr(), self.G.data_ptr(), self.SQ.data_ptr(), self.MOM.data_ptr(), self.WT.data_ptr(),
+                                                  self.wg_ws.data_ptr(), self.segs.data_ptr(), self.n_segs, *hyper, st), "pn_update")
+            self._step_ops[self._opt_slot] = update
             self._hyper = hyper
             self._step_graph = None
 

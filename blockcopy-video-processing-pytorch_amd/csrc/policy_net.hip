@@ -989,6 +989,8 @@ struct PnSeg {
     float *param;
     long long s_co, s_ci, s_ky, s_kx;
     int taps, kw, cin, cin_pad, cout, numel;     // numel = taps * cin_pad * cout (weights) or the vector length (taps = 0)
+    long long ws_off;           // bc_pn_update: the segment's gradient is the sum of `groups` partial copies at ws + ws_off (groups = 0: it is in G)
+    int groups, pad_;
 };
 
 __global__ __launch_bounds__(256) void k_pn_sync_params(float *__restrict__ flat, float *__restrict__ flat_t, const PnSeg *__restrict__ segs, int dir)
@@ -1011,6 +1013,73 @@ __global__ __launch_bounds__(256) void k_pn_sync_params(float *__restrict__ flat
             flat[s.off + i] = v;
         }
         if (s.off_t >= 0 && flat_t) flat_t[s.off_t + ((long long)t * s.cout + co) * s.cin_pad + ci] = v;
+    }
+}
+
+// The tail of a training step in ONE launch: the weight gradients' group partials summed in a fixed order (the reduction of k_pn_reduce_groups:
+// eight slices of consecutive groups per element, joined through the LDS), torch.optim.RMSprop on the flat parameters, and the export of the
+// new values into the module's parameter tensors and the transposed copies the data gradient reads (k_pn_rmsprop + k_pn_sync_params).
+__global__ __launch_bounds__(256) void k_pn_update(float *__restrict__ p, float *__restrict__ g, float *__restrict__ sq, float *__restrict__ mom,
+                                                   float *__restrict__ flat_t, const float *__restrict__ ws, const PnSeg *__restrict__ segs, float lr, float alpha,
+                                                   float eps, float wd, float momentum)
+{
+    __shared__ float red[8][32];
+    const PnSeg s = segs[blockIdx.y];
+    const int e = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    for (int base = blockIdx.x * 32; base < s.numel; base += gridDim.x * 32) {
+        const int i = base + e;
+        const bool live = i < s.numel;
+        float acc = 0.f;
+        if (s.groups > 0) {
+            const int per = (s.groups + 7) / 8, g0 = slice * per, g1 = min(s.groups, g0 + per);
+            if (live) {
+                const float *src = ws + s.ws_off + i;
+                int k = g0;
+                for (; k + 8 <= g1; k += 8) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(k + j) * s.numel];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc += v[j];
+                }
+                for (; k < g1; ++k) acc += src[(size_t)k * s.numel];
+            }
+            red[slice][e] = acc;
+            __syncthreads();
+        }
+        if (slice == 0 && live) {
+            float grad;
+            if (s.groups > 0) {
+                grad = red[0][e];
+#pragma unroll
+                for (int j = 1; j < 8; ++j) grad += red[j][e];
+                g[s.off + i] = grad;
+            } else {
+                grad = g[s.off + i];
+            }
+            const float w = p[s.off + i];
+            if (wd != 0.f) grad = fmaf(w, wd, grad);
+            const float sv = sq[s.off + i] * alpha + (1.0f - alpha) * grad * grad;
+            sq[s.off + i] = sv;
+            const float avg = sqrtf(sv) + eps;
+            float v;
+            if (momentum > 0.f) {
+                const float b = mom[s.off + i] * momentum + grad / avg;
+                mom[s.off + i] = b;
+                v = w - lr * b;
+            } else {
+                v = w - lr * (grad / avg);
+            }
+            p[s.off + i] = v;
+            if (s.taps == 0) {
+                s.param[i] = v;
+            } else {
+                const int co = i % s.cout, ci = (i / s.cout) % s.cin_pad, t = i / (s.cout * s.cin_pad);
+                if (ci < s.cin) s.param[co * s.s_co + ci * s.s_ci + (t / s.kw) * s.s_ky + (t % s.kw) * s.s_kx] = v;
+                if (s.off_t >= 0 && flat_t) flat_t[s.off_t + ((long long)t * s.cout + co) * s.cin_pad + ci] = v;
+            }
+        }
+        if (s.groups > 0) __syncthreads();
     }
 }
 
@@ -1188,7 +1257,7 @@ BC_EXPORT long long bc_pn_conv_partials(int N, int Hy, int Wy, int Cy)
 BC_EXPORT int bc_pn_wgrad_nhwc(float *dw, float *part, long long part_capacity, const float *x, const float *gz, int N, int Hx, int Wx, int Cx, int Hy, int Wy,
                                int Cy, int ks, int stride, const float *in_scale, const float *in_shift, int in_relu, void *stream)
 {
-    if (!dw || !part || !x || !gz) return BC_ERR_NULL;
+    if (!part || !x || !gz) return BC_ERR_NULL;      // (dw NULL: the partials stay in `part` for bc_pn_update)
     if (N <= 0 || Hx <= 0 || Wx <= 0 || Hy <= 0 || Wy <= 0 || Cx <= 0 || Cy <= 0 || Cx % 32 != 0 || Cy % 32 != 0) return BC_ERR_SHAPE;
     if (!(ks == 3 || ks == 1) || !(stride == 1 || stride == 2) || (ks == 1 && stride != 2)) return BC_ERR_SHAPE;
     const int pad = ks == 3 ? 1 : 0;
@@ -1206,8 +1275,7 @@ BC_EXPORT int bc_pn_wgrad_nhwc(float *dw, float *part, long long part_capacity, 
     if (!a.pw_magic) return BC_ERR_SHAPE;
     // groups: about one workgroup per CU over all (ci, co) blocks (more tiles per workgroup: the final reduction and the partials are paid once)
     const int blocks = (Cx / 32) * (Cy / 32);
-    static const int wg_target = [] { const char *e = getenv("PN_WGRAD_WGS"); return e ? atoi(e) : 256; }();      // (measurement knob)
-    int groups = (wg_target + blocks - 1) / blocks;
+    int groups = (256 + blocks - 1) / blocks;      // (512: measured the same)
     groups = groups < 1 ? 1 : (groups > a.n_tiles ? a.n_tiles : groups);
     a.tiles_per_group = (a.n_tiles + groups - 1) / groups;
     groups = (a.n_tiles + a.tiles_per_group - 1) / a.tiles_per_group;
@@ -1232,18 +1300,23 @@ BC_EXPORT int bc_pn_wgrad_nhwc(float *dw, float *part, long long part_capacity, 
     else if (ks == 3) PN_WG(9, 2);
     else PN_WG(1, 2);
 #undef PN_WG
-    hipLaunchKernelGGL(k_pn_reduce_groups, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, st, dw, part, (int)n, groups);
+    if (dw) hipLaunchKernelGGL(k_pn_reduce_groups, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, st, dw, part, (int)n, groups);
     return pn_status();
+}
+
+// number of pixel-tile groups (partial copies of the gradient) a launch of this geometry leaves in its workspace
+BC_EXPORT int bc_pn_wgrad_groups(int N, int Hy, int Wy, int Cx, int Cy)
+{
+    const int n_tiles = N * ((Hy + PN_TH - 1) / PN_TH) * ((Wy + PN_TW - 1) / PN_TW), blocks = (Cx / 32) * (Cy / 32);
+    int groups = (256 + blocks - 1) / blocks;
+    groups = groups < 1 ? 1 : (groups > n_tiles ? n_tiles : groups);
+    const int per = (n_tiles + groups - 1) / groups;
+    return (n_tiles + per - 1) / per;
 }
 
 BC_EXPORT long long bc_pn_wgrad_workspace(int N, int Hy, int Wy, int Cx, int Cy, int ks)
 {
-    const int n_tiles = N * ((Hy + PN_TH - 1) / PN_TH) * ((Wy + PN_TW - 1) / PN_TW), blocks = (Cx / 32) * (Cy / 32);
-    int groups = (512 + blocks - 1) / blocks;      // (upper bound of what bc_pn_wgrad_nhwc uses)
-    groups = groups < 1 ? 1 : (groups > n_tiles ? n_tiles : groups);
-    const int per = (n_tiles + groups - 1) / groups;
-    groups = (n_tiles + per - 1) / per;
-    return (long long)groups * ks * ks * Cx * Cy;
+    return (long long)bc_pn_wgrad_groups(N, Hy, Wy, Cx, Cy) * ks * ks * Cx * Cy;
 }
 
 BC_EXPORT int bc_pn_bn_finalize(const float *part, long long n_part, int C, double count, const float *gamma, const float *beta, float eps, float momentum,
@@ -1357,7 +1430,7 @@ BC_EXPORT int bc_pn_sync_params(float *flat, float *flat_t, const void *segs, in
 {
     if (!flat || !segs) return BC_ERR_NULL;
     if (n_segs <= 0 || !(dir == 0 || dir == 1)) return BC_ERR_SHAPE;
-    static_assert(sizeof(PnSeg) == 80, "PnSeg layout: 7 x int64 + 6 x int32");
+    static_assert(sizeof(PnSeg) == 96, "PnSeg layout: 7 x int64 + 6 x int32 + int64 + 2 x int32");
     hipLaunchKernelGGL(k_pn_sync_params, dim3(64, (unsigned)n_segs), dim3(256), 0, (hipStream_t)stream, flat, flat_t, (const PnSeg *)segs, dir);
     return pn_status();
 }
@@ -1365,6 +1438,17 @@ BC_EXPORT int bc_pn_sync_params(float *flat, float *flat_t, const void *segs, in
 /* measurement only: device buffer that receives 8 x uint64 (100 MHz s_memrealtime) per workgroup of the next bc_pn_conv_nhwc launches:
  * [0] entry, [1] first patch requested, [2] first stage in the LDS, [3] first tile multiplied, [4] first tile stored, [5] all tiles done; NULL = off */
 BC_EXPORT int bc_pn_set_stamps(void *buf) { g_pn_stamps = (unsigned long long *)buf; return BC_OK; }
+
+// reduce (weight-gradient partials) + RMSprop + export in one launch; segs as bc_pn_sync_params, with ws_off / groups filled for the conv weights
+BC_EXPORT int bc_pn_update(float *p, float *g, float *sq, float *mom, float *flat_t, const float *ws, const void *segs, int n_segs, float lr, float alpha,
+                           float eps, float wd, float momentum, void *stream)
+{
+    if (!p || !g || !sq || !segs || (momentum > 0.f && !mom)) return BC_ERR_NULL;
+    if (n_segs <= 0) return BC_ERR_SHAPE;
+    hipLaunchKernelGGL(k_pn_update, dim3(1152, (unsigned)n_segs), dim3(256), 0, (hipStream_t)stream, p, g, sq, mom, flat_t, ws, (const PnSeg *)segs, lr, alpha, eps,
+                       wd, momentum);
+    return pn_status();
+}
 
 BC_EXPORT int bc_pn_seg_bytes(void) { return (int)sizeof(PnSeg); }
 

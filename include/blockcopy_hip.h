@@ -487,6 +487,7 @@ long long bc_pn_conv_partials(int N, int Hy, int Wy, int Cy);
 int bc_pn_wgrad_nhwc(float *dw, float *part, long long part_capacity, const float *x, const float *gz, int N, int Hx, int Wx, int Cx, int Hy, int Wy,
                      int Cy, int ks, int stride, const float *in_scale, const float *in_shift, int in_relu, void *stream);
 long long bc_pn_wgrad_workspace(int N, int Hy, int Wy, int Cx, int Cy, int ks);
+int bc_pn_wgrad_groups(int N, int Hy, int Wy, int Cx, int Cy);      /* partial copies a launch leaves in `part` (dw = NULL: not summed, see bc_pn_update) */
 /* training-mode BatchNorm from the conv's partial sums: scale / shift (the consumers' prologue), save_mean / save_invstd (backward), running
  * statistics (momentum, unbiased variance) and the batch counter updated in place (F.batch_norm(training=True) semantics). */
 int bc_pn_bn_finalize(const float *part, long long n_part, int C, double count, const float *gamma, const float *beta, float eps, float momentum,
@@ -522,9 +523,14 @@ int bc_pn_rmsprop(float *p, const float *g, float *sq, float *mom, long long n, 
                   void *stream);
 /* flat buffer <-> torch parameters in one launch (dir 0: flat -> parameters + transposed copies, 1: parameters -> flat + transposed copies);
  * segs = DEVICE array of bc_pn_seg_bytes()-byte records: int64 off, off_t, param address, s_co, s_ci, s_ky, s_kx; int32 taps (0 = plain
- * vector), kw, cin, cin_pad, cout, numel. */
+ * vector), kw, cin, cin_pad, cout, numel; int64 ws_off; int32 groups, 0 (the last three: bc_pn_update). */
 int bc_pn_sync_params(float *flat, float *flat_t, const void *segs, int n_segs, int dir, void *stream);
 int bc_pn_seg_bytes(void);
+/* the tail of a training step in ONE launch: for every segment, gradient = the fixed-order sum of its `groups` partial copies at ws + ws_off
+ * (weight gradients left by bc_pn_wgrad_nhwc with dw = NULL; groups = 0: the gradient is already in g), torch.optim.RMSprop on p / sq / mom, and the
+ * export of the new values into the module's parameter tensors and the transposed copies (bc_pn_rmsprop + bc_pn_sync_params dir 0). */
+int bc_pn_update(float *p, float *g, float *sq, float *mom, float *flat_t, const float *ws, const void *segs, int n_segs, float lr, float alpha,
+                 float eps, float wd, float momentum, void *stream);
 /* decision bookkeeping of a frame: probs = sigmoid(logits), log_probs = log-probability of the decided grid under Bernoulli(logits)
  * (= -binary_cross_entropy_with_logits; torch.distributions.Bernoulli's own formulas, policy/policy.py:283-288) in one launch */
 int bc_pn_probs(float *probs, float *log_probs, const float *logits, const uint8_t *grid, int n, void *stream);
