@@ -494,8 +494,16 @@ class HipBackend:
         w0 = weight.detach().as_subclass(torch.Tensor)
         w = w0.permute(2, 3, 1, 0).reshape(kh * kw, Cin // 32, steps, 2, epv, Cout // 32, 32)   # tap, unit, step, h, j, nb, n
         direct = w.permute(5, 1, 0, 2, 3, 6, 4).contiguous().view(-1)                                    # nb, unit, tap, step, h, n, j
-        if (kh, kw) != (3, 3) or w0.dtype != torch.float32:
+        if w0.dtype != torch.float32:
             return direct
+        # fp32: the SPLIT stream of the direct form on the 16-bit matrix pipe (codes | 0x2000, csrc/conv3x3_v2.inc BC_F32S) -- the direct stream
+        # position by position, every 16-byte vector of four weights replaced by [hi0..3 | lo0..3] in fp16 with 16 w = hi + lo
+        x16 = direct.view(-1, 4) * 16.0
+        hi = x16.to(torch.float16)
+        lo = (x16 - hi.float()).to(torch.float16)
+        split = torch.cat([hi, lo], dim=1).contiguous().view(torch.float32).view(-1)
+        if (kh, kw) != (3, 3):
+            return torch.cat([direct, split])
         # fp32 3x3: the Winograd F(2x2,3x3) stream of csrc/conv3x3_wino.inc follows (16 values per (cin, cout)): U = G g Gt computed
         # in fp64, wino[nb16][chunk][step][q][lane = 16*kq + n][w] = U[f][32*chunk + 8*step + 2*kq + t][16*nb16 + n], 2*f + t = 4*q + w
         # G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1] applied along both filter axes as plain device arithmetic (no host constant: this may
@@ -519,7 +527,7 @@ class HipBackend:
             return torch.stack([a / 4, -(a + b + c) / 6, -(a - b + c) / 6, a / 24 + b / 12 + c / 6, a / 24 - b / 12 + c / 6, c], dim)
         U4 = g4_rows(g4_rows(w0.double(), 2), 3).permute(2, 3, 1, 0).reshape(36, Cin, Cout).float()          # f, cin, cout
         U4 = U4.reshape(36, Cin // 16, 4, 4, Cout // 16, 16).permute(4, 1, 0, 2, 5, 3)                      # cb, chunk, f, kq, n, j
-        return torch.cat([direct, U16.contiguous().view(-1), V.contiguous().view(-1), U4.contiguous().view(-1)])
+        return torch.cat([direct, U16.contiguous().view(-1), V.contiguous().view(-1), U4.contiguous().view(-1), split])
 
     # ---- pyramid pooling of a dense map in two launches (csrc/spp.inc): bc_spp_levels_nhwc + bc_spp_fuse_nhwc
     SPP_LDS_LIMIT = 150 * 1024      # both launchers refuse (BC_ERR_SHAPE) above this much dynamic LDS
@@ -690,7 +698,7 @@ class HipBackend:
         N, _, GH, GW = grid_idx.shape
         B, C, bs, _ = data_exec.shape
         n_exec = mapping_exec.numel()
-        assert n_exec == B and wpk.numel() in (9 * C * cout, 77 * C * cout)     # (fp32: direct + three Winograd streams)
+        assert n_exec == B and wpk.numel() in (9 * C * cout, 77 * C * cout, 86 * C * cout)     # (fp32: direct + three Winograd streams + the split stream)
         assert dilation in (1, 2) and (dilation == 1 or stride == 1)
         assert tuple(ring.shape) == (N * GH * GW, C, 4 * dilation * bs), (ring.shape, (N * GH * GW, C, 4 * dilation * bs))
         assert stride in (1, 2) and bs % stride == 0
@@ -782,6 +790,8 @@ class HipBackend:
         if out.numel() > 0:
             with torch.cuda.device_of(data):
                 want = int(cfg) if cfg is not None else self._conv_cfg_pinned
+                if want >= 0 and (want & 0x2000) and wpk.numel() < 2 * C * cout:
+                    want &= ~0x2000      # (a buffer packed without the split stream: the fp32 pipe)
                 if upsample is not None and want >= 0 and (want & 0x800):
                     want = -1       # (the GEMM form has no resampling epilogue: the library picks a direct decomposition)
                 if want != self._conv_cfg:

@@ -189,6 +189,7 @@ CONV_TUNE_LOG = []    # (key, {candidate: microseconds}, choice) of every measur
 WINOGRAD_FLAG = 0x600  # decomposition codes with one of these bits run a Winograd F(2x2,3x3) form (0x200: csrc/conv3x3_wino.inc,
 WINOGRAD_WIDE = 0x400  # 0x400: the wide wave tile of csrc/conv3x3_wino32.inc)
 WINOGRAD_F4 = 0x1000   # codes with this bit: the Winograd F(4x4,3x3) form of csrc/conv3x3_wino4.inc
+SPLIT_FLAG = 0x2000    # codes with this bit: the direct form of an fp32 layer on the 16-bit matrix pipe, operands split hi + lo (conv3x3_v2.inc BC_F32S)
 
 # Plan table persistence.  A plan decides which KERNEL FORM a layer runs in (library conv / direct MFMA form / Winograd form), and
 # the forms differ by fp32 rounding, so a run is only reproducible -- from run to run and from rank to rank -- with a fixed table.
@@ -290,6 +291,12 @@ def conv3x3_plan(n_exec: int, bs: int, cin: int, cout: int, n_total: int, dtype,
     if CONV_MODE == "library":
         return None
     if CONV_MODE == "native":
+        return -1
+    if CONV_MODE == "split":      # every fp32 layer in the direct form on the 16-bit matrix pipe (codes | 0x2000), the rest as "native"
+        if dtype == torch.float32 and candidates is not None:
+            sp = [c for c in candidates() if c >= 0 and (c & SPLIT_FLAG) and not (c & 0x100)]
+            if sp:
+                return sp[0]
         return -1
     if CONV_MODE in ("winograd", "winograd-wide", "winograd4"):
         if ks == 3 and stride == 1 and dtype == torch.float32 and candidates is not None:

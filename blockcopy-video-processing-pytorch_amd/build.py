@@ -17,7 +17,7 @@ ARCH = "gfx950"
 # the one source is compiled as 7 translation units (-DBC_PART=n, see ConvV2Args in csrc/blockcopy_hip.hip): part 0 = everything
 # but the decompositions of the fused conv kernel, parts 1..6 = one (dtype, kernel size) slice of them each, part 7 = its Winograd form,
 # part 8 = the wide-tile Winograd form, part 9 = the dilation-2 form of the direct kernel, part 10 = the Winograd F(4x4,3x3) form
-PARTS = list(range(11))
+PARTS = list(range(11)) + [12, 13]      # 12 / 13: the split (16-bit matrix pipe) form of the fp32 direct conv, kernel size 3 / 1
 
 
 def hipcc() -> str:
@@ -55,7 +55,7 @@ def build_hip_library(force: bool = False, verbose: bool = False) -> str:
         if n >= len(PARTS):
             subprocess.check_call([hipcc()] + flags + ["-c", "-o", objs[n], EXTRA_SRC[n - len(PARTS)]])
         else:
-            subprocess.check_call([hipcc()] + flags + [f"-DBC_PART={n}", "-c", "-o", objs[n]] + SRC)
+            subprocess.check_call([hipcc()] + flags + [f"-DBC_PART={PARTS[n]}", "-c", "-o", objs[n]] + SRC)
 
     jobs = int(os.environ.get("BC_BUILD_JOBS", "0")) or max(1, min(len(objs), os.cpu_count() or 1))
     with ThreadPoolExecutor(max_workers=jobs) as pool:

@@ -2566,11 +2566,13 @@ static const Conv2Cfg CONV2_CFGS[] = {{2, 2, 4, 2, 1}, {2, 1, 4, 2, 1}, {1, 2, 4
 // geometry of one decomposition for a layer (bs = OUTPUT tile size); false if the decomposition does not cover the layer
 struct Conv2Plan { long long wgs; size_t lds_bytes; uint32_t n_rows, patches_per_tile, patches_x; };
 
-static bool conv2_plan(const Conv2Cfg &k, int E, int S, int n_exec, int Cin, int Cout, int bs, Conv2Plan &p, int KS = 3, int D = 1)
+// split = the fp32 tensor on the 16-bit matrix pipe (BC_F32S, code | 0x2000): steps are consumed in pairs, so a wave must own an even number of
+// steps per tap -- K-group decompositions stage more 32-channel units per iteration (WKW 4: 2, WKW 8: 4)
+static bool conv2_plan(const Conv2Cfg &k, int E, int S, int n_exec, int Cin, int Cout, int bs, Conv2Plan &p, int KS = 3, int D = 1, bool split = false)
 {
     const int pw = bs == 4 ? 4 : 8;
     const int uv = E == 4 ? 8 : 4, sc_lo = E == 4 ? 1 : 2;
-    const int sc = k.WKW == 8 ? 2 * sc_lo : sc_lo;
+    const int sc = split ? (k.WKW == 8 ? 4 : (k.WKW == 4 ? 2 : 1)) : (k.WKW == 8 ? 2 * sc_lo : sc_lo);
     if (pw == 8 && bs % 8 != 0) return false;
     if (pw == 4 && k.RM != 1 && k.WMW != 1) return false;       // 4x4 tiles: 4 tile slots per wave row only in single-row workgroups (LDS)
     if (pw == 8 && bs % (4 * k.RM) != 0) return false;
@@ -2641,7 +2643,8 @@ static int conv_v2_run(ConvV2Args &a)
     constexpr int E = CvType<DT>::E;
     const int n_exec = a.n_exec, Cin = a.Cin, Cout = a.Cout, GH = a.GH, GW = a.GW, bs = a.bs;
     LaunchProf ps{a.prof_on != 0, {a.ev_a, a.ev_b}};
-    constexpr int SC_LO = DT == BC_F32 ? 1 : 2, SC_HI = 2 * SC_LO;      // 32-channel units staged per iteration (SC_HI with 8 K groups)
+    constexpr int SC_LO = (DT == BC_F32 || DT == BC_F32S) ? 1 : 2, SC_HI = 2 * SC_LO;      // 32-channel units staged per iteration (SC_HI with 8 K groups)
+    constexpr bool SPLIT = DT == BC_F32S;
     // forced decomposition: bits 0-7 = index into CONV2_CFGS, bit 8 = no LDS floor (two workgroups may share a CU: the prologue /
     // epilogue bursts of one overlap the matrix phase of the other; pays when the launch is several rounds of workgroups)
     const int force = a.force_cfg < 0 ? -1 : (a.force_cfg & 0xff);
@@ -2655,7 +2658,7 @@ static int conv_v2_run(ConvV2Args &a)
     for (int c = 0; c < (int)(sizeof(CONV2_CFGS) / sizeof(CONV2_CFGS[0])); ++c) {
         const Conv2Cfg &k = CONV2_CFGS[c];
         if (force >= 0 && c != force) continue;
-        if (!conv2_plan(k, E, S, n_exec, Cin, Cout, bs, plan, KS)) continue;
+        if (!conv2_plan(k, E, S, n_exec, Cin, Cout, bs, plan, KS, 1, SPLIT)) continue;
         if (KS == 1 && pw == 4 && S == 1) continue;            // (pointwise stride-1 launches are re-tiled to 8x8 by the caller)
         const long long rounds = (plan.wgs + cus - 1) / cus;
         const double mf = (double)k.RM * k.RN * (double)(KS * KS) * (Cin / 8) * 4.0 / k.WKW;   // fp32 MFMAs per wave (16-bit: the same ranking)
@@ -2683,7 +2686,7 @@ static int conv_v2_run(ConvV2Args &a)
     // (decompositions whose double-buffered patch images cannot fit the LDS are never chosen by conv2_plan and are not compiled)
 #define BC_CV2(RM_, RN_, WMW_, WNW_, WKW_)                                                                                   \
     do {                                                                                                                 \
-        constexpr int SC_ = WKW_ == 8 ? SC_HI : SC_LO;                                                                   \
+        constexpr int SC_ = SPLIT ? (WKW_ == 8 ? 4 : (WKW_ == 4 ? 2 : 1)) : (WKW_ == 8 ? SC_HI : SC_LO);                  \
         constexpr int RM4_ = WMW_ == 1 ? RM_ : 1;                                                                        \
         constexpr size_t img8_ = (size_t)WMW_ * (S * 7 + KS) * (S * (4 * RM_ - 1) + KS) * (CvType<DT>::UV * SC_ + 1) * 32;  \
         constexpr size_t img4_ = (size_t)WMW_ * 2 * RM4_ * (S * 3 + KS) * (S * 3 + KS) * (CvType<DT>::UV * SC_ + 1) * 32; \
@@ -3034,7 +3037,8 @@ extern "C" int bc_part_conv_wino4(void *p) { return conv_wino4_run(*static_cast<
 extern "C" int BC_PART_NAME(BC_PART)(void *p)
 {
     ConvV2Args &a = *static_cast<ConvV2Args *>(p);
-    constexpr int DT = (BC_PART - 1) / 2, KS = (BC_PART - 1) % 2 == 0 ? 3 : 1;
+    // parts 1..6: dtype (BC_PART - 1) / 2; parts 12 / 13: the split form of the fp32 tensors (BC_F32S), kernel size 3 / 1
+    constexpr int DT = BC_PART >= 12 ? BC_F32S : (BC_PART - 1) / 2, KS = (BC_PART >= 12 ? BC_PART - 12 : BC_PART - 1) % 2 == 0 ? 3 : 1;
     return a.stride == 1 ? conv_v2_run<DT, 1, KS>(a) : conv_v2_run<DT, 2, KS>(a);
 }
 #endif
@@ -3066,6 +3070,7 @@ int bc_part_conv_wino(void *);
 int bc_part_conv_wino32(void *);
 int bc_part_conv_wino4(void *);
 int bc_part_conv_v2_dil(void *);
+int bc_part_conv_v2_12(void *); int bc_part_conv_v2_13(void *);
 }
 #endif
 
@@ -3100,6 +3105,19 @@ static int launch_conv3x3_v2(ProfScope &ps, void *out, const void *features, voi
 #endif
         if (a.chosen >= 0) g_tune.conv_last_cfg = a.chosen;
         return rcw;
+    }
+    if (DT == BC_F32 && a.force_cfg >= 0 && (a.force_cfg & 0x2000)) {
+        // the direct form on the 16-bit matrix pipe (operands split hi + lo, conv3x3_v2.inc BC_F32S): its own weight stream behind the others
+        ps.add_aux(direct_flops * 3.0 / 16.0);      // three 16-bit MFMAs of 16 channels where the fp32 pipe runs eight of 2
+        a.wpk = reinterpret_cast<const float *>(a.wpk) + (size_t)(KS == 3 ? 77 : 1) * a.Cin * a.Cout;
+        a.force_cfg &= ~0x2000;
+#if defined(BC_MONO)
+        const int rcs = conv_v2_run<BC_F32S, S, KS>(a);
+#else
+        const int rcs = KS == 3 ? bc_part_conv_v2_12(&a) : bc_part_conv_v2_13(&a);
+#endif
+        if (a.chosen >= 0) { a.chosen |= 0x2000; g_tune.conv_last_cfg = a.chosen; }
+        return rcs;
     }
     ps.add_aux(direct_flops);
 #if defined(BC_MONO)
@@ -3823,6 +3841,14 @@ static int conv_candidates(int dtype, int stride, int ks, int n_exec, int Cin, i
         Wino4Plan wp4;
         for (int c = 0; c < WINO4_N && n < max_out; ++c)
             if (wino4_plan(WINO4_CFGS[c], n_exec, Cin, Cout, bs, wp4)) out[n++] = c | 0x1000;
+    }
+    // the direct form on the 16-bit matrix pipe (fp32 tensors, operands split hi + lo; BC_F32S): with and without the LDS floor
+    if (dtype == BC_F32) {
+        for (int c = 0; c < n_cfg && n < max_out; ++c)
+            if (conv2_plan(CONV2_CFGS[c], E, stride, n_exec, Cin, Cout, bs, plan, ks, 1, true)) out[n++] = c | 0x2000;
+        for (int c = 0; c < n_cfg && n < max_out; ++c)
+            if (conv2_plan(CONV2_CFGS[c], E, stride, n_exec, Cin, Cout, bs, plan, ks, 1, true) && plan.lds_bytes <= (size_t)78 * 1024 && plan.wgs > device_cu_count())
+                out[n++] = c | 0x2100;
     }
     // the plain-GEMM form of a pointwise conv (fp32, stride 1; gemm1x1.inc): workgroup tiles 128x128, 128x64, 64x128, 64x64
     if (dtype == BC_F32 && stride == 1 && ks == 1 && Cin % 32 == 0) {
