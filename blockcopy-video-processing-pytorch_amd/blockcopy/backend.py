@@ -562,7 +562,7 @@ class HipBackend:
         Kp = (K + 31) // 32 * 32
         w = torch.zeros((N, Kp, 1, 1), dtype=torch.float32, device=weight.device)
         w[:, :K] = weight.detach().float()
-        return self.pack_conv3x3_weights(w)
+        return self.pack_conv3x3_weights(w)[:N * Kp].contiguous()      # (the direct one-tap stream only: no split stream behind it)
 
     def spp_levels(self, x, scale, shift, w, grids):
         """lv[bin][CO] of every level: conv1x1_l(relu(bn_l(adaptive_avg_pool2d(x, grid_l)))); bins of level l start at sum of the earlier grids.
@@ -827,7 +827,7 @@ class HipBackend:
         w = weight.detach().as_subclass(torch.Tensor)
         full = torch.zeros((32, w.shape[1], 1, 1), dtype=w.dtype, device=w.device)
         full[:w.shape[0]] = w
-        return self.pack_conv3x3_weights(full)
+        return self.pack_conv3x3_weights(full)[:32 * w.shape[1]].contiguous()      # (the direct one-tap stream only)
 
     def _head_launch(self, out, data, wpk, cout, prologue, bias, scatter, grid_idx=None, mapping_exec=None, prev=None, slots=None, dyn=None):
         B, C, bs, _ = data.shape
