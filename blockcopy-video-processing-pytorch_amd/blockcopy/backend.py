@@ -204,6 +204,7 @@ class HipBackend:
 
     def __init__(self, path: str = None):
         self.lib = load_library(path)
+        self.lib.bc_tune_set(b"stem_split", int(os.environ.get("BLOCKCOPY_STEM_SPLIT", "1")))      # (pack_stem7x7_weights provides the split streams)
         self._conv_cfg = None          # value last handed to the library
         self._conv_cfg_pinned = -1     # value pinned through tune("conv2_cfg", ...) for calls that do not choose themselves
 
@@ -999,8 +1000,14 @@ class HipBackend:
         seg[:, :, :21] = w.permute(0, 2, 3, 1).reshape(64, 7, 21)                 # [co][ky][3*kx + c]
         if w.element_size() == 4:
             v = seg.reshape(2, 32, 7, 3, 4, 2).permute(0, 2, 3, 5, 1, 4)            # nb, n, ky, t4, j, h -> nb, ky, t4, h, n, j
-        else:
-            v = seg.reshape(2, 32, 7, 2, 2, 8).permute(0, 2, 3, 4, 1, 5)            # nb, n, ky, s, h, j  -> nb, ky, s, h, n, j
+            # + the SPLIT streams (bc_tune "stem_split": the fp32 frame on the 16-bit matrix pipe): 16 w = hi + lo in fp16, each in the 16-bit order
+            seg16 = torch.zeros((64, 7, 32), dtype=torch.float32, device=w.device)
+            seg16[:, :, :21] = seg[:, :, :21] * 16.0
+            hi = seg16.to(torch.float16)
+            lo = (seg16 - hi.float()).to(torch.float16)
+            order16 = lambda t: t.reshape(2, 32, 7, 2, 2, 8).permute(0, 2, 3, 4, 1, 5).contiguous().view(-1).view(torch.float32)
+            return torch.cat([v.contiguous().view(-1), order16(hi), order16(lo)])
+        v = seg.reshape(2, 32, 7, 2, 2, 8).permute(0, 2, 3, 4, 1, 5)                # nb, n, ky, s, h, j  -> nb, ky, s, h, n, j
         return v.contiguous().view(-1)
 
     def stem7x7(self, frame_state, wpk, mapping_exec, bs, epilogue=None, dyn=None):

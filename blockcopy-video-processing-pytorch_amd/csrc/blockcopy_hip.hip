@@ -3058,6 +3058,8 @@ struct TuneState {
     // order cuts the weight-dominated launches to a third (PMC, profiles/r04/21: layer4 Winograd 7.76x -> 2.52x of the algorithmic bytes,
     // direct 4.57x -> 2.12x, dilated detector stage 5.8x -> 3.35x) -- fabric bandwidth a concurrent copy or replica does not have to share
     int xcd_remap = [] { const char *e = getenv("BC_XCD_REMAP"); return e ? atoi(e) : -1; }();
+    // fp32 stem on the 16-bit matrix pipe: needs the hi / lo weight streams behind the fp32 one (blockcopy.backend packs them and switches this on)
+    int stem_split = [] { const char *e = getenv("BC_STEM_SPLIT"); return e ? atoi(e) : 0; }();
     int head_split = [] { const char *e = getenv("BC_HEAD_SPLIT"); return e ? atoi(e) : 0; }();            // 1: k_head1x1_s for fp32 / Cout <= 20 (measured neutral in the frame, profiles/r05/09: stays off)
 } g_tune;
 
@@ -3960,6 +3962,7 @@ BC_EXPORT int bc_tune_set(const char *key, int value)
     if (!key) return BC_ERR_NULL;
     if (!strcmp(key, "conv_impl")) g_tune.conv_impl = value;
     else if (!strcmp(key, "conv2_cfg")) g_tune.conv2_cfg = value;
+    else if (!strcmp(key, "stem_split")) g_tune.stem_split = value;
     else if (!strcmp(key, "conv2_min_lds")) g_tune.conv2_min_lds = value;
     else if (!strcmp(key, "xcd_remap")) g_tune.xcd_remap = value;
     else if (!strcmp(key, "head_split")) g_tune.head_split = value;
@@ -3981,6 +3984,7 @@ BC_EXPORT int bc_tune_get(const char *key, int *value)
     if (!key || !value) return BC_ERR_NULL;
     if (!strcmp(key, "conv_impl")) *value = g_tune.conv_impl;
     else if (!strcmp(key, "conv2_cfg")) *value = g_tune.conv2_cfg;
+    else if (!strcmp(key, "stem_split")) *value = g_tune.stem_split;
     else if (!strcmp(key, "conv2_min_lds")) *value = g_tune.conv2_min_lds;
     else if (!strcmp(key, "xcd_remap")) *value = g_tune.xcd_remap;
     else if (!strcmp(key, "head_split")) *value = g_tune.head_split;
@@ -4127,19 +4131,25 @@ BC_EXPORT int bc_stem7x7s2_nhwc(void *out, const void *frame_state, const void *
     // one workgroup per CU at a time (LDS request > half a CU's): the 67 MB output of a C2 launch is then written by one round
     // of workgroups while the next round computes, instead of by all of them at the end (stem_min_lds = 0: natural occupancy)
     // (measured, tools/kbench_stem.py: fp32 67 -> 61 us; 16-bit launches are too short to gain: 19.8 -> 23.3 us, so fp32 only)
-    if (dtype == BC_F32 && lds < (size_t)g_tune.stem_min_lds) lds = g_tune.stem_min_lds;
+    // (the split form is as short as the 16-bit launches: natural occupancy 31.6 us against 36.4 with the floor)
+    if (dtype == BC_F32 && !g_tune.stem_split && lds < (size_t)g_tune.stem_min_lds) lds = g_tune.stem_min_lds;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stem7x7<BC_F32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stem7x7<BC_F16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stem7x7<BC_BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stem7x7<BC_F32S>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
         attr_set = true;
     }
     ProfScope ps(BC_OP_CONV3X3, 2.0 * n_exec * (bs / 2) * (bs / 2) * 147.0 * 64);
     // issued: 7 row taps x a K segment of 24 (fp32, 11 of its 12 k pairs: the all-padding pair is skipped) / 32 (16-bit) instead of 21
     ps.add_aux(2.0 * n_exec * (bs / 2) * (bs / 2) * (dtype == BC_F32 ? 154.0 : 224.0) * 64);
     const dim3 grid((unsigned)n_exec * g.patches_per_tile);
-    if (dtype == BC_F32)
+    if (dtype == BC_F32 && g_tune.stem_split)
+        // fp32 frame on the 16-bit matrix pipe (operands split hi + lo, stem7x7.inc BC_F32S): the hi / lo 16-bit weight streams follow the fp32 one
+        BC_LAUNCH(ps, (k_stem7x7<BC_F32S>), grid, dim3(512), lds, (hipStream_t)stream, (float *)out, (const float *)frame_state,
+                  (const uint4 *)weights_packed + 2 * 21 * 64, mapping_exec, g, ep);
+    else if (dtype == BC_F32)
         BC_LAUNCH(ps, (k_stem7x7<BC_F32>), grid, dim3(512), lds, (hipStream_t)stream, (float *)out, (const float *)frame_state,
                   (const uint4 *)weights_packed, mapping_exec, g, ep);
     else if (dtype == BC_F16)

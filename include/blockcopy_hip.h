@@ -316,7 +316,10 @@ int bc_conv_upsample_arm(const void *src, int src_bs, int out_bs, int align_corn
  *   weights_packed: per output-row tap ky the 21 (kx, c) values as one K segment, zero-padded to 24 (fp32) / 32 (16-bit):
  *     fp32   wpk[nb][ky][t4<3][lane][j<4] = Wseg[32*nb + lane%32][ky][8*t4 + 2*j + lane/32]
  *     16-bit wpk[nb][ky][s<2][lane][j<8]  = Wseg[32*nb + lane%32][ky][16*s + 8*(lane/32) + j],   Wseg[co][ky][3*kx + c] = W[co][c][ky][kx]
- *   Cout = 64, bs/2 a multiple of 32. */
+ *   Cout = 64, bs/2 a multiple of 32.
+ *   bc_tune_set("stem_split", 1): an fp32 frame is multiplied on the 16-bit matrix pipe at fp32 accuracy (every operand split hi + lo into two
+ *   fp16 numbers, 16 x = hi + lo, three MFMAs per product; measured error <= 1e-6 of the result's largest element): weights_packed then holds,
+ *   behind the fp32 stream, the hi and the lo stream in the 16-bit order (blockcopy.backend.pack_stem7x7_weights; 2 x 14 x 64 vectors each). */
 int bc_stem7x7s2_nhwc(void *out, const void *frame_state, const void *weights_packed, const int32_t *mapping_exec, int n_exec,
                       int N, int H, int W, int bs, int Cout, int dtype, const float *out_scale, const float *out_shift,
                       const void *out_add, int out_relu, void *stream);
@@ -362,14 +365,21 @@ int bc_adaptive_avg_pool_nhwc(void *out, const void *in, int N, int C, int H, in
  * fp32, stride 1: bc_conv1x1_candidates) for the plain-GEMM form csrc/gemm1x1.inc (index 0..3 = workgroup tile 128x128, 128x64,
  * 64x128, 64x64; reads the same packed one-tap weight stream) | 0x1000 for the Winograd F(4x4,3x3) form (fp32, stride 1, 3x3, tiles
  * of a multiple of 16 pixels or 8x8 tiles: csrc/conv3x3_wino4.inc; index 0..2 = (columns of 16*NB output channels, frequency groups,
- * NB) = (4,2,1), (2,4,1), (2,4,2) of its eight waves).  At most 128 codes.
+ * NB) = (4,2,1), (2,4,1), (2,4,2) of its eight waves) | 0x2000 (fp32 tensors, 3x3 and pointwise, both strides): decomposition `index` of the
+ * direct form on the 16-BIT matrix pipe at fp32 accuracy -- every staged value is split x = hi + lo into two fp16 numbers (16 x = hi + lo: |x| < 4094,
+ * 22 bits of mantissa) and a product is hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation (three MFMAs of 16 channels where the
+ * fp32 pipe runs eight of 2; measured error 3e-7 .. 1e-6 of the result's largest element, the fp32 direct form's own level); reads its own weight
+ * stream (below).  At most 128 codes.
  * The Winograd forms read further weight streams placed behind the direct one in weights_packed (fp32 3x3 only; 9 + 16 + 16 + 36 = 77
  * floats per (cin, cout) pair in all: direct, F(2x2) 16-channel tile, F(2x2) wide tile (conv3x3_wino32.inc), F(4x4)):
  *   wino[nb16][chunk][step < 4][q < 8][lane = 16*kq + n][e < 4] = (G g Gt)[f][cin = 32*chunk + 8*step + 2*kq + t][cout = 16*nb16 + n],
  *   2*f + t = 4*q + e, f = 4*xi + nu, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]  (16 * Cin * Cout floats after the 9 * Cin * Cout);
  *   wino4[cb][chunk][f < 36][lane = 16*kq + n][j < 4] = (G4 g G4t)[f][cin = 16*chunk + 4*kq + j][cout = 16*cb + n], f = 6*xi + nu,
  *   G4 = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]  (36 * Cin * Cout floats after the first 41 * Cin * Cout;
- *   products computed in fp64, rounded once).  A caller that never forces a 0x1000 code may pass a buffer without the last stream. */
+ *   products computed in fp64, rounded once).  A caller that never forces a 0x1000 code may pass a buffer without the last stream.
+ *   split (codes | 0x2000): the direct stream position by position, every 16-byte vector of four weights w0..w3 replaced by the eight fp16 numbers
+ *   [hi0..3 | lo0..3] with 16 w = hi + lo (9 * Cin * Cout floats after the first 77 * Cin * Cout; pointwise convs: Cin * Cout floats after the first
+ *   Cin * Cout). */
 /* The same fused halo + 3x3 conv with DILATION 2 (padding = dilation = 2, stride 1): the dilated last stage of a detector backbone
  * (Pedestron/mmdet/models/backbones/resnet.py:155-162; reference path: BlockPadFunction with pad 2 + F.conv2d(dilation=2),
  * core/tensorwrapper.py:529-575).  Everything as bc_conv3x3_ring_nhwc except: taps 2 pixels apart, halo / zero border 2 pixels
@@ -543,6 +553,7 @@ int bc_pn_features_nhwc(float *out, int N, int h, int w, int Cpad, const void *c
 /* tuning / A-B knob (measurement infrastructure; defaults are the shipped behaviour): key in
  *   "conv_impl"      1 = first-generation fused conv kernel, 2 = CU-balanced kernel (default)
  *   "conv2_cfg"      -1 = choose the decomposition per launch (default), 0..15 = force one (BC_ERR_SHAPE at launch if it does not fit)
+ *   "stem_split"     1 = bc_stem7x7s2_nhwc runs fp32 frames on the 16-bit matrix pipe (see there; default 0: the caller must have packed the streams)
  *   "xcd_remap"      1 = XCD-aware workgroup order in the fused conv kernels (workgroups that share an XCD take a contiguous,
  *                    output-channel-group-major run of logical ids); 0 (default) = launch order.  Speed only, results identical
  *   "conv2_min_lds"  dynamic LDS floor in bytes (default 84 KiB: one 8-wave workgroup per CU)
