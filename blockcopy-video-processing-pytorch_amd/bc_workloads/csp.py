@@ -109,12 +109,71 @@ class CSPNeck(nn.Module):
         self.p3_l2, self.p4_l2, self.p5_l2 = L2Norm(256, 10), L2Norm(256, 10), L2Norm(256, 10)
 
     def forward(self, inputs):
+        fused = self._deconv_l2norm_cat_fused(inputs)
+        if fused is not None:
+            return (fused,)
         ups = [self.p3(inputs[0]), self.p4(inputs[1]), self.p5(inputs[2])]
         fused = self._l2norm_cat_fused(ups)
         if fused is not None:
             return (fused,)
         p3, p4, p5 = self.p3_l2(ups[0]), self.p4_l2(ups[1]), self.p5_l2(ups[2])
         return (torch.cat([p3, p4, p5], dim=1),)
+
+    def _deconv_l2norm_cat_fused(self, inputs):
+        """The whole neck without a transposed-conv launch: per level ONE pointwise conv to 16 x 256 channels on the matrix cores (the 16 taps of
+        every input pixel: exactly the transposed conv's multiplications, bc_conv1x1_nhwc) and one pass that gathers the taps of every output
+        pixel, adds the bias, L2-normalises and writes the level's slice of the 768-channel tensor (bc_l2norm_cat_deconv_nhwc).  The reference
+        (csp_neck.py:37-43, 68-100) runs conv_transpose2d per packed tile WITHOUT a halo, then six elementwise passes per level and a cat.
+        Channels-last GPU tensors of the reference's geometry only (k4 s2 p1 / k4 s4 p0 / k4 s4 p0); anything else takes the stock ops."""
+        x0 = inputs[0]
+        if (not (torch.is_tensor(x0) and x0.is_cuda) or os.environ.get("BLOCKCOPY_FUSED_NECK", "1") == "0"
+                or os.environ.get("BLOCKCOPY_FUSED_DECONV", "1") == "0" or len(inputs) != 3):
+            return None
+        from blockcopy.backend import get_backend, is_nhwc
+        from blockcopy.core import fusion
+
+        be = get_backend()
+        if not hasattr(be, "l2norm_cat_deconv"):
+            return None
+        levels = ((self.p3, self.p3_l2, 2, (1, 1)), (self.p4, self.p4_l2, 4, (0, 0)), (self.p5, self.p5_l2, 4, (0, 0)))
+        for ct, _, st, pad in levels:
+            if not (isinstance(ct, nn.ConvTranspose2d) and ct.kernel_size == (4, 4) and ct.stride == (st, st) and ct.padding == pad
+                    and ct.output_padding == (0, 0) and ct.groups == 1 and ct.dilation == (1, 1)):
+                return None
+        raws = [u._materialize()._raw() if hasattr(u, "_raw") else u for u in inputs]
+        params = [t for ct, l2, _, _ in levels for t in (ct.weight, ct.bias, l2.weight) if t is not None]
+        if torch.is_grad_enabled() and any(t.requires_grad for t in (*raws, *params)):
+            return None
+        B, dt = raws[0].shape[0], raws[0].dtype
+        size = None
+        for r, (ct, l2, st, _) in zip(raws, levels):
+            cin_unit = 32 if dt == torch.float32 else 64
+            ve = 16 // r.element_size()
+            ok = (r.dim() == 4 and r.is_cuda and r.dtype == dt and is_nhwc(r) and r.shape[0] == B and r.shape[1] == ct.in_channels and r.shape[1] % cin_unit == 0
+                  and ct.out_channels % ve == 0 and ct.out_channels // ve <= 64 and ct.weight.dtype == dt and be.conv1x1_geometry(r, 1) is not None)
+            if not ok or (size is not None and (r.shape[2] * st, r.shape[3] * st) != size):
+                return None
+            size = (r.shape[2] * st, r.shape[3] * st)
+        c_total = sum(ct.out_channels for ct, _, _, _ in levels)
+        out = torch.empty((B, size[0], size[1], c_total), dtype=dt, device=raws[0].device).permute(0, 3, 1, 2)
+        off = 0
+        for r, (ct, l2, st, _) in zip(raws, levels):
+            cout16 = 16 * ct.out_channels
+            wpk = fusion.packed_conv3x3_weight(ct.weight, be.pack_deconv4_weights)
+
+            def tuner(r=r, wpk=wpk, cout16=cout16):
+                routes = {str(c): (lambda c_: lambda: be.conv1x1(r, wpk, cout16, None, None, cfg=c_, stride=1))(c) for c in be.conv1x1_candidates(r, cout16, 1)}
+                return be.time_routes(routes) if routes else None
+
+            n_px = r.shape[0] * r.shape[2] * r.shape[3]
+            plan = fusion.conv3x3_plan(max(1, n_px // 64), 8, r.shape[1], cout16, 0, dt, tuner, 1, ks=1)
+            taps = be.conv1x1(r, wpk, cout16, None, None, cfg=-1 if plan is None else plan, stride=1)
+            bias = ct.bias.detach().float().contiguous() if ct.bias is not None else None
+            be.l2norm_cat_deconv(out, off, taps, bias, l2.weight.detach().float().contiguous(), st, l2.eps)
+            off += ct.out_channels
+        if hasattr(x0, "_raw"):
+            return type(x0)._wrap_result(out, x0)
+        return out
 
     def _l2norm_cat_fused(self, ups):
         """The three L2Norms and the concatenation as one pass per level straight into the 768-channel tensor (bc_l2norm_cat_nhwc:
@@ -208,6 +267,16 @@ class CSPHead(nn.Module):
             from blockcopy.backend import get_backend
 
             # (maps no larger than nms_pre take the route below: without a top-k the reference keeps the candidates in raster order)
+            be = get_backend()
+            if (os.environ.get("BLOCKCOPY_FUSED_TOPK", "1") != "0" and hasattr(be, "csp_topk_decode_nms") and bbox_pred.dtype == torch.float32
+                    and offset_pred.dtype == torch.float32 and h * w < (1 << 30)):
+                # ... and the top-k itself inside the decode launch: two launches from the head's maps to the kept boxes
+                om = offset_pred[0]
+                if om.stride(1) != w * om.stride(2):
+                    om = om.contiguous()
+                dets = be.csp_topk_decode_nms(cls_score[0, 0].contiguous(), bbox_pred[0, 0].contiguous(), om, nms_pre, s, self.wh_ratio, img_shape,
+                                              score_thr, iou_thr, max_per_img)
+                return dets, torch.zeros(dets.shape[0], dtype=torch.long, device=dev)
             scores, top = cls_score[0].reshape(-1).float().sigmoid().topk(nms_pre)
             heights = bbox_pred[0].reshape(-1)[top].exp()
             off = offset_pred[0].reshape(2, -1)[:, top]

@@ -140,6 +140,7 @@ def load_library(path: str = None) -> ctypes.CDLL:
         "bc_conv_upsample_arm": [p, i, i, i, ctypes.c_float, ctypes.c_float],
         "bc_nms_sorted_dev": [p, i, p, ctypes.c_float, p, p, p, p],
         "bc_csp_decode": [p, p, p, p, p, i, i, i, ctypes.c_float, i, i, ctypes.c_float, p, p, p],
+        "bc_csp_topk_decode": [p, i, p, p, ctypes.c_longlong, ctypes.c_longlong, i, i, i, i, ctypes.c_float, i, i, ctypes.c_float, p, p, p, p],
         "bc_interp_bilinear_nhwc": [p, p, ctypes.c_longlong, i, i, i, i, i, i, ctypes.c_float, ctypes.c_float, i, p],
         "bc_upsample_argmax": [p, p, i, i, i, i, i, i, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, i,
                                ctypes.c_float, ctypes.c_float, i, p],
@@ -151,6 +152,7 @@ def load_library(path: str = None) -> ctypes.CDLL:
         "bc_group_norm_affine_nhwc": [p, ctypes.c_longlong, i, i, i, ctypes.c_float, p, p, p, p, p, ctypes.c_longlong, p],
         "bc_nms_sorted": [p, i, ctypes.c_float, p, p, p, p],
         "bc_l2norm_cat_nhwc": [p, p, p, ctypes.c_longlong, i, i, i, ctypes.c_float, i, p],
+        "bc_l2norm_cat_deconv_nhwc": [p, p, p, p, i, i, i, i, i, i, i, ctypes.c_float, i, p],
         "bc_policy_step": [p, i, ctypes.c_ulonglong, ctypes.c_ulonglong, i, i, p, p, p, p, p, p],
         "bc_policy_features": [p, i, i, i, p, p, p, p, p],
         "bc_pn_conv_nhwc": [p, p, p] + [i] * 10 + [p, p, i, p, p, i, p, ctypes.c_longlong, i, p],
@@ -951,6 +953,28 @@ class HipBackend:
                                                     _DTYPE_CODE[x.dtype], self._stream()), "l2norm_cat_nhwc")
         return out
 
+    @staticmethod
+    def pack_deconv4_weights(weight):
+        """ConvTranspose2d weight (Cin, Cout, 4, 4) -> the pointwise conv (16 Cout, Cin, 1, 1) whose output channel (4 ky + kx) Cout + co is
+        tap (ky, kx) of output channel co, packed for bc_conv1x1_nhwc (l2norm_cat_deconv gathers the taps)."""
+        cin, cout, kh, kw = weight.shape
+        assert (kh, kw) == (4, 4)
+        w = weight.detach().as_subclass(torch.Tensor).permute(2, 3, 1, 0).reshape(16 * cout, cin, 1, 1).contiguous()
+        return HipBackend.pack_conv3x3_weights(w)
+
+    def l2norm_cat_deconv(self, out, c_off, t, bias, weight, stride, eps):
+        """out[:, c_off : c_off + C] = L2Norm(conv_transpose(k4, stride 4 pad 0 | stride 2 pad 1) + bias) from the 16-tap patches t (B, 16 C, h, w)
+        (channels-last) of a pointwise conv with pack_deconv4_weights."""
+        B, C16, h, w = t.shape
+        C = C16 // 16
+        assert is_nhwc(t) and is_nhwc(out) and out.dtype == t.dtype and out.shape[0] == B and tuple(out.shape[2:]) == (h * stride, w * stride)
+        assert _ok(weight, torch.float32) and weight.numel() == C and (bias is None or (_ok(bias, torch.float32) and bias.numel() == C))
+        with torch.cuda.device_of(t):
+            self._check(self.lib.bc_l2norm_cat_deconv_nhwc(out.data_ptr(), t.data_ptr(), bias.data_ptr() if bias is not None else None, weight.data_ptr(),
+                                                           B, h, w, C, out.shape[1], int(c_off), int(stride), float(eps), _DTYPE_CODE[t.dtype],
+                                                           self._stream()), "l2norm_cat_deconv_nhwc")
+        return out
+
     # -- group_norm over all executed tiles as a per-channel affine map (one read of the tensor)
     @staticmethod
     def group_norm_affine_supported(data, groups):
@@ -1226,6 +1250,32 @@ class HipBackend:
                                                    cnt.data_ptr() + 4, self._stream()), "nms_sorted_dev")
         n_keep = int(cnt[1].item())
         return dets[keep[:min(n_keep, int(max_out))].long()]
+
+    def csp_topk_decode_nms(self, cls_map, reg_map, off_map, k, stride, wh_ratio, img_shape, score_thr, iou_thr, max_out, return_top=False):
+        """The whole decode from the head's maps to the kept boxes in TWO launches (bc_csp_topk_decode + bc_nms_sorted_dev) and one read of
+        the kept count: ``cls_map`` (h, w) centre logits (any supported float type), ``reg_map`` (h, w) float scale predictions, ``off_map``
+        (2, h, w) float offsets in any dense layout (strides are passed on).  Equal scores: lowest position first."""
+        h, w = cls_map.shape[-2:]
+        n = h * w
+        assert cls_map.numel() == n and reg_map.numel() == n and off_map.numel() == 2 * n and off_map.shape[0] == 2 and 0 < k <= min(n, 4096)
+        assert cls_map.is_cuda and cls_map.dtype in _DTYPES and cls_map.is_contiguous() and _ok(reg_map, torch.float32) and reg_map.is_contiguous()
+        assert off_map.dtype == torch.float32 and off_map.stride(1) == w * off_map.stride(2)
+        dev = cls_map.device
+        dets = torch.empty((k, 5), dtype=torch.float32, device=dev)
+        cnt = torch.empty(2, dtype=torch.int32, device=dev)           # [selected, kept]
+        ws = torch.empty(k * ((k + 63) // 64) + k, dtype=torch.int64, device=dev)
+        keep = torch.empty(k, dtype=torch.int32, device=dev)
+        top = torch.empty(k, dtype=torch.int32, device=dev) if return_top else None
+        with torch.cuda.device_of(cls_map):
+            self._check(self.lib.bc_csp_topk_decode(cls_map.data_ptr(), _DTYPES[cls_map.dtype], reg_map.data_ptr(), off_map.data_ptr(),
+                                                    off_map.stride(0), off_map.stride(2), n, int(k), int(w), int(stride), float(wh_ratio),
+                                                    int(img_shape[0]), int(img_shape[1]), float(score_thr), dets.data_ptr(), cnt.data_ptr(),
+                                                    top.data_ptr() if top is not None else None, self._stream()), "csp_topk_decode")
+            self._check(self.lib.bc_nms_sorted_dev(dets.data_ptr(), k, cnt.data_ptr(), float(iou_thr), ws.data_ptr(), keep.data_ptr(),
+                                                   cnt.data_ptr() + 4, self._stream()), "nms_sorted_dev")
+        n_keep = int(cnt[1].item())
+        out = dets[keep[:min(n_keep, int(max_out))].long()]
+        return (out, top, dets, cnt) if return_top else out
 
     # -- C. measurement -----------------------------------------------------------------------------------
     def tune(self, key: str, value: int):

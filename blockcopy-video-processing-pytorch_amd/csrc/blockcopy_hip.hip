@@ -2166,6 +2166,183 @@ __global__ __launch_bounds__(1024) void k_csp_decode(DecodeGeom g, const float *
     }
 }
 
+// The head's top-k IN the decode launch (csp_head.py:262-267: cls.sigmoid().topk(nms_pre), then the gathers of scale and offset): one workgroup,
+// no sort of the map.  (1) every thread keeps the maxima of M strided groups of the score map (G = 1024 M groups): the k-th largest group
+// maximum L is a LOWER bound of the k-th largest score (k groups hold k distinct elements >= L); a bitonic sort of the G maxima in LDS finds it.
+// (2) elements >= L are appended to an LDS list (about k (1 + k / 2G) of them on a typical map); (3) the list, as (score bits, ~position)
+// words, is sorted and its first k rows decoded.  A map with more than TOPK_CAP elements >= L (constant maps, long runs of saturated scores)
+// takes an exact radix select on the same 64-bit words first.  Order among equal scores: lowest flat position first (torch.topk leaves it
+// unspecified; with distinct scores the rows are torch.topk's).  sigmoid = 1 / (1 + exp(-x)) in fp32, as the reference's tensor expression.
+constexpr int TOPK_CAP = 8192;
+struct TopkGeom { int n, k, W, stride; float wh_ratio, x_max, y_max, thr; long long off_cs, off_ps; int cls_dtype; };
+
+template <typename K>
+__device__ __forceinline__ void lds_bitonic_desc(K *s, int P)
+{
+    for (int size = 2; size <= P; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = threadIdx.x; t < P / 2; t += 1024) {
+                const int i = 2 * t - (t & (stride - 1)), j = i + stride;
+                const K a = s[i], b = s[j];
+                if ((a < b) == ((i & size) == 0)) { s[i] = b; s[j] = a; }
+            }
+            __syncthreads();
+        }
+}
+
+template <int M>
+__global__ __launch_bounds__(1024) void k_csp_topk_decode(TopkGeom g, const void *__restrict__ cls, const float *__restrict__ reg,
+                                                          const float *__restrict__ off, float *__restrict__ dets, int32_t *__restrict__ n_sel,
+                                                          int32_t *__restrict__ top_out)
+{
+    extern __shared__ __align__(16) unsigned char topk_lds[];
+    unsigned long long *cand = reinterpret_cast<unsigned long long *>(topk_lds);      // TOPK_CAP words; first the G group maxima (uint32)
+    uint32_t *gmax = reinterpret_cast<uint32_t *>(topk_lds);
+    uint32_t *hist = reinterpret_cast<uint32_t *>(topk_lds + (size_t)TOPK_CAP * 8);   // 2048 bins (radix route only)
+    __shared__ uint32_t s_cnt, s_digit, s_above, s_bin;
+    __shared__ int wave_cnt[16];
+    constexpr int G = 1024 * M;
+    const int tid = threadIdx.x, lane = tid & 63;
+    auto key_of = [&](int i) -> uint32_t {          // score bits + 1 (scores are >= 0: the bits order like the values; 0 = "no element")
+        float x;
+        if (g.cls_dtype == BC_F32) x = static_cast<const float *>(cls)[i];
+        else if (g.cls_dtype == BC_F16) x = __half2float(static_cast<const __half *>(cls)[i]);
+        else x = Cvt<hip_bfloat16>::ld(static_cast<const hip_bfloat16 *>(cls) + i);
+        const float sc = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-x)));
+        return __builtin_bit_cast(uint32_t, sc) + 1u;
+    };
+    auto word_of = [&](uint32_t key, int i) -> unsigned long long { return ((unsigned long long)key << 32) | (uint32_t)(0xffffffffu - (uint32_t)i); };
+    // (1) group maxima
+    uint32_t mx[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) mx[m] = 0u;
+    for (int base = 0; base < g.n; base += G) {
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const int i = base + m * 1024 + tid;
+            if (i < g.n) mx[m] = max(mx[m], key_of(i));
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < M; ++m) gmax[m * 1024 + tid] = mx[m];
+    if (tid == 0) s_cnt = 0u;
+    __syncthreads();
+    lds_bitonic_desc(gmax, G);
+    const uint32_t L = gmax[g.k - 1];
+    __syncthreads();
+    // (2) candidates (one LDS atomic per wave and trip)
+    auto append = [&](bool take, unsigned long long word) {
+        const unsigned long long bal = __ballot(take);
+        uint32_t base = 0;
+        if (lane == 0 && bal) base = atomicAdd(&s_cnt, (uint32_t)__builtin_popcountll(bal));
+        base = __builtin_amdgcn_readfirstlane(base);
+        const uint32_t slot = base + (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
+        if (take && slot < (uint32_t)TOPK_CAP) cand[slot] = word;
+    };
+    for (int base = 0; base < g.n; base += 1024) {
+        const int i = base + tid;
+        const uint32_t key = i < g.n ? key_of(i) : 0u;
+        append(i < g.n && key >= L, word_of(key, i));
+    }
+    __syncthreads();
+    uint32_t n_cand = s_cnt;
+    if (n_cand > (uint32_t)TOPK_CAP) {
+        // exact selection of the k-th largest WORD (words are distinct): 11-bit digits from the top, stop when the digit's bin is taken whole
+        unsigned long long prefix = 0ull;
+        uint32_t r = (uint32_t)g.k;
+        int consumed = 0;
+        for (int pass = 0; pass < 6; ++pass) {
+            const int bits = pass < 5 ? 11 : 9, shift = 64 - consumed - bits;
+            for (int b = tid; b < 2048; b += 1024) hist[b] = 0u;
+            __syncthreads();
+            for (int base = 0; base < g.n; base += 1024) {
+                const int i = base + tid;
+                if (i < g.n) {
+                    const uint32_t key = key_of(i);
+                    if (key >= L) {
+                        const unsigned long long wd = word_of(key, i);
+                        if (consumed == 0 || (wd >> (64 - consumed)) == prefix) atomicAdd(&hist[(uint32_t)(wd >> shift) & ((1u << bits) - 1u)], 1u);
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid < 64) {             // bins from the top: lane l owns bins 2047 - 32 l ... 2016 - 32 l
+                uint32_t sum = 0;
+                for (int q = 0; q < 32; ++q) sum += hist[2047 - (32 * lane + q)];
+                uint32_t incl = sum;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t v = __shfl_up(incl, o);
+                    if (lane >= o) incl += v;
+                }
+                const uint32_t excl = incl - sum;
+                if (excl < r && r <= incl) {
+                    uint32_t above = excl;
+                    for (int q = 0; q < 32; ++q) {
+                        const uint32_t c = hist[2047 - (32 * lane + q)];
+                        if (r <= above + c) { s_digit = 2047u - (uint32_t)(32 * lane + q); s_above = above; s_bin = c; break; }
+                        above += c;
+                    }
+                }
+            }
+            __syncthreads();
+            r -= s_above;
+            prefix = (prefix << bits) | s_digit;
+            consumed += bits;
+            const bool whole = (r == s_bin);
+            __syncthreads();
+            if (whole) break;
+        }
+        const unsigned long long T = consumed == 64 ? prefix : (prefix << (64 - consumed));
+        if (tid == 0) s_cnt = 0u;
+        __syncthreads();
+        for (int base = 0; base < g.n; base += 1024) {
+            const int i = base + tid;
+            const uint32_t key = i < g.n ? key_of(i) : 0u;
+            const unsigned long long wd = word_of(key, i);
+            append(i < g.n && key >= L && wd >= T, wd);
+        }
+        __syncthreads();
+        n_cand = s_cnt;                 // == k
+    }
+    // (3) sort the candidates (padding: 0 < every word), decode the first k
+    int P = 2;
+    while (P < (int)n_cand) P <<= 1;
+    for (int t = (int)n_cand + tid; t < P; t += 1024) cand[t] = 0ull;
+    __syncthreads();
+    lds_bitonic_desc(cand, P);
+    const float sf = (float)g.stride, half = (float)(g.stride / 2);
+    int mine = 0;
+    for (int k = tid; k < g.k; k += 1024) {
+        const unsigned long long wd = cand[k];
+        const int i = (int)(0xffffffffu - (uint32_t)wd);
+        const float sc = __builtin_bit_cast(float, (uint32_t)(wd >> 32) - 1u);
+        const int row = i / g.W, col = i - row * g.W;
+        const float px = __fadd_rn((float)(col * g.stride), half), py = __fadd_rn((float)(row * g.stride), half);
+        const float oy = off[(size_t)i * g.off_ps], ox = off[(size_t)g.off_cs + (size_t)i * g.off_ps];
+        const float x = __fadd_rn(px, __fmul_rn(ox, sf)), y = __fadd_rn(py, __fmul_rn(oy, sf));
+        const float hh = __fmul_rn(expf(reg[i]), sf);
+        const float a = __fmul_rn(__fmul_rn(g.wh_ratio, hh), 0.5f), b = __fmul_rn(hh, 0.5f);
+        float *d = dets + (size_t)k * 5;
+        d[0] = fminf(fmaxf(__fsub_rn(x, a), 0.0f), g.x_max);
+        d[1] = fminf(fmaxf(__fsub_rn(y, b), 0.0f), g.y_max);
+        d[2] = fminf(fmaxf(__fadd_rn(x, a), 0.0f), g.x_max);
+        d[3] = fminf(fmaxf(__fadd_rn(y, b), 0.0f), g.y_max);
+        d[4] = sc;
+        if (top_out) top_out[k] = i;
+        mine += sc > g.thr ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+    if (lane == 0) wave_cnt[tid >> 6] = mine;
+    __syncthreads();
+    if (tid == 0) {
+        int t = 0;
+        for (int w = 0; w < 16; ++w) t += wave_cnt[w];
+        *n_sel = t;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ L2 normalisation into a channel slice
 // out[p][c_off + c] = weight[c] * (x[p][c] / (sqrt(sum_c x[p][c]^2) + eps)) for the pixels p of a channels-last tensor: the detector
 // neck's L2Norm (Pedestron/mmdet/models/necks/csp_neck.py:85 -- pow, sum over channels, sqrt, + eps, div, scale: six elementwise /
@@ -2207,6 +2384,79 @@ __global__ __launch_bounds__(256) void k_l2norm_cat(T *__restrict__ out, const T
 #pragma unroll
             for (int j = 0; j < EPV; ++j) eo[j] = Cvt<T>::st(weight[q * EPV + j] * (Cvt<T>::ld(e + j) / norm));
             reinterpret_cast<uint4 *>(out + (size_t)p * C_total + c_off)[q] = o;
+        }
+    }
+}
+
+// The detector neck's TRANSPOSED convs (Pedestron/mmdet/models/necks/csp_neck.py:37-39: k4 s2 p1 on the stride-8 stage, k4 s4 p0 on the stride-16
+// stages) as a pointwise GEMM + this pass.  conv_transpose2d(x, W)[Y][X][co] = sum over the taps (ky, kx) that reach the pixel of
+// sum_ci x[y][x][ci] W[ci][co][ky][kx]: the inner sum for ALL 16 taps of an input pixel is ONE 1x1 conv to 16 C channels (t[y][x][(4 ky + kx) C + co],
+// bc_conv1x1_nhwc on the matrix cores, exactly the transposed conv's multiplications -- no zeros inserted, no im2col), and what is left is a
+// gather: stride 4 -- every output pixel has one tap, (y, ky) = (Y / 4, Y % 4): depth-to-space; stride 2, pad 1 -- up to 2 x 2 taps,
+// Y = 2 y + ky - 1, contributions from outside the TILE are absent (the reference applies the layer to packed tiles without a halo).  The gather
+// rides in the L2Norm + concat pass that reads the result anyway (k_l2norm_cat): the up-sampled map is never written.  + bias, one wave per
+// output pixel, C = 64 lanes x 4 channels (C <= 256 per 16-byte lane vector of fp32; 16-bit: 8 per lane).
+template <typename T, int STRIDE>
+__global__ __launch_bounds__(256) void k_l2norm_cat_deconv(T *__restrict__ out, const T *__restrict__ t, const float *__restrict__ bias,
+                                                           const float *__restrict__ weight, uint32_t n_img, uint32_t h, uint32_t w, uint32_t C,
+                                                           uint32_t C_total, uint32_t c_off, float eps)
+{
+    constexpr int EPV = 16 / sizeof(T);
+    const uint32_t lane = threadIdx.x & 63, vecs = C / EPV;
+    const uint32_t H = h * STRIDE, W = w * STRIDE;
+    const long long n_pix = (long long)n_img * H * W;
+    const long long wave0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (long long)gridDim.x * 4;
+    for (long long p = wave0; p < n_pix; p += n_waves) {
+        const uint32_t X = (uint32_t)(p % W), Y = (uint32_t)((p / W) % H), img = (uint32_t)(p / ((long long)W * H));
+        float f[EPV];
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) f[j] = 0.0f;
+        if (lane < vecs) {
+            auto add_tap = [&](uint32_t y, uint32_t x, uint32_t ky, uint32_t kx) {
+                const uint4 v = reinterpret_cast<const uint4 *>(t + ((((size_t)img * h + y) * w + x) * 16 + (ky * 4 + kx)) * C)[lane];
+                const T *e = reinterpret_cast<const T *>(&v);
+#pragma unroll
+                for (int j = 0; j < EPV; ++j) f[j] += Cvt<T>::ld(e + j);
+            };
+            if (STRIDE == 4) {
+                add_tap(Y >> 2, X >> 2, Y & 3, X & 3);
+            } else {
+                // Y = 2 y + ky - 1: ky has the parity of Y + 1; (ky, y) = (p, (Y + 1 - p) / 2), (p + 2, (Y - 1 - p) / 2)
+                const uint32_t py = (Y + 1) & 1, px = (X + 1) & 1;
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const int y = ((int)Y + 1 - (int)py - 2 * a) / 2;
+                    if ((int)Y + 1 - (int)py - 2 * a < 0 || y >= (int)h) continue;
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const int x = ((int)X + 1 - (int)px - 2 * b) / 2;
+                        if ((int)X + 1 - (int)px - 2 * b < 0 || x >= (int)w) continue;
+                        add_tap((uint32_t)y, (uint32_t)x, py + 2 * a, px + 2 * b);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) {
+                if (bias) f[j] += bias[lane * EPV + j];
+                f[j] = Cvt<T>::ld_round(f[j]);      // (the transposed conv's result in the tensor's type, as the stock op stores it)
+            }
+        }
+        float sq = 0.0f;
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) sq = fmaf(f[j], f[j], sq);
+        sq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sq), 0x111, 0xf, 0xf, false));
+        sq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sq), 0x112, 0xf, 0xf, false));
+        sq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sq), 0x114, 0xf, 0xf, false));
+        sq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sq), 0x118, 0xf, 0xf, false));
+        sq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sq), 0x142, 0xa, 0xf, false));
+        sq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sq), 0x143, 0xc, 0xf, false));
+        const float norm = sqrtf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sq), 63))) + eps;
+        if (lane < vecs) {
+            uint4 o;
+            T *eo = reinterpret_cast<T *>(&o);
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) eo[j] = Cvt<T>::st(weight[lane * EPV + j] * (f[j] / norm));
+            reinterpret_cast<uint4 *>(out + (size_t)p * C_total + c_off)[lane] = o;
         }
     }
 }
@@ -3738,6 +3988,27 @@ BC_EXPORT int bc_csp_decode(const float *scores, const long long *top, const flo
     return launch_status();
 }
 
+BC_EXPORT int bc_csp_topk_decode(const void *cls, int cls_dtype, const float *reg, const float *off, long long off_channel_stride,
+                                 long long off_pixel_stride, int n, int k, int map_w, int stride, float wh_ratio, int img_h, int img_w,
+                                 float score_thr, float *dets, int32_t *n_sel, int32_t *top_out, void *stream)
+{
+    if (n <= 0 || k <= 0 || k > n || k > 4096 || map_w <= 0 || stride <= 0 || img_h <= 0 || img_w <= 0 || n > (1 << 30)) return BC_ERR_SHAPE;
+    if (cls_dtype != BC_F32 && cls_dtype != BC_F16 && cls_dtype != BC_BF16) return BC_ERR_ELEM;
+    if (!cls || !reg || !off || !dets || !n_sel) return BC_ERR_NULL;
+    TopkGeom g{n, k, map_w, stride, wh_ratio, (float)(img_w - 1), (float)(img_h - 1), score_thr, off_channel_stride, off_pixel_stride, cls_dtype};
+    const size_t lds = (size_t)TOPK_CAP * 8 + 2048 * 4;
+    static thread_local bool attr_set[2] = {false, false};          // (per thread: cheap, and no cross-device assumption: the attribute is per function)
+    ProfScope ps(BC_OP_NMS, 4.0 * n + 44.0 * k);
+    if (k <= 1024) {
+        if (!attr_set[0]) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_csp_topk_decode<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set[0] = true; }
+        BC_LAUNCH(ps, k_csp_topk_decode<4>, dim3(1), dim3(1024), lds, (hipStream_t)stream, g, cls, reg, off, dets, n_sel, top_out);
+    } else {
+        if (!attr_set[1]) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_csp_topk_decode<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set[1] = true; }
+        BC_LAUNCH(ps, k_csp_topk_decode<16>, dim3(1), dim3(1024), lds, (hipStream_t)stream, g, cls, reg, off, dets, n_sel, top_out);
+    }
+    return launch_status();
+}
+
 BC_EXPORT int bc_interp_bilinear(void *out, const void *in, long long planes, int h, int w, int H, int W,
                                  int align_corners, float rh, float rw, int dtype, void *stream)
 {
@@ -4344,6 +4615,39 @@ BC_EXPORT int bc_l2norm_cat_nhwc(void *out, const void *x, const float *weight, 
     else BC_L2T(hip_bfloat16);
 #undef BC_L2T
 #undef BC_L2
+    return launch_status();
+}
+
+/* transposed conv (k4 s4 p0 or k4 s2 p1, per image = per packed tile, no halo) + bias + L2Norm + concat from the 16-tap patches
+ * t (n_img, h, w, 16 C) a pointwise conv produced (see k_l2norm_cat_deconv): out (n_img, stride h, stride w, C_total)[..., c_off : c_off + C] */
+BC_EXPORT int bc_l2norm_cat_deconv_nhwc(void *out, const void *t, const float *bias, const float *weight, int n_img, int h, int w, int C, int C_total,
+                                        int c_off, int stride, float eps, int dtype, void *stream)
+{
+    if (dtype < BC_F32 || dtype > BC_BF16) return BC_ERR_ELEM;
+    const int E = dtype == BC_F32 ? 4 : 2, epv = 16 / E;
+    if (n_img < 0 || h <= 0 || w <= 0 || C <= 0 || C_total < C || c_off < 0 || c_off + C > C_total || C % epv || c_off % epv || C_total % epv ||
+        C / epv > 64 || !(stride == 4 || stride == 2))
+        return BC_ERR_SHAPE;
+    if (n_img == 0) return BC_OK;
+    if (!out || !t || !weight) return BC_ERR_NULL;
+    const long long n_pix = (long long)n_img * h * w * stride * stride;
+    if ((uint64_t)n_pix * (uint64_t)C_total >= (1ull << 40) || (uint64_t)n_img * h * w * 16 * C >= (1ull << 40)) return BC_ERR_RANGE;
+    if (!aligned(out, 16) || !aligned(t, 16)) return BC_ERR_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    long long wgs = (n_pix + 3) / 4;
+    if (wgs > 256 * 16) wgs = 256 * 16;
+    ProfScope ps(BC_OP_AFFINE, (double)n_pix * C * E * (stride == 4 ? 2.0 : 5.0));
+#define BC_LD(T_)                                                                                                                                   \
+    do {                                                                                                                                             \
+        if (stride == 4) BC_LAUNCH(ps, (k_l2norm_cat_deconv<T_, 4>), dim3((unsigned)wgs), dim3(256), 0, st, (T_ *)out, (const T_ *)t, bias, weight, \
+                                   (uint32_t)n_img, (uint32_t)h, (uint32_t)w, (uint32_t)C, (uint32_t)C_total, (uint32_t)c_off, eps);                  \
+        else BC_LAUNCH(ps, (k_l2norm_cat_deconv<T_, 2>), dim3((unsigned)wgs), dim3(256), 0, st, (T_ *)out, (const T_ *)t, bias, weight,             \
+                       (uint32_t)n_img, (uint32_t)h, (uint32_t)w, (uint32_t)C, (uint32_t)C_total, (uint32_t)c_off, eps);                             \
+    } while (0)
+    if (dtype == BC_F32) BC_LD(float);
+    else if (dtype == BC_F16) BC_LD(__half);
+    else BC_LD(hip_bfloat16);
+#undef BC_LD
     return launch_status();
 }
 

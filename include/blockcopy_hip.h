@@ -419,6 +419,14 @@ int bc_maxpool3x3s2_ring_nhwc(void *out, const void *features, void *ring, const
  * order), one rounding at the store.  C, c_off, C_total multiples of 16 / elem_size, C <= 256 * 16 / elem_size. */
 int bc_l2norm_cat_nhwc(void *out, const void *x, const float *weight, long long n_pix, int C, int C_total, int c_off, float eps, int dtype,
                        void *stream);
+/* The detector neck's transposed convs without a transposed-conv launch (Pedestron/mmdet/models/necks/csp_neck.py:37-39, 68-83): t = the 16-tap
+ * patches of every input pixel, t (n_img, h, w, 16 C) with channel (4 ky + kx) C + co = sum_ci x[ci] W[ci][co][ky][kx] -- ONE pointwise conv to
+ * 16 C channels (bc_conv1x1_nhwc: exactly the transposed conv's multiplications on the matrix cores) -- and this pass gathers the taps of every
+ * output pixel (stride 4, pad 0: depth-to-space; stride 2, pad 1: up to 2 x 2 overlapping taps, nothing from outside the image = the packed tile),
+ * adds the bias, rounds to the tensor type, L2-normalises over the channels and writes channels [c_off, c_off + C) of out (n_img, stride h, stride w,
+ * C_total): conv_transpose2d + L2Norm + cat of the reference in one read of t.  C <= 256 (fp32) / 512 (16-bit). */
+int bc_l2norm_cat_deconv_nhwc(void *out, const void *t, const float *bias, const float *weight, int n_img, int h, int w, int C, int C_total,
+                              int c_off, int stride, float eps, int dtype, void *stream);
 
 /* detector post-processing (config C5).  replaces nms_kernel + the host sweep of
  * Pedestron/mmdet/ops/nms/src/nms_kernel.cu:23-130: boxes (n,5) float32 [x1,y1,x2,y2,score] ALREADY sorted by score
@@ -442,6 +450,16 @@ int bc_nms_sorted_dev(const float *boxes, int n_max, const int32_t *n_dev, float
  * operation is the single fp32 operation of the reference's tensor expression, in its order: identical boxes.  One launch for ~25. */
 int bc_csp_decode(const float *scores, const long long *top, const float *heights, const float *off_y, const float *off_x, int k,
                   int map_w, int stride, float wh_ratio, int img_h, int img_w, float score_thr, float *dets, int32_t *n_sel, void *stream);
+
+/* the same WITH the top-k in the launch (csp_head.py:262-267 cls.sigmoid().topk(nms_pre) + the gathers of scale and offset at the kept positions):
+ * cls = the centre logits of the map (n = map_h * map_w values, row-major; BC_F32 / BC_F16 / BC_BF16, converted to float as `.float()`), reg = the
+ * scale predictions (float, n), off = the offset map: value (channel c, position i) at off[c * off_channel_stride + i * off_pixel_stride] (c = 0:
+ * y, 1: x; any of NCHW / channels-last).  Selects the k (<= 4096, <= n) largest sigmoid(cls) -- equal scores: lowest position first, where
+ * torch.topk leaves the order unspecified -- and writes dets / *n_sel as bc_csp_decode does for that selection (heights = exp(reg)), plus the
+ * positions (top_out, k x int32, may be NULL).  One workgroup, one launch: sigmoid + top-k (~10 library launches) + 3 gathers + exp + decode. */
+int bc_csp_topk_decode(const void *cls, int cls_dtype, const float *reg, const float *off, long long off_channel_stride,
+                       long long off_pixel_stride, int n, int k, int map_w, int stride, float wh_ratio, int img_h, int img_w, float score_thr,
+                       float *dets, int32_t *n_sel, int32_t *top_out, void *stream);
 
 /* device policy step: the per-frame decision of the online-RL policies without leaving the GPU.
  * Replaces, in one launch: Bernoulli(logits).sample() + `.cpu()` (policy/policy.py:283-288), quantize_number_exec_grid

@@ -507,9 +507,94 @@ def test_csp_decode_matches_the_tensor_expression(be, monkeypatch):
         monkeypatch.setenv("BLOCKCOPY_FUSED_DECODE", "0")
         want, wl = head.get_bboxes(cls, reg, off, shape, nms_pre=pre, score_thr=thr, iou_thr=0.5, max_per_img=cap)
         monkeypatch.setenv("BLOCKCOPY_FUSED_DECODE", "1")
+        monkeypatch.setenv("BLOCKCOPY_FUSED_TOPK", "0")
         got, gl = head.get_bboxes(cls, reg, off, shape, nms_pre=pre, score_thr=thr, iou_thr=0.5, max_per_img=cap)
         assert tuple(got.shape) == tuple(want.shape) and tuple(gl.shape) == tuple(wl.shape), (h, w, bias, got.shape, want.shape)
         assert torch.equal(got, want), (h, w, bias, float((got - want).abs().max()))
+        monkeypatch.setenv("BLOCKCOPY_FUSED_TOPK", "1")
+
+
+def _stable_topk(self, k):
+    v, i = torch.sort(self, descending=True, stable=True)
+    return v[:k], i[:k]
+
+
+@pytest.mark.parametrize("case", [(64, 128, -3.0, 2.0, 1000, torch.float32), (64, 128, 4.0, 2.0, 1000, torch.float32), (256, 512, -4.0, 1.5, 1000, torch.float32),
+                                  (256, 512, -4.0, 1.5, 4096, torch.float32), (48, 80, -1.0, 2.0, 300, torch.float16), (40, 40, -2.0, 2.0, 1599, torch.float32),
+                                  (128, 256, 30.0, 1.0, 1000, torch.float32), (128, 256, 0.0, 0.0, 1000, torch.float32), (64, 128, 2.0, 3.0, 1025, torch.bfloat16),
+                                  (33, 31, -2.0, 2.0, 1, torch.float32), (33, 31, -2.0, 2.0, 1022, torch.float32)])
+def test_csp_topk_decode_in_one_launch(be, monkeypatch, case):
+    """bc_csp_topk_decode (sigmoid + top-k + gathers + exp + decode + score count in ONE one-workgroup launch) + bc_nms_sorted_dev == the
+    reference's tensor expression (csp_head.py:229-284) with the top-k's order among EQUAL scores fixed to lowest position first (torch.topk
+    leaves it unspecified; a stable descending sort states it): identical positions, boxes and kept rows, bit for bit -- on spread scores,
+    saturated scores (thousands of exact ties: the radix route), a constant map, k = 1 / 4096 / n - 1, 16-bit logits, channels-last offsets."""
+    from bc_workloads.csp import CSPHead
+
+    h, w, bias, spread, pre, dt = case
+    head = CSPHead()
+    gen = torch.Generator().manual_seed(h * 7 + pre)
+    cls = (torch.randn((1, 1, h, w), generator=gen) * spread + bias).to(dt).cuda()
+    reg = (torch.randn((1, 1, h, w), generator=gen) * 0.5 + 2.0).cuda()
+    off = (torch.randn((1, 2, h, w), generator=gen) * 0.4).cuda()
+    shape = (h * 4 - 3, w * 4 - 5)
+    for layout in ("nchw", "nhwc"):
+        o = off if layout == "nchw" else off.contiguous(memory_format=torch.channels_last)
+        monkeypatch.setenv("BLOCKCOPY_FUSED_DECODE", "0")
+        with monkeypatch.context() as m:
+            m.setattr(torch.Tensor, "topk", _stable_topk)
+            want, _ = head.get_bboxes(cls, reg, o, shape, nms_pre=pre, score_thr=0.1, iou_thr=0.5, max_per_img=100)
+            scores, top = cls[0].reshape(-1).float().sigmoid().topk(pre)
+        monkeypatch.setenv("BLOCKCOPY_FUSED_DECODE", "1")
+        calls = []
+        orig = be.csp_topk_decode_nms
+        monkeypatch.setattr(be, "csp_topk_decode_nms", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+        got, _ = head.get_bboxes(cls, reg, o, shape, nms_pre=pre, score_thr=0.1, iou_thr=0.5, max_per_img=100)
+        monkeypatch.setattr(be, "csp_topk_decode_nms", orig)
+        assert len(calls) == 1
+        _, top_got, dets, cnt = be.csp_topk_decode_nms(cls[0, 0].contiguous(), reg[0, 0].contiguous(), o[0], pre, 4, head.wh_ratio, shape, 0.1, 0.5, 100, return_top=True)
+        assert torch.equal(top_got.long(), top), (case, layout, int((top_got.long() != top).sum()))
+        assert torch.equal(dets[:, 4], scores) and int(cnt[0]) == int((scores > 0.1).sum())
+        assert tuple(got.shape) == tuple(want.shape) and torch.equal(got, want), (case, layout)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.float16, 4e-3)])
+def test_csp_neck_without_transposed_convs(be, monkeypatch, dtype, tol):
+    """CSPNeck's fused route (per level: bc_conv1x1_nhwc to 16 taps x 256 channels + bc_l2norm_cat_deconv_nhwc gathering the taps of every
+    output pixel, bias, L2 norm, slice of the 768-channel tensor) == conv_transpose2d + L2Norm + cat (csp_neck.py:37-43, 68-100) on the
+    same weights: k4 s2 p1 (overlapping taps, image-border taps dropped) and k4 s4 p0, odd tile counts, non-square maps, random L2 weights."""
+    from bc_workloads.csp import CSPNeck
+
+    torch.manual_seed(7)
+    neck = CSPNeck().cuda().eval()
+    with torch.no_grad():
+        for l2 in (neck.p3_l2, neck.p4_l2, neck.p5_l2):
+            l2.weight.mul_(torch.rand_like(l2.weight) + 0.5)
+        for ct in (neck.p3, neck.p4, neck.p5):
+            ct.bias.normal_(0, 0.05)
+    neck = neck.to(dtype)
+    for (n, h, w) in [(3, 8, 8), (1, 8, 16), (5, 16, 8)]:
+        xs = [torch.randn((n, 512, 2 * h, 2 * w)), torch.randn((n, 1024, h, w)), torch.randn((n, 2048, h, w))]
+        xs = [x.to(dtype).cuda().contiguous(memory_format=torch.channels_last) for x in xs]
+        with torch.no_grad():
+            monkeypatch.setenv("BLOCKCOPY_FUSED_NECK", "0")
+            want = neck.double()([x.double() for x in xs])[0] if dtype == torch.float32 else neck.float()([x.float() for x in xs])[0]
+            neck.to(dtype)
+            monkeypatch.setenv("BLOCKCOPY_FUSED_NECK", "1")
+            monkeypatch.setenv("BLOCKCOPY_FUSED_DECONV", "0")
+            stock = neck(xs)[0]
+            monkeypatch.setenv("BLOCKCOPY_FUSED_DECONV", "1")
+            calls = []
+            orig = be.l2norm_cat_deconv
+            monkeypatch.setattr(be, "l2norm_cat_deconv", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+            got = neck(xs)[0]
+            monkeypatch.setattr(be, "l2norm_cat_deconv", orig)
+        assert len(calls) == 3 and tuple(got.shape) == (n, 768, 4 * h, 4 * w) and got.dtype == dtype
+        err, err_stock = float((got.double() - want.double()).abs().max()), float((stock.double() - want.double()).abs().max())
+        assert err <= tol * float(want.abs().max()), (n, h, w, err, err_stock)
+    x_req = [x.clone().requires_grad_(True) for x in xs]
+    monkeypatch.setattr(be, "l2norm_cat_deconv", lambda *a, **k: (_ for _ in ()).throw(AssertionError("fused neck taken under autograd")))
+    neck(x_req)[0].float().sum().backward()
+    assert x_req[0].grad is not None and neck.p3.weight.grad is not None
 
 
 def test_plain_c_consumer_runs():
