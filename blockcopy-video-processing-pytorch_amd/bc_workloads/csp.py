@@ -155,8 +155,7 @@ class CSPNeck(nn.Module):
                 return None
             size = (r.shape[2] * st, r.shape[3] * st)
         c_total = sum(ct.out_channels for ct, _, _, _ in levels)
-        out = torch.empty((B, size[0], size[1], c_total), dtype=dt, device=raws[0].device).permute(0, 3, 1, 2)
-        off = 0
+        plans = []
         for r, (ct, l2, st, _) in zip(raws, levels):
             cout16 = 16 * ct.out_channels
             wpk = fusion.packed_conv3x3_weight(ct.weight, be.pack_deconv4_weights)
@@ -167,7 +166,13 @@ class CSPNeck(nn.Module):
 
             n_px = r.shape[0] * r.shape[2] * r.shape[3]
             plan = fusion.conv3x3_plan(max(1, n_px // 64), 8, r.shape[1], cout16, 0, dt, tuner, 1, ks=1)
-            taps = be.conv1x1(r, wpk, cout16, None, None, cfg=-1 if plan is None else plan, stride=1)
+            if plan is None and fusion.CONV_MODE == "library":
+                return None
+            plans.append((wpk, cout16, -1 if plan is None else plan))      # (the untuned rule's "library" for tiny maps means a pointwise conv, not this one: cost model)
+        out = torch.empty((B, size[0], size[1], c_total), dtype=dt, device=raws[0].device).permute(0, 3, 1, 2)
+        off = 0
+        for r, (ct, l2, st, _), (wpk, cout16, plan) in zip(raws, levels, plans):
+            taps = be.conv1x1(r, wpk, cout16, None, None, cfg=plan, stride=1)
             bias = ct.bias.detach().float().contiguous() if ct.bias is not None else None
             be.l2norm_cat_deconv(out, off, taps, bias, l2.weight.detach().float().contiguous(), st, l2.eps)
             off += ct.out_channels

@@ -140,6 +140,7 @@ def load_library(path: str = None) -> ctypes.CDLL:
         "bc_conv_upsample_arm": [p, i, i, i, ctypes.c_float, ctypes.c_float],
         "bc_nms_sorted_dev": [p, i, p, ctypes.c_float, p, p, p, p],
         "bc_csp_decode": [p, p, p, p, p, i, i, i, ctypes.c_float, i, i, ctypes.c_float, p, p, p],
+        "bc_csp_score_monotone": [p, p],
         "bc_csp_topk_decode": [p, i, p, p, ctypes.c_longlong, ctypes.c_longlong, i, i, i, i, ctypes.c_float, i, i, ctypes.c_float, p, p, p, p],
         "bc_interp_bilinear_nhwc": [p, p, ctypes.c_longlong, i, i, i, i, i, i, ctypes.c_float, ctypes.c_float, i, p],
         "bc_upsample_argmax": [p, p, i, i, i, i, i, i, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, i,
@@ -1251,14 +1252,20 @@ class HipBackend:
         n_keep = int(cnt[1].item())
         return dets[keep[:min(n_keep, int(max_out))].long()]
 
+    def csp_score_monotone_violations(self) -> int:
+        """The self-test bc_csp_topk_decode's selection rests on (every neighbouring float pair: the fp32 sigmoid never decreases)."""
+        v = torch.zeros(1, dtype=torch.int64, device="cuda")
+        self._check(self.lib.bc_csp_score_monotone(v.data_ptr(), self._stream()), "csp_score_monotone")
+        return int(v.item())
+
     def csp_topk_decode_nms(self, cls_map, reg_map, off_map, k, stride, wh_ratio, img_shape, score_thr, iou_thr, max_out, return_top=False):
         """The whole decode from the head's maps to the kept boxes in TWO launches (bc_csp_topk_decode + bc_nms_sorted_dev) and one read of
         the kept count: ``cls_map`` (h, w) centre logits (any supported float type), ``reg_map`` (h, w) float scale predictions, ``off_map``
-        (2, h, w) float offsets in any dense layout (strides are passed on).  Equal scores: lowest position first."""
+        (2, h, w) float offsets in any dense layout (strides are passed on).  Equal scores: larger logit first, then lowest position."""
         h, w = cls_map.shape[-2:]
         n = h * w
         assert cls_map.numel() == n and reg_map.numel() == n and off_map.numel() == 2 * n and off_map.shape[0] == 2 and 0 < k <= min(n, 4096)
-        assert cls_map.is_cuda and cls_map.dtype in _DTYPES and cls_map.is_contiguous() and _ok(reg_map, torch.float32) and reg_map.is_contiguous()
+        assert cls_map.is_cuda and cls_map.dtype in _DTYPE_CODE and cls_map.is_contiguous() and _ok(reg_map, torch.float32) and reg_map.is_contiguous()
         assert off_map.dtype == torch.float32 and off_map.stride(1) == w * off_map.stride(2)
         dev = cls_map.device
         dets = torch.empty((k, 5), dtype=torch.float32, device=dev)
@@ -1267,7 +1274,7 @@ class HipBackend:
         keep = torch.empty(k, dtype=torch.int32, device=dev)
         top = torch.empty(k, dtype=torch.int32, device=dev) if return_top else None
         with torch.cuda.device_of(cls_map):
-            self._check(self.lib.bc_csp_topk_decode(cls_map.data_ptr(), _DTYPES[cls_map.dtype], reg_map.data_ptr(), off_map.data_ptr(),
+            self._check(self.lib.bc_csp_topk_decode(cls_map.data_ptr(), _DTYPE_CODE[cls_map.dtype], reg_map.data_ptr(), off_map.data_ptr(),
                                                     off_map.stride(0), off_map.stride(2), n, int(k), int(w), int(stride), float(wh_ratio),
                                                     int(img_shape[0]), int(img_shape[1]), float(score_thr), dets.data_ptr(), cnt.data_ptr(),
                                                     top.data_ptr() if top is not None else None, self._stream()), "csp_topk_decode")

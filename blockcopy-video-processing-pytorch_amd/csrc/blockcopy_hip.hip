@@ -2167,15 +2167,23 @@ __global__ __launch_bounds__(1024) void k_csp_decode(DecodeGeom g, const float *
 }
 
 // The head's top-k IN the decode launch (csp_head.py:262-267: cls.sigmoid().topk(nms_pre), then the gathers of scale and offset): one workgroup,
-// no sort of the map.  (1) every thread keeps the maxima of M strided groups of the score map (G = 1024 M groups): the k-th largest group
-// maximum L is a LOWER bound of the k-th largest score (k groups hold k distinct elements >= L); a bitonic sort of the G maxima in LDS finds it.
-// (2) elements >= L are appended to an LDS list (about k (1 + k / 2G) of them on a typical map); (3) the list, as (score bits, ~position)
-// words, is sorted and its first k rows decoded.  A map with more than TOPK_CAP elements >= L (constant maps, long runs of saturated scores)
-// takes an exact radix select on the same 64-bit words first.  Order among equal scores: lowest flat position first (torch.topk leaves it
-// unspecified; with distinct scores the rows are torch.topk's).  sigmoid = 1 / (1 + exp(-x)) in fp32, as the reference's tensor expression.
-constexpr int TOPK_CAP = 8192;
-struct TopkGeom { int n, k, W, stride; float wh_ratio, x_max, y_max, thr; long long off_cs, off_ps; int cls_dtype; };
+// no sort of the map, and no sigmoid outside the k selected rows.  The score is a function of the logit, and the fp32 expression
+// 1 / (1 + exp(-x)) as this device evaluates it is monotone non-decreasing over the whole float line (k_csp_score_monotone checks every pair
+// of neighbouring floats; tests/test_gpu_ops.py) -- so the k largest scores are the k largest LOGITS, and rows ordered by logit are ordered
+// by score.  Order among equal scores (torch.topk leaves it unspecified): the larger logit first, equal logits: lowest position first.
+// An exact radix select on the logits (as order-preserving integers), whatever their distribution -- hot regions, saturated scores, flat maps:
+// (1) a sweep over the map (16-byte loads, eight in flight) histograms the top 11 bits -- one histogram per wave, and every lane
+//     accumulates runs of equal digits in a register, so the common digit of a map costs no LDS atomics; the digit that holds the k-th largest
+//     logit follows from a scan.  While the elements at or above that digit number more than 2048, the next 11 (10) bits inside it.
+// (2) the elements at or above the final digit go to an LDS list as (logit, ~position) words, one LDS atomic per wave and 32 elements;
+// (3) the list is sorted and its first k rows are scored and decoded.
+// If 32 bits leave more than TOPK_CAP elements (a long run of EQUAL logits at the k-th: flat maps), the run is counted per block of 16-byte
+// vectors in position order and a scan finds the position of its last selected element.
+constexpr int TOPK_CAP = 8192, TOPK_RUN = 32768;
+struct TopkGeom { int n, k, W, stride; float wh_ratio, x_max, y_max, thr; long long off_cs, off_ps; int cls_dtype, vec; };
 
+// descending bitonic sort of P (a power of two) keys in LDS by 1024 threads.  Compare distances <= 64 stay inside the 128 keys a wave owns:
+// those stages need no workgroup barrier (LDS operations of one wave complete in order)
 template <typename K>
 __device__ __forceinline__ void lds_bitonic_desc(K *s, int P)
 {
@@ -2186,127 +2194,199 @@ __device__ __forceinline__ void lds_bitonic_desc(K *s, int P)
                 const K a = s[i], b = s[j];
                 if ((a < b) == ((i & size) == 0)) { s[i] = b; s[j] = a; }
             }
-            __syncthreads();
+            if (stride > 64 || stride == 1) __syncthreads();          // (stride 1 ends a merge: the next one starts across waves)
+            else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
         }
 }
 
-template <int M>
+__device__ __forceinline__ float csp_score(float x) { return __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-x))); }
+// floats in the order of the real line as unsigned integers (-inf = 0x007fffff ... +inf = 0xff800000; NaNs at either end)
+__device__ __forceinline__ uint32_t float_ord(float f) { const uint32_t u = __builtin_bit_cast(uint32_t, f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float ord_float(uint32_t o) { return __builtin_bit_cast(float, (o & 0x80000000u) ? (o ^ 0x80000000u) : ~o); }
+
+// self-test of the property the selection rests on: counts the neighbouring float pairs (x, next x) in [-inf, +inf] with score(x) > score(next x)
+__global__ __launch_bounds__(256) void k_csp_score_monotone(unsigned long long *__restrict__ violations)
+{
+    unsigned long long bad = 0;
+    for (unsigned long long o = 0x007fffffull + blockIdx.x * 256ull + threadIdx.x; o < 0xff800000ull; o += (unsigned long long)gridDim.x * 256ull)
+        bad += csp_score(ord_float((uint32_t)o)) > csp_score(ord_float((uint32_t)o + 1u)) ? 1ull : 0ull;
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) bad += __shfl_xor(bad, sh);
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(violations, bad);
+}
+
 __global__ __launch_bounds__(1024) void k_csp_topk_decode(TopkGeom g, const void *__restrict__ cls, const float *__restrict__ reg,
                                                           const float *__restrict__ off, float *__restrict__ dets, int32_t *__restrict__ n_sel,
                                                           int32_t *__restrict__ top_out)
 {
     extern __shared__ __align__(16) unsigned char topk_lds[];
-    unsigned long long *cand = reinterpret_cast<unsigned long long *>(topk_lds);      // TOPK_CAP words; first the G group maxima (uint32)
-    uint32_t *gmax = reinterpret_cast<uint32_t *>(topk_lds);
-    uint32_t *hist = reinterpret_cast<uint32_t *>(topk_lds + (size_t)TOPK_CAP * 8);   // 2048 bins (radix route only)
+    // one region, three lives: 16 histograms of 2048 bins (pitch 2049: the replicas of a bin sit in different banks) -> the run table ->
+    // the candidate words; the summed histogram behind it
+    uint32_t *rep = reinterpret_cast<uint32_t *>(topk_lds), *tot = rep + 16 * 2049;
+    uint32_t *run = reinterpret_cast<uint32_t *>(topk_lds);
+    unsigned long long *cand = reinterpret_cast<unsigned long long *>(topk_lds);
     __shared__ uint32_t s_cnt, s_digit, s_above, s_bin;
     __shared__ int wave_cnt[16];
-    constexpr int G = 1024 * M;
+    constexpr int U = 8;
     const int tid = threadIdx.x, lane = tid & 63;
-    auto key_of = [&](int i) -> uint32_t {          // score bits + 1 (scores are >= 0: the bits order like the values; 0 = "no element")
-        float x;
-        if (g.cls_dtype == BC_F32) x = static_cast<const float *>(cls)[i];
-        else if (g.cls_dtype == BC_F16) x = __half2float(static_cast<const __half *>(cls)[i]);
-        else x = Cvt<hip_bfloat16>::ld(static_cast<const hip_bfloat16 *>(cls) + i);
-        const float sc = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-x)));
-        return __builtin_bit_cast(uint32_t, sc) + 1u;
+    auto logit = [&](int i) -> float {
+        if (g.cls_dtype == BC_F32) return static_cast<const float *>(cls)[i];
+        if (g.cls_dtype == BC_F16) return __half2float(static_cast<const __half *>(cls)[i]);
+        return Cvt<hip_bfloat16>::ld(static_cast<const hip_bfloat16 *>(cls) + i);
     };
-    auto word_of = [&](uint32_t key, int i) -> unsigned long long { return ((unsigned long long)key << 32) | (uint32_t)(0xffffffffu - (uint32_t)i); };
-    // (1) group maxima
-    uint32_t mx[M];
+    auto load4 = [&](int v, uint32_t *o) {        // float_ord of elements 4 v .. 4 v + 3
+        if (g.vec) {
+            if (4 * v < g.n) {
+                const float4 q = static_cast<const float4 *>(cls)[v];
+                o[0] = float_ord(q.x), o[1] = float_ord(q.y), o[2] = float_ord(q.z), o[3] = float_ord(q.w);
+            } else o[0] = o[1] = o[2] = o[3] = 0u;
+        } else {
 #pragma unroll
-    for (int m = 0; m < M; ++m) mx[m] = 0u;
-    for (int base = 0; base < g.n; base += G) {
-#pragma unroll
-        for (int m = 0; m < M; ++m) {
-            const int i = base + m * 1024 + tid;
-            if (i < g.n) mx[m] = max(mx[m], key_of(i));
+            for (int e = 0; e < 4; ++e) o[e] = 4 * v + e < g.n ? float_ord(logit(4 * v + e)) : 0u;
         }
-    }
+    };
+    auto word_of = [&](uint32_t o, int i) -> unsigned long long { return ((unsigned long long)o << 32) | (uint32_t)(0xffffffffu - (uint32_t)i); };
+    const int nvec = (g.n + 3) / 4, trips = (nvec + 1023) / 1024;
+    // visit(o, i) for every element of the map, in batches of U vectors per thread
+    auto sweep = [&](auto &&visit, auto &&batch_done) {
+        for (int j0 = 0; j0 < trips; j0 += U) {
+            uint32_t o[U][4];
+            int vidx[U];
 #pragma unroll
-    for (int m = 0; m < M; ++m) gmax[m * 1024 + tid] = mx[m];
+            for (int jj = 0; jj < U; ++jj) { vidx[jj] = (j0 + jj) * 1024 + tid; load4(vidx[jj], o[jj]); }
+            uint32_t mask = 0;
+#pragma unroll
+            for (int jj = 0; jj < U; ++jj)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * vidx[jj] + e;
+                    if (i < g.n && visit(o[jj][e], i)) mask |= 1u << (4 * jj + e);
+                }
+            batch_done(mask, o, vidx);
+        }
+    };
+    auto nothing = [](uint32_t, const uint32_t (&)[U][4], const int (&)[U]) {};
+    // (1) digits from the top until the elements at or above the k-th's digit fit the list
+    uint32_t prefix = 0u, r = (uint32_t)g.k, total = 0u;      // r: rank of the k-th inside the current digit's bin; total: elements at or above the bin
+    int consumed = 0;
+    for (int pass = 0; pass < 3; ++pass) {
+        const int bits = pass < 2 ? 11 : 10, shift = 32 - consumed - bits;
+        for (int b = tid; b < 16 * 2049; b += 1024) rep[b] = 0u;
+        __syncthreads();
+        uint32_t *mine = rep + (tid >> 6) * 2049;
+        uint32_t cd = 0u, cc = 0u;                  // a run of equal digits
+        sweep([&](uint32_t o, int) {
+            if (consumed == 0 || (o >> (32 - consumed)) == prefix) {
+                const uint32_t d = (o >> shift) & ((1u << bits) - 1u);
+                if (d == cd) ++cc;
+                else { if (cc) atomicAdd(&mine[cd], cc); cd = d; cc = 1u; }
+            }
+            return false; }, nothing);
+        if (cc) atomicAdd(&mine[cd], cc);
+        __syncthreads();
+        for (int b = tid; b < 2048; b += 1024) {
+            uint32_t t = 0;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) t += rep[w * 2049 + b];
+            tot[b] = t;
+        }
+        __syncthreads();
+        if (tid < 64) {                 // bins from the top: lane l owns bins 2047 - 32 l ... 2016 - 32 l
+            uint32_t sum = 0;
+            for (int q = 0; q < 32; ++q) sum += tot[2047 - (32 * lane + q)];
+            uint32_t incl = sum;
+#pragma unroll
+            for (int sh = 1; sh < 64; sh <<= 1) {
+                const uint32_t v = __shfl_up(incl, sh);
+                if (lane >= sh) incl += v;
+            }
+            const uint32_t excl = incl - sum;
+            if (excl < r && r <= incl) {
+                uint32_t above = excl;
+                for (int q = 0; q < 32; ++q) {
+                    const uint32_t c = tot[2047 - (32 * lane + q)];
+                    if (r <= above + c) { s_digit = 2047u - (uint32_t)(32 * lane + q); s_above = above; s_bin = c; break; }
+                    above += c;
+                }
+            }
+        }
+        __syncthreads();
+        total = ((uint32_t)g.k - r) + s_above + s_bin;
+        r -= s_above;
+        prefix = (prefix << bits) | s_digit;
+        consumed += bits;
+        __syncthreads();
+        if (total <= 2048u) break;      // (a list of 2048 sorts in the time of one more sweep; anything up to TOPK_CAP is sorted if 32 bits leave it)
+    }
+    const uint32_t T = consumed == 32 ? prefix : (prefix << (32 - consumed));       // the lowest logit of the final bin
+    // (2) candidates
+    auto append = [&](uint32_t mask, const uint32_t (&o)[U][4], const int (&vidx)[U]) {        // mask: bit 4 jj + e = take element e of vector jj
+        const uint32_t cnt = (uint32_t)__builtin_popcount(mask);
+        uint32_t incl = cnt;
+#pragma unroll
+        for (int sh = 1; sh < 64; sh <<= 1) {
+            const uint32_t v = __shfl_up(incl, sh);
+            if (lane >= sh) incl += v;
+        }
+        const uint32_t all = __shfl(incl, 63);
+        uint32_t base = 0;
+        if (lane == 0 && all) base = atomicAdd(&s_cnt, all);
+        base = __shfl(base, 0);
+        uint32_t slot = base + incl - cnt;
+#pragma unroll
+        for (int jj = 0; jj < U; ++jj)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (mask & (1u << (4 * jj + e))) {
+                    if (slot < (uint32_t)TOPK_CAP) cand[slot] = word_of(o[jj][e], 4 * vidx[jj] + e);
+                    ++slot;
+                }
+    };
+    int last = g.n;                     // of the elements EQUAL to T, positions <= last are candidates
+    if (total > (uint32_t)TOPK_CAP) {
+        // 32 bits consumed: more than TOPK_CAP - k elements EQUAL the k-th largest logit, r of them are selected: the first r in position order.
+        // Count the run per block of B vectors (position order), scan, walk the block that holds the r-th.
+        const int B = (nvec + TOPK_RUN - 1) / TOPK_RUN, n_blk = (nvec + B - 1) / B, bpt = (n_blk + 1023) / 1024;
+        for (int b = tid; b < n_blk; b += 1024) run[b] = 0u;
+        __syncthreads();
+        sweep([&](uint32_t o, int i) { if (o == T) atomicAdd(&run[(i >> 2) / B], 1u); return false; }, nothing);
+        __syncthreads();
+        uint32_t mine = 0;
+        for (int q = 0; q < bpt; ++q) mine += (tid * bpt + q) < n_blk ? run[tid * bpt + q] : 0u;
+        uint32_t incl = mine;
+#pragma unroll
+        for (int sh = 1; sh < 64; sh <<= 1) {
+            const uint32_t v = __shfl_up(incl, sh);
+            if (lane >= sh) incl += v;
+        }
+        if (lane == 63) wave_cnt[tid >> 6] = (int)incl;
+        __syncthreads();
+        uint32_t before = incl - mine;
+        for (int w = 0; w < (tid >> 6); ++w) before += (uint32_t)wave_cnt[w];
+        if (before < r && r <= before + mine) {
+            for (int q = 0; q < bpt; ++q) {
+                const int blk = tid * bpt + q;
+                const uint32_t c = blk < n_blk ? run[blk] : 0u;
+                if (r <= before + c) {
+                    bool found = false;
+                    for (int i = 4 * blk * B; i < g.n && !found; ++i)
+                        if (float_ord(logit(i)) == T && ++before == r) { s_bin = (uint32_t)i; found = true; }
+                    break;
+                }
+                before += c;
+            }
+        }
+        __syncthreads();
+        last = (int)s_bin;
+        __syncthreads();
+    }
     if (tid == 0) s_cnt = 0u;
     __syncthreads();
-    lds_bitonic_desc(gmax, G);
-    const uint32_t L = gmax[g.k - 1];
+    sweep([&](uint32_t o, int i) { return o > T || (o == T && i <= last); }, append);
     __syncthreads();
-    // (2) candidates (one LDS atomic per wave and trip)
-    auto append = [&](bool take, unsigned long long word) {
-        const unsigned long long bal = __ballot(take);
-        uint32_t base = 0;
-        if (lane == 0 && bal) base = atomicAdd(&s_cnt, (uint32_t)__builtin_popcountll(bal));
-        base = __builtin_amdgcn_readfirstlane(base);
-        const uint32_t slot = base + (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
-        if (take && slot < (uint32_t)TOPK_CAP) cand[slot] = word;
-    };
-    for (int base = 0; base < g.n; base += 1024) {
-        const int i = base + tid;
-        const uint32_t key = i < g.n ? key_of(i) : 0u;
-        append(i < g.n && key >= L, word_of(key, i));
-    }
-    __syncthreads();
-    uint32_t n_cand = s_cnt;
-    if (n_cand > (uint32_t)TOPK_CAP) {
-        // exact selection of the k-th largest WORD (words are distinct): 11-bit digits from the top, stop when the digit's bin is taken whole
-        unsigned long long prefix = 0ull;
-        uint32_t r = (uint32_t)g.k;
-        int consumed = 0;
-        for (int pass = 0; pass < 6; ++pass) {
-            const int bits = pass < 5 ? 11 : 9, shift = 64 - consumed - bits;
-            for (int b = tid; b < 2048; b += 1024) hist[b] = 0u;
-            __syncthreads();
-            for (int base = 0; base < g.n; base += 1024) {
-                const int i = base + tid;
-                if (i < g.n) {
-                    const uint32_t key = key_of(i);
-                    if (key >= L) {
-                        const unsigned long long wd = word_of(key, i);
-                        if (consumed == 0 || (wd >> (64 - consumed)) == prefix) atomicAdd(&hist[(uint32_t)(wd >> shift) & ((1u << bits) - 1u)], 1u);
-                    }
-                }
-            }
-            __syncthreads();
-            if (tid < 64) {             // bins from the top: lane l owns bins 2047 - 32 l ... 2016 - 32 l
-                uint32_t sum = 0;
-                for (int q = 0; q < 32; ++q) sum += hist[2047 - (32 * lane + q)];
-                uint32_t incl = sum;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const uint32_t v = __shfl_up(incl, o);
-                    if (lane >= o) incl += v;
-                }
-                const uint32_t excl = incl - sum;
-                if (excl < r && r <= incl) {
-                    uint32_t above = excl;
-                    for (int q = 0; q < 32; ++q) {
-                        const uint32_t c = hist[2047 - (32 * lane + q)];
-                        if (r <= above + c) { s_digit = 2047u - (uint32_t)(32 * lane + q); s_above = above; s_bin = c; break; }
-                        above += c;
-                    }
-                }
-            }
-            __syncthreads();
-            r -= s_above;
-            prefix = (prefix << bits) | s_digit;
-            consumed += bits;
-            const bool whole = (r == s_bin);
-            __syncthreads();
-            if (whole) break;
-        }
-        const unsigned long long T = consumed == 64 ? prefix : (prefix << (64 - consumed));
-        if (tid == 0) s_cnt = 0u;
-        __syncthreads();
-        for (int base = 0; base < g.n; base += 1024) {
-            const int i = base + tid;
-            const uint32_t key = i < g.n ? key_of(i) : 0u;
-            const unsigned long long wd = word_of(key, i);
-            append(i < g.n && key >= L && wd >= T, wd);
-        }
-        __syncthreads();
-        n_cand = s_cnt;                 // == k
-    }
-    // (3) sort the candidates (padding: 0 < every word), decode the first k
-    int P = 2;
+    const uint32_t n_cand = s_cnt;      // k <= n_cand <= TOPK_CAP
+    // (3) sort the candidates (padding: 0 < every word), score and decode the first k
+    int P = 128;
     while (P < (int)n_cand) P <<= 1;
     for (int t = (int)n_cand + tid; t < P; t += 1024) cand[t] = 0ull;
     __syncthreads();
@@ -2316,7 +2396,7 @@ __global__ __launch_bounds__(1024) void k_csp_topk_decode(TopkGeom g, const void
     for (int k = tid; k < g.k; k += 1024) {
         const unsigned long long wd = cand[k];
         const int i = (int)(0xffffffffu - (uint32_t)wd);
-        const float sc = __builtin_bit_cast(float, (uint32_t)(wd >> 32) - 1u);
+        const float sc = csp_score(ord_float((uint32_t)(wd >> 32)));
         const int row = i / g.W, col = i - row * g.W;
         const float px = __fadd_rn((float)(col * g.stride), half), py = __fadd_rn((float)(row * g.stride), half);
         const float oy = off[(size_t)i * g.off_ps], ox = off[(size_t)g.off_cs + (size_t)i * g.off_ps];
@@ -2333,7 +2413,7 @@ __global__ __launch_bounds__(1024) void k_csp_topk_decode(TopkGeom g, const void
         mine += sc > g.thr ? 1 : 0;
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+    for (int sh = 32; sh > 0; sh >>= 1) mine += __shfl_xor(mine, sh);
     if (lane == 0) wave_cnt[tid >> 6] = mine;
     __syncthreads();
     if (tid == 0) {
@@ -3995,17 +4075,22 @@ BC_EXPORT int bc_csp_topk_decode(const void *cls, int cls_dtype, const float *re
     if (n <= 0 || k <= 0 || k > n || k > 4096 || map_w <= 0 || stride <= 0 || img_h <= 0 || img_w <= 0 || n > (1 << 30)) return BC_ERR_SHAPE;
     if (cls_dtype != BC_F32 && cls_dtype != BC_F16 && cls_dtype != BC_BF16) return BC_ERR_ELEM;
     if (!cls || !reg || !off || !dets || !n_sel) return BC_ERR_NULL;
-    TopkGeom g{n, k, map_w, stride, wh_ratio, (float)(img_w - 1), (float)(img_h - 1), score_thr, off_channel_stride, off_pixel_stride, cls_dtype};
-    const size_t lds = (size_t)TOPK_CAP * 8 + 2048 * 4;
-    static thread_local bool attr_set[2] = {false, false};          // (per thread: cheap, and no cross-device assumption: the attribute is per function)
-    ProfScope ps(BC_OP_NMS, 4.0 * n + 44.0 * k);
-    if (k <= 1024) {
-        if (!attr_set[0]) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_csp_topk_decode<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set[0] = true; }
-        BC_LAUNCH(ps, k_csp_topk_decode<4>, dim3(1), dim3(1024), lds, (hipStream_t)stream, g, cls, reg, off, dets, n_sel, top_out);
-    } else {
-        if (!attr_set[1]) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_csp_topk_decode<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set[1] = true; }
-        BC_LAUNCH(ps, k_csp_topk_decode<16>, dim3(1), dim3(1024), lds, (hipStream_t)stream, g, cls, reg, off, dets, n_sel, top_out);
-    }
+    const int vec = (cls_dtype == BC_F32 && (reinterpret_cast<uintptr_t>(cls) & 15u) == 0 && n % 4 == 0) ? 1 : 0;    // 16-byte loads
+    TopkGeom g{n, k, map_w, stride, wh_ratio, (float)(img_w - 1), (float)(img_h - 1), score_thr, off_channel_stride, off_pixel_stride, cls_dtype, vec};
+    const size_t lds = (size_t)16 * 2049 * 4 + 2048 * 4;            // (>= TOPK_CAP words, >= TOPK_RUN counters)
+    static thread_local bool attr_set = false;                      // (the attribute is per function; setting it again is harmless)
+    ProfScope ps(BC_OP_NMS, 12.0 * n + 44.0 * k);
+    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_csp_topk_decode), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+    BC_LAUNCH(ps, k_csp_topk_decode, dim3(1), dim3(1024), lds, (hipStream_t)stream, g, cls, reg, off, dets, n_sel, top_out);
+    return launch_status();
+}
+
+BC_EXPORT int bc_csp_score_monotone(unsigned long long *violations, void *stream)
+{
+    if (!violations) return BC_ERR_NULL;
+    (void)hipMemsetAsync(violations, 0, sizeof(unsigned long long), (hipStream_t)stream);      // (a failure surfaces in launch_status below)
+    ProfScope ps(BC_OP_NMS, 0.0);
+    BC_LAUNCH(ps, k_csp_score_monotone, dim3(65536), dim3(256), 0, (hipStream_t)stream, violations);
     return launch_status();
 }
 

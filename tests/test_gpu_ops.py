@@ -514,9 +514,10 @@ def test_csp_decode_matches_the_tensor_expression(be, monkeypatch):
         monkeypatch.setenv("BLOCKCOPY_FUSED_TOPK", "1")
 
 
-def _stable_topk(self, k):
-    v, i = torch.sort(self, descending=True, stable=True)
-    return v[:k], i[:k]
+def test_csp_score_is_monotone_in_the_logit(be):
+    """The property bc_csp_topk_decode selects by: the fp32 expression 1 / (1 + exp(-x)), as the device evaluates it, never decreases from
+    one float to the next over the whole line [-inf, +inf] -- every pair checked."""
+    assert be.csp_score_monotone_violations() == 0
 
 
 @pytest.mark.parametrize("case", [(64, 128, -3.0, 2.0, 1000, torch.float32), (64, 128, 4.0, 2.0, 1000, torch.float32), (256, 512, -4.0, 1.5, 1000, torch.float32),
@@ -525,9 +526,10 @@ def _stable_topk(self, k):
                                   (33, 31, -2.0, 2.0, 1, torch.float32), (33, 31, -2.0, 2.0, 1022, torch.float32)])
 def test_csp_topk_decode_in_one_launch(be, monkeypatch, case):
     """bc_csp_topk_decode (sigmoid + top-k + gathers + exp + decode + score count in ONE one-workgroup launch) + bc_nms_sorted_dev == the
-    reference's tensor expression (csp_head.py:229-284) with the top-k's order among EQUAL scores fixed to lowest position first (torch.topk
-    leaves it unspecified; a stable descending sort states it): identical positions, boxes and kept rows, bit for bit -- on spread scores,
-    saturated scores (thousands of exact ties: the radix route), a constant map, k = 1 / 4096 / n - 1, 16-bit logits, channels-last offsets."""
+    reference's tensor expression (csp_head.py:229-284) with the top-k's order among EQUAL scores fixed (torch.topk leaves it unspecified):
+    the larger logit first, equal logits lowest position first -- stated here as stable descending sorts by logit, then by score: identical
+    positions, boxes and kept rows, bit for bit -- on spread scores, saturated scores (thousands of equal scores), a constant map (the radix
+    route), k = 1 / 4096 / n - 1, 16-bit logits (many equal logits), channels-last offsets."""
     from bc_workloads.csp import CSPHead
 
     h, w, bias, spread, pre, dt = case
@@ -540,8 +542,12 @@ def test_csp_topk_decode_in_one_launch(be, monkeypatch, case):
     for layout in ("nchw", "nhwc"):
         o = off if layout == "nchw" else off.contiguous(memory_format=torch.channels_last)
         monkeypatch.setenv("BLOCKCOPY_FUSED_DECODE", "0")
+        logits = cls[0].reshape(-1).float()
+        by_logit = torch.sort(logits, descending=True, stable=True)[1]
+        order = by_logit[torch.sort(logits[by_logit].sigmoid(), descending=True, stable=True)[1]][:pre]
+        assert torch.equal(order, by_logit[:pre])         # (monotone scores: the second sort moves nothing)
         with monkeypatch.context() as m:
-            m.setattr(torch.Tensor, "topk", _stable_topk)
+            m.setattr(torch.Tensor, "topk", lambda self, k: (self[order], order))
             want, _ = head.get_bboxes(cls, reg, o, shape, nms_pre=pre, score_thr=0.1, iou_thr=0.5, max_per_img=100)
             scores, top = cls[0].reshape(-1).float().sigmoid().topk(pre)
         monkeypatch.setenv("BLOCKCOPY_FUSED_DECODE", "1")

@@ -28,6 +28,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--filter", default="")
+    ap.add_argument("--all", action="store_true", help="print every candidate of the split family")
     a = ap.parse_args()
     be = bk.get_backend()
     for name, GH, GW, n_exec, Cin, Cout, bs in CASES:
@@ -53,6 +54,8 @@ def main():
                 err = float((got.double() - want).abs().max() / max(1.0, float(want.abs().max())))
             finally:
                 be.tune("conv2_cfg", -1)
+            if a.all and (c & 0x2000):
+                print(f"    0x{c:x}: {us:7.1f} us  {2.0 * n_exec * bs * bs * 9 * Cin * Cout / us / 1e6:6.1f} TFLOP/s", flush=True)
             for fam, pred in fams.items():
                 if pred(c) and (fam not in best or us < best[fam][0]):
                     best[fam] = (us, c, err)
