@@ -401,7 +401,13 @@ def test_conv3x3_weight_packing_matches_the_header_formula():
     Cout, Cin = 64, 96
     w = torch.arange(Cout * Cin * 9, dtype=torch.float32).reshape(Cout, Cin, 3, 3)
     both = HipBackend.pack_conv3x3_weights(w)
-    assert both.numel() == 77 * Cout * Cin      # fp32 3x3: the direct stream, the two Winograd F(2x2,3x3) streams (16 values per pair each), the F(4x4,3x3) stream (36)
+    # fp32 3x3: the direct stream (9 values per (cout, cin) pair), the two Winograd F(2x2,3x3) streams (16 each), the F(4x4,3x3) stream (36) and the
+    # split stream of the direct form on the 16-bit matrix pipe (9: the direct stream position by position, four weights -> [hi0..3 | lo0..3] fp16)
+    assert both.numel() == 86 * Cout * Cin
+    sp = HipBackend.pack_conv3x3_weights(w / 977.0)
+    d4, s8 = sp[:9 * Cout * Cin].reshape(-1, 4), sp[77 * Cout * Cin:].view(torch.float16).reshape(-1, 8).double()
+    assert float((16.0 * d4.double() - (s8[:, :4] + s8[:, 4:])).abs().max()) <= 16.0 * float(d4.abs().max()) * 2.0 ** -21     # hi + lo = 16 w to 22 bits
+    assert torch.equal(s8[:, :4].half(), (16.0 * d4).half())
     wpk = both[:9 * Cout * Cin].reshape(Cout // 32, Cin // 32, 9, 4, 64, 4)
     assert wpk.numel() == w.numel() and sorted(wpk.reshape(-1).tolist()) == sorted(w.reshape(-1).tolist())
     # Winograd stream: wino[nb16][chunk][step][q][lane = 16*kq + n][e] = (G g Gt)[f][cin = 32*chunk + 8*step + 2*kq + t][cout = 16*nb16 + n], 2*f + t = 4*q + e
@@ -424,7 +430,7 @@ def test_conv3x3_weight_packing_matches_the_header_formula():
         U = G @ wr.float().double()[cout, cin] @ G.T
         assert abs(float(wide[nb, chunk, ss, q, lane, e]) - float(U[f // 4, f % 4])) <= 1e-6
     # F(4x4,3x3) stream: wino4[cb][chunk][f][lane = 16*kq + n][j] = (G4 g G4t)[f][cin = 16*chunk + 4*kq + j][cout = 16*cb + n], f = 6*xi + nu
-    w4s = HipBackend.pack_conv3x3_weights(wr.float())[41 * Cout * Cin:].reshape(Cout // 16, Cin // 16, 36, 64, 4)
+    w4s = HipBackend.pack_conv3x3_weights(wr.float())[41 * Cout * Cin:77 * Cout * Cin].reshape(Cout // 16, Cin // 16, 36, 64, 4)
     G4 = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], dtype=torch.float64)
     for _ in range(300):
         cb, chunk, f, lane, j = (int(rngw.integers(n)) for n in (Cout // 16, Cin // 16, 36, 64, 4))
