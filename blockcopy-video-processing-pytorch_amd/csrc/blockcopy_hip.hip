@@ -3057,7 +3057,7 @@ static int conv_v2_run(ConvV2Args &a)
 #endif
 
 // ---- dilation 2 (3x3, stride 1, tiles of a multiple of 8 pixels): the decompositions of CONV2_CFGS with one 32-channel column per wave
-static const int CONV2_DIL_CFGS[] = {3, 5, 6, 7, 11, 15};
+static const int CONV2_DIL_CFGS[] = {3, 5, 6, 7, 11, 15, 8, 9};      // (8, 9: 2x2 wave tiles, split form only)
 constexpr int CONV2_DIL_N = (int)(sizeof(CONV2_DIL_CFGS) / sizeof(CONV2_DIL_CFGS[0]));
 
 #if defined(BC_MONO) || BC_PART == 9
@@ -3065,8 +3065,9 @@ template <int DT>
 static int conv_v2_dil_run(ConvV2Args &a)
 {
     constexpr int E = CvType<DT>::E;
+    constexpr bool SPLIT = DT == BC_F32S;
     LaunchProf ps{a.prof_on != 0, {a.ev_a, a.ev_b}};
-    constexpr int SC_LO = DT == BC_F32 ? 1 : 2, SC_HI = 2 * SC_LO;
+    constexpr int SC_LO = (DT == BC_F32 || SPLIT) ? 1 : 2, SC_HI = SPLIT ? 4 : 2 * SC_LO, SC_K4 = SPLIT ? 2 : SC_LO;    // (split: WKW 4 stages 2 units, WKW 8 stages 4)
     const int force = a.force_cfg < 0 ? -1 : (a.force_cfg & 0xff);
     const int min_lds = (a.force_cfg >= 0 && (a.force_cfg & 0x100)) ? 0 : a.min_lds;
     if (a.bs % 8 != 0) return BC_ERR_SHAPE;
@@ -3078,7 +3079,8 @@ static int conv_v2_dil_run(ConvV2Args &a)
         const int c = CONV2_DIL_CFGS[i];
         const Conv2Cfg &k = CONV2_CFGS[c];
         if (force >= 0 && c != force) continue;
-        if (!conv2_plan(k, E, 1, a.n_exec, a.Cin, a.Cout, a.bs, plan, 3, 2)) continue;
+        if (!SPLIT && k.RM * k.RN >= 4) continue;
+        if (!conv2_plan(k, E, 1, a.n_exec, a.Cin, a.Cout, a.bs, plan, 3, 2, SPLIT)) continue;
         const long long rounds = (plan.wgs + cus - 1) / cus;
         const double mf = (double)k.RM * k.RN * 9.0 * (a.Cin / 8) * 4.0 / k.WKW;
         const double t = rounds * (mf / (k.RM == 2 ? 0.79 : 0.70) + 70.0 + 12.0 * (k.WKW - 1) * k.RM * k.RN);
@@ -3103,8 +3105,10 @@ static int conv_v2_dil_run(ConvV2Args &a)
     case 3: launch_conv3x3_v2_cfg<DT, 1, 1, 4, 2, 1, SC_LO, 8, 1, 3, 2>(ps, grid, lds_bytes, a, g); break;
     case 5: launch_conv3x3_v2_cfg<DT, 1, 1, 2, 2, 2, SC_LO, 8, 1, 3, 2>(ps, grid, lds_bytes, a, g); break;
     case 6: launch_conv3x3_v2_cfg<DT, 1, 1, 1, 4, 2, SC_LO, 8, 1, 3, 2>(ps, grid, lds_bytes, a, g); break;
-    case 7: launch_conv3x3_v2_cfg<DT, 1, 1, 1, 2, 4, SC_LO, 8, 1, 3, 2>(ps, grid, lds_bytes, a, g); break;
+    case 7: launch_conv3x3_v2_cfg<DT, 1, 1, 1, 2, 4, SC_K4, 8, 1, 3, 2>(ps, grid, lds_bytes, a, g); break;
     case 11: launch_conv3x3_v2_cfg<DT, 2, 1, 1, 4, 2, SC_LO, 8, 1, 3, 2>(ps, grid, lds_bytes, a, g); break;
+    case 8: if constexpr (SPLIT) launch_conv3x3_v2_cfg<DT, 2, 2, 2, 2, 2, SC_LO, 8, 1, 3, 2>(ps, grid, lds_bytes, a, g); break;
+    case 9: if constexpr (SPLIT) launch_conv3x3_v2_cfg<DT, 2, 2, 1, 2, 4, SC_K4, 8, 1, 3, 2>(ps, grid, lds_bytes, a, g); break;
     default: launch_conv3x3_v2_cfg<DT, 1, 1, 1, 1, 8, SC_HI, 8, 1, 3, 2>(ps, grid, lds_bytes, a, g); break;
     }
     return launch_status();
@@ -3116,7 +3120,8 @@ extern "C" int bc_part_conv_v2_dil(void *p)
 {
     ConvV2Args &a = *static_cast<ConvV2Args *>(p);
     // dtype travels in `stride` for this part (the stride of a dilated launch is always 1)
-    return a.stride == BC_F32 ? conv_v2_dil_run<BC_F32>(a) : (a.stride == BC_F16 ? conv_v2_dil_run<BC_F16>(a) : conv_v2_dil_run<BC_BF16>(a));
+    return a.stride == BC_F32S ? conv_v2_dil_run<BC_F32S>(a)
+                               : (a.stride == BC_F32 ? conv_v2_dil_run<BC_F32>(a) : (a.stride == BC_F16 ? conv_v2_dil_run<BC_F16>(a) : conv_v2_dil_run<BC_BF16>(a)));
 }
 #endif
 
@@ -4437,17 +4442,20 @@ BC_EXPORT int bc_conv3x3_dil_ring_nhwc(void *out, const void *features, void *ri
     EpilogueT ept{out_scale, out_shift, out_add, out_relu};
     const double flops = 2.0 * n_exec * bs * bs * 9.0 * Cin * Cout;
     ProfScope ps(BC_OP_CONV3X3, flops);
-    ps.add_aux(flops);
+    // code | 0x2000 (fp32 only): the products on the 16-bit matrix pipe, operands split hi + lo (conv3x3_v2.inc BC_F32S; its weight stream sits behind the others)
+    const bool split = dtype == BC_F32 && g_tune.conv2_cfg >= 0 && (g_tune.conv2_cfg & 0x2000);
+    ps.add_aux(split ? flops * 3.0 / 16.0 : flops);
     // (this part's dispatcher reads the dtype from the `stride` field: the stride of a dilated launch is always 1)
-    ConvV2Args a{out, features, ring, weights_packed, grid_idx, mapping_exec, n_exec, Cin, Cout, GH, GW, bs, dtype, pr, ept, (hipStream_t)stream,
-                 ps.on ? 1 : 0, ps.rec.a, ps.rec.b, g_tune.conv2_cfg, g_tune.conv2_min_lds, g_tune.conv_stamps, -2, g_tune.xcd_remap, 2};
+    ConvV2Args a{out, features, ring, split ? static_cast<const void *>(static_cast<const float *>(weights_packed) + (size_t)77 * Cin * Cout) : weights_packed,
+                 grid_idx, mapping_exec, n_exec, Cin, Cout, GH, GW, bs, split ? BC_F32S : dtype, pr, ept, (hipStream_t)stream,
+                 ps.on ? 1 : 0, ps.rec.a, ps.rec.b, split ? (g_tune.conv2_cfg & ~0x2000) : g_tune.conv2_cfg, g_tune.conv2_min_lds, g_tune.conv_stamps, -2, g_tune.xcd_remap, 2};
     if (!dyn_tiles(arm, n_exec, 1, a.dyn)) return BC_ERR_SHAPE;
 #if defined(BC_MONO)
-    const int rc = dtype == BC_F32 ? conv_v2_dil_run<BC_F32>(a) : (dtype == BC_F16 ? conv_v2_dil_run<BC_F16>(a) : conv_v2_dil_run<BC_BF16>(a));
+    const int rc = split ? conv_v2_dil_run<BC_F32S>(a) : (dtype == BC_F32 ? conv_v2_dil_run<BC_F32>(a) : (dtype == BC_F16 ? conv_v2_dil_run<BC_F16>(a) : conv_v2_dil_run<BC_BF16>(a)));
 #else
     const int rc = bc_part_conv_v2_dil(&a);
 #endif
-    if (a.chosen >= 0) g_tune.conv_last_cfg = a.chosen;
+    if (a.chosen >= 0) g_tune.conv_last_cfg = split ? (a.chosen | 0x2000) : a.chosen;
     return rc;
 }
 
@@ -4459,8 +4467,13 @@ BC_EXPORT int bc_conv3x3_dil_candidates(int dtype, int dilation, int n_exec, int
     const int E = dtype == BC_F32 ? 4 : 2;
     int n = 0;
     Conv2Plan plan;
-    for (int i = 0; i < CONV2_DIL_N && n < max_out; ++i)
-        if (conv2_plan(CONV2_CFGS[CONV2_DIL_CFGS[i]], E, 1, n_exec, Cin, Cout, bs, plan, 3, 2)) out[n++] = CONV2_DIL_CFGS[i];
+    for (int i = 0; i < CONV2_DIL_N && n < max_out; ++i) {
+        const Conv2Cfg &k = CONV2_CFGS[CONV2_DIL_CFGS[i]];
+        if (k.RM * k.RN < 4 && conv2_plan(k, E, 1, n_exec, Cin, Cout, bs, plan, 3, 2)) out[n++] = CONV2_DIL_CFGS[i];
+    }
+    if (dtype == BC_F32)        // the same decompositions (and the 2x2 wave tiles) on the 16-bit matrix pipe, operands split hi + lo
+        for (int i = 0; i < CONV2_DIL_N && n < max_out; ++i)
+            if (conv2_plan(CONV2_CFGS[CONV2_DIL_CFGS[i]], E, 1, n_exec, Cin, Cout, bs, plan, 3, 2, true)) out[n++] = CONV2_DIL_CFGS[i] | 0x2000;
     return n;
 }
 
