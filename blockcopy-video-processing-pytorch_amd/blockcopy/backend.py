@@ -484,7 +484,8 @@ class HipBackend:
         return (data_exec.dtype in _DTYPE_CODE and weight.dtype == data_exec.dtype and is_nhwc(data_exec)
                 and tuple(weight.shape[2:]) == (3, 3) and _one(padding) == 1 and dil == 1
                 and groups == 1 and weight.shape[1] % cin_unit == 0 and weight.shape[0] % 64 == 0
-                and data_exec.shape[2] == data_exec.shape[3] and (bs == 4 or (bs % 8 == 0 and bs * st <= 248)))
+                and data_exec.shape[2] == data_exec.shape[3]
+                and (bs == 4 or (bs == 2 and data_exec.dtype != torch.bfloat16) or (bs % 8 == 0 and bs * st <= 248)))      # (2x2 tiles: fp16, fp32 in the split form)
 
     @staticmethod
     def pack_conv3x3_weights(weight):
@@ -742,7 +743,7 @@ class HipBackend:
         B, C, H, W = data.shape
         if stride == 1:
             return ((B * H * W) // 64, 8) if (B * H * W) % 64 == 0 else None
-        if H != W or H % 2 or not ((H // 2) % 8 == 0 or H // 2 == 4) or H > 248:
+        if H != W or H % 2 or not ((H // 2) % 8 == 0 or H // 2 == 4 or (H // 2 == 2 and data.dtype != torch.bfloat16)) or H > 248:
             return None
         return B, H
 

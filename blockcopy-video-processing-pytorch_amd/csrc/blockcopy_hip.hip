@@ -2900,20 +2900,22 @@ struct Conv2Plan { long long wgs; size_t lds_bytes; uint32_t n_rows, patches_per
 // steps per tap -- K-group decompositions stage more 32-channel units per iteration (WKW 4: 2, WKW 8: 4)
 static bool conv2_plan(const Conv2Cfg &k, int E, int S, int n_exec, int Cin, int Cout, int bs, Conv2Plan &p, int KS = 3, int D = 1, bool split = false)
 {
-    const int pw = bs == 4 ? 4 : 8;
+    const int pw = bs == 4 ? 4 : (bs == 2 ? 2 : 8);
     const int uv = E == 4 ? 8 : 4, sc_lo = E == 4 ? 1 : 2;
     const int sc = split ? (k.WKW == 8 ? 4 : (k.WKW == 4 ? 2 : 1)) : (k.WKW == 8 ? 2 * sc_lo : sc_lo);
     if (pw == 8 && bs % 8 != 0) return false;
     if (pw == 4 && k.RM != 1 && k.WMW != 1) return false;       // 4x4 tiles: 4 tile slots per wave row only in single-row workgroups (LDS)
+    if (pw == 2 && k.RM != 1) return false;                     // 2x2 tiles: eight tiles per wave row, one 32-pixel block
     if (pw == 8 && bs % (4 * k.RM) != 0) return false;
     if (Cout % (32 * k.RN * k.WNW) != 0 || Cin % (32 * sc) != 0) return false;
-    const uint32_t ph = pw == 8 ? 4u * k.RM : 4u, tpr = pw == 8 ? 1u : 2u * k.RM;
-    const uint32_t slot_px = (uint32_t)(S * (pw - 1) + D * (KS - 1) + 1) * (S * (ph - 1) + D * (KS - 1) + 1);
+    const uint32_t ph = pw == 8 ? 4u * k.RM : (uint32_t)pw, tpr = pw == 8 ? 1u : (32u / (pw * pw)) * k.RM;
+    const int ss = KS == 1 ? 1 : S;                              // (a pointwise stride-2 conv stages only the pixels it reads)
+    const uint32_t slot_px = (uint32_t)(ss * (pw - 1) + D * (KS - 1) + 1) * (ss * (ph - 1) + D * (KS - 1) + 1);
     const size_t img = (size_t)k.WMW * tpr * slot_px * (uv * sc + 1) * 16;
     const size_t red = (size_t)k.WMW * k.WNW * (k.WKW - 1) * k.RM * k.RN * 16 * 64 * sizeof(float);
     p.lds_bytes = 2 * img > red ? 2 * img : red;
     if (p.lds_bytes < 8 * 4096) p.lds_bytes = 8 * 4096;         // the epilogue transposes through 4 KB per wave
-    if (p.lds_bytes > 160 * 1024 - 2048 - 1024) return false;   // (static tables of the kernel take < 1 KB)
+    if (p.lds_bytes > 160 * 1024 - 2048 - 1024 - (pw == 2 ? 6144 : 0)) return false;   // (static tables of the kernel take < 1 KB; 2x2 tiles < 5 KB)
     p.patches_x = pw == 8 ? bs / 8 : 1;
     p.patches_per_tile = pw == 8 ? (bs / 8) * (bs / ph) : 1;
     p.n_rows = pw == 8 ? (uint32_t)n_exec * p.patches_per_tile : ((uint32_t)n_exec + tpr - 1) / tpr;
@@ -2958,8 +2960,9 @@ static void launch_conv3x3_v2_cfg(LaunchProf &ps, dim3 grid, size_t lds_bytes, c
 {
     static bool attr_set = false;   // > 64 KB of dynamic LDS needs the opt-in once per kernel
     if (!attr_set) {
+        // (the kernel's static tables: < 1 KB, 2x2-pixel tiles -- up to 32 tile slots per workgroup -- < 5 KB)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_v2<DT, RM, RN, WMW, WNW, WKW, SC, PW, S, KS, D>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (PW == 2 ? 8192 : 2048));
         attr_set = true;
     }
     BC_LAUNCH(ps, (k_conv3x3_v2<DT, RM, RN, WMW, WNW, WKW, SC, PW, S, KS, D>), grid, dim3(512), lds_bytes, a.st, (typename CvType<DT>::T *)a.out,
@@ -2979,7 +2982,7 @@ static int conv_v2_run(ConvV2Args &a)
     // epilogue bursts of one overlap the matrix phase of the other; pays when the launch is several rounds of workgroups)
     const int force = a.force_cfg < 0 ? -1 : (a.force_cfg & 0xff);
     const int min_lds = (a.force_cfg >= 0 && (a.force_cfg & 0x100)) ? 0 : a.min_lds;
-    const int pw = bs == 4 ? 4 : 8;
+    const int pw = bs == 4 ? 4 : (bs == 2 ? 2 : 8);
     const int cus = device_cu_count();
     static const bool dbg_model = getenv("BC_CONV2_DEBUG") != nullptr;
     int best = -1;
@@ -2989,7 +2992,7 @@ static int conv_v2_run(ConvV2Args &a)
         const Conv2Cfg &k = CONV2_CFGS[c];
         if (force >= 0 && c != force) continue;
         if (!conv2_plan(k, E, S, n_exec, Cin, Cout, bs, plan, KS, 1, SPLIT)) continue;
-        if (KS == 1 && pw == 4 && S == 1) continue;            // (pointwise stride-1 launches are re-tiled to 8x8 by the caller)
+        if (KS == 1 && pw != 8 && S == 1) continue;            // (pointwise stride-1 launches are re-tiled to 8x8 by the caller)
         const long long rounds = (plan.wgs + cus - 1) / cus;
         const double mf = (double)k.RM * k.RN * (double)(KS * KS) * (Cin / 8) * 4.0 / k.WKW;   // fp32 MFMAs per wave (16-bit: the same ranking)
         // per-MFMA slowdown from operand delivery (tools/probes/mfma_probe2: 1x1 tiles ~0.72, 2x1 ~0.79, 2x2 ~0.82 of peak)
@@ -3018,14 +3021,19 @@ static int conv_v2_run(ConvV2Args &a)
     do {                                                                                                                 \
         constexpr int SC_ = SPLIT ? (WKW_ == 8 ? 4 : (WKW_ == 4 ? 2 : 1)) : (WKW_ == 8 ? SC_HI : SC_LO);                  \
         constexpr int RM4_ = WMW_ == 1 ? RM_ : 1;                                                                        \
-        constexpr size_t img8_ = (size_t)WMW_ * (S * 7 + KS) * (S * (4 * RM_ - 1) + KS) * (CvType<DT>::UV * SC_ + 1) * 32;  \
-        constexpr size_t img4_ = (size_t)WMW_ * 2 * RM4_ * (S * 3 + KS) * (S * 3 + KS) * (CvType<DT>::UV * SC_ + 1) * 32; \
+        constexpr int SS_ = KS == 1 ? 1 : S;                                                                             \
+        constexpr size_t img8_ = (size_t)WMW_ * (SS_ * 7 + KS) * (SS_ * (4 * RM_ - 1) + KS) * (CvType<DT>::UV * SC_ + 1) * 32; \
+        constexpr size_t img4_ = (size_t)WMW_ * 2 * RM4_ * (SS_ * 3 + KS) * (SS_ * 3 + KS) * (CvType<DT>::UV * SC_ + 1) * 32; \
         if (pw == 8) {                                                                                                   \
             if constexpr (img8_ <= 160 * 1024 - 3072)                                                                    \
                 launch_conv3x3_v2_cfg<DT, RM_, RN_, WMW_, WNW_, WKW_, SC_, 8, S, KS>(ps, grid, lds_bytes, a, g); \
-        } else {                                                                                                         \
+        } else if (pw == 4) {                                                                                            \
             if constexpr (img4_ <= 160 * 1024 - 3072 && !(KS == 1 && S == 1))                                            \
                 launch_conv3x3_v2_cfg<DT, RM4_, RN_, WMW_, WNW_, WKW_, SC_, 4, S, KS>(ps, grid, lds_bytes, a, g); \
+        } else {                                                                                                         \
+            if constexpr (RM_ == 1 && !(KS == 1 && S == 1) && (DT == BC_F32S || DT == BC_F16))                           \
+                launch_conv3x3_v2_cfg<DT, 1, RN_, WMW_, WNW_, WKW_, SC_, 2, S, KS>(ps, grid, lds_bytes, a, g);  \
+            else return BC_ERR_SHAPE;                                                                                    \
         }                                                                                                                \
     } while (0)
     switch (best) {
@@ -3443,11 +3451,12 @@ static int launch_conv3x3_v2(ProfScope &ps, void *out, const void *features, voi
         if (a.chosen >= 0) g_tune.conv_last_cfg = a.chosen;
         return rcw;
     }
-    if (DT == BC_F32 && a.force_cfg >= 0 && (a.force_cfg & 0x2000)) {
+    if (DT == BC_F32 && ((a.force_cfg >= 0 && (a.force_cfg & 0x2000)) || a.bs == 2)) {
         // the direct form on the 16-bit matrix pipe (operands split hi + lo, conv3x3_v2.inc BC_F32S): its own weight stream behind the others
+        // (2x2 output tiles of an fp32 layer exist in this form only: any request is served by it)
         ps.add_aux(direct_flops * 3.0 / 16.0);      // three 16-bit MFMAs of 16 channels where the fp32 pipe runs eight of 2
         a.wpk = reinterpret_cast<const float *>(a.wpk) + (size_t)(KS == 3 ? 77 : 1) * a.Cin * a.Cout;
-        a.force_cfg &= ~0x2000;
+        if (a.force_cfg >= 0) a.force_cfg &= ~0x2000;
 #if defined(BC_MONO)
         const int rcs = conv_v2_run<BC_F32S, S, KS>(a);
 #else
@@ -4176,15 +4185,16 @@ static int conv_candidates(int dtype, int stride, int ks, int n_exec, int Cin, i
 {
     if (dtype < BC_F32 || dtype > BC_BF16 || (stride != 1 && stride != 2) || !out || bs_in % stride) return BC_ERR_SHAPE;
     const int E = dtype == BC_F32 ? 4 : 2, bs = bs_in / stride;
-    if (!(bs == 4 || bs % 8 == 0) || bs > 248 / stride) return 0;
-    if (ks == 1 && stride == 1 && bs == 4) return 0;
+    if (!(bs == 4 || bs % 8 == 0 || bs == 2) || bs > 248 / stride) return 0;
+    if (ks == 1 && stride == 1 && bs <= 4) return 0;
+    const bool direct_ok = bs != 2 || dtype == BC_F16;          // 2x2 tiles: compiled for fp16 and for the split form of fp32 only
     int n = 0;
     Conv2Plan plan;
     const int n_cfg = (int)(sizeof(CONV2_CFGS) / sizeof(CONV2_CFGS[0]));
-    for (int c = 0; c < n_cfg && n < max_out; ++c)
+    for (int c = 0; c < n_cfg && n < max_out && direct_ok; ++c)
         if (conv2_plan(CONV2_CFGS[c], E, stride, n_exec, Cin, Cout, bs, plan, ks)) out[n++] = c;
     // the same decompositions without the one-workgroup-per-CU LDS floor, where two workgroups fit a CU at all
-    for (int c = 0; c < n_cfg && n < max_out; ++c)
+    for (int c = 0; c < n_cfg && n < max_out && direct_ok; ++c)
         if (conv2_plan(CONV2_CFGS[c], E, stride, n_exec, Cin, Cout, bs, plan, ks) && plan.lds_bytes <= (size_t)78 * 1024 && plan.wgs > device_cu_count())
             out[n++] = c | 0x100;
     // the Winograd form (fp32, 3x3, stride 1, tiles of a multiple of 8 pixels)
@@ -4258,7 +4268,7 @@ BC_EXPORT int bc_conv1x1_nhwc(void *out, const void *features, const void *weigh
     if (dtype < BC_F32 || dtype > BC_BF16) return BC_ERR_ELEM;
     if (n_tiles < 0 || Cin <= 0 || Cout <= 0 || bs <= 0 || (stride != 1 && stride != 2) || bs % stride) return BC_ERR_SHAPE;
     const int bso = bs / stride;
-    if (Cin % CV_CH != 0 || Cout % 64 != 0 || !(bso % 8 == 0 || (bso == 4 && stride == 2)) || bs > 248) return BC_ERR_SHAPE;
+    if (Cin % CV_CH != 0 || Cout % 64 != 0 || !(bso % 8 == 0 || ((bso == 4 || (bso == 2 && dtype != BC_BF16)) && stride == 2)) || bs > 248) return BC_ERR_SHAPE;
     if (n_tiles == 0) return BC_OK;
     if (!out || !features || !weights_packed) return BC_ERR_NULL;
     if ((uint64_t)n_tiles * bs * bs * (uint64_t)(Cin > Cout ? Cin : Cout) >= (1ull << 31)) return BC_ERR_RANGE;
@@ -4363,7 +4373,7 @@ BC_EXPORT int bc_conv3x3_ring_nhwc(void *out, const void *features, void *ring, 
     if (dtype < BC_F32 || dtype > BC_BF16) return BC_ERR_ELEM;
     if (n_exec < 0 || N <= 0 || Cin <= 0 || Cout <= 0 || GH <= 0 || GW <= 0 || bs <= 0) return BC_ERR_SHAPE;
     if (Cin % CV_CH != 0 || Cout % 64 != 0) return BC_ERR_SHAPE;
-    if (!(bs == 4 || bs % 8 == 0) || bs > 248) return BC_ERR_SHAPE;
+    if (!(bs == 4 || bs % 8 == 0 || (bs == 2 && dtype != BC_BF16)) || bs > 248) return BC_ERR_SHAPE;      // (2x2 tiles: fp16, and fp32 in the split form only)
     if (n_exec == 0) return BC_OK;
     if (!out || !features || !ring || !weights_packed || !grid_idx || !mapping_exec) return BC_ERR_NULL;
     if ((uint64_t)n_exec * bs * bs * (uint64_t)(Cin > Cout ? Cin : Cout) >= (1ull << 31) ||
@@ -4539,7 +4549,7 @@ BC_EXPORT int bc_conv3x3s2_ring_nhwc(void *out, const void *features, void *ring
     if (dtype < BC_F32 || dtype > BC_BF16) return BC_ERR_ELEM;
     if (n_exec < 0 || N <= 0 || Cin <= 0 || Cout <= 0 || GH <= 0 || GW <= 0 || bs <= 0 || bs % 2) return BC_ERR_SHAPE;
     const int bso = bs / 2;
-    if (Cin % CV_CH != 0 || Cout % 64 != 0 || !(bso == 4 || bso % 8 == 0) || bs > 248) return BC_ERR_SHAPE;
+    if (Cin % CV_CH != 0 || Cout % 64 != 0 || !(bso == 4 || bso % 8 == 0 || (bso == 2 && dtype != BC_BF16)) || bs > 248) return BC_ERR_SHAPE;
     if (n_exec == 0) return BC_OK;
     if (!out || !features || !ring || !weights_packed || !grid_idx || !mapping_exec) return BC_ERR_NULL;
     if ((uint64_t)n_exec * bs * bs * (uint64_t)(Cin > Cout ? Cin : Cout) >= (1ull << 31) ||

@@ -1021,6 +1021,73 @@ def test_fused_conv3x3_every_decomposition(be, cfg):
         be.tune("conv2_cfg", -1)
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.float16, 2e-3)])
+def test_fused_conv_on_2x2_pixel_tiles(be, dtype, tol):
+    """The last stage of a ResNet-50 at block 64 works on tiles of 2x2 pixels (config C4: stride 32).  The fused conv kernel's form for them
+    (conv3x3_v2.inc PW = 2: eight whole tiles per 32-pixel block; fp16, and fp32 with the operands split hi + lo): 3x3 stride 1 on 2x2
+    tiles, 3x3 stride 2 and 1x1 stride 2 from 4x4 to 2x2 tiles -- every decomposition the library lists and its own choice, ragged tile
+    counts, empty neighbours, prologue / epilogue / residual -- against halo gather + fp64 conv, ring caches bit-identical."""
+    import torch.nn.functional as F
+
+    rng = np.random.default_rng(61)
+    gen = torch.Generator().manual_seed(61)
+    assert not be.conv3x3_supported(_cl(torch.zeros((1, 64, 2, 2), dtype=torch.bfloat16).cuda()), torch.zeros((64, 64, 3, 3), dtype=torch.bfloat16).cuda(), 1, 1, 1, 1)
+    try:
+        for (Cin, Cout, N, GH, GW, stride) in [(64, 64, 1, 3, 4, 1), (512, 512, 1, 5, 7, 1), (128, 256, 2, 3, 3, 1), (256, 512, 1, 4, 5, 2), (64, 128, 1, 2, 3, 2)]:
+            T, bs = N * GH * GW, 2 * stride
+            w = (torch.randn((Cout, Cin, 3, 3), generator=gen) * (2.0 / (9 * Cin)) ** 0.5).cuda().to(dtype)
+            assert be.conv3x3_supported(_cl(torch.zeros((1, Cin, bs, bs), dtype=dtype).cuda()), w, stride, 1, 1, 1)
+            wpk = be.pack_conv3x3_weights(w)
+            cands = be.conv3x3_candidates(T, Cin, Cout, bs, w.element_size(), stride)
+            assert cands and (dtype != torch.float32 or all(c & 0x2000 for c in cands)), (Cin, Cout, stride, cands)
+            for cfg in [-1] + cands:
+                be.tune("conv2_cfg", cfg)
+                ring_a, ring_b = torch.zeros((T, Cin, 4 * bs), dtype=dtype).cuda(), torch.zeros((T, Cin, 4 * bs), dtype=dtype).cuda()
+                for t in range(3):
+                    g = np.ones(T, bool) if t == 0 else rng.random(T) < (0.5, 0.7)[t - 1]
+                    if not g.any():
+                        g[int(rng.integers(T))] = True
+                    gi, m = O.c_grid_mappings(g.reshape(N, 1, GH, GW))
+                    gi_d, m_d = _dev(gi), _dev(m)
+                    feats = _cl(torch.randn((len(m), Cin, bs, bs), generator=gen).cuda().to(dtype))
+                    pro = None if t == 0 else ((torch.rand(Cin, generator=gen) + 0.5).cuda(), (torch.randn(Cin, generator=gen) * 0.1).cuda(), t == 2)
+                    add = _cl(torch.randn((len(m), Cout, 2, 2), generator=gen).cuda().to(dtype)) if t == 1 else None
+                    epi = None if t == 0 else ((torch.rand(Cout, generator=gen) + 0.5).cuda(), (torch.randn(Cout, generator=gen) * 0.1).cuda(), add, t == 1)
+                    want = F.conv2d(be.pad_ring(feats, ring_a, gi_d, m_d, 1, pro).double(), w.double(), stride=stride)
+                    if stride == 2:
+                        want = want[:, :, :2, :2]        # (pad_ring pads both sides; a stride-2 conv with padding 1 reads the top / left halo only)
+                    if epi is not None:
+                        want = want * epi[0].view(1, -1, 1, 1) + epi[1].view(1, -1, 1, 1)
+                        if epi[2] is not None:
+                            want = want + epi[2].double()
+                        if epi[3]:
+                            want = torch.relu(want)
+                    got = be.conv3x3_ring(feats, ring_b, wpk, Cout, gi_d, m_d, pro, epi, **({} if stride == 1 else {"stride": 2}))
+                    assert tuple(got.shape) == (len(m), Cout, 2, 2) and got.dtype == dtype
+                    assert cfg < 0 or be.tune_get("conv_last_cfg") == cfg, (cfg, be.tune_get("conv_last_cfg"))
+                    err = (got.double() - want).abs().max().item()
+                    assert err <= tol * max(1.0, want.abs().max().item()), (Cin, Cout, stride, cfg, t, err)
+                    assert torch.equal(ring_a, ring_b), (Cin, Cout, stride, cfg, t)
+        be.tune("conv2_cfg", -1)
+        # the pointwise stride-2 shortcut of the same stage: 4x4 -> 2x2 tiles
+        for (B, Cin, Cout) in [(7, 256, 512), (3, 1024, 2048), (1, 64, 64)]:
+            x = _cl(torch.randn((B, Cin, 4, 4), generator=gen).cuda().to(dtype))
+            w = (torch.randn((Cout, Cin, 1, 1), generator=gen) * (2.0 / Cin) ** 0.5).cuda().to(dtype)
+            assert be.conv1x1_supported(x, w, 2)
+            wpk = be.pack_conv3x3_weights(w)
+            cands = be.conv1x1_candidates(x, Cout, 2)
+            assert cands, (B, Cin, Cout)
+            osc, osh = (torch.rand(Cout, generator=gen) + 0.5).cuda(), (torch.randn(Cout, generator=gen) * 0.1).cuda()
+            for cfg in [None] + cands:
+                want = F.conv2d(x.double(), w.double(), stride=2) * osc.view(1, -1, 1, 1) + osh.view(1, -1, 1, 1)
+                got = be.conv1x1(x, wpk, Cout, None, (osc, osh, None, False), cfg=cfg, stride=2)
+                assert got.dtype == dtype and tuple(got.shape) == (B, Cout, 2, 2)
+                err = (got.double() - want).abs().max().item()
+                assert err <= tol * max(1.0, want.abs().max().item()), (B, Cin, Cout, cfg, err)
+    finally:
+        be.tune("conv2_cfg", -1)
+
+
 @pytest.mark.parametrize("cfg", [6, 0x207, 0x20c, 0x20d, 0x404, 0x1000, 0x1001])
 def test_conv_result_does_not_depend_on_the_workgroup_order(be, cfg):
     """Which workgroup computes which (patch row, channel group) is a placement matter only (xcd_remap in csrc/conv3x3_v2.inc: launch
