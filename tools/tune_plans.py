@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEFAULT_OUT = os.path.join(ROOT, "blockcopy-video-processing-pytorch_amd", "blockcopy", "plans", "gfx950.json")
 CONFIGS = {
     "C2": ["--config", "C2"], "C2h": ["--config", "C2", "--half"], "C2b2": ["--config", "C2", "--batch", "2"],
-    "C3": ["--config", "C3"], "C3h": ["--config", "C3", "--half"],
+    "C3": ["--config", "C3"], "C3h": ["--config", "C3h"],
     "C4": ["--config", "C4"], "C4h": ["--config", "C4", "--half"],
     "C5": ["--config", "C5"], "C5h": ["--config", "C5", "--half"],
 }
