@@ -765,13 +765,7 @@ class HipBackend:
             return []
         buf = (ctypes.c_int * 64)()
         n = self.lib.bc_conv1x1_candidates(_DTYPE_CODE[data.dtype], int(stride), geo[0], data.shape[1], int(cout), geo[1], buf, 64)
-        out = [int(buf[k]) for k in range(max(n, 0))]
-        # the four-wave decompositions (codes 0x2000 | 20..24: 8 x 16-pixel patches) see a stride-1 launch as 16x16 re-tilings of the pixels
-        n_px = data.shape[0] * data.shape[2] * data.shape[3]
-        if stride == 1 and data.dtype == torch.float32 and n_px % 256 == 0:
-            n = self.lib.bc_conv1x1_candidates(0, 1, n_px // 256, data.shape[1], int(cout), 16, buf, 64)
-            out += [int(buf[k]) for k in range(max(n, 0)) if (int(buf[k]) & 0x2000) and (int(buf[k]) & 0xff) >= 20 and int(buf[k]) not in out]
-        return out
+        return [int(buf[k]) for k in range(max(n, 0))]
 
     def conv1x1_upsample_supported(self, launch_kw, interp) -> bool:
         """Can the deferred pointwise conv ``launch_kw`` (the keyword arguments of conv1x1) carry "+ bilinear(interp[0])" in its epilogue
@@ -789,13 +783,6 @@ class HipBackend:
         assert _ok(data, *_DTYPE_CODE) and _ok(wpk, data.dtype)
         B, C, H, W = data.shape
         n_tiles, bs = self.conv1x1_geometry(data, stride)
-        if cfg is not None and int(cfg) >= 0 and (int(cfg) & 0x2000) and (int(cfg) & 0xff) >= 20 and stride == 1:
-            # a four-wave decomposition (8 x 16-pixel patches): the launch sees 16x16 re-tilings of the pixels (conv1x1_candidates lists these
-            # codes only where that exists); with a resampling epilogue, which is written for 8x8 re-tiles, the library picks an eight-wave one
-            if upsample is not None or (B * H * W) % 256 != 0:
-                cfg = -1
-            else:
-                n_tiles, bs = (B * H * W) // 256, 16
         out = torch.empty((B, cout, H // stride, W // stride), dtype=data.dtype, device=data.device, memory_format=torch.channels_last)
         isc, ish, irelu = prologue if prologue is not None else (None, None, False)
         osc, osh, oadd, orelu = epilogue if epilogue is not None else (None, None, None, False)

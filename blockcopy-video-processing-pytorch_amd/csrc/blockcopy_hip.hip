@@ -2891,9 +2891,7 @@ static const Conv2Cfg CONV2_CFGS[] = {{2, 2, 4, 2, 1}, {2, 1, 4, 2, 1}, {1, 2, 4
                                       {1, 1, 2, 4, 1}, {1, 1, 2, 2, 2}, {1, 1, 1, 4, 2}, {1, 1, 1, 2, 4},     // 4-7: 1x1 wave tiles
                                       {2, 2, 2, 2, 2}, {2, 2, 1, 2, 4}, {2, 1, 2, 2, 2}, {2, 1, 1, 4, 2},     // 8-11: 2-block tiles + K groups
                                       {2, 1, 1, 2, 4}, {2, 1, 1, 1, 8}, {1, 2, 1, 1, 8}, {1, 1, 1, 1, 8},     // 12-15
-                                      {2, 2, 4, 1, 2}, {2, 2, 2, 1, 4}, {1, 2, 4, 1, 2}, {1, 2, 2, 1, 4},     // 16-19: one 64-channel column (2x2 / 1x2 wave tiles)
-                                      // 20-24: FOUR waves with 4 x 2-block tiles (128 px x 64 channels per wave, split form only, 8 px x 16 px patches)
-                                      {4, 2, 2, 2, 1}, {4, 2, 1, 2, 2}, {4, 2, 2, 1, 2}, {4, 2, 1, 4, 1}, {4, 2, 4, 1, 1}};
+                                      {2, 2, 4, 1, 2}, {2, 2, 2, 1, 4}, {1, 2, 4, 1, 2}, {1, 2, 2, 1, 4}};    // 16-19: one 64-channel column (2x2 / 1x2 wave tiles)
 
 // geometry of one decomposition for a layer (bs = OUTPUT tile size); false if the decomposition does not cover the layer
 struct Conv2Plan { long long wgs; size_t lds_bytes; uint32_t n_rows, patches_per_tile, patches_x; };
@@ -2908,7 +2906,6 @@ static bool conv2_plan(const Conv2Cfg &k, int E, int S, int n_exec, int Cin, int
     if (pw == 8 && bs % 8 != 0) return false;
     if (pw == 4 && k.RM != 1 && k.WMW != 1) return false;       // 4x4 tiles: 4 tile slots per wave row only in single-row workgroups (LDS)
     if (pw == 2 && k.RM != 1) return false;                     // 2x2 tiles: eight tiles per wave row, one 32-pixel block
-    if (k.RM == 4 && (!split || pw != 8)) return false;         // 4-block wave columns: split form on 8-pixel-wide patches only
     if (pw == 8 && bs % (4 * k.RM) != 0) return false;
     if (Cout % (32 * k.RN * k.WNW) != 0 || Cin % (32 * sc) != 0) return false;
     const uint32_t ph = pw == 8 ? 4u * k.RM : (uint32_t)pw, tpr = pw == 8 ? 1u : (32u / (pw * pw)) * k.RM;
@@ -2917,7 +2914,7 @@ static bool conv2_plan(const Conv2Cfg &k, int E, int S, int n_exec, int Cin, int
     const size_t img = (size_t)k.WMW * tpr * slot_px * (uv * sc + 1) * 16;
     const size_t red = (size_t)k.WMW * k.WNW * (k.WKW - 1) * k.RM * k.RN * 16 * 64 * sizeof(float);
     p.lds_bytes = 2 * img > red ? 2 * img : red;
-    if (p.lds_bytes < 8 * 4096) p.lds_bytes = 8 * 4096;         // the epilogue transposes through 4 KB per wave (four-wave workgroups: 16 KB would do)
+    if (p.lds_bytes < 8 * 4096) p.lds_bytes = 8 * 4096;         // the epilogue transposes through 4 KB per wave
     if (p.lds_bytes > 160 * 1024 - 2048 - 1024 - (pw == 2 ? 6144 : 0)) return false;   // (static tables of the kernel take < 1 KB; 2x2 tiles < 5 KB)
     p.patches_x = pw == 8 ? bs / 8 : 1;
     p.patches_per_tile = pw == 8 ? (bs / 8) * (bs / ph) : 1;
@@ -2968,7 +2965,7 @@ static void launch_conv3x3_v2_cfg(LaunchProf &ps, dim3 grid, size_t lds_bytes, c
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (PW == 2 ? 8192 : 2048));
         attr_set = true;
     }
-    BC_LAUNCH(ps, (k_conv3x3_v2<DT, RM, RN, WMW, WNW, WKW, SC, PW, S, KS, D>), grid, dim3(64 * WMW * WNW * WKW), lds_bytes, a.st, (typename CvType<DT>::T *)a.out,
+    BC_LAUNCH(ps, (k_conv3x3_v2<DT, RM, RN, WMW, WNW, WKW, SC, PW, S, KS, D>), grid, dim3(512), lds_bytes, a.st, (typename CvType<DT>::T *)a.out,
               (const uint4 *)a.features, (long long)(((const char *)a.ring - (const char *)a.features) / 16), (uint4 *)a.ring, (const uint4 *)a.wpk,
               a.grid_idx, a.mapping_exec, g, a.pr, a.ep, a.stamps);
 }
@@ -2994,7 +2991,6 @@ static int conv_v2_run(ConvV2Args &a)
     for (int c = 0; c < (int)(sizeof(CONV2_CFGS) / sizeof(CONV2_CFGS[0])); ++c) {
         const Conv2Cfg &k = CONV2_CFGS[c];
         if (force >= 0 && c != force) continue;
-        if (force < 0 && k.RM == 4) continue;                  // (the four-wave forms run where the plan table names them: the cost model below knows eight-wave workgroups)
         if (!conv2_plan(k, E, S, n_exec, Cin, Cout, bs, plan, KS, 1, SPLIT)) continue;
         if (KS == 1 && pw != 8 && S == 1) continue;            // (pointwise stride-1 launches are re-tiled to 8x8 by the caller)
         const long long rounds = (plan.wgs + cus - 1) / cus;
@@ -3040,25 +3036,7 @@ static int conv_v2_run(ConvV2Args &a)
             else return BC_ERR_SHAPE;                                                                                    \
         }                                                                                                                \
     } while (0)
-    // four-wave workgroups with 4 x 2-block wave tiles: the split form on 8-pixel-wide patches, staged units as the split form's K groups
-#define BC_CV2W4(WMW_, WNW_, WKW_)                                                                                         \
-    do {                                                                                                                 \
-        if constexpr (SPLIT) {                                                                                           \
-            constexpr int SC_ = WKW_ == 4 ? 2 : 1;                                                                       \
-            constexpr int SS_ = KS == 1 ? 1 : S;                                                                         \
-            constexpr size_t img8_ = (size_t)WMW_ * (SS_ * 7 + KS) * (SS_ * 15 + KS) * (CvType<DT>::UV * SC_ + 1) * 32;  \
-            if constexpr (img8_ <= 160 * 1024 - 3072) {                                                                  \
-                if (pw != 8) return BC_ERR_SHAPE;                                                                        \
-                launch_conv3x3_v2_cfg<DT, 4, 2, WMW_, WNW_, WKW_, SC_, 8, S, KS>(ps, grid, lds_bytes, a, g);             \
-            } else return BC_ERR_SHAPE;                                                                                  \
-        } else return BC_ERR_SHAPE;                                                                                      \
-    } while (0)
     switch (best) {
-    case 20: BC_CV2W4(2, 2, 1); break;
-    case 21: BC_CV2W4(1, 2, 2); break;
-    case 22: BC_CV2W4(2, 1, 2); break;
-    case 23: BC_CV2W4(1, 4, 1); break;
-    case 24: BC_CV2W4(4, 1, 1); break;
     case 0: BC_CV2(2, 2, 4, 2, 1); break;
     case 1: BC_CV2(2, 1, 4, 2, 1); break;
     case 2: BC_CV2(1, 2, 4, 2, 1); break;
@@ -3081,7 +3059,6 @@ static int conv_v2_run(ConvV2Args &a)
     default: BC_CV2(1, 2, 2, 1, 4); break;
     }
 #undef BC_CV2
-#undef BC_CV2W4
     return launch_status();
 }
 
