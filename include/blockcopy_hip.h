@@ -272,7 +272,9 @@ int bc_upsample_argmax(long long *out, const void *in, int N, int C, int h, int 
  * with fp32 accumulation, epilogue in fp32, ONE rounding to the tensor dtype at the store; the prologue rounds each gathered
  * element to the tensor dtype exactly like bc_pad_ring_nhwc does.  Summation order: cin-unit / tap / channel (K groups of one
  * workgroup are added in a fixed order: deterministic).
- * Constraints: Cin % 32 == 0 (16-bit: % 64), Cout % 64 == 0, bs = 4 or a multiple of 8 (<= 248), 16-byte aligned pointers. */
+ * Constraints: Cin % 32 == 0 (16-bit: % 64), Cout % 64 == 0, bs = 4 or a multiple of 8 (<= 248), 16-byte aligned pointers;
+ * bs = 2 (ResNet-50's last stage at block 64) for fp16, and for fp32 where the launch is always served by the split form (code | 0x2000:
+ * the only form compiled for 2x2-pixel tiles; bf16: BC_ERR_SHAPE). */
 int bc_conv3x3_ring_nhwc(void *out, const void *features, void *ring, const void *weights_packed,
                          const int32_t *grid_idx, const int32_t *mapping_exec, int n_exec, int N, int Cin, int Cout,
                          int GH, int GW, int bs, int dtype, const float *in_scale, const float *in_shift, int in_relu,
@@ -280,7 +282,7 @@ int bc_conv3x3_ring_nhwc(void *out, const void *features, void *ring, const void
 
 /* the same for a 3x3 / STRIDE 2 / pad 1 conv (the first conv of a ResNet stage): features (n_exec, bs, bs, Cin) ->
  * out (n_exec, bs/2, bs/2, Cout); halo, ring (pad 1, over the INPUT tiles), prologue, epilogue and weight stream as above.
- * bs even with bs/2 = 4 or a multiple of 8. */
+ * bs even with bs/2 = 4 or a multiple of 8, or bs/2 = 2 as above. */
 int bc_conv3x3s2_ring_nhwc(void *out, const void *features, void *ring, const void *weights_packed,
                            const int32_t *grid_idx, const int32_t *mapping_exec, int n_exec, int N, int Cin, int Cout,
                            int GH, int GW, int bs, int dtype, const float *in_scale, const float *in_shift, int in_relu,
@@ -291,7 +293,8 @@ int bc_conv3x3s2_ring_nhwc(void *out, const void *features, void *ring, const vo
  * their own (ResNet bottlenecks and decoder blocks are  ... -> ReLU -> conv1x1 -> ...).  features = n_tiles tiles of bs x bs pixels x Cin
  * (stride 1: any view with the same number of pixels, e.g. a dense map as 8x8 tiles; stride 2: the real packed tiles, out has
  * bs/2 x bs/2 per tile); weights_packed: the bc_conv3x3_ring_nhwc stream with a single tap; prologue / epilogue as there.
- * Cin % 32 == 0 (16-bit: % 64), Cout % 64 == 0, bs/stride a multiple of 8 (or 4 with stride 2). */
+ * Cin % 32 == 0 (16-bit: % 64), Cout % 64 == 0, bs/stride a multiple of 8 (or 4, or 2 as above, with stride 2).  A stride-2 launch stages only
+ * the pixels it reads (every second pixel of every second row). */
 int bc_conv1x1_nhwc(void *out, const void *features, const void *weights_packed, int n_tiles, int Cin, int Cout, int bs, int stride,
                     int dtype, const float *in_scale, const float *in_shift, int in_relu, const float *out_scale,
                     const float *out_shift, const void *out_add, int out_relu, void *stream);
@@ -385,7 +388,8 @@ int bc_adaptive_avg_pool_nhwc(void *out, const void *in, int N, int C, int H, in
  * core/tensorwrapper.py:529-575).  Everything as bc_conv3x3_ring_nhwc except: taps 2 pixels apart, halo / zero border 2 pixels
  * wide, `ring` = (N*GH*GW, 8*bs, Cin) records of the pad-2 layout of bc_pad_ring_nhwc (bit-identical refresh), bs a multiple of 8,
  * Cout a multiple of 32.  dilation = 1 forwards to bc_conv3x3_ring_nhwc.  bc_conv3x3_dil_candidates lists the decompositions
- * (indices into the direct form's table) that cover a layer. */
+ * (indices into the direct form's table; fp32: also `index | 0x2000`, the same decompositions and the 2x2 wave tiles 8 / 9 in the split
+ * form on the 16-bit matrix pipe, selected through bc_tune_set("conv2_cfg", code) like every other form) that cover a layer. */
 int bc_conv3x3_dil_ring_nhwc(void *out, const void *features, void *ring, const void *weights_packed,
                              const int32_t *grid_idx, const int32_t *mapping_exec, int n_exec, int N, int Cin, int Cout,
                              int GH, int GW, int bs, int dilation, int dtype, const float *in_scale, const float *in_shift, int in_relu,
