@@ -531,8 +531,14 @@ class HipBackend:
             a, b, c = t.unbind(dim)
             return torch.stack([a / 4, -(a + b + c) / 6, -(a - b + c) / 6, a / 24 + b / 12 + c / 6, a / 24 - b / 12 + c / 6, c], dim)
         U4 = g4_rows(g4_rows(w0.double(), 2), 3).permute(2, 3, 1, 0).reshape(36, Cin, Cout).float()          # f, cin, cout
-        U4 = U4.reshape(36, Cin // 16, 4, 4, Cout // 16, 16).permute(4, 1, 0, 2, 5, 3)                      # cb, chunk, f, kq, n, j
-        return torch.cat([direct, U16.contiguous().view(-1), V.contiguous().view(-1), U4.contiguous().view(-1), split])
+        U4 = U4.reshape(36, Cin // 16, 4, 4, Cout // 16, 16).permute(4, 1, 0, 2, 5, 3).contiguous()         # cb, chunk, f, kq, n, j
+        # sixth stream: the F(4x4) stream position by position for its products on the 16-bit matrix pipe (codes 0x5000 | c, conv3x3_wino4.inc
+        # SP): every 16-byte vector of four transformed weights replaced by [hi0..3 | lo0..3] in fp16 with 256 U = hi + lo
+        u256 = U4.view(-1, 4) * 256.0
+        uh = u256.to(torch.float16)
+        ul = (u256 - uh.float()).to(torch.float16)
+        u4_split = torch.cat([uh, ul], dim=1).contiguous().view(torch.float32).view(-1)
+        return torch.cat([direct, U16.contiguous().view(-1), V.contiguous().view(-1), U4.view(-1), split, u4_split])
 
     # ---- pyramid pooling of a dense map in two launches (csrc/spp.inc): bc_spp_levels_nhwc + bc_spp_fuse_nhwc
     SPP_LDS_LIMIT = 150 * 1024      # both launchers refuse (BC_ERR_SHAPE) above this much dynamic LDS
@@ -703,7 +709,7 @@ class HipBackend:
         N, _, GH, GW = grid_idx.shape
         B, C, bs, _ = data_exec.shape
         n_exec = mapping_exec.numel()
-        assert n_exec == B and wpk.numel() in (9 * C * cout, 77 * C * cout, 86 * C * cout)     # (fp32: direct + three Winograd streams + the split stream)
+        assert n_exec == B and wpk.numel() in (9 * C * cout, 77 * C * cout, 86 * C * cout, 122 * C * cout)     # (fp32: direct + three Winograd streams + the two split streams)
         assert dilation in (1, 2) and (dilation == 1 or stride == 1)
         assert tuple(ring.shape) == (N * GH * GW, C, 4 * dilation * bs), (ring.shape, (N * GH * GW, C, 4 * dilation * bs))
         assert stride in (1, 2) and bs % stride == 0

@@ -170,7 +170,7 @@ def packed_conv3x3_weight(weight: torch.Tensor, pack) -> torch.Tensor:
     return v
 
 
-CONV_MODE = os.environ.get("BLOCKCOPY_CONV", "auto")   # auto | native | winograd | winograd-wide | winograd4 | library
+CONV_MODE = os.environ.get("BLOCKCOPY_CONV", "auto")   # auto | native | winograd | winograd-wide | winograd4 | winograd4-split | split | library
 CONV_TUNE = os.environ.get("BLOCKCOPY_CONV_TUNE", "1") != "0"   # auto mode: measure a layer shape the plan table does not know (eager runs only)
 _conv_plans = {}      # (n_exec, bs, cin, cout, n_total, dtype, stride, ks) -> None (library conv) | decomposition code (-1 = library's own choice)
 DEFER_CONV = os.environ.get("BLOCKCOPY_DEFER_CONV", "1") != "0"   # fused convs launch lazily with the recorded elementwise work as epilogue
@@ -298,14 +298,16 @@ def conv3x3_plan(n_exec: int, bs: int, cin: int, cout: int, n_total: int, dtype,
             if sp:
                 return sp[0]
         return -1
-    if CONV_MODE in ("winograd", "winograd-wide", "winograd4"):
+    if CONV_MODE in ("winograd", "winograd-wide", "winograd4", "winograd4-split"):
         if ks == 3 and stride == 1 and dtype == torch.float32 and candidates is not None:
-            flag = WINOGRAD_WIDE if CONV_MODE == "winograd-wide" else (WINOGRAD_F4 if CONV_MODE == "winograd4" else 0x200)
+            flag = WINOGRAD_WIDE if CONV_MODE == "winograd-wide" else (WINOGRAD_F4 if CONV_MODE.startswith("winograd4") else 0x200)
             cands = [c for c in candidates() if c >= 0]
             wino = [c for c in cands if c & flag]
+            if CONV_MODE == "winograd4-split":      # the F(4x4) form with its products on the 16-bit matrix pipe (codes 0x5000 | c)
+                wino = [c for c in cands if (c & 0x5000) == 0x5000]
             if wino:
                 return wino[0]
-            if CONV_MODE == "winograd4":      # (tiles the F(4x4) form does not cover: 4x4 tiles, sizes that are no multiple of 16: the F(2x2) form)
+            if CONV_MODE.startswith("winograd4"):      # (tiles the F(4x4) form does not cover: 4x4 tiles, sizes that are no multiple of 16: the F(2x2) form)
                 wino = [c for c in cands if c & 0x200]
                 if wino:
                     return wino[0]

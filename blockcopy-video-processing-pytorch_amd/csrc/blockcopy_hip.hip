@@ -3318,26 +3318,32 @@ static bool wino4_plan(const Wino4Cfg &k, int n_exec, int Cin, int Cout, int bs,
 }
 
 #if defined(BC_MONO) || BC_PART == 10
-template <int TS, int WNW, int WFW, int NB>
+template <int TS, int WNW, int WFW, int NB, bool SP>
 static void launch_wino4_ts(LaunchProf &ps, dim3 grid, size_t lds_bytes, const ConvV2Args &a, const ConvGeom2 &g)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_wino4<TS, WNW, WFW, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_wino4<TS, WNW, WFW, NB, SP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
         attr_set = true;
     }
-    // the F(4x4) stream follows the direct and the two F(2x2) streams (pack_conv3x3_weights: 9 + 16 + 16 + 36 values per pair)
-    const float4 *w4 = reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(a.wpk) + (size_t)41 * a.Cin * a.Cout);
-    BC_LAUNCH(ps, (k_conv3x3_wino4<TS, WNW, WFW, NB>), grid, dim3(512), lds_bytes, a.st, (float *)a.out, (const uint4 *)a.features,
+    // the F(4x4) stream follows the direct and the two F(2x2) streams (pack_conv3x3_weights: 9 + 16 + 16 + 36 values per pair); its split form
+    // (SP: [hi | lo] halves of 256 U) is the sixth stream, behind the split stream of the direct form (9)
+    const float4 *w4 = reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(a.wpk) + (size_t)(SP ? 86 : 41) * a.Cin * a.Cout);
+    BC_LAUNCH(ps, (k_conv3x3_wino4<TS, WNW, WFW, NB, SP>), grid, dim3(512), lds_bytes, a.st, (float *)a.out, (const uint4 *)a.features,
               (long long)(((const char *)a.ring - (const char *)a.features) / 16), (uint4 *)a.ring, w4, a.grid_idx, a.mapping_exec, g, a.pr, a.ep, a.stamps);
 }
 
 template <int WNW, int WFW, int NB>
 static void launch_wino4_cfg(LaunchProf &ps, dim3 grid, size_t lds_bytes, const ConvV2Args &a, const ConvGeom2 &g)
 {
+    const bool sp = (a.force_cfg & 0x4000) != 0;
     if (a.bs == 8) {
-        if constexpr (WFW == 4 && NB == 1) launch_wino4_ts<8, WNW, WFW, NB>(ps, grid, lds_bytes, a, g);
-    } else launch_wino4_ts<16, WNW, WFW, NB>(ps, grid, lds_bytes, a, g);
+        if constexpr (WFW == 4 && NB == 1) {
+            if (sp) launch_wino4_ts<8, WNW, WFW, NB, true>(ps, grid, lds_bytes, a, g);
+            else launch_wino4_ts<8, WNW, WFW, NB, false>(ps, grid, lds_bytes, a, g);
+        }
+    } else if (sp) launch_wino4_ts<16, WNW, WFW, NB, true>(ps, grid, lds_bytes, a, g);
+    else launch_wino4_ts<16, WNW, WFW, NB, false>(ps, grid, lds_bytes, a, g);
 }
 
 static int conv_wino4_run(ConvV2Args &a)
@@ -3364,7 +3370,7 @@ static int conv_wino4_run(ConvV2Args &a)
     case 2: launch_wino4_cfg<2, 4, 2>(ps, grid, plan.lds_bytes, a, g); break;
     default: return BC_ERR_SHAPE;
     }
-    a.chosen = a.force_cfg & 0x10ff;
+    a.chosen = a.force_cfg & 0x50ff;
     return launch_status();
 }
 #endif
@@ -3432,7 +3438,8 @@ static int launch_conv3x3_v2(ProfScope &ps, void *out, const void *features, voi
     g_conv_dyn = DynCount{};
     const double direct_flops = 2.0 * n_exec * (double)(bs / S) * (bs / S) * (KS * KS) * (double)Cin * Cout;
     if (DT == BC_F32 && S == 1 && KS == 3 && a.force_cfg >= 0 && (a.force_cfg & 0x1000)) {      // Winograd F(4x4,3x3) (conv3x3_wino4.inc)
-        ps.add_aux(direct_flops * 36.0 / 144.0);    // 36 multiplications per 4x4 outputs instead of 144
+        // 36 multiplications per 4x4 outputs instead of 144; | 0x4000: on the 16-bit pipe (three MFMAs of 16 cycles where the fp32 pipe runs four of 32)
+        ps.add_aux(direct_flops * 36.0 / 144.0 * ((a.force_cfg & 0x4000) ? 3.0 / 8.0 : 1.0));
 #if defined(BC_MONO)
         const int rcw = conv_wino4_run(a);
 #else
@@ -4214,6 +4221,9 @@ static int conv_candidates(int dtype, int stride, int ks, int n_exec, int Cin, i
         Wino4Plan wp4;
         for (int c = 0; c < WINO4_N && n < max_out; ++c)
             if (wino4_plan(WINO4_CFGS[c], n_exec, Cin, Cout, bs, wp4)) out[n++] = c | 0x1000;
+        // ... and with its products on the 16-bit matrix pipe (split operands, conv3x3_wino4.inc SP)
+        for (int c = 0; c < WINO4_N && n < max_out; ++c)
+            if (wino4_plan(WINO4_CFGS[c], n_exec, Cin, Cout, bs, wp4)) out[n++] = c | 0x5000;
     }
     // the direct form on the 16-bit matrix pipe (fp32 tensors, operands split hi + lo; BC_F32S): with and without the LDS floor
     if (dtype == BC_F32) {

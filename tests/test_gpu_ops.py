@@ -969,7 +969,7 @@ def test_fused_conv3x3_dilation2(be, dtype, tol):
         be.tune("conv2_cfg", -1)
 
 
-@pytest.mark.parametrize("cfg", list(range(20)) + [0x200 | w for w in range(14)] + [0x400 | w for w in range(5)] + [0x1000 | w for w in range(3)] + [0x2000 | c for c in range(20)])
+@pytest.mark.parametrize("cfg", list(range(20)) + [0x200 | w for w in range(14)] + [0x400 | w for w in range(5)] + [0x1000 | w for w in range(3)] + [0x2000 | c for c in range(20)] + [0x5000 | w for w in range(3)])
 def test_fused_conv3x3_every_decomposition(be, cfg):
     """The CU-balanced conv kernel (csrc/conv3x3_v2.inc) picks one of 20 decompositions per launch (register blocking
     RM x RN, wave grid, in-workgroup split-K); here each one is FORCED in turn on shapes it covers -- incl. ragged wave
@@ -977,7 +977,8 @@ def test_fused_conv3x3_every_decomposition(be, cfg):
     (2e-5 relative: fp32 summation order), with the ring cache left bit-identical.  Codes 0x200 | w: the Winograd F(2x2,3x3)
     form of the same layer (csrc/conv3x3_wino.inc), codes 0x400 | w its wide wave tile (csrc/conv3x3_wino32.inc), same bar; codes
     0x1000 | w: the F(4x4,3x3) form (csrc/conv3x3_wino4.inc; 6x6 transforms with the points 0, +-1, +-2: 5e-5); codes 0x2000 | c: decomposition c
-    on the 16-bit matrix pipe with the operands split hi + lo in fp16 (BC_F32S: fp32-level accuracy, the 2e-5 bar)."""
+    on the 16-bit matrix pipe with the operands split hi + lo in fp16 (BC_F32S: fp32-level accuracy, the 2e-5 bar); codes 0x5000 | w: the F(4x4) form
+    with ITS products on the 16-bit pipe (transformed input and weights split hi + lo; the F(4x4) bar)."""
     import torch.nn.functional as F
 
     rng = np.random.default_rng(500 + cfg)

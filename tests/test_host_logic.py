@@ -403,9 +403,13 @@ def test_conv3x3_weight_packing_matches_the_header_formula():
     both = HipBackend.pack_conv3x3_weights(w)
     # fp32 3x3: the direct stream (9 values per (cout, cin) pair), the two Winograd F(2x2,3x3) streams (16 each), the F(4x4,3x3) stream (36) and the
     # split stream of the direct form on the 16-bit matrix pipe (9: the direct stream position by position, four weights -> [hi0..3 | lo0..3] fp16)
-    assert both.numel() == 86 * Cout * Cin
+    # ... and the split stream of the F(4x4) form (36: its stream position by position, [hi0..3 | lo0..3] fp16 of 256 U)
+    assert both.numel() == 122 * Cout * Cin
     sp = HipBackend.pack_conv3x3_weights(w / 977.0)
-    d4, s8 = sp[:9 * Cout * Cin].reshape(-1, 4), sp[77 * Cout * Cin:].view(torch.float16).reshape(-1, 8).double()
+    u4, u8 = sp[41 * Cout * Cin:77 * Cout * Cin].reshape(-1, 4), sp[86 * Cout * Cin:].view(torch.float16).reshape(-1, 8).double()
+    assert float((256.0 * u4.double() - (u8[:, :4] + u8[:, 4:])).abs().max()) <= 256.0 * float(u4.abs().max()) * 2.0 ** -21
+    assert torch.equal(u8[:, :4].half(), (256.0 * u4).half())
+    d4, s8 = sp[:9 * Cout * Cin].reshape(-1, 4), sp[77 * Cout * Cin:86 * Cout * Cin].view(torch.float16).reshape(-1, 8).double()
     assert float((16.0 * d4.double() - (s8[:, :4] + s8[:, 4:])).abs().max()) <= 16.0 * float(d4.abs().max()) * 2.0 ** -21     # hi + lo = 16 w to 22 bits
     assert torch.equal(s8[:, :4].half(), (16.0 * d4).half())
     wpk = both[:9 * Cout * Cin].reshape(Cout // 32, Cin // 32, 9, 4, 64, 4)

@@ -42,7 +42,7 @@ def main():
         sc = torch.rand(Cin, device="cuda") + 0.5
         pro = (sc, sc * 0.1, True)
         want = F.conv2d(be.pad_ring(feats, ring, gi, m, 1, pro).double(), w.double())
-        fams = {"direct fp32": lambda c: c < 0x100, "winograd F(2x2)": lambda c: bool(c & 0x600), "winograd F(4x4)": lambda c: bool(c & 0x1000),
+        fams = {"direct fp32": lambda c: c < 0x100, "winograd F(2x2)": lambda c: bool(c & 0x600), "winograd F(4x4)": lambda c: (c & 0x5000) == 0x1000, "F(4x4) split": lambda c: (c & 0x5000) == 0x5000,
                 "split 16-bit": lambda c: bool(c & 0x2000)}
         best = {}
         for c in be.conv3x3_candidates(n_exec, Cin, Cout, bs, 4, 1):
@@ -54,7 +54,7 @@ def main():
                 err = float((got.double() - want).abs().max() / max(1.0, float(want.abs().max())))
             finally:
                 be.tune("conv2_cfg", -1)
-            if a.all and (c & 0x2000):
+            if a.all and (c & 0x6000):
                 print(f"    0x{c:x}: {us:7.1f} us  {2.0 * n_exec * bs * bs * 9 * Cin * Cout / us / 1e6:6.1f} TFLOP/s", flush=True)
             for fam, pred in fams.items():
                 if pred(c) and (fam not in best or us < best[fam][0]):

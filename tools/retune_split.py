@@ -26,7 +26,9 @@ def main():
     ap.add_argument("--margin", type=float, default=0.03)
     ap.add_argument("--dry-run", action="store_true")
     ap.add_argument("--max-mb", type=float, default=1500.0)
+    ap.add_argument("--family", default="0x2000", help="candidate family, as mask of code bits that must all be set: 0x2000 the split direct form (default), 0x5000 the split F(4x4) form")
     a = ap.parse_args()
+    fam = int(a.family, 0)
     be = bk.get_backend()
     doc = json.load(open(PLAN))
     plans = doc["plans"]
@@ -35,7 +37,7 @@ def main():
         f = text.split(",")
         n, bs, cin, cout, n_total, dt, stride, ks = int(f[0]), int(f[1]), int(f[2]), int(f[3]), int(f[4]), f[5], int(f[6]), int(f[7])
         cur = plans[text]
-        if dt != "f32" or cur is None or n <= 0 or ks not in (1, 3) or cin % 32 or cout % 32 or n * bs * bs * max(cin, cout) * 4 / 1e6 > a.max_mb:
+        if dt != "f32" or cur is None or n <= 0 or ks not in (1, 3) or (fam == 0x5000 and (ks != 3 or stride != 1)) or cin % 32 or cout % 32 or n * bs * bs * max(cin, cout) * 4 / 1e6 > a.max_mb:
             continue
         feats = torch.relu(torch.randn((n, cin, bs, bs), device="cuda")).contiguous(memory_format=torch.channels_last)
         w = (torch.randn((cout, cin, ks, ks), device="cuda") * (2.0 / (ks * ks * cin)) ** 0.5).contiguous(memory_format=torch.channels_last)
@@ -46,7 +48,7 @@ def main():
             if ks == 3:
                 if n_total < n or n_total <= 1:
                     continue
-                cands = [c for c in be.conv3x3_candidates(n, cin, cout, bs, 4, stride) if c & 0x2000]
+                cands = [c for c in be.conv3x3_candidates(n, cin, cout, bs, 4, stride) if (c & fam) == fam]
                 gh = 1
                 while gh * gh * 2 <= n_total and n_total % (gh * 2) == 0:
                     gh *= 2
@@ -56,7 +58,7 @@ def main():
             else:
                 if not be.conv1x1_supported(feats, w, stride):
                     continue
-                cands = [c for c in be.conv1x1_candidates(feats, cout, stride) if c & 0x2000]
+                cands = [c for c in be.conv1x1_candidates(feats, cout, stride) if (c & fam) == fam]
                 run = lambda cfg: be.conv1x1(feats, wpk, cout, pro, None, cfg=cfg, stride=stride)
             if not cands:
                 continue
@@ -77,7 +79,7 @@ def main():
         print(f"{text:38s} {cur:#7x} {times[cur]:8.1f} us | best split {best:#7x} {times[best]:8.1f} us {tag}", flush=True)
     print(f"{changed} entries switched, {kept} kept")
     if not a.dry_run:
-        doc["note"] = (doc.get("note") or "") + " | fp32 entries re-measured against the split 16-bit form (tools/retune_split.py)"
+        doc["note"] = (doc.get("note") or "") + f" | fp32 entries re-measured against the candidates of family {fam:#x} (tools/retune_split.py)"
         tmp = PLAN + ".tmp"
         with open(tmp, "w") as fh:
             json.dump(doc, fh, indent=0, sort_keys=True)
