@@ -368,7 +368,9 @@ int bc_adaptive_avg_pool_nhwc(void *out, const void *in, int N, int C, int H, in
  * fp32, stride 1: bc_conv1x1_candidates) for the plain-GEMM form csrc/gemm1x1.inc (index 0..3 = workgroup tile 128x128, 128x64,
  * 64x128, 64x64; reads the same packed one-tap weight stream) | 0x1000 for the Winograd F(4x4,3x3) form (fp32, stride 1, 3x3, tiles
  * of a multiple of 16 pixels or 8x8 tiles: csrc/conv3x3_wino4.inc; index 0..2 = (columns of 16*NB output channels, frequency groups,
- * NB) = (4,2,1), (2,4,1), (2,4,2) of its eight waves) | 0x2000 (fp32 tensors, 3x3 and pointwise, both strides): decomposition `index` of the
+ * NB) = (4,2,1), (2,4,1), (2,4,2) of its eight waves; | 0x4000 on top, i.e. 0x5000 | index: the same with its 36 element-wise products on the
+ * 16-bit matrix pipe -- transformed input and weights split hi + lo in fp16 as for 0x2000 below, three v_mfma_f32_16x16x16_f16 where the fp32 pipe runs
+ * four v_mfma_f32_16x16x4_f32; needs |x| < 655) | 0x2000 (fp32 tensors, 3x3 and pointwise, both strides): decomposition `index` of the
  * direct form on the 16-BIT matrix pipe at fp32 accuracy -- every staged value is split x = hi + lo into two fp16 numbers (16 x = hi + lo: |x| < 4094,
  * 22 bits of mantissa) and a product is hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation (three MFMAs of 16 channels where the
  * fp32 pipe runs eight of 2; measured error 3e-7 .. 1e-6 of the result's largest element, the fp32 direct form's own level); reads its own weight
@@ -382,7 +384,9 @@ int bc_adaptive_avg_pool_nhwc(void *out, const void *in, int N, int C, int H, in
  *   products computed in fp64, rounded once).  A caller that never forces a 0x1000 code may pass a buffer without the last stream.
  *   split (codes | 0x2000): the direct stream position by position, every 16-byte vector of four weights w0..w3 replaced by the eight fp16 numbers
  *   [hi0..3 | lo0..3] with 16 w = hi + lo (9 * Cin * Cout floats after the first 77 * Cin * Cout; pointwise convs: Cin * Cout floats after the first
- *   Cin * Cout). */
+ *   Cin * Cout);
+ *   F(4x4) split (codes 0x5000 | index): the wino4 stream position by position, [hi0..3 | lo0..3] with 256 U = hi + lo (36 * Cin * Cout floats after the
+ *   first 86 * Cin * Cout: 122 floats per pair in all). */
 /* The same fused halo + 3x3 conv with DILATION 2 (padding = dilation = 2, stride 1): the dilated last stage of a detector backbone
  * (Pedestron/mmdet/models/backbones/resnet.py:155-162; reference path: BlockPadFunction with pad 2 + F.conv2d(dilation=2),
  * core/tensorwrapper.py:529-575).  Everything as bc_conv3x3_ring_nhwc except: taps 2 pixels apart, halo / zero border 2 pixels
