@@ -66,6 +66,11 @@ class BlockCopyModel(nn.Module):
             # a policy that decides on the device need not tell the host its executed-tile count when the frame runs as the ONE
             # dynamic graph (every launch reads the count from the device); any other execution mode needs the number
             self.policy.wait_free = self.use_graph == 2 and blockcopy.core.tensorwrapper.ENGINE == "fused"
+            if self.policy.wait_free:
+                # ... and it can write its index tables straight into the captured frame's table buffer (same layout), once that exists
+                gf = self._graphed.get((tuple(inputs.shape), inputs.dtype, inputs.device))
+                if gf is not None:
+                    self.policy_meta["tables_target"] = gf.tables[:2 * gf.n_total + 4]
         with timings.env("blockcopy/policy_forward", 3):
             # the policy writes the execution grid into policy_meta['grid'] (+ optional CPU mirror 'grid_host')
             self.policy_meta = self.policy(self.policy_meta)

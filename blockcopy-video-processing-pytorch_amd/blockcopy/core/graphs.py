@@ -115,7 +115,8 @@ class GraphedFrame:
         n_words = 2 * self.n_total + COUNT_WORDS
         assert tables.numel() == n_words and tables.dtype == torch.int32
         assert n_exec is not None or self.dynamic, "an executed-tile count only the device knows needs the dynamic graph (block_graph=2)"
-        self.tables[:n_words].copy_(tables, non_blocking=True)
+        if tables.data_ptr() != self.tables.data_ptr():       # (a policy that was handed this buffer as its target has written it in place)
+            self.tables[:n_words].copy_(tables, non_blocking=True)
         ring = pinned_ring(SLOT_WORDS, torch.int64, self.device.type == "cuda")
         staging = ring.next()
         staging.numpy()[:] = self._slot_words(inputs)

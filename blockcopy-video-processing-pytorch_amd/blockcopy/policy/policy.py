@@ -444,6 +444,7 @@ class PolicyTrainRL(Policy, metaclass=abc.ABCMeta):
         policy_meta["loss_policy"] = loss
 
     MAILBOX_ROWS = 64      # pinned rows the device step reports its counts into, one per frame, reused round robin
+    GRID_RING = 8          # device buffers the wait-free step writes its grid into, round robin (a frame's grid lives eight frames)
 
     def _device_step(self, policy_meta: dict, grid_logits: torch.Tensor, shape):
         """Decision on the device: one launch samples, rounds the executed count up to the quantisation step and builds the
@@ -472,19 +473,31 @@ class PolicyTrainRL(Policy, metaclass=abc.ABCMeta):
         if st["owners"][row_k] is not None:
             st["owners"][row_k].resolve()      # (MAILBOX_ROWS frames old: answered long ago) the row is about to be rewritten
         row = (st["mailbox_dev"] if self.wait_free else st["mailbox"])[row_k]
-        be.policy_step(logits, self.rng_seed, self.rng_counter, multiple, self.at_least_one, st["grid"], st["tables"][:2 * n_total], st["counts"], row)
-        self.rng_counter += 1
         if self.wait_free:
-            # nobody waits: the engine's launches read the count from the device (dynamic graph), the host asks lazily
+            # nobody waits: the engine's launches read the count from the device (dynamic graph), the host asks lazily.  No copy either: the
+            # tables are written straight into the captured frame's table buffer when the engine has named one (``tables_target``, same layout;
+            # the frame's graph is behind this launch in the stream), and the grid into one of GRID_RING buffers (it is read by this frame's
+            # bookkeeping and the next frame's policy input -- eight frames of life instead of a clone per frame)
+            tables = policy_meta.pop("tables_target", None)
+            if tables is None or tables.numel() != 2 * n_total + 4 or tables.device != dev or tables.dtype != torch.int32:
+                tables = st["tables"]
+            if "grid_ring" not in st:
+                st["grid_ring"] = [torch.zeros(n_total, dtype=torch.uint8, device=dev) for _ in range(self.GRID_RING)]
+            ring = st["grid_ring"]
+            grid_u8 = ring[self.rng_counter % self.GRID_RING]
+            be.policy_step(logits, self.rng_seed, self.rng_counter, multiple, self.at_least_one, grid_u8, tables[:2 * n_total], tables[2 * n_total:], row)
+            self.rng_counter += 1
             ev = torch.cuda.Event()
             ev.record()
             lazy = st["owners"][row_k] = LazyCount(row, ev, n_total)
-            grid = st["grid"].view(torch.bool).view(shape).clone()
-            policy_meta["grid"] = grid
+            policy_meta["grid"] = grid_u8.view(torch.bool).view(shape)
             policy_meta.pop("grid_host", None)
-            policy_meta["grid_tables"] = (st["tables"], None)
+            policy_meta["grid_tables"] = (tables, None)
             policy_meta["num_exec_known"] = lazy
         else:
+            policy_meta.pop("tables_target", None)
+            be.policy_step(logits, self.rng_seed, self.rng_counter, multiple, self.at_least_one, st["grid"], st["tables"][:2 * n_total], st["counts"], row)
+            self.rng_counter += 1
             st["owners"][row_k] = None
             st["host"].copy_(st["grid"], non_blocking=True)
             st["event"].record()
