@@ -1108,35 +1108,39 @@ __device__ __forceinline__ float pn_feat_load(const PnFeatSrc &s, long long off)
     }
 }
 
-// a lane per output pixel (consecutive lanes = consecutive columns: every source row is read in order), the channels of the pixel in a loop,
-// 16-byte stores of its Cpad-channel run
+// a lane per (output pixel, channel quad): the Cpad / 4 quads of a pixel sit in neighbouring lanes, so the stores of a wave are whole 16-byte
+// runs of consecutive pixels and every lane has at most four independent loads in flight (a lane per pixel looping over 26 channels was
+// latency-bound: 37 us for the 8 MB policy input of a batch of two frames; the sources it samples are 25 MB)
 __global__ __launch_bounds__(256) void k_pn_features(float *__restrict__ out, const PnFeatGeom g)
 {
-    const long long total = (long long)g.N * g.h * g.w;
+    const int Cq = g.Cpad >> 2;
+    const long long total = (long long)g.N * g.h * g.w * Cq;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
-    const int x = (int)(i % g.w);
-    const long long p = i / g.w;
+    const int q = (int)(i % Cq);
+    const long long pix = i / Cq;
+    const int x = (int)(pix % g.w);
+    const long long p = pix / g.w;
     const int y = (int)(p % g.h), n = (int)(p / g.h);
-    float4 *o = reinterpret_cast<float4 *>(out + i * g.Cpad);
-    float v[4];
-    int c = 0;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    int c0 = 0;                                       // first channel of source k in the concatenation
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const PnFeatSrc &s = g.src[k];
-        int sy = (int)floorf((float)y * s.scale_h), sx = (int)floorf((float)x * s.scale_w);
-        sy = sy < s.H - 1 ? sy : s.H - 1;
-        sx = sx < s.W - 1 ? sx : s.W - 1;
-        const long long base = n * s.sn + sy * s.sh + sx * s.sw;
-        for (int cc = 0; cc < s.C; ++cc, ++c) {
-            v[c & 3] = pn_feat_load(s, base + cc * s.sc) + s.offset;
-            if ((c & 3) == 3) o[c >> 2] = make_float4(v[0], v[1], v[2], v[3]);
+        if (4 * q + 3 >= c0 && 4 * q < c0 + s.C) {    // the quad holds channels of this source
+            int sy = (int)floorf((float)y * s.scale_h), sx = (int)floorf((float)x * s.scale_w);
+            sy = sy < s.H - 1 ? sy : s.H - 1;
+            sx = sx < s.W - 1 ? sx : s.W - 1;
+            const long long base = n * s.sn + sy * s.sh + sx * s.sw;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int cc = 4 * q + j - c0;
+                if (cc >= 0 && cc < s.C) v[j] = pn_feat_load(s, base + cc * s.sc) + s.offset;
+            }
         }
+        c0 += s.C;
     }
-    for (; c < g.Cpad; ++c) {
-        v[c & 3] = 0.f;
-        if ((c & 3) == 3) o[c >> 2] = make_float4(v[0], v[1], v[2], v[3]);
-    }
+    reinterpret_cast<float4 *>(out + pix * g.Cpad)[q] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
 // decision bookkeeping of a frame (policy.py:283-288 via torch.distributions.Bernoulli): probs = sigmoid(l), log_prob(grid) = -BCE-with-logits
@@ -1471,8 +1475,8 @@ BC_EXPORT int bc_pn_features_nhwc(float *out, int N, int h, int w, int Cpad, con
         ctot += s.C;
     }
     if (ctot > Cpad) return BC_ERR_SHAPE;
-    const long long total = (long long)N * h * w;
-    if (total > 0x7fffffffLL) return BC_ERR_RANGE;
+    const long long total = (long long)N * h * w * (Cpad / 4);
+    if (total > 0x7fffffffLL * 64) return BC_ERR_RANGE;
     hipLaunchKernelGGL(k_pn_features, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, g);
     return pn_status();
 }
