@@ -160,6 +160,11 @@ def load_library(path: str = None) -> ctypes.CDLL:
         "bc_pn_wgrad_nhwc": [p, p, ctypes.c_longlong, p, p] + [i] * 9 + [p, p, i, p],
         "bc_pn_bn_finalize": [p, ctypes.c_longlong, i, ctypes.c_double, p, p, ctypes.c_float, ctypes.c_float, p, p, p, p, p, p, p, p],
         "bc_pn_join": [p, p, p, p, p, p, p, i, i, ctypes.c_longlong, p],
+        "bc_pn_arm_bn": [p, p, p, ctypes.c_double, ctypes.c_float, i, p],
+        "bc_pn_join_acc": [p, p, p, p, p, p, p, p, p, ctypes.c_double, ctypes.c_float, i, i, ctypes.c_longlong, p],
+        "bc_pn_head_fwd_acc": [p, p, p, p, p, ctypes.c_double, ctypes.c_float, p, p, i, i, i, i, p],
+        "bc_pn_bn_layer_bytes": [],
+        "bc_pn_bn_finalize_acc": [p, i, p],
         "bc_pn_bn_bwd": [p, p, p, p, p, p, p, p, i, p, p, p, p, p, i, ctypes.c_longlong, p],
         "bc_pn_head_fwd": [p, p, p, p, p, p, i, i, i, i, p],
         "bc_pn_head_bwd": [p, p, p, p, p, p, p, p, i, i, i, i, p],

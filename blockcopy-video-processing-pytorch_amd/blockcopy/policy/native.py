@@ -30,6 +30,8 @@ import torch.nn as nn
 
 ENABLED = os.environ.get("BLOCKCOPY_NATIVE_POLICY", "1") != "0"
 USE_GRAPH = os.environ.get("BLOCKCOPY_NATIVE_POLICY_GRAPH", "1") != "0"
+# BatchNorm statistics through fixed-point accumulators (no finish launch per layer: bc_pn_arm_bn); 0 = per-workgroup partial sums + bc_pn_bn_finalize
+BN_ACC = os.environ.get("BLOCKCOPY_NATIVE_POLICY_BN_ACC", "1") != "0"
 CPAD = 32
 # forward convs: 1 = split-fp16 products on the 16-bit matrix pipe (fp32-level accuracy, 5.3 x the fp32 matrix rate; bc_pn_conv_nhwc), 0 = fp32 pipe
 FWD_PRECISION = int(os.environ.get("BLOCKCOPY_POLICY_FWD_PRECISION", "1"))
@@ -65,6 +67,9 @@ class _BN:
         self.off_g = self.off_b = -1
         v = lambda: torch.zeros(self.C, dtype=torch.float32, device=dev)
         self.scale, self.shift, self.mean, self.invstd = v(), v(), v(), v()
+        # fixed-point accumulators [sum x | sum x^2] of the layer's input (bc_pn_arm_bn) and the pixel count of the conv that feeds it
+        self.acc = torch.zeros(16 * 2 * self.C, dtype=torch.int64, device=dev)      # (16 replicas: include/blockcopy_hip.h bc_pn_arm_bn)
+        self.count = 0.0
 
 
 class _Block:
@@ -138,7 +143,7 @@ class NativePolicyNet:
         self._alloc()
         self._segs_key = None
         self._import_params()
-        self._fwd_ops = self._build_forward()
+        self._fwd_ops = self._build_forward_acc() if BN_ACC else self._build_forward()
         self._step_ops = self._build_step()
         self._fwd_graph = self._step_graph = None
         self._fwd_warm = self._step_warm = 0
@@ -299,7 +304,7 @@ class NativePolicyNet:
         if self._segs_key != self._ptr_key():
             # the module's tensors moved (``.to()``): every captured pointer is stale
             self._import_params()
-            self._fwd_ops, self._step_ops = self._build_forward(), self._build_step()
+            self._fwd_ops, self._step_ops = (self._build_forward_acc() if BN_ACC else self._build_forward()), self._build_step()
             self._fwd_graph = self._step_graph = None
         elif self._seen_versions != self._versions():
             self._import_params()      # somebody wrote the parameters (load_state_dict, an eager optimizer step)
@@ -336,6 +341,65 @@ class NativePolicyNet:
             self._check(lib.bc_pn_conv_nhwc(*args, st), "pn_conv_nhwc")
             self._check(lib.bc_pn_bn_finalize(*fin, st), "pn_bn_finalize")
         return run
+
+    def _conv_fwd_acc(self, c: _Conv, x, pro: Optional[_BN], bn: _BN):
+        """conv whose output statistics go to ``bn``'s fixed-point accumulators and whose prologue derives the coefficients of ``pro`` from ITS
+        accumulators: no BatchNorm finish between the layers (bc_pn_arm_bn; one bc_pn_bn_finalize_acc at the end of the pass)."""
+        lib, P = self.lib, self.P
+        bn.count = float(c.N * c.Hy * c.Wy)
+        arm = ((pro.acc.data_ptr(), P.data_ptr() + 4 * pro.off_g, P.data_ptr() + 4 * pro.off_b, pro.count, float(pro.mod.eps), pro.C) if pro is not None
+               else (None, None, None, 0.0, 0.0, 0)) + (bn.acc.data_ptr(),)
+        assert pro is None or (pro.count > 0 and pro.C == c.Cxp)
+        args = (c.z.data_ptr(), x.data_ptr(), P.data_ptr() + 4 * c.off, c.N, c.Hx, c.Wx, c.Cxp, c.Hy, c.Wy, c.Cy, c.ks, c.stride, 0, None, None,
+                1 if pro is not None else 0, None, None, 0, None, 0, FWD_PRECISION)
+
+        def run(st):
+            self._check(lib.bc_pn_arm_bn(*arm), "pn_arm_bn")
+            self._check(lib.bc_pn_conv_nhwc(*args, st), "pn_conv_nhwc")
+        return run
+
+    def _build_forward_acc(self):
+        """The forward pass without BatchNorm finish launches (11 fewer): see _conv_fwd_acc."""
+        lib, P = self.lib, self.P
+        gb = lambda bn: (bn.acc.data_ptr(), P.data_ptr() + 4 * bn.off_g, P.data_ptr() + 4 * bn.off_b)
+        ops = [self._conv_fwd_acc(self.stem, self.feat, None, self.stem_bn)]
+        for b in self.blocks:
+            x, pro = self._block_input(b)
+            ops.append(self._conv_fwd_acc(b.c1, x, pro, b.b1))
+            ops.append(self._conv_fwd_acc(b.c2, b.c1.z, b.b1, b.b2))
+            pixels = b.c2.N * b.c2.Hy * b.c2.Wy
+            eps = float(b.b2.mod.eps)
+            if b.cd is not None:
+                ops.append(self._conv_fwd_acc(b.cd, x, pro, b.bd))
+                assert b.bd.count == b.b2.count and float(b.bd.mod.eps) == eps
+                jargs = (b.out.data_ptr(), b.c2.z.data_ptr()) + gb(b.b2) + (b.cd.z.data_ptr(),) + gb(b.bd) + (b.b2.count, eps, 1, b.c2.Cy, pixels)
+            elif pro is not None:
+                assert pro.count == b.b2.count and float(pro.mod.eps) == eps
+                jargs = (b.out.data_ptr(), b.c2.z.data_ptr()) + gb(b.b2) + (x.data_ptr(),) + gb(pro) + (b.b2.count, eps, 2, b.c2.Cy, pixels)
+            else:
+                jargs = (b.out.data_ptr(), b.c2.z.data_ptr()) + gb(b.b2) + (x.data_ptr(), None, None, None, b.b2.count, eps, 0, b.c2.Cy, pixels)
+            ops.append(lambda st, a=jargs: self._check(lib.bc_pn_join_acc(*a, st), "pn_join_acc"))
+        ops.append(self._conv_fwd_acc(self.head0, self.blocks[-1].out, None, self.head0_bn))
+        ops.append(self._conv_fwd_acc(self.head1, self.head0.z, self.head0_bn, self.head1_bn))
+        h1 = self.head1_bn
+        hargs = (self.logits.data_ptr(), self.head1.z.data_ptr()) + gb(h1) + (h1.count, float(h1.mod.eps), P.data_ptr() + 4 * self.off_last_w,
+                                                                               P.data_ptr() + 4 * self.off_last_b, self.N, self.last_Hi, self.last_Wi, self.last_C)
+        ops.append(lambda st: self._check(lib.bc_pn_head_fwd_acc(*hargs, st), "pn_head_fwd_acc"))
+        # end of the pass: the arrays the backward pass reads, running statistics, batch counters; accumulators zeroed
+        rec = np.dtype([("acc", "<i8"), ("gamma", "<i8"), ("beta", "<i8"), ("rm", "<i8"), ("rv", "<i8"), ("batches", "<i8"), ("scale", "<i8"), ("shift", "<i8"),
+                        ("mean", "<i8"), ("invstd", "<i8"), ("count", "<f8"), ("eps", "<f4"), ("momentum", "<f4"), ("C", "<i4"), ("pad", "<i4")])
+        assert rec.itemsize == lib.bc_pn_bn_layer_bytes()
+        tab = np.zeros(len(self.bns), dtype=rec)
+        for k, bn in enumerate(self.bns):
+            assert bn.count > 0, bn.name
+            m = bn.mod
+            tab[k] = (bn.acc.data_ptr(), P.data_ptr() + 4 * bn.off_g, P.data_ptr() + 4 * bn.off_b, m.running_mean.data_ptr(), m.running_var.data_ptr(),
+                      m.num_batches_tracked.data_ptr(), bn.scale.data_ptr(), bn.shift.data_ptr(), bn.mean.data_ptr(), bn.invstd.data_ptr(), bn.count,
+                      float(m.eps), float(m.momentum), bn.C, 0)
+        self._bn_layers = torch.from_numpy(tab.view(np.uint8).copy()).to(self.P.device)
+        n_layers, layers_ptr = len(self.bns), self._bn_layers.data_ptr()
+        ops.append(lambda st: self._check(lib.bc_pn_bn_finalize_acc(layers_ptr, n_layers, st), "pn_bn_finalize_acc"))
+        return ops
 
     def _block_input(self, b: _Block):
         """(tensor, BN prologue or None) of a block's input."""

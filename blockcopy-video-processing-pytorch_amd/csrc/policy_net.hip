@@ -58,12 +58,47 @@ struct PnTapSet {
     int8_t dy[PN_MAXTAPS], dx[PN_MAXTAPS], wt[PN_MAXTAPS];
 };
 
+// training-mode BatchNorm coefficients from fixed-point sums (k_pn_bn_finalize's arithmetic, so that every consumer and the end-of-forward
+// finalize derive bit-identical values): S1 = sum x, S2 = sum x^2 in units of 2^-24
+constexpr double PN_ACC_UNIT = 16777216.0;
+constexpr int PN_ACC_R = 16;         // replicas of an accumulator set (workgroup w adds to replica w mod 16: 1/16 of the same-address atomics)
+struct PnBnSrc {
+    const unsigned long long *acc;   // [PN_ACC_R][2][C]
+    const float *gamma, *beta;
+    double count;
+    float eps;
+    int C;
+};
+constexpr int PN_COEF_MAX = 128;      // channels of a BatchNorm whose coefficients a kernel derives in its LDS
+__device__ __forceinline__ void pn_bn_coef(const PnBnSrc &b, int c, float &scale, float &shift, float *mean_out = nullptr, float *invstd_out = nullptr,
+                                           double *var_out = nullptr)
+{
+    long long i1 = 0, i2 = 0;
+#pragma unroll
+    for (int r = 0; r < PN_ACC_R; ++r) { i1 += (long long)b.acc[(size_t)r * 2 * b.C + c]; i2 += (long long)b.acc[(size_t)r * 2 * b.C + b.C + c]; }
+    const double s1 = (double)i1 / PN_ACC_UNIT, s2 = (double)i2 / PN_ACC_UNIT;
+    const double mean = s1 / b.count;
+    double var = s2 / b.count - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)b.eps));
+    const float g = b.gamma ? b.gamma[c] : 1.0f, bt = b.beta ? b.beta[c] : 0.0f;
+    scale = g * invstd;
+    shift = bt - (float)mean * scale;
+    if (mean_out) *mean_out = (float)mean;
+    if (invstd_out) *invstd_out = invstd;
+    if (var_out) *var_out = var;
+}
+
 struct PnConvArgs {
     const float *x, *w;
     float *out;
     const float *in_scale, *in_shift;
     const float *add, *add_mask;
     float *stats;
+    // BatchNorm without a finalize launch (bc_pn_arm_bn): the producer adds its per-workgroup sums to FIXED-POINT accumulators (order-independent:
+    // run-to-run identical), the consumer derives scale / shift of its input channels from them at kernel start
+    PnBnSrc in_bn;           // acc != nullptr: the prologue's coefficients come from these sums instead of in_scale / in_shift
+    unsigned long long *out_acc;      // [PN_ACC_R][2][Nn] sums of the output and of its squares, in units of 2^-24
     int N, Hi, Wi, K, Nn;    // input map, reduction channels, output channels
     int Hout, Wout;          // full output map
     int S, out_s;            // input stride, output pixel stride
@@ -131,6 +166,7 @@ __global__ __launch_bounds__(256, (KC == 16 && S == 1 && !TS) ? 2 : 1) void k_pn
     unsigned long long *stp = a.stamps ? a.stamps + 8 * ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) : nullptr;
     auto stamp = [&](int k) { if (stp && tid == 0) stp[k] = __builtin_amdgcn_s_memrealtime(); };
     stamp(0);
+    __shared__ __align__(16) float pn_coef[2 * PN_COEF_MAX];      // [scale | shift] of the input channels (in_bn): derived under the first loads' latency
 
     auto tile_origin = [&](int tile, int &n, int &oy0, int &ox0) {
         n = tile / tiles_img;
@@ -192,7 +228,10 @@ __global__ __launch_bounds__(256, (KC == 16 && S == 1 && !TS) ? 2 : 1) void k_pn
                 float4 v = pa[i];
                 if (aoff[i] >= 0) {      // (zero padding is applied AFTER the prologue)
                     const int c = chunk * KC + 4 * c4;
-                    if (a.in_scale) {
+                    if (a.in_bn.acc) {
+                        const float4 sc = *reinterpret_cast<const float4 *>(pn_coef + c), sh = *reinterpret_cast<const float4 *>(pn_coef + PN_COEF_MAX + c);
+                        v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+                    } else if (a.in_scale) {
                         const float4 sc = *reinterpret_cast<const float4 *>(a.in_scale + c), sh = *reinterpret_cast<const float4 *>(a.in_shift + c);
                         v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
                     }
@@ -270,6 +309,10 @@ __global__ __launch_bounds__(256, (KC == 16 && S == 1 && !TS) ? 2 : 1) void k_pn
                 if (boff[i] >= 0) v = *reinterpret_cast<const float4 *>(a.w + (size_t)boff[i]);
                 pb[i] = v;
             }
+        }
+        if (a.in_bn.acc) {      // (the first patch and the weights are in flight)
+            for (int c = tid; c < a.in_bn.C; c += 256) pn_bn_coef(a.in_bn, c, pn_coef[c], pn_coef[PN_COEF_MAX + c]);
+            __syncthreads();
         }
         stamp(1);
         store_stage(As0, Bs0, 0, true);
@@ -388,7 +431,7 @@ __global__ __launch_bounds__(256, (KC == 16 && S == 1 && !TS) ? 2 : 1) void k_pn
         tile = next_live(tile);
     }
     stamp(5);
-    if (a.stats) {
+    if (a.stats || a.out_acc) {
         // per-workgroup partial sums of the output (training-mode batch statistics): a lane holds the sums of ITS pixels for 16 channels;
         // transpose through the LDS (row = (wave, h, e, which), column = lane's pixel column; row stride 33: conflict-free both ways),
         // a thread sums a row, then the four waves are joined in a fixed order
@@ -411,7 +454,8 @@ __global__ __launch_bounds__(256, (KC == 16 && S == 1 && !TS) ? 2 : 1) void k_pn
             const int row = (hh * 16 + e) * 2 + which;
             const float v = ((red[0 * 64 + row] + red[1 * 64 + row]) + red[2 * 64 + row]) + red[3 * 64 + row];
             const size_t wg = (size_t)blockIdx.z * gridDim.x + blockIdx.x;
-            a.stats[(wg * 2 + which) * a.Nn + n0 + c] = v;
+            if (a.stats) a.stats[(wg * 2 + which) * a.Nn + n0 + c] = v;
+            if (a.out_acc) atomicAdd(&a.out_acc[((wg & (PN_ACC_R - 1)) * 2 + which) * a.Nn + n0 + c], (unsigned long long)__double2ll_rn((double)v * PN_ACC_UNIT));
         }
     }
 }
@@ -433,12 +477,12 @@ int pn_conv_launch(const PnConvArgs &a, hipStream_t st)
     size_t lds = (2 * (size_t)KC * a.npix_pad + n_b * (size_t)PN_MAXTAPS * KC * 32 * NB) * sizeof(float);      // images double buffered
     if (TS) lds += 4 * 16 * 64 * sizeof(float);                                                            // + the accumulator join
     if (lds < (256 * 33 + 256) * sizeof(float)) lds = (256 * 33 + 256) * sizeof(float);                    // (the statistics transpose)
-    if (lds > 160 * 1024 - 512) return BC_ERR_SHAPE;
+    if (lds > 160 * 1024 - 2048) return BC_ERR_SHAPE;      // (the kernel's static tables: 1 KB of BatchNorm coefficients)
     static bool attr_set[16];      // per device (the first launch on a device is never inside a stream capture: the host runs a warm pass first)
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pn_conv<NB, KC, S, TS, PREC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pn_conv<NB, KC, S, TS, PREC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
         attr_set[dev] = true;
     }
     const long long n_tiles = (long long)a.N * a.tiles_y * a.tiles_x;
@@ -678,6 +722,63 @@ __global__ __launch_bounds__(256) void k_pn_join(float4 *__restrict__ out, const
     out[i] = make_float4(fmaxf(y.x + v.x, 0.f), fmaxf(y.y + v.y, 0.f), fmaxf(y.z + v.z, 0.f), fmaxf(y.w + v.w, 0.f));
 }
 
+// the same with the coefficients derived from the producers' fixed-point sums (no finalize launch in between; PnBnSrc above)
+__global__ __launch_bounds__(256) void k_pn_join_acc(float4 *__restrict__ out, const float4 *__restrict__ za, PnBnSrc ba, const float4 *__restrict__ zb,
+                                                     PnBnSrc bb, int mode, int C4, long long total4)
+{
+    __shared__ __align__(16) float coef[4 * PN_COEF_MAX];       // [scale a | shift a | scale b | shift b]
+    for (int c = threadIdx.x; c < 4 * C4; c += 256) {
+        pn_bn_coef(ba, c, coef[c], coef[PN_COEF_MAX + c]);
+        if (mode >= 1) pn_bn_coef(bb, c, coef[2 * PN_COEF_MAX + c], coef[3 * PN_COEF_MAX + c]);
+    }
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C4) * 4;
+        const float4 a = za[i], b = zb[i];
+        const float4 s = *reinterpret_cast<const float4 *>(coef + c), t = *reinterpret_cast<const float4 *>(coef + PN_COEF_MAX + c);
+        float4 y = make_float4(fmaf(a.x, s.x, t.x), fmaf(a.y, s.y, t.y), fmaf(a.z, s.z, t.z), fmaf(a.w, s.w, t.w));
+        float4 v = b;
+        if (mode >= 1) {
+            const float4 s2 = *reinterpret_cast<const float4 *>(coef + 2 * PN_COEF_MAX + c), t2 = *reinterpret_cast<const float4 *>(coef + 3 * PN_COEF_MAX + c);
+            v = make_float4(fmaf(b.x, s2.x, t2.x), fmaf(b.y, s2.y, t2.y), fmaf(b.z, s2.z, t2.z), fmaf(b.w, s2.w, t2.w));
+            if (mode == 2) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+        }
+        out[i] = make_float4(fmaxf(y.x + v.x, 0.f), fmaxf(y.y + v.y, 0.f), fmaxf(y.z + v.z, 0.f), fmaxf(y.w + v.w, 0.f));
+    }
+}
+
+// end of a forward pass: every BatchNorm layer's arrays for the backward pass and for bookkeeping (scale / shift / mean / invstd, running statistics,
+// batch counter) from its accumulators, which are then ZEROED for the next pass -- one launch for all layers (grid = layers)
+struct PnBnLayer {
+    unsigned long long *acc;      // [PN_ACC_R][2][C]
+    const float *gamma, *beta;
+    float *running_mean, *running_var;
+    long long *batches;
+    float *scale, *shift, *mean, *invstd;
+    double count;
+    float eps, momentum;
+    int C, pad;
+};
+__global__ __launch_bounds__(PN_COEF_MAX) void k_pn_bn_finalize_acc(const PnBnLayer *__restrict__ layers)
+{
+    const PnBnLayer L = layers[blockIdx.x];
+    const int c = threadIdx.x;
+    if (c >= L.C) return;
+    const PnBnSrc b{L.acc, L.gamma, L.beta, L.count, L.eps, L.C};
+    float sc, sh, mean, invstd;
+    double var;
+    pn_bn_coef(b, c, sc, sh, &mean, &invstd, &var);
+    L.scale[c] = sc; L.shift[c] = sh; L.mean[c] = mean; L.invstd[c] = invstd;
+    if (L.running_mean) {
+        const double unbiased = L.count > 1.0 ? var * L.count / (L.count - 1.0) : var;
+        L.running_mean[c] = (1.0f - L.momentum) * L.running_mean[c] + L.momentum * mean;
+        L.running_var[c] = (1.0f - L.momentum) * L.running_var[c] + L.momentum * (float)unbiased;
+    }
+    if (L.batches && c == 0) *L.batches += 1;
+#pragma unroll
+    for (int r = 0; r < PN_ACC_R; ++r) { L.acc[(size_t)r * 2 * L.C + c] = 0ull; L.acc[(size_t)r * 2 * L.C + L.C + c] = 0ull; }
+}
+
 // backward of training-mode BatchNorm, pass 1: per-workgroup partial sums of g_m and g_m * xhat, g_m = g * mask
 //   mask_mode 0: none; 1: own output  z * scale + shift > 0  (BN -> ReLU); 2: external map m > 0 (the block output after the residual join)
 struct PnBnBwdArgs {
@@ -792,6 +893,25 @@ __global__ __launch_bounds__(64) void k_pn_head_fwd(float *__restrict__ logits, 
         if (iy < 0 || iy >= Hi || ix < 0 || ix >= Wi) continue;
         const float *zp = z + (((size_t)n * Hi + iy) * Wi + ix) * C;
         for (int c = lane; c < C; c += 64) s = fmaf(fmaxf(fmaf(zp[c], scale[c], shift[c]), 0.f), w[t * C + c], s);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+    if (lane == 0) logits[o] = s + (bias ? bias[0] : 0.f);
+}
+
+__global__ __launch_bounds__(64) void k_pn_head_fwd_acc(float *__restrict__ logits, const float *__restrict__ z, PnBnSrc bn, const float *__restrict__ w /* [9][C] */,
+                                                        const float *__restrict__ bias, int N, int Hi, int Wi, int C, int Ho, int Wo)
+{
+    __shared__ float coef[2 * PN_COEF_MAX];
+    const int o = blockIdx.x, ox = o % Wo, oy = (o / Wo) % Ho, n = o / (Wo * Ho), lane = threadIdx.x;
+    for (int c = lane; c < C; c += 64) pn_bn_coef(bn, c, coef[c], coef[PN_COEF_MAX + c]);
+    __syncthreads();
+    float s = 0.f;
+    for (int t = 0; t < 9; ++t) {
+        const int iy = 2 * oy + t / 3 - 1, ix = 2 * ox + t % 3 - 1;
+        if (iy < 0 || iy >= Hi || ix < 0 || ix >= Wi) continue;
+        const float *zp = z + (((size_t)n * Hi + iy) * Wi + ix) * C;
+        for (int c = lane; c < C; c += 64) s = fmaf(fmaxf(fmaf(zp[c], coef[c], coef[PN_COEF_MAX + c]), 0.f), w[t * C + c], s);
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
@@ -1156,6 +1276,11 @@ __global__ __launch_bounds__(256) void k_pn_probs(float *__restrict__ probs, flo
 
 bool pn_aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// one-shot, per host thread: BatchNorm sources / sink of the NEXT bc_pn_conv_nhwc (slot 0: its input's BatchNorm, slot 2: accumulators for its
+// output), bc_pn_join_acc / bc_pn_head_fwd_acc take theirs as arguments
+thread_local PnBnSrc g_pn_arm_in = {nullptr, nullptr, nullptr, 0.0, 0.f, 0};
+thread_local unsigned long long *g_pn_arm_out = nullptr;
+
 }  // namespace
 
 // ====================================================================================================================== C ABI
@@ -1177,6 +1302,10 @@ BC_EXPORT int bc_pn_conv_nhwc(float *out, const float *x, const float *w, int N,
     PnConvArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.w = w; a.out = out; a.in_scale = in_scale; a.in_shift = in_shift; a.add = add; a.add_mask = add_mask; a.stats = stats;
+    a.in_bn = g_pn_arm_in; a.out_acc = g_pn_arm_out;
+    g_pn_arm_in = PnBnSrc{nullptr, nullptr, nullptr, 0.0, 0.f, 0}; g_pn_arm_out = nullptr;
+    if (a.in_bn.acc && (direction != 0 || a.in_bn.C != Cx || Cx > PN_COEF_MAX || in_scale)) return BC_ERR_SHAPE;
+    if (a.out_acc && direction != 0) return BC_ERR_SHAPE;
     a.N = N; a.in_relu = in_relu; a.accumulate = accumulate;
     {
         static const int dbg = [] { const char *e = getenv("PN_DBG"); return e ? atoi(e) : 0; }();
@@ -1345,6 +1474,44 @@ BC_EXPORT int bc_pn_join(float *out, const float *za, const float *sa, const flo
     return pn_status();
 }
 
+// BatchNorm without finalize launches.  bc_pn_arm_bn(in_acc, gamma, beta, count, eps, C, out_acc): the NEXT bc_pn_conv_nhwc of this host thread (forward) takes
+// the prologue's scale / shift from the fixed-point sums in_acc ([2][C] 64-bit words in units of 2^-24; NULL: none; in_scale / in_shift must then be NULL
+// in that call) and ADDS the sums of its output and of its squares to out_acc ([2][Cy]; NULL: none).  Integer additions: the result does not depend on
+// their order.  bc_pn_bn_finalize_acc turns the accumulators of ALL layers into the arrays the backward pass reads and zeroes them.
+BC_EXPORT int bc_pn_arm_bn(const void *in_acc, const float *gamma, const float *beta, double count, float eps, int C, void *out_acc)
+{
+    if (in_acc && (count <= 0 || C <= 0 || C > PN_COEF_MAX)) return BC_ERR_SHAPE;
+    g_pn_arm_in = PnBnSrc{static_cast<const unsigned long long *>(in_acc), gamma, beta, count, eps, C};
+    g_pn_arm_out = static_cast<unsigned long long *>(out_acc);
+    return BC_OK;
+}
+
+BC_EXPORT int bc_pn_join_acc(float *out, const float *za, const void *acc_a, const float *gamma_a, const float *beta_a, const float *zb, const void *acc_b,
+                             const float *gamma_b, const float *beta_b, double count, float eps, int mode, int C, long long pixels, void *stream)
+{
+    if (!out || !za || !acc_a || !zb || (mode >= 1 && !acc_b)) return BC_ERR_NULL;
+    if (C <= 0 || C % 4 != 0 || C > PN_COEF_MAX || pixels <= 0 || mode < 0 || mode > 2 || count <= 0) return BC_ERR_SHAPE;
+    const long long total4 = pixels * (C / 4);
+    long long wgs = (total4 + 255) / 256;
+    if (wgs > 1024) wgs = 1024;         // (every workgroup derives the coefficients once: grid-stride over the map)
+    const PnBnSrc ba{static_cast<const unsigned long long *>(acc_a), gamma_a, beta_a, count, eps, C};
+    const PnBnSrc bb{static_cast<const unsigned long long *>(acc_b), gamma_b, beta_b, count, eps, C};
+    hipLaunchKernelGGL(k_pn_join_acc, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, (float4 *)out, (const float4 *)za, ba, (const float4 *)zb, bb, mode,
+                       C / 4, total4);
+    return pn_status();
+}
+
+// layers: DEVICE array of n_layers records {acc, gamma, beta, running_mean, running_var, batches, scale, shift, mean, invstd (pointers), count (double),
+// eps, momentum (float), C, pad (int)} = 104 bytes each (bc_pn_bn_layer_bytes)
+BC_EXPORT int bc_pn_bn_layer_bytes(void) { return (int)sizeof(PnBnLayer); }
+BC_EXPORT int bc_pn_bn_finalize_acc(const void *layers, int n_layers, void *stream)
+{
+    if (!layers) return BC_ERR_NULL;
+    if (n_layers <= 0) return BC_ERR_SHAPE;
+    hipLaunchKernelGGL(k_pn_bn_finalize_acc, dim3((unsigned)n_layers), dim3(PN_COEF_MAX), 0, (hipStream_t)stream, static_cast<const PnBnLayer *>(layers));
+    return pn_status();
+}
+
 // backward of training-mode BatchNorm (+ the ReLU behind it): gz, and dgamma / dbeta; part = workspace of bc_pn_bn_bwd_partials(pixels) x 2 x C floats,
 // coef = 3 C floats.  mask_mode 0 none, 1 own output (z * scale + shift > 0), 2 external map (mask > 0)
 // partial rows of a backward launch: 64 pixels per workgroup or more, at most 1024 rows
@@ -1382,6 +1549,17 @@ BC_EXPORT int bc_pn_head_fwd(float *logits, const float *z, const float *scale, 
     if (N <= 0 || Hi <= 0 || Wi <= 0 || C <= 0) return BC_ERR_SHAPE;
     const int Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1;
     hipLaunchKernelGGL(k_pn_head_fwd, dim3((unsigned)(N * Ho * Wo)), dim3(64), 0, (hipStream_t)stream, logits, z, scale, shift, w, bias, N, Hi, Wi, C, Ho, Wo);
+    return pn_status();
+}
+
+BC_EXPORT int bc_pn_head_fwd_acc(float *logits, const float *z, const void *acc, const float *gamma, const float *beta, double count, float eps, const float *w,
+                                 const float *bias, int N, int Hi, int Wi, int C, void *stream)
+{
+    if (!logits || !z || !acc || !w) return BC_ERR_NULL;
+    if (N <= 0 || Hi <= 0 || Wi <= 0 || C <= 0 || C > PN_COEF_MAX || count <= 0) return BC_ERR_SHAPE;
+    const int Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1;
+    const PnBnSrc bn{static_cast<const unsigned long long *>(acc), gamma, beta, count, eps, C};
+    hipLaunchKernelGGL(k_pn_head_fwd_acc, dim3((unsigned)(N * Ho * Wo)), dim3(64), 0, (hipStream_t)stream, logits, z, bn, w, bias, N, Hi, Wi, C, Ho, Wo);
     return pn_status();
 }
 

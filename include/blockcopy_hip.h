@@ -535,6 +535,26 @@ int bc_pn_wgrad_groups(int N, int Hy, int Wy, int Cx, int Cy);      /* partial c
 int bc_pn_bn_finalize(const float *part, long long n_part, int C, double count, const float *gamma, const float *beta, float eps, float momentum,
                       float *running_mean, float *running_var, long long *batches, float *scale, float *shift, float *save_mean, float *save_invstd,
                       void *stream);
+/* The same BatchNorm WITHOUT a finalize launch between a conv and its consumers (a forward pass of the policy net: 11 launches less).  The producer adds
+ * its per-workgroup sums (sum x, sum x^2 of its output, per channel) as 64-bit FIXED-POINT numbers in units of 2^-24 to accumulators acc[16][2][C]
+ * (16 replicas, workgroup w adds to replica w mod 16: a sixteenth of the same-address atomics; readers add the replicas up) -- integer
+ * additions: the result is independent of their order, i.e. run-to-run identical without a fixed reduction order -- and every consumer derives
+ * scale / shift of its input channels from the accumulators at kernel start (bc_pn_bn_finalize's arithmetic in double precision: all consumers and
+ * bc_pn_bn_finalize_acc get bit-identical coefficients).  C <= 128.
+ *   bc_pn_arm_bn: one shot, per host thread, for the NEXT bc_pn_conv_nhwc (direction 0): in_acc (NULL: none; in_scale / in_shift must then be NULL in that
+ *     call) with gamma / beta / count (= N * H * W of the producer) / eps / C of the input's BatchNorm, out_acc (NULL: none) for the conv's own output.
+ *   bc_pn_join_acc / bc_pn_head_fwd_acc: bc_pn_join / bc_pn_head_fwd with (acc, gamma, beta) in place of (scale, shift); mode 0: acc_b unused.
+ *   bc_pn_bn_finalize_acc: ONE launch at the end of the pass for all layers -- scale / shift / mean / invstd arrays (what the backward pass and the
+ *     weight gradient's prologue read), running statistics and batch counters as bc_pn_bn_finalize, accumulators ZEROED for the next pass.  `layers`:
+ *     device array of bc_pn_bn_layer_bytes()-byte records {acc, gamma, beta, running_mean, running_var, batches, scale, shift, mean, invstd (pointers);
+ *     count (double); eps, momentum (float); C, 0 (int)}. */
+int bc_pn_arm_bn(const void *in_acc, const float *gamma, const float *beta, double count, float eps, int C, void *out_acc);
+int bc_pn_join_acc(float *out, const float *za, const void *acc_a, const float *gamma_a, const float *beta_a, const float *zb, const void *acc_b,
+                   const float *gamma_b, const float *beta_b, double count, float eps, int mode, int C, long long pixels, void *stream);
+int bc_pn_head_fwd_acc(float *logits, const float *z, const void *acc, const float *gamma, const float *beta, double count, float eps, const float *w,
+                       const float *bias, int N, int Hi, int Wi, int C, void *stream);
+int bc_pn_bn_layer_bytes(void);
+int bc_pn_bn_finalize_acc(const void *layers, int n_layers, void *stream);
 /* residual join: out = relu(za * sa + ta + B), B = zb (mode 0) | zb * sb + tb (mode 1: projection shortcut) | relu(zb * sb + tb) (mode 2) */
 int bc_pn_join(float *out, const float *za, const float *sa, const float *ta, const float *zb, const float *sb, const float *tb, int mode, int C,
                long long pixels, void *stream);
