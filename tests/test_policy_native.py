@@ -321,6 +321,34 @@ def test_native_policy_forward_and_gradients_match_autograd(N, H, W, open_gates)
         print(f"N={N} {H}x{W} rep {rep}: worst relative gradient error (native, torch fp32, layer) = {worst}")
 
 
+@pytest.mark.parametrize("N,H,W", [(1, 128, 256), (2, 96, 160)])
+def test_batchnorm_through_accumulators_equals_the_partial_sum_route(N, H, W, monkeypatch):
+    """The forward pass with its BatchNorm statistics in fixed-point accumulators (bc_pn_arm_bn: integer atomics, the consumers derive their
+    coefficients, ONE finish launch per pass) against the per-layer route (per-workgroup partial sums + bc_pn_bn_finalize after every conv) on the
+    same module: logits within 2e-6 (the sums differ only by the 2^-24 quantum of a workgroup's partial sum), running statistics and batch counters
+    alike, three passes each (eager, captured, replay), and the accumulators back at zero after every pass."""
+    from blockcopy.policy import native
+
+    pol_a, pol_b = _small_policy(H=H, W=W, N=N, lr=0.0), _small_policy(H=H, W=W, N=N, lr=0.0)
+    pol_b.net.load_state_dict(pol_a.net.state_dict())
+    monkeypatch.setattr(native, "BN_ACC", True)
+    nat_a = _native(pol_a, (N, 3, H, W))
+    monkeypatch.setattr(native, "BN_ACC", False)
+    nat_b = _native(pol_b, (N, 3, H, W))
+    g = torch.Generator().manual_seed(5)
+    for rep in range(3):
+        feat = torch.zeros((N, H, W, 32), device="cuda")
+        feat[..., :26] = torch.randn((N, H, W, 26), generator=g).cuda()
+        la, lb = nat_a.forward_on(feat).clone(), nat_b.forward_on(feat).clone()
+        assert float((la - lb).abs().max()) <= 2e-6 * max(1.0, float(lb.abs().max())), rep
+        assert all(int(bn.acc.abs().max()) == 0 for bn in nat_a.bns), rep
+    for (k, ba), (_, bb) in zip(pol_a.net.named_buffers(), pol_b.net.named_buffers()):
+        assert torch.allclose(ba.double(), bb.double(), rtol=1e-6, atol=1e-7), k
+    for bn_a, bn_b in zip(nat_a.bns, nat_b.bns):
+        for name in ("scale", "shift", "mean", "invstd"):
+            assert torch.allclose(getattr(bn_a, name), getattr(bn_b, name), rtol=2e-6, atol=1e-7), (bn_a.name, name)
+
+
 @pytest.mark.parametrize("momentum,wd", [(0.0, 0.0), (0.5, 1e-3)])
 def test_pn_rmsprop_kernel_matches_torch(momentum, wd):
     """bc_pn_rmsprop == torch.optim.RMSprop (uncentred) on the same gradients, three steps with carried state."""
