@@ -530,18 +530,22 @@ def main(argv=None):
                                 **({"miopen_dir": os.path.join(miopen_base_dir(), f"rank{r}")} if world > 1 else {})} for r in range(world)]
         details["per_rank_plans_equal"] = len(set(int(v) for v in per_rank_plan)) == 1
         # halo-gather kernel statistics from one extra, untimed clip (events around all 21 launches per frame)
-        be.prof_reset()
-        be.prof_enable(["pad_ring", "split", "combine", "conv3x3", "head1x1", "combine_copy"])
         inner = model.det if is_csp else model
         use_graph, inner.use_graph = inner.use_graph, False   # per-launch events (eager mode, NOT the timed mode) need eager launches
-        harness.run_clip(model, clips[0])
+        harness.run_clip(model, clips[0])                     # (the eager route's own first pass: allocations, cold caches -- not measured)
+        torch.cuda.synchronize(device)
+        be.prof_reset()
+        be.prof_enable(["pad_ring", "split", "combine", "conv3x3", "head1x1", "combine_copy"])
+        PROF_CLIPS = 2
+        for k in range(PROF_CLIPS):
+            harness.run_clip(model, clips[k % len(clips)])
         torch.cuda.synchronize(device)
         be.prof_enable([])
         for op in ("pad_ring", "split", "combine"):
             r = be.prof_read(op)
             if r["launches"]:
-                extra[op] = {"launches_per_frame": r["launches"] / CLIP_LEN, "avg_us": 1e3 * r["total_ms"] / r["launches"],
-                             "GBps": r["total_bytes"] / (r["total_ms"] * 1e-3) / 1e9, "MB_per_frame": r["total_bytes"] / CLIP_LEN / 1e6,
+                extra[op] = {"launches_per_frame": r["launches"] / (PROF_CLIPS * CLIP_LEN), "avg_us": 1e3 * r["total_ms"] / r["launches"],
+                             "GBps": r["total_bytes"] / (r["total_ms"] * 1e-3) / 1e9, "MB_per_frame": r["total_bytes"] / (PROF_CLIPS * CLIP_LEN) / 1e6,
                              }
         cc_eager = be.prof_read("combine_copy")
         hd = be.prof_read("head1x1")
@@ -550,7 +554,7 @@ def main(argv=None):
             # tiles, copy of the skipped ones from the previous frame's map) in ONE launch -- the fused scatter+copy of rounds 1-2
             # is its epilogue now.  HBM-bound: algorithmic bytes = packed features read + 2 x logits map (SURVEY 8(d) formula)
             gb = hd["total_bytes"] / (hd["total_ms"] * 1e-3) / 1e9
-            extra["head1x1"] = {"kernel": "k_head1x1 (logits conv with the scatter+copy as its epilogue)", "launches_per_frame": hd["launches"] / CLIP_LEN,
+            extra["head1x1"] = {"kernel": "k_head1x1 (logits conv with the scatter+copy as its epilogue)", "launches_per_frame": hd["launches"] / (PROF_CLIPS * CLIP_LEN), "launches_measured": hd["launches"],
                                 "avg_us": 1e3 * hd["total_ms"] / hd["launches"], "algorithmic_MB_per_launch": hd["total_bytes"] / hd["launches"] / 1e6,
                                 "achieved": gb, "frac": gb / HBM_PEAK_GBS}
         r = be.prof_read("conv3x3")
@@ -565,8 +569,8 @@ def main(argv=None):
                                                 "(F(2x2,3x3): 16/36) + k_stem7x7; per-layer form: details file",
                                       "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "issued_frac": tf / peak,
                                       "effective_TFLOPs": tf_alg, "effective_frac": tf_alg / peak, "traffic": None,
-                                      "launches_per_frame": r["launches"] / CLIP_LEN, "ms_per_frame": r["total_ms"] / CLIP_LEN,
-                                      "GFLOP_issued_per_frame": r["total_aux"] / CLIP_LEN / 1e9, "GFLOP_algorithmic_per_frame": r["total_bytes"] / CLIP_LEN / 1e9,
+                                      "launches_per_frame": r["launches"] / (PROF_CLIPS * CLIP_LEN), "ms_per_frame": r["total_ms"] / (PROF_CLIPS * CLIP_LEN),
+                                      "GFLOP_issued_per_frame": r["total_aux"] / (PROF_CLIPS * CLIP_LEN) / 1e9, "GFLOP_algorithmic_per_frame": r["total_bytes"] / (PROF_CLIPS * CLIP_LEN) / 1e9,
                                       "note": "achieved / frac = ISSUED matrix work in fp32-pipe FLOPs (a split-form launch issues 3/16 of its direct FLOPs: frac is the share of the "
                                               "kernel time the matrix pipe is busy) over the summed kernel time of an eager clip (dispatch-attached events); "
                                               "effective_* = FLOPs of the direct definition over the same time (> 1 x the fp32 peak: the products run on the 16-bit pipe)"}
@@ -673,14 +677,14 @@ def main(argv=None):
         if not cc["launches"] and "head1x1" in extra:
             # no stand-alone scatter+copy launch exists in this configuration any more: the op is the epilogue of the logits conv
             h = extra["head1x1"]
-            cc = {"launches": int(round(h["launches_per_frame"] * CLIP_LEN)), "total_ms": h["avg_us"] * 1e-3 * h["launches_per_frame"] * CLIP_LEN,
-                  "total_bytes": h["algorithmic_MB_per_launch"] * 1e6 * h["launches_per_frame"] * CLIP_LEN, "kernel": h["kernel"],
-                  "method": "dispatch-attached HIP events (hipExtLaunchKernelGGL) over one eager clip run inside bench.py right after the timed region "
+            cc = {"launches": int(h["launches_measured"]), "total_ms": h["avg_us"] * 1e-3 * h["launches_measured"],
+                  "total_bytes": h["algorithmic_MB_per_launch"] * 1e6 * h["launches_measured"], "kernel": h["kernel"],
+                  "method": "dispatch-attached HIP events (hipExtLaunchKernelGGL) over two eager clips (after one eager warm clip) run inside bench.py right after the timed region "
                             "(graph kernel nodes cannot carry events); rocprofv3 trace of the graph replays: profiles/"}
         elif not cc["launches"] and cc_eager["launches"]:
             # (the detector: its out-of-place combines -- three 134 MB head maps per frame -- are nodes of the frame's graph)
             cc = dict(cc_eager, kernel="k_combine_copy (fused scatter+copy: the out-of-place combine of the head maps)",
-                      method="dispatch-attached HIP events (hipExtLaunchKernelGGL) over one eager clip run inside bench.py right after the timed region "
+                      method="dispatch-attached HIP events (hipExtLaunchKernelGGL) over two eager clips (after one eager warm clip) run inside bench.py right after the timed region "
                              "(graph kernel nodes cannot carry events)")
         achieved = (cc["total_bytes"] / (cc["total_ms"] * 1e-3) / 1e9) if cc["total_ms"] > 0 else 0.0
         # (the segmentation logits map: batch x 19 classes x H/4 x W/4)
