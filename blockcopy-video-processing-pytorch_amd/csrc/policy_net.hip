@@ -1290,6 +1290,10 @@ BC_EXPORT int bc_pn_conv_nhwc(float *out, const float *x, const float *w, int N,
                               int direction, const float *in_scale, const float *in_shift, int in_relu, const float *add, const float *add_mask,
                               int accumulate, float *stats, long long stats_capacity, int precision, void *stream)
 {
+    // (one shot: whatever happens below, an armed BatchNorm source / sink is consumed by THIS call and never leaks into a later one)
+    const PnBnSrc arm_in = g_pn_arm_in;
+    unsigned long long *const arm_out = g_pn_arm_out;
+    g_pn_arm_in = PnBnSrc{nullptr, nullptr, nullptr, 0.0, 0.f, 0}; g_pn_arm_out = nullptr;
     if (precision < 0 || precision > 2) return BC_ERR_SHAPE;
     if (!out || !x || !w) return BC_ERR_NULL;
     if (N <= 0 || Hx <= 0 || Wx <= 0 || Hy <= 0 || Wy <= 0 || Cx <= 0 || Cy <= 0) return BC_ERR_SHAPE;
@@ -1302,8 +1306,7 @@ BC_EXPORT int bc_pn_conv_nhwc(float *out, const float *x, const float *w, int N,
     PnConvArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.w = w; a.out = out; a.in_scale = in_scale; a.in_shift = in_shift; a.add = add; a.add_mask = add_mask; a.stats = stats;
-    a.in_bn = g_pn_arm_in; a.out_acc = g_pn_arm_out;
-    g_pn_arm_in = PnBnSrc{nullptr, nullptr, nullptr, 0.0, 0.f, 0}; g_pn_arm_out = nullptr;
+    a.in_bn = arm_in; a.out_acc = arm_out;
     if (a.in_bn.acc && (direction != 0 || a.in_bn.C != Cx || Cx > PN_COEF_MAX || in_scale)) return BC_ERR_SHAPE;
     if (a.out_acc && direction != 0) return BC_ERR_SHAPE;
     a.N = N; a.in_relu = in_relu; a.accumulate = accumulate;

@@ -321,6 +321,53 @@ def test_native_policy_forward_and_gradients_match_autograd(N, H, W, open_gates)
         print(f"N={N} {H}x{W} rep {rep}: worst relative gradient error (native, torch fp32, layer) = {worst}")
 
 
+def test_pn_conv_with_armed_batchnorm_accumulators():
+    """bc_pn_arm_bn at the kernel level: a conv whose prologue derives scale / shift from fixed-point sums (16 replicas of [sum x | sum x^2] in
+    units of 2^-24) and whose epilogue adds the sums of ITS output to accumulators == the same conv with explicit coefficients from the same
+    statistics; the accumulators hold the output's sums to 2^-24 per workgroup; an arm is ONE shot -- consumed by the next call even when that
+    call fails, never by a later one."""
+    be, lib = _lib()
+    N, H, W, Ci, Co = 2, 24, 40, 32, 64
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn((N, Ci, H, W), generator=g) * 1.5 + 0.3
+    w = torch.randn((Co, Ci, 3, 3), generator=g) * 0.1
+    gamma, beta = torch.rand(Ci, generator=g) + 0.5, torch.randn(Ci, generator=g) * 0.2
+    count, eps = float(N * H * W), 1e-5
+    # accumulators of x as a producer would have left them: its sums spread over the replicas
+    s1, s2 = x.double().sum((0, 2, 3)), (x.double() ** 2).sum((0, 2, 3))
+    acc = torch.zeros((16, 2, Ci), dtype=torch.int64)
+    share = torch.rand((16, 1), generator=g).double()
+    share /= share.sum()
+    acc[:, 0] = torch.round(share * s1 * 2.0 ** 24).long()
+    acc[:, 1] = torch.round(share * s2 * 2.0 ** 24).long()
+    S1, S2 = acc[:, 0].sum(0).double() / 2.0 ** 24, acc[:, 1].sum(0).double() / 2.0 ** 24
+    mean = S1 / count
+    var = (S2 / count - mean * mean).clamp_min(0)
+    scale = gamma.double() / torch.sqrt(var + eps)
+    shift = beta.double() - mean * scale
+    want, _ = _conv_ref(x, w, 3, 1, scale.float(), shift.float(), True)
+    xg, wg, accg = _nhwc(x), _wk(w), acc.cuda()
+    gg, bg = gamma.cuda(), beta.cuda()
+    out_acc = torch.zeros((16, 2, Co), dtype=torch.int64, device="cuda")
+    out = torch.full((N, H, W, Co), float("nan"), device="cuda")
+    args = (out.data_ptr(), xg.data_ptr(), wg.data_ptr(), N, H, W, Ci, H, W, Co, 3, 1, 0, None, None, 1, None, None, 0, None, 0, 1, _st())
+    assert lib.bc_pn_arm_bn(accg.data_ptr(), gg.data_ptr(), bg.data_ptr(), count, eps, Ci, out_acc.data_ptr()) == 0
+    assert lib.bc_pn_conv_nhwc(*args) == 0
+    got = _nchw(out)
+    assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    sums = out_acc.cpu().sum(0).double() / 2.0 ** 24
+    assert torch.allclose(sums[0], got.sum((0, 2, 3)), rtol=1e-5, atol=1e-3) and torch.allclose(sums[1], (got * got).sum((0, 2, 3)), rtol=1e-5, atol=1e-3)
+    # one shot: an arm in front of a FAILING call is gone afterwards (explicit coefficients in the next call would otherwise be refused)
+    assert lib.bc_pn_arm_bn(accg.data_ptr(), gg.data_ptr(), bg.data_ptr(), count, eps, Ci, None) == 0
+    assert lib.bc_pn_conv_nhwc(None, *args[1:]) != 0
+    sc32, sh32 = scale.float().cuda(), shift.float().cuda()
+    out2 = torch.full_like(out, float("nan"))
+    assert lib.bc_pn_conv_nhwc(out2.data_ptr(), xg.data_ptr(), wg.data_ptr(), N, H, W, Ci, H, W, Co, 3, 1, 0, sc32.data_ptr(), sh32.data_ptr(), 1, None, None, 0,
+                               None, 0, 1, _st()) == 0
+    assert float((_nchw(out2) - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    assert int(out_acc.cpu().sum(0)[0].sum()) == int(torch.round(sums[0] * 2.0 ** 24).sum())      # (untouched by the un-armed call)
+
+
 @pytest.mark.parametrize("N,H,W", [(1, 128, 256), (2, 96, 160)])
 def test_batchnorm_through_accumulators_equals_the_partial_sum_route(N, H, W, monkeypatch):
     """The forward pass with its BatchNorm statistics in fixed-point accumulators (bc_pn_arm_bn: integer atomics, the consumers derive their
