@@ -492,11 +492,15 @@ def main(argv=None):
     be.prof_enable([])
     cc = be.prof_read("combine_copy")
     cc["method"] = "HIP events attached to each eager dispatch (hipExtLaunchKernelGGL) over the timed region"
-    stamp_us, stamp_bytes = [], 0.0
+    stamp_us, stamp_bytes, head_stamp_us = [], 0.0, []
     for gf in gfs:
+        is_head = getattr(gf, "stamp_head", False)
         us, nb = gf.timing_read()
-        stamp_us += us
-        stamp_bytes = nb or stamp_bytes
+        if is_head:
+            head_stamp_us += us          # (records of k_head1x1, the logits conv that carries the scatter+copy: bytes come from its algorithmic count below)
+        else:
+            stamp_us += us
+            stamp_bytes = nb or stamp_bytes
     if stamp_us:
         # graph kernel nodes cannot carry events: the node stamps the constant 100 MHz clock itself (min workgroup entry, max
         # workgroup exit; include/blockcopy_hip.h bc_combine_copy_indirect), one record per frame of the timed region
@@ -677,10 +681,21 @@ def main(argv=None):
         if not cc["launches"] and "head1x1" in extra:
             # no stand-alone scatter+copy launch exists in this configuration any more: the op is the epilogue of the logits conv
             h = extra["head1x1"]
-            cc = {"launches": int(h["launches_measured"]), "total_ms": h["avg_us"] * 1e-3 * h["launches_measured"],
-                  "total_bytes": h["algorithmic_MB_per_launch"] * 1e6 * h["launches_measured"], "kernel": h["kernel"],
-                  "method": "dispatch-attached HIP events (hipExtLaunchKernelGGL) over two eager clips (after one eager warm clip) run inside bench.py right after the timed region "
-                            "(graph kernel nodes cannot carry events); rocprofv3 trace of the graph replays: profiles/"}
+            if head_stamp_us:
+                # the timed region itself: every frame's k_head1x1 graph node stamps the constant 100 MHz clock (first workgroup entry -> last
+                # workgroup exit); bytes = the launch's algorithmic count averaged over a clip (eager pass below: same clips, same masks)
+                cc = {"launches": len(head_stamp_us), "total_ms": sum(head_stamp_us) * 1e-3,
+                      "total_bytes": h["algorithmic_MB_per_launch"] * 1e6 * len(head_stamp_us), "kernel": h["kernel"],
+                      "method": "in-kernel s_memrealtime stamps of the hipGraph node k_head1x1 (first workgroup entry -> last workgroup exit, 10 ns ticks), every frame "
+                                "of the timed region (graph kernel nodes cannot carry HIP events); eager_events_avg_launch_us = the same kernel under dispatch-attached "
+                                "HIP events in two eager clips after the timed region; rocprofv3 trace of the graph replays: profiles/",
+                      "p50_us": sorted(head_stamp_us)[len(head_stamp_us) // 2], "min_us": min(head_stamp_us), "max_us": max(head_stamp_us),
+                      "eager_events_avg_launch_us": h["avg_us"]}
+            else:
+                cc = {"launches": int(h["launches_measured"]), "total_ms": h["avg_us"] * 1e-3 * h["launches_measured"],
+                      "total_bytes": h["algorithmic_MB_per_launch"] * 1e6 * h["launches_measured"], "kernel": h["kernel"],
+                      "method": "dispatch-attached HIP events (hipExtLaunchKernelGGL) over two eager clips (after one eager warm clip) run inside bench.py right after the timed region "
+                                "(graph kernel nodes cannot carry events); rocprofv3 trace of the graph replays: profiles/"}
         elif not cc["launches"] and cc_eager["launches"]:
             # (the detector: its out-of-place combines -- three 134 MB head maps per frame -- are nodes of the frame's graph)
             cc = dict(cc_eager, kernel="k_combine_copy (fused scatter+copy: the out-of-place combine of the head maps)",
@@ -723,6 +738,7 @@ def main(argv=None):
                             if cc["launches"] and pure_scatter else {}),
                          "launches": cc["launches"], "avg_launch_us": (1e3 * cc["total_ms"] / cc["launches"]) if cc["launches"] else None,
                          **({"p50_us": cc["p50_us"], "min_us": cc["min_us"], "max_us": cc["max_us"]} if "p50_us" in cc else {}),
+                         **({"eager_events_avg_launch_us": cc["eager_events_avg_launch_us"]} if "eager_events_avg_launch_us" in cc else {}),
                          "algorithmic_bytes_per_launch": (cc["total_bytes"] / cc["launches"]) if cc["launches"] else None,
                          **rocprof_fields,
                          "method": cc["method"]},

@@ -161,10 +161,20 @@ class GraphedFrame:
     # ------------------------------------------------------------------ measurement of the in-graph scatter+copy
     def timing_start(self, capacity: int):
         """Give each of the next ``capacity`` frames a timing record for its in-graph scatter+copy launch."""
-        if self.out_meta is None or self.out_blocks_like is None:
+        if self.out_meta is None:
+            return
+        if self.out_blocks_like is None:
+            # the output stage is bc_head1x1_scatter_nhwc (logits conv with the scatter+copy as its epilogue): its record is cell 0 = {capacity, -}
+            # and one cell per workgroup behind it (at most one per 128 output pixels: four 32-pixel blocks or copy rows per workgroup)
+            shape = self.out_meta[0]
+            cells = 2 + (shape[0] * shape[2] * shape[3] + 127) // 128
+            self.stamps, self.stamp_pos = torch.zeros((capacity, cells, 2), dtype=torch.int64, device=self.device), 0
+            self.stamps[:, 0, 0] = cells
+            self.stamp_head = True
             return
         cells = get_backend().combine_copy_cells(self.out_blocks_like, self.out_meta[0])
         self.stamps, self.stamp_pos = torch.zeros((capacity, cells, 2), dtype=torch.int64, device=self.device), 0
+        self.stamp_head = False
 
     def timing_read(self):
         """(durations in microseconds of the recorded launches, algorithmic bytes per launch); synchronises."""
@@ -173,6 +183,13 @@ class GraphedFrame:
         torch.cuda.synchronize(self.device)
         st = self.stamps[:self.stamp_pos].cpu().numpy()
         self.stamps = None
+        if getattr(self, "stamp_head", False):
+            ticks = []
+            for rec in st[:, 1:]:                  # (cell 0 is the header; cells of workgroups that did not exist in a frame stay zero)
+                live = rec[:, 1] != 0
+                if live.any():
+                    ticks.append(float(rec[live, 1].max() - rec[live, 0].min()))
+            return [t * 0.01 for t in ticks], 0.0      # (bytes: the caller's algorithmic count of the launch)
         ok = st[:, 0, 1] != 0                      # frames whose graph ended with the node (cell 0 written)
         ticks = (st[ok, :, 1].max(axis=1) - st[ok, :, 0].min(axis=1)).astype(np.float64)
         shape, dtype, _ = self.out_meta

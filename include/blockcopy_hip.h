@@ -130,7 +130,10 @@ int bc_tile_copy_indirect(void *dst, const void *src_slot, const int32_t *mappin
  *   scatter = 1     out = the fresh dense map (N, GH*bs, GW*bs, Cout) channels-last: executed tiles are written at their grid
  *                   position (mapping_exec), every skipped tile (grid_idx < 0) is copied from `prev` (same shape; may be NULL
  *                   only if every tile is executed).  slots != NULL: prev / out are read from slots[0] / slots[1] at run time
- *                   as in bc_combine_copy_indirect (hipGraph node), the out / prev arguments are ignored.
+ *                   as in bc_combine_copy_indirect (hipGraph node), the out / prev arguments are ignored.  slots[2] != 0 (measurement only):
+ *                   a timing record of 16-byte cells -- cell 0 = {capacity in cells, -} written by the CALLER, cell 1 + i = {entry, exit}
+ *                   of workgroup i's first wave on the constant 100 MHz clock (workgroups beyond the capacity leave nothing): a graph
+ *                   kernel node cannot carry events; launch time = max(exit) - min(entry) over the written cells (bench.py `roofline`).
  * bs: multiple of 8, and of 32 when larger than 32.  Results: fp32 accumulation over Cin in matrix-core order, one rounding. */
 int bc_head1x1_scatter_nhwc(void *out, const void *features, const void *weights_packed, const void *prev, const void *slots,
                             const int32_t *grid_idx, const int32_t *mapping_exec, int n_exec, int N, int Cin, int Cout,
