@@ -773,6 +773,17 @@ def main(argv=None):
                 return {k: shed(v) for k, v in o.items() if k not in ("note", "method")} if isinstance(o, dict) else o
             out = shed(out)
             line = json.dumps(out)
+        if len(line) >= 4096:
+            # ... then the provenance strings and the long kernel list of roofline_conv (all of it is in the details file)
+            for k in ("traffic_source", "rocprof_source"):
+                out.get("roofline", {}).pop(k, None)
+            if isinstance(out.get("roofline_conv"), dict) and len(out["roofline_conv"].get("kernel", "")) > 96:
+                out["roofline_conv"]["kernel"] = out["roofline_conv"]["kernel"][:93] + "..."
+            line = json.dumps(out)
+        for k in ("roofline_large", "upload_inclusive", "conv_plan"):      # ... then secondary measurements, one at a time
+            if len(line) >= 4096 and isinstance(out.get("kernels"), dict) and k in out["kernels"]:
+                out["kernels"][k] = {"moved_to": out["details_file"]}
+                line = json.dumps(out)
         for k in ("kernels", "roofline_conv"):
             if len(line) >= 4096 and k in out:
                 out[k] = {"moved_to": out["details_file"]}
