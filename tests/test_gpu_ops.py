@@ -1612,6 +1612,19 @@ def test_head1x1_prologue_conv_bias_scatter_copy(be, geo, dtype, tol):
         slots = torch.tensor([prev.data_ptr(), out2.data_ptr(), 0], dtype=torch.int64).cuda()
         be.head1x1_scatter(x, wpk, cout, prologue, b, _dev(gi), _dev(m), slots=slots)
         assert torch.equal(out2, out)
+        # (c') ... with a timing record in slot word 2 (what bench.py's `roofline` reads): same bits; cell 0 (capacity) is the caller's, every
+        # written cell has entry <= exit on the 100 MHz clock, nothing is written beyond the capacity
+        out4 = cl(torch.full((N, cout, GH * bs, GW * bs), 5.0, dtype=dtype).cuda())
+        for cap in (2 + (N * GH * bs * GW * bs + 127) // 128, 2):
+            rec = torch.zeros((2 + (N * GH * bs * GW * bs + 127) // 128, 2), dtype=torch.int64).cuda()
+            rec[0, 0] = cap
+            slots4 = torch.tensor([prev.data_ptr(), out4.data_ptr(), rec.data_ptr()], dtype=torch.int64).cuda()
+            be.head1x1_scatter(x, wpk, cout, prologue, b, _dev(gi), _dev(m), slots=slots4)
+            assert torch.equal(out4, out)
+            r = rec.cpu().numpy()
+            live = r[1:, 1] != 0
+            assert r[0, 0] == cap and r[0, 1] == 0 and live.sum() >= 1 and not live[cap - 1:].any(), (geo, n_exec, cap, int(live.sum()))
+            assert (r[1:][live, 0] <= r[1:][live, 1]).all() and int(r[1:][live, 1].max() - r[1:][live, 0].min()) < 100 * 1000 * 100      # (< 0.1 s)
         # (d) all-active: prev may be absent
         if n_exec == total:
             out3 = cl(torch.full((N, cout, GH * bs, GW * bs), 3.0, dtype=dtype).cuda())
